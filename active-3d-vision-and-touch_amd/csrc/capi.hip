@@ -1,0 +1,362 @@
+// capi.hip — extern "C" entry points declared in include/a3vt.h, plus the GCN stack orchestration
+// (the layer loop of reconstruction/vision/model.py:316-331 lives here so that Python makes one call
+// per refinement stage and nothing syncs the host).
+#include <stdarg.h>
+#include <string.h>
+
+#include "../../include/a3vt.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace a3vt {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// 256 bytes of zeros in the code object: source for out-of-range LDS-DMA lanes.
+__device__ float g_zero_page[64];
+static const float *zero_page() {
+  static const float *ptr = nullptr;
+  if (!ptr) {
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_zero_page)) != hipSuccess) return nullptr;
+    ptr = static_cast<const float *>(p);
+  }
+  return ptr;
+}
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Scratch layout of a GCN stack call (float offsets, every region 256-B aligned).
+struct StackLayout {
+  size_t wt, wt_stride;  // per hidden layer: transposed (fwd) or padded (bwd) weight image
+  size_t za;             // [M][cpad]
+  size_t z3;             // [2][M][4]
+  size_t ping[2];        // [M][hidden] each (fwd without acts: layer outputs; bwd: gradients)
+  size_t dw_slab, db_slab, thin_dw_slab, thin_db_slab;
+  size_t total;
+};
+
+static StackLayout stack_layout(int batch, int n_vert, int in_features, int hidden, int num_layers, int cut_len,
+                                int need_backward) {
+  StackLayout L{};
+  const size_t m = (size_t)batch * n_vert;
+  const int cpad = pad4(cut_len);
+  size_t off = 0;
+  auto take = [&](size_t nfloats) {
+    const size_t o = off;
+    off = align_up(off + nfloats, 64);
+    return o;
+  };
+  const int kmax = hidden > pad4(in_features) ? hidden : pad4(in_features);
+  L.wt_stride = align_up((size_t)rowgemm_bt_rows(kmax) * pad16(kmax), 64);
+  L.wt = take(L.wt_stride * (num_layers > 1 ? num_layers - 1 : 1));
+  L.za = take(m * (cpad > 4 ? cpad : 4));
+  L.z3 = take(2 * m * 4);
+  L.ping[0] = take(m * hidden);
+  L.ping[1] = take(m * hidden);
+  if (need_backward) {
+    const size_t kin = kmax;
+    L.dw_slab = take((size_t)dw_num_slabs(hidden) * kin * hidden);
+    L.db_slab = take((size_t)csr_bwd_num_slabs(batch, n_vert) * cpad);
+    L.thin_dw_slab = take((size_t)thin_num_slabs() * kin * 3);
+    L.thin_db_slab = take((size_t)thin_num_slabs() * 3);
+  }
+  L.total = off;
+  return L;
+}
+
+static int check_stack_dims(int ld_feats, int in_features, int num_layers, int hidden, int cut_len) {
+  if (num_layers < 1) { set_error("gcn_stack: num_layers=%d", num_layers); return -1; }
+  if (ld_feats % 4 != 0 || ld_feats < in_features) {
+    set_error("gcn_stack: ld_feats=%d must be a multiple of 4 and >= in_features=%d", ld_feats, in_features);
+    return -1;
+  }
+  if (num_layers > 1 && (hidden % 4 != 0 || hidden > 304 || cut_len < 0 || cut_len > hidden)) {
+    set_error("gcn_stack: hidden=%d (must be a multiple of 4, <= 304) cut_len=%d unsupported", hidden, cut_len);
+    return -1;
+  }
+  if (ld_feats > 304) { set_error("gcn_stack: in_features=%d > 304 unsupported", in_features); return -1; }
+  return 0;
+}
+
+}  // namespace a3vt
+
+using namespace a3vt;
+
+extern "C" {
+
+int a3vt_version(void) { return A3VT_VERSION; }
+const char *a3vt_last_error(void) { return g_err; }
+
+int a3vt_csr_validate(const int32_t *rowptr, const int32_t *col, int n_vert, int nnz) {
+  A3VT_CHECK_ARG(rowptr && col && n_vert > 0 && nnz >= 0);
+  if (rowptr[0] != 0 || rowptr[n_vert] != nnz) {
+    set_error("csr: rowptr[0]=%d rowptr[n]=%d nnz=%d", rowptr[0], rowptr[n_vert], nnz);
+    return -1;
+  }
+  for (int i = 0; i < n_vert; ++i)
+    if (rowptr[i + 1] < rowptr[i]) { set_error("csr: rowptr not monotone at %d", i); return -1; }
+  for (int e = 0; e < nnz; ++e)
+    if (col[e] < 0 || col[e] >= n_vert) { set_error("csr: col[%d]=%d out of range", e, col[e]); return -1; }
+  return 0;
+}
+
+size_t a3vt_gcn_stack_scratch_bytes(int batch, int n_vert, int in_features, int hidden, int num_layers, int cut_len,
+                                    int need_backward) {
+  return stack_layout(batch, n_vert, in_features, hidden, num_layers, cut_len, need_backward).total * sizeof(float);
+}
+
+int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const float *const *weights,
+                       const float *const *biases, int num_layers, int hidden, int cut_len,
+                       const int32_t *rowptr, const int32_t *col, const float *val, int n_vert, int batch,
+                       float *acts, float *scratch, float *update, void *stream) {
+  A3VT_CHECK_ARG(feats && weights && biases && rowptr && col && val && scratch && update);
+  A3VT_CHECK_ARG(n_vert > 0 && batch > 0);
+  if (int rc = check_stack_dims(ld_feats, in_features, num_layers, hidden, cut_len)) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const float *zeros = zero_page();
+  A3VT_CHECK_ARG(zeros != nullptr);
+  const StackLayout L = stack_layout(batch, n_vert, in_features, hidden, num_layers, cut_len, 0);
+  const size_t m = (size_t)batch * n_vert;
+  const int cpad = pad4(cut_len);
+
+  const float *x = feats;
+  int ldx = ld_feats;
+  for (int i = 0; i + 1 < num_layers; ++i) {
+    const int k = i == 0 ? ld_feats : hidden;       // K walked by the kernel (pad columns of feats are zero)
+    const int kin = i == 0 ? in_features : hidden;  // rows of W_i
+    float *wt = scratch + L.wt + L.wt_stride * i;
+    if (int rc = launch_transpose_pad(weights[i], kin, hidden, wt, rowgemm_bt_rows(hidden), pad16(k), s)) return rc;
+    float *y = acts ? acts + (size_t)i * m * hidden : scratch + L.ping[i & 1];
+    RowGemmArgs g{};
+    g.a0 = g.a1 = x;
+    g.lda0 = g.lda1 = ldx;
+    g.ksplit = k;
+    g.bt = wt;
+    g.ldb = pad16(k);
+    g.zeros = zeros;
+    g.m = (int)m;
+    g.k = k;
+    g.n_store = hidden;
+    g.c = y;
+    g.ldc = hidden;
+    g.c2 = scratch + L.za;
+    g.ldc2 = cpad;
+    g.csplit = cut_len;
+    if (int rc = launch_rowgemm(g, EPI_FWD_HIDDEN, s)) return rc;
+    if (cut_len > 0)
+      if (int rc = launch_csr_fwd(scratch + L.za, cpad, biases[i], cut_len, rowptr, col, val, n_vert, batch, y, hidden, s))
+        return rc;
+    x = y;
+    ldx = hidden;
+  }
+  const int klast = num_layers == 1 ? in_features : hidden;
+  return launch_thin_fwd(x, ldx, klast, weights[num_layers - 1], biases[num_layers - 1], rowptr, col, val, n_vert,
+                         batch, scratch + L.z3, update, s);
+}
+
+int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const float *const *weights,
+                       const float *const *biases, int num_layers, int hidden, int cut_len,
+                       const int32_t *rowptr, const int32_t *col, const float *val, const int32_t *rowptrT,
+                       const int32_t *colT, const float *valT, int n_vert, int batch, const float *acts,
+                       const float *grad_update, float *const *grad_weights, float *const *grad_biases,
+                       float *grad_feats, float *scratch, void *stream) {
+  (void)biases; (void)rowptr; (void)col; (void)val;
+  A3VT_CHECK_ARG(feats && weights && rowptrT && colT && valT && grad_update && grad_weights && grad_biases);
+  A3VT_CHECK_ARG(grad_feats && scratch && n_vert > 0 && batch > 0);
+  A3VT_CHECK_ARG(num_layers == 1 || acts != nullptr);
+  if (int rc = check_stack_dims(ld_feats, in_features, num_layers, hidden, cut_len)) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const float *zeros = zero_page();
+  A3VT_CHECK_ARG(zeros != nullptr);
+  const StackLayout L = stack_layout(batch, n_vert, in_features, hidden, num_layers, cut_len, 1);
+  const size_t m = (size_t)batch * n_vert;
+  const int cpad = pad4(cut_len);
+  const int last = num_layers - 1;
+
+  // ---- output layer
+  {
+    const float *x = num_layers == 1 ? feats : acts + (size_t)(last - 1) * m * hidden;
+    const int ldx = num_layers == 1 ? ld_feats : hidden;
+    const int k = num_layers == 1 ? in_features : hidden;
+    float *gprev = num_layers == 1 ? grad_feats : scratch + L.ping[0];
+    if (int rc = launch_thin_bwd(x, ldx, k, weights[last], rowptrT, colT, valT, n_vert, batch, grad_update,
+                                 scratch + L.z3, num_layers > 1, gprev, ldx, ldx, scratch + L.thin_dw_slab,
+                                 scratch + L.thin_db_slab, s))
+      return rc;
+    if (int rc = launch_slab_reduce(scratch + L.thin_dw_slab, thin_num_slabs(), (size_t)k * 3, (size_t)k * 3,
+                                    grad_weights[last], s))
+      return rc;
+    if (int rc = launch_slab_reduce(scratch + L.thin_db_slab, thin_num_slabs(), 3, 3, grad_biases[last], s)) return rc;
+  }
+
+  // ---- hidden layers, last to first.  g = dL/dY_i already multiplied by the ReLU mask of layer i.
+  int cur = 0;
+  for (int i = last - 1; i >= 0; --i) {
+    float *g = scratch + L.ping[cur];
+    float *dza = scratch + L.za;
+    const float *x = i == 0 ? feats : acts + (size_t)(i - 1) * m * hidden;
+    const int ldx = i == 0 ? ld_feats : hidden;
+    const int kin = i == 0 ? in_features : hidden;
+
+    // bias gradient + A^T gather on the aggregated channels
+    if (int rc = launch_fill_zero(grad_biases[i], hidden, s)) return rc;
+    if (cut_len > 0) {
+      if (int rc = launch_csr_bwd(g, hidden, cut_len, rowptrT, colT, valT, n_vert, batch, dza, cpad,
+                                  scratch + L.db_slab, s))
+        return rc;
+      if (int rc = launch_slab_reduce(scratch + L.db_slab, csr_bwd_num_slabs(batch, n_vert), cpad, cut_len,
+                                      grad_biases[i], s))
+        return rc;
+    }
+
+    // dW_i = X_i^T dZ
+    DwArgs d{};
+    d.x = x;
+    d.ldx = ldx;
+    d.z0 = dza;
+    d.ldz0 = cpad > 0 ? cpad : 4;
+    d.z1 = g;
+    d.ldz1 = hidden;
+    d.zsplit = cpad;
+    d.zeros = zeros;
+    d.slab = scratch + L.dw_slab;
+    d.m = (int)m;
+    d.k_in = kin;
+    d.n_out = hidden;
+    if (int rc = launch_dw(d, s)) return rc;
+    if (int rc = launch_slab_reduce(scratch + L.dw_slab, dw_num_slabs(hidden), (size_t)kin * hidden,
+                                    (size_t)kin * hidden, grad_weights[i], s))
+      return rc;
+
+    // dX_i = dZ W_i^T  (masked by the ReLU of layer i-1, whose output is X_i)
+    const int n_store = i == 0 ? ld_feats : hidden;
+    float *wp = scratch + L.wt + L.wt_stride * i;
+    if (int rc = launch_copy_pad(weights[i], kin, hidden, wp, rowgemm_bt_rows(n_store), pad16(hidden), s)) return rc;
+    RowGemmArgs r{};
+    r.a0 = dza;
+    r.lda0 = cpad > 0 ? cpad : 4;
+    r.a1 = g;
+    r.lda1 = hidden;
+    r.ksplit = cpad;
+    r.bt = wp;
+    r.ldb = pad16(hidden);
+    r.zeros = zeros;
+    r.m = (int)m;
+    r.k = hidden;
+    r.n_store = n_store;
+    if (i == 0) {
+      r.c = grad_feats;
+      r.ldc = ld_feats;
+      if (int rc = launch_rowgemm(r, EPI_PLAIN, s)) return rc;
+    } else {
+      r.c = scratch + L.ping[cur ^ 1];
+      r.ldc = hidden;
+      r.mask = x;
+      r.ldmask = hidden;
+      if (int rc = launch_rowgemm(r, EPI_DX_MASK, s)) return rc;
+      cur ^= 1;
+    }
+  }
+  return 0;
+}
+
+int a3vt_wt_rows(int n_out) { return rowgemm_bt_rows(n_out); }
+int a3vt_wt_ld(int k) { return pad16(k); }
+
+int a3vt_transpose_weight(const float *w, int k, int n_out, float *wt, void *stream) {
+  A3VT_CHECK_ARG(w && wt && k > 0 && n_out > 0 && n_out <= 304);
+  return launch_transpose_pad(w, k, n_out, wt, rowgemm_bt_rows(n_out), pad16(k), static_cast<hipStream_t>(stream));
+}
+
+int a3vt_rowgemm(const float *a, int lda, int m, int k, const float *wt, int n_out, float *c, int ldc, void *stream) {
+  A3VT_CHECK_ARG(a && wt && c && m > 0 && k > 0 && k % 4 == 0 && lda >= k && ldc >= n_out && n_out <= 304);
+  RowGemmArgs g{};
+  g.a0 = g.a1 = a;
+  g.lda0 = g.lda1 = lda;
+  g.ksplit = k;
+  g.bt = wt;
+  g.ldb = pad16(k);
+  g.zeros = zero_page();
+  A3VT_CHECK_ARG(g.zeros != nullptr);
+  g.m = m;
+  g.k = k;
+  g.n_store = n_out;
+  g.c = c;
+  g.ldc = ldc;
+  return launch_rowgemm(g, EPI_PLAIN, static_cast<hipStream_t>(stream));
+}
+
+size_t a3vt_posenc_param_count(int input_size) { return posenc_param_count(input_size); }
+size_t a3vt_posenc_scratch_bytes(int m, int input_size) {
+  return (size_t)posenc_num_slabs(m) * posenc_param_count(input_size) * sizeof(float);
+}
+int a3vt_posenc_mask_fwd(const float *verts, const float *mask, int m, int input_size, const float *pe_params,
+                         float *feats, int ld_feats, void *stream) {
+  A3VT_CHECK_ARG(verts && mask && pe_params && feats && m > 0 && ld_feats >= input_size);
+  return launch_posenc_fwd(verts, mask, m, input_size, pe_params, feats, ld_feats, static_cast<hipStream_t>(stream));
+}
+int a3vt_posenc_mask_bwd(const float *verts, const float *mask, int m, int input_size, const float *pe_params,
+                         const float *grad_feats, int ld_feats, float *grad_verts, float *grad_params, float *scratch,
+                         void *stream) {
+  A3VT_CHECK_ARG(verts && mask && pe_params && grad_feats && grad_verts && grad_params && scratch && m > 0);
+  return launch_posenc_bwd(verts, mask, m, input_size, pe_params, grad_feats, ld_feats, grad_verts, grad_params,
+                           scratch, static_cast<hipStream_t>(stream));
+}
+
+int a3vt_vertex_update(const float *verts_in, const float *update, int batch, int n_vert, int n_vision,
+                       float *verts_out, void *stream) {
+  A3VT_CHECK_ARG(verts_in && update && verts_out && batch > 0 && n_vert > 0 && n_vision >= 0 && n_vision <= n_vert);
+  return launch_vertex_update(verts_in, update, batch, n_vert, n_vision, verts_out, static_cast<hipStream_t>(stream));
+}
+
+int a3vt_face_cdf(const float *verts, const int32_t *faces, int batch, int n_vert, int n_faces, float *cdf,
+                  void *stream) {
+  A3VT_CHECK_ARG(verts && faces && cdf && batch > 0 && n_vert > 0 && n_faces > 0);
+  return launch_face_cdf(verts, faces, batch, n_vert, n_faces, cdf, static_cast<hipStream_t>(stream));
+}
+
+int a3vt_sample_points_fwd(const float *verts, const int32_t *faces, const float *cdf, int batch, int n_vert,
+                           int n_faces, int draws, int num, const int32_t *face_idx_in, const float *u_in,
+                           const float *v_in, uint64_t seed, uint64_t offset, float *points, int32_t *face_idx_out,
+                           float *u_out, float *v_out, void *stream) {
+  A3VT_CHECK_ARG(verts && faces && points && batch > 0 && n_vert > 0 && n_faces > 0 && draws > 0 && num > 0);
+  return launch_sample_fwd(verts, faces, cdf, batch, n_vert, n_faces, draws, num, face_idx_in, u_in, v_in, seed,
+                           offset, points, face_idx_out, u_out, v_out, static_cast<hipStream_t>(stream));
+}
+
+int a3vt_sample_points_bwd(const int32_t *faces, int batch, int n_vert, int n_faces, int draws, int num,
+                           const int32_t *face_idx, const float *u, const float *v, const float *grad_points,
+                           float *grad_verts, void *stream) {
+  A3VT_CHECK_ARG(faces && face_idx && u && v && grad_points && grad_verts && batch > 0 && draws > 0 && num > 0);
+  return launch_sample_bwd(faces, batch, n_vert, n_faces, draws, num, face_idx, u, v, grad_points, grad_verts,
+                           static_cast<hipStream_t>(stream));
+}
+
+int a3vt_chamfer_fwd(const float *x, const float *y, int draws, int batch, int p, int q, float *dist_xy,
+                     int32_t *idx_xy, float *dist_yx, int32_t *idx_yx, float *cd, void *stream) {
+  A3VT_CHECK_ARG(x && y && dist_xy && idx_xy && dist_yx && idx_yx && cd);
+  return launch_chamfer_fwd(x, y, draws, batch, p, q, dist_xy, idx_xy, dist_yx, idx_yx, cd,
+                            static_cast<hipStream_t>(stream));
+}
+
+int a3vt_chamfer_bwd(const float *x, const float *y, int draws, int batch, int p, int q, const int32_t *idx_xy,
+                     const int32_t *idx_yx, const float *grad_cd, float *grad_x, float *grad_y, void *stream) {
+  A3VT_CHECK_ARG(x && y && idx_xy && idx_yx && grad_cd && grad_x && draws > 0 && batch > 0 && p > 0 && q > 0);
+  return launch_chamfer_bwd(x, y, draws, batch, p, q, idx_xy, idx_yx, grad_cd, grad_x, grad_y,
+                            static_cast<hipStream_t>(stream));
+}
+
+int a3vt_check_finite(const float *data, size_t n, int32_t *flag, void *stream) {
+  A3VT_CHECK_ARG(data && flag);
+  return launch_check_finite(data, n, flag, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

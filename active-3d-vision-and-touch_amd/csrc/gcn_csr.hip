@@ -1,0 +1,430 @@
+// gcn_csr.hip — CSR neighbour aggregation and the 3-channel output layer of the GCN stack (gfx950).
+//
+// Replaces the DENSE (N,N) adjacency products of reconstruction/vision/model.py:356,360
+// (torch.matmul(adj, features[:, :, :length]) / torch.matmul(adj, features)) with gathers over the
+// row-normalised CSR adjacency (nnz 17,922 on the 2562-vertex icosphere vs 6.6 M dense entries), fused
+// with the partial bias add and ReLU of model.py:357-358,361,363.  All of these are HBM/L2-bound
+// gathers of 400-byte rows; the neighbour rows of one mesh (<= 1 MB) live in the XCD's L2.
+#include "common.h"
+#include "kernels.h"
+
+namespace a3vt {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// ------------------------------------------------------------------------------------------------
+// Forward: Y[m][ch] = relu( sum_e val[e] * Za[b][col[e]][ch] + bias[ch] ), ch < c.
+// A half-wave (32 lanes) owns one vertex; lane l handles channels 4l..4l+3 (16-byte loads of the
+// neighbour row), so up to 128 aggregated channels are covered per pass.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void csr_fwd_kernel(const float *__restrict__ za, int ldza,
+                                                      const float *__restrict__ bias, int c,
+                                                      const int32_t *__restrict__ rowptr,
+                                                      const int32_t *__restrict__ colidx,
+                                                      const float *__restrict__ val, int n_vert, long long m,
+                                                      float *__restrict__ y, int ldy) {
+  const int hl = threadIdx.x & 31;
+  const long long row = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (row >= m) return;
+  const long long b = row / n_vert;
+  const int v = (int)(row - b * n_vert);
+  const float *zb = za + b * n_vert * (long long)ldza;
+  const int e0 = rowptr[v], e1 = rowptr[v + 1];
+  for (int ch0 = 0; ch0 < c; ch0 += 128) {
+    const int ch = ch0 + hl * 4;
+    if (ch >= c) continue;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int e = e0;
+    for (; e + 3 < e1; e += 4) {  // 4 neighbour rows in flight
+      const int n0 = colidx[e], n1 = colidx[e + 1], n2 = colidx[e + 2], n3 = colidx[e + 3];
+      const float w0 = val[e], w1 = val[e + 1], w2 = val[e + 2], w3 = val[e + 3];
+      const f32x4 r0 = *reinterpret_cast<const f32x4 *>(zb + (long long)n0 * ldza + ch);
+      const f32x4 r1 = *reinterpret_cast<const f32x4 *>(zb + (long long)n1 * ldza + ch);
+      const f32x4 r2 = *reinterpret_cast<const f32x4 *>(zb + (long long)n2 * ldza + ch);
+      const f32x4 r3 = *reinterpret_cast<const f32x4 *>(zb + (long long)n3 * ldza + ch);
+      acc += w0 * r0;
+      acc += w1 * r1;
+      acc += w2 * r2;
+      acc += w3 * r3;
+    }
+    for (; e < e1; ++e) {
+      const f32x4 r0 = *reinterpret_cast<const f32x4 *>(zb + (long long)colidx[e] * ldza + ch);
+      acc += val[e] * r0;
+    }
+    float *yo = y + row * ldy + ch;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (ch + t < c) {
+        const float o = acc[t] + bias[ch + t];
+        yo[t] = o > 0.f ? o : 0.f;
+      }
+    }
+  }
+}
+
+int launch_csr_fwd(const float *za, int ldza, const float *bias, int c, const int32_t *rowptr, const int32_t *col,
+                   const float *val, int n_vert, int batch, float *y, int ldy, hipStream_t s) {
+  if (ldza % 4 != 0 || ldza < pad4(c)) {
+    set_error("csr_fwd: ldza=%d must be a multiple of 4 and >= pad4(c=%d)", ldza, c);
+    return -1;
+  }
+  const long long m = (long long)batch * n_vert;
+  hipLaunchKernelGGL(csr_fwd_kernel, dim3(cdiv(m, 8)), dim3(256), 0, s, za, ldza, bias, c, rowptr, col, val, n_vert, m,
+                     y, ldy);
+  A3VT_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward: dZa[m][ch] = sum_e valT[e] * G[b][colT[e]][ch]   (ch < c;  A^T gather)
+//           dZa[m][ch] = G[m][ch]                              (c <= ch < cpad: pass-through columns)
+//           db_slab[block][ch] = sum over the block's rows of G[m][ch]   (ch < c)
+// Persistent blocks (grid-stride over groups of 8 rows) so the bias-gradient partials stay few.
+// ------------------------------------------------------------------------------------------------
+constexpr int kCsrBwdMaxBlocks = 2048;
+
+__global__ __launch_bounds__(256) void csr_bwd_kernel(const float *__restrict__ g, int ldg, int c, int cpad,
+                                                      const int32_t *__restrict__ rowptr,
+                                                      const int32_t *__restrict__ colidx,
+                                                      const float *__restrict__ val, int n_vert, long long m,
+                                                      float *__restrict__ dza, int lddza,
+                                                      float *__restrict__ db_slab) {
+  __shared__ float red[8][128];
+  const int hl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  for (int ch0 = 0; ch0 < cpad; ch0 += 128) {
+    const int ch = ch0 + hl * 4;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    if (ch < cpad) {
+      for (long long row = (long long)blockIdx.x * 8 + grp; row < m; row += (long long)gridDim.x * 8) {
+        const long long b = row / n_vert;
+        const int v = (int)(row - b * n_vert);
+        const float *gb = g + b * n_vert * (long long)ldg;
+        const f32x4 own = *reinterpret_cast<const f32x4 *>(gb + (long long)v * ldg + ch);
+        bsum += own;
+        const int e0 = rowptr[v], e1 = rowptr[v + 1];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        int e = e0;
+        for (; e + 3 < e1; e += 4) {
+          const int n0 = colidx[e], n1 = colidx[e + 1], n2 = colidx[e + 2], n3 = colidx[e + 3];
+          const float w0 = val[e], w1 = val[e + 1], w2 = val[e + 2], w3 = val[e + 3];
+          const f32x4 r0 = *reinterpret_cast<const f32x4 *>(gb + (long long)n0 * ldg + ch);
+          const f32x4 r1 = *reinterpret_cast<const f32x4 *>(gb + (long long)n1 * ldg + ch);
+          const f32x4 r2 = *reinterpret_cast<const f32x4 *>(gb + (long long)n2 * ldg + ch);
+          const f32x4 r3 = *reinterpret_cast<const f32x4 *>(gb + (long long)n3 * ldg + ch);
+          acc += w0 * r0;
+          acc += w1 * r1;
+          acc += w2 * r2;
+          acc += w3 * r3;
+        }
+        for (; e < e1; ++e) {
+          const f32x4 r0 = *reinterpret_cast<const f32x4 *>(gb + (long long)colidx[e] * ldg + ch);
+          acc += val[e] * r0;
+        }
+        f32x4 out;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) out[t] = ch + t < c ? acc[t] : own[t];
+        *reinterpret_cast<f32x4 *>(dza + row * lddza + ch) = out;
+      }
+    }
+    // block partial of the bias gradient
+#pragma unroll
+    for (int t = 0; t < 4; ++t) red[grp][hl * 4 + t] = bsum[t];
+    __syncthreads();
+    if (threadIdx.x < 128 && ch0 + threadIdx.x < cpad) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) s += red[r][threadIdx.x];
+      db_slab[(size_t)blockIdx.x * cpad + ch0 + threadIdx.x] = s;
+    }
+    __syncthreads();
+  }
+}
+
+int csr_bwd_num_slabs(int batch, int n_vert) {
+  const long long groups = ((long long)batch * n_vert + 7) / 8;
+  return (int)(groups < kCsrBwdMaxBlocks ? groups : kCsrBwdMaxBlocks);
+}
+
+int launch_csr_bwd(const float *g, int ldg, int c, const int32_t *rowptrT, const int32_t *colT, const float *valT,
+                   int n_vert, int batch, float *dza, int lddza, float *db_slab, hipStream_t s) {
+  const int cpad = pad4(c);
+  if (ldg % 4 != 0 || lddza % 4 != 0 || lddza < cpad || ldg < cpad) {
+    set_error("csr_bwd: ldg=%d lddza=%d c=%d violate alignment rules", ldg, lddza, c);
+    return -1;
+  }
+  const long long m = (long long)batch * n_vert;
+  hipLaunchKernelGGL(csr_bwd_kernel, dim3(csr_bwd_num_slabs(batch, n_vert)), dim3(256), 0, s, g, ldg, c, cpad, rowptrT,
+                     colT, valT, n_vert, m, dza, lddza, db_slab);
+  A3VT_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Output layer (out_features = 3): z3 = X W (thin product, HBM-bound on X), then the 3-channel
+// aggregation + bias (no activation).  16 lanes share one row of X; each lane keeps the W rows of
+// its k-pieces in registers.  k <= 320.
+// ------------------------------------------------------------------------------------------------
+constexpr int kThinPieces = 5;  // 16 lanes * 5 pieces * 4 floats = 320 channels max
+constexpr int kThinBlocks = 1024;
+int thin_num_slabs() { return kThinBlocks; }
+
+__global__ __launch_bounds__(256) void thin_fwd_kernel(const float *__restrict__ x, int ldx, int k,
+                                                       const float *__restrict__ w, long long m,
+                                                       float *__restrict__ z3) {
+  const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;  // 16 row groups per block
+  float wr[kThinPieces][4][3];
+#pragma unroll
+  for (int p = 0; p < kThinPieces; ++p)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int kk = (p * 16 + l16) * 4 + t;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) wr[p][t][j] = kk < k ? w[kk * 3 + j] : 0.f;
+    }
+  for (long long row = (long long)blockIdx.x * 16 + grp; row < m; row += (long long)gridDim.x * 16) {
+    const float *xr = x + row * ldx;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int p = 0; p < kThinPieces; ++p) {
+      const int kk = (p * 16 + l16) * 4;
+      if (kk < k) {
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(xr + kk);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          s0 += xv[t] * wr[p][t][0];
+          s1 += xv[t] * wr[p][t][1];
+          s2 += xv[t] * wr[p][t][2];
+        }
+      }
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+      s0 += __shfl_xor(s0, off, 16);
+      s1 += __shfl_xor(s1, off, 16);
+      s2 += __shfl_xor(s2, off, 16);
+    }
+    if (l16 == 0) *reinterpret_cast<f32x4 *>(z3 + row * 4) = f32x4{s0, s1, s2, 0.f};
+  }
+}
+
+// out[m][0..2] = sum_e val[e] * z[b][col[e]][0..2] (+ bias) ; z rows are float4 (4th lane unused)
+__global__ __launch_bounds__(256) void csr3_kernel(const float *__restrict__ z, const float *__restrict__ bias,
+                                                   const int32_t *__restrict__ rowptr,
+                                                   const int32_t *__restrict__ colidx,
+                                                   const float *__restrict__ val, int n_vert, long long m,
+                                                   float *__restrict__ out, int ldo) {
+  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= m) return;
+  const long long b = row / n_vert;
+  const int v = (int)(row - b * n_vert);
+  const float *zb = z + b * n_vert * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int e = rowptr[v]; e < rowptr[v + 1]; ++e)
+    acc += val[e] * *reinterpret_cast<const f32x4 *>(zb + (long long)colidx[e] * 4);
+  if (bias) {
+    acc[0] += bias[0];
+    acc[1] += bias[1];
+    acc[2] += bias[2];
+  }
+  if (ldo == 4) {
+    acc[3] = 0.f;
+    *reinterpret_cast<f32x4 *>(out + row * 4) = acc;
+  } else {
+    out[row * ldo + 0] = acc[0];
+    out[row * ldo + 1] = acc[1];
+    out[row * ldo + 2] = acc[2];
+  }
+}
+
+int launch_thin_fwd(const float *x, int ldx, int k, const float *w, const float *bias, const int32_t *rowptr,
+                    const int32_t *col, const float *val, int n_vert, int batch, float *z3, float *update,
+                    hipStream_t s) {
+  if (k > kThinPieces * 64 || ldx % 4 != 0) {
+    set_error("thin_fwd: k=%d (max %d) ldx=%d unsupported", k, kThinPieces * 64, ldx);
+    return -1;
+  }
+  const long long m = (long long)batch * n_vert;
+  const int grid = (int)(cdiv(m, 16) < 4096 ? cdiv(m, 16) : 4096);
+  hipLaunchKernelGGL(thin_fwd_kernel, dim3(grid), dim3(256), 0, s, x, ldx, k, w, m, z3);
+  A3VT_CHECK_LAUNCH();
+  hipLaunchKernelGGL(csr3_kernel, dim3(cdiv(m, 256)), dim3(256), 0, s, z3, bias, rowptr, col, val, n_vert, m, update, 3);
+  A3VT_CHECK_LAUNCH();
+  return 0;
+}
+
+// Backward of the output layer.  dz3 = A^T dU (csr3 with the transposed CSR, no bias), then one pass over X:
+//   G_prev[m][k] = (sum_j dz3[m][j] W[k][j]) * (apply_mask ? X[m][k] > 0 : 1)
+//   dW[k][j]    += X[m][k] dz3[m][j]      (register partials -> LDS -> slab per block)
+//   db[j]        = sum_m dU[m][j]         (slab per block)
+__global__ __launch_bounds__(256) void thin_bwd_kernel(const float *__restrict__ x, int ldx, int k,
+                                                       const float *__restrict__ w,
+                                                       const float *__restrict__ dz3,
+                                                       const float *__restrict__ du, long long m, int apply_mask,
+                                                       float *__restrict__ gprev, int ldg, int n_store,
+                                                       float *__restrict__ dw_slab,
+                                                       float *__restrict__ db_slab) {
+  __shared__ float red[16][kThinPieces * 64 * 3 / 16 + 1];  // [row group][this lane-column's 60 partials] per l16 pass
+  const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  float wr[kThinPieces][4][3], dwp[kThinPieces][4][3];
+#pragma unroll
+  for (int p = 0; p < kThinPieces; ++p)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int kk = (p * 16 + l16) * 4 + t;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        wr[p][t][j] = kk < k ? w[kk * 3 + j] : 0.f;
+        dwp[p][t][j] = 0.f;
+      }
+    }
+  float db0 = 0.f, db1 = 0.f, db2 = 0.f;
+  for (long long row = (long long)blockIdx.x * 16 + grp; row < m; row += (long long)gridDim.x * 16) {
+    const f32x4 d = *reinterpret_cast<const f32x4 *>(dz3 + row * 4);
+    if (l16 == 0) {
+      db0 += du[row * 3 + 0];
+      db1 += du[row * 3 + 1];
+      db2 += du[row * 3 + 2];
+    }
+    const float *xr = x + row * ldx;
+    float *gr = gprev + row * ldg;
+#pragma unroll
+    for (int p = 0; p < kThinPieces; ++p) {
+      const int kk = (p * 16 + l16) * 4;
+      if (kk < k) {
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(xr + kk);
+        f32x4 o;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float gk = d[0] * wr[p][t][0] + d[1] * wr[p][t][1] + d[2] * wr[p][t][2];
+          o[t] = (!apply_mask || xv[t] > 0.f) ? gk : 0.f;
+          dwp[p][t][0] += xv[t] * d[0];
+          dwp[p][t][1] += xv[t] * d[1];
+          dwp[p][t][2] += xv[t] * d[2];
+        }
+        if (kk + 3 < n_store) {
+          *reinterpret_cast<f32x4 *>(gr + kk) = o;
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (kk + t < n_store) gr[kk + t] = o[t];
+        }
+      }
+    }
+  }
+  // Reduce dW partials over the 16 row groups of the block, one l16 column at a time.
+  float *slab = dw_slab + (size_t)blockIdx.x * k * 3;
+  for (int col = 0; col < 16; ++col) {
+    if (l16 == col) {
+#pragma unroll
+      for (int p = 0; p < kThinPieces; ++p)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) red[grp][(p * 4 + t) * 3 + j] = dwp[p][t][j];
+    }
+    __syncthreads();
+    if (threadIdx.x < kThinPieces * 12) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += red[r][threadIdx.x];
+      const int p = threadIdx.x / 12, t = (threadIdx.x % 12) / 3, j = threadIdx.x % 3;
+      const int kk = (p * 16 + col) * 4 + t;
+      if (kk < k) slab[kk * 3 + j] = s;
+    }
+    __syncthreads();
+  }
+  // bias gradient partial
+  if (l16 == 0) {
+    red[grp][0] = db0;
+    red[grp][1] = db1;
+    red[grp][2] = db2;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += red[r][threadIdx.x];
+    db_slab[(size_t)blockIdx.x * 3 + threadIdx.x] = s;
+  }
+}
+
+__global__ void pad3to4_kernel(const float *__restrict__ in, long long m, float *__restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  *reinterpret_cast<f32x4 *>(out + i * 4) = f32x4{in[i * 3], in[i * 3 + 1], in[i * 3 + 2], 0.f};
+}
+static int launch_pad3to4(const float *in, long long m, float *out, hipStream_t s) {
+  hipLaunchKernelGGL(pad3to4_kernel, dim3(cdiv(m, 256)), dim3(256), 0, s, in, m, out);
+  A3VT_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_thin_bwd(const float *x, int ldx, int k, const float *w, const int32_t *rowptrT, const int32_t *colT,
+                    const float *valT, int n_vert, int batch, const float *grad_update, float *dz3, int apply_mask,
+                    float *g_prev, int ldg, int n_store, float *dw_slab, float *db_slab, hipStream_t s) {
+  if (k > kThinPieces * 64 || ldx % 4 != 0 || ldg % 4 != 0) {
+    set_error("thin_bwd: k=%d ldx=%d ldg=%d unsupported", k, ldx, ldg);
+    return -1;
+  }
+  const long long m = (long long)batch * n_vert;
+  // dz3 = A^T dU.  csr3_kernel gathers float4 rows, so dU [M][3] is first padded to [M][4].
+  // The dz3 scratch is [2][M][4]: first half = padded dU, second half = A^T dU.
+  float *du4 = dz3;
+  float *res = dz3 + m * 4;
+  if (int rc = launch_pad3to4(grad_update, m, du4, s)) return rc;
+  hipLaunchKernelGGL(csr3_kernel, dim3(cdiv(m, 256)), dim3(256), 0, s, du4, (const float *)nullptr, rowptrT, colT, valT,
+                     n_vert, m, res, 4);
+  A3VT_CHECK_LAUNCH();
+  hipLaunchKernelGGL(thin_bwd_kernel, dim3(kThinBlocks), dim3(256), 0, s, x, ldx, k, w, res, grad_update, m, apply_mask,
+                     g_prev, ldg, n_store, dw_slab, db_slab);
+  A3VT_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Vertex update (model.py:250,270,283), finite check (replaces the blocking NaN trap at model.py:326), fill.
+// ------------------------------------------------------------------------------------------------
+__global__ void vertex_update_kernel(const float *__restrict__ vin, const float *__restrict__ upd, long long total,
+                                     int n_vert, int n_vision, float *__restrict__ vout) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int v = (int)((i / 3) % n_vert);
+  vout[i] = v < n_vision ? vin[i] + upd[i] : vin[i];
+}
+
+int launch_vertex_update(const float *vin, const float *upd, int batch, int n_vert, int n_vision, float *vout,
+                         hipStream_t s) {
+  const long long total = (long long)batch * n_vert * 3;
+  hipLaunchKernelGGL(vertex_update_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, vin, upd, total, n_vert, n_vision,
+                     vout);
+  A3VT_CHECK_LAUNCH();
+  return 0;
+}
+
+__global__ void check_finite_kernel(const float *__restrict__ d, size_t n, int32_t *flag) {
+  bool bad = false;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = d[i];
+    bad |= !(v - v == 0.f);  // NaN or +-Inf
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+int launch_check_finite(const float *d, size_t n, int32_t *flag, hipStream_t s) {
+  const int grid = (int)(cdiv((long long)n, 256) < 2048 ? cdiv((long long)n, 256) : 2048);
+  hipLaunchKernelGGL(check_finite_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, s, d, n, flag);
+  A3VT_CHECK_LAUNCH();
+  return 0;
+}
+
+__global__ void fill_zero_kernel(float *__restrict__ d, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) d[i] = 0.f;
+}
+int launch_fill_zero(float *d, size_t n, hipStream_t s) {
+  const int grid = (int)(cdiv((long long)n, 256) < 2048 ? cdiv((long long)n, 256) : 2048);
+  hipLaunchKernelGGL(fill_zero_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, s, d, n);
+  A3VT_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace a3vt

@@ -1,0 +1,91 @@
+// kernels.h — internal launcher declarations shared by the .hip translation units and capi.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace a3vt {
+
+enum { EPI_PLAIN = 0, EPI_FWD_HIDDEN = 1, EPI_DX_MASK = 2 };
+
+// C[M][*] = A[M][K] * Bt[*][K]^T.  A columns [0,ksplit) come from a0, [ksplit,K) from a1 (same column index).
+struct RowGemmArgs {
+  const float *a0;
+  const float *a1;
+  const float *bt;     // [rowgemm_bt_rows(n_store)][ldb], zero padded (rows >= n_out, cols >= k)
+  const float *zeros;  // >= 16 B of zeros
+  const float *mask;   // EPI_DX_MASK: [M][ldmask]
+  float *c;            // main output [M][ldc]
+  float *c2;           // EPI_FWD_HIDDEN: raw output for cols < csplit, [M][ldc2]
+  int lda0, lda1, ksplit, ldb;
+  int m, k, n_store;
+  int ldc, ldc2, csplit, ldmask;
+};
+int rowgemm_bt_rows(int n_store);
+int launch_rowgemm(const RowGemmArgs &a, int epi, hipStream_t s);
+int launch_transpose_pad(const float *w, int k, int n, float *wt, int rows, int ld, hipStream_t s);
+int launch_copy_pad(const float *w, int rows_in, int cols_in, float *out, int rows, int ld, hipStream_t s);
+
+// slab[wg][k_in][n_out] = X[rows of wg]^T * dZ[rows of wg];  dZ cols [0,zsplit) from z0, rest from z1.
+struct DwArgs {
+  const float *x;   // [M][ldx], ldx % 4 == 0, rows contiguous
+  const float *z0;  // [M][ldz0], ldz0 >= zsplit (may be a 4-float dummy row when zsplit == 0)
+  const float *z1;  // [M][ldz1], ldz1 >= n_out
+  const float *zeros;
+  float *slab;  // [dw_num_slabs(n_out)][k_in][n_out]
+  int ldx, ldz0, ldz1, zsplit;
+  int m, k_in, n_out;
+};
+int dw_num_slabs(int n_out);
+int launch_dw(const DwArgs &a, hipStream_t s);
+int launch_slab_reduce(const float *slab, int nslab, size_t stride, size_t n, float *out, hipStream_t s);
+
+// CSR neighbour aggregation on the first c channels (+ bias + ReLU), model.py:356-358,363.
+int launch_csr_fwd(const float *za, int ldza, const float *bias, int c, const int32_t *rowptr, const int32_t *col,
+                   const float *val, int n_vert, int batch, float *y, int ldy, hipStream_t s);
+// dZa[:, :c] = A^T G[:, :c];  dZa[:, c:cpad] = G[:, c:cpad];  db partial sums of G[:, :c] -> slab [nslab][cpad].
+int csr_bwd_num_slabs(int batch, int n_vert);
+int launch_csr_bwd(const float *g, int ldg, int c, const int32_t *rowptrT, const int32_t *colT, const float *valT,
+                   int n_vert, int batch, float *dza, int lddza, float *db_slab, hipStream_t s);
+
+// Last layer (out = 3 channels, all aggregated, no activation), model.py:359-361.
+int thin_num_slabs();
+int launch_thin_fwd(const float *x, int ldx, int k, const float *w /*[k][3]*/, const float *bias /*[3]*/,
+                    const int32_t *rowptr, const int32_t *col, const float *val, int n_vert, int batch,
+                    float *z3 /*[M][4] scratch*/, float *update /*[M][3]*/, hipStream_t s);
+int launch_thin_bwd(const float *x, int ldx, int k, const float *w, const int32_t *rowptrT, const int32_t *colT,
+                    const float *valT, int n_vert, int batch, const float *grad_update /*[M][3]*/,
+                    float *dz3 /*[M][4] scratch*/, int apply_mask, float *g_prev /*[M][ldg]*/, int ldg, int n_store,
+                    float *dw_slab /*[thin_num_slabs()][k*3]*/, float *db_slab /*[thin_num_slabs()][3]*/,
+                    hipStream_t s);
+
+int launch_vertex_update(const float *vin, const float *upd, int batch, int n_vert, int n_vision, float *vout,
+                         hipStream_t s);
+int launch_check_finite(const float *d, size_t n, int32_t *flag, hipStream_t s);
+int launch_fill_zero(float *d, size_t n, hipStream_t s);
+
+// posenc.hip
+size_t posenc_param_count(int input_size);
+int posenc_num_slabs(int m);
+int launch_posenc_fwd(const float *verts, const float *mask, int m, int input_size, const float *params, float *feats,
+                      int ld, hipStream_t s);
+int launch_posenc_bwd(const float *verts, const float *mask, int m, int input_size, const float *params,
+                      const float *gfeats, int ld, float *gverts, float *gparams, float *scratch, hipStream_t s);
+
+// sample.hip
+int launch_face_cdf(const float *verts, const int32_t *faces, int batch, int n_vert, int n_faces, float *cdf,
+                    hipStream_t s);
+int launch_sample_fwd(const float *verts, const int32_t *faces, const float *cdf, int batch, int n_vert, int n_faces,
+                      int draws, int num, const int32_t *fi_in, const float *u_in, const float *v_in, uint64_t seed,
+                      uint64_t offset, float *points, int32_t *fi_out, float *u_out, float *v_out, hipStream_t s);
+int launch_sample_bwd(const int32_t *faces, int batch, int n_vert, int n_faces, int draws, int num,
+                      const int32_t *fi, const float *u, const float *v, const float *gpoints, float *gverts,
+                      hipStream_t s);
+
+// chamfer.hip
+int launch_chamfer_fwd(const float *x, const float *y, int draws, int batch, int p, int q, float *dxy, int32_t *ixy,
+                       float *dyx, int32_t *iyx, float *cd, hipStream_t s);
+int launch_chamfer_bwd(const float *x, const float *y, int draws, int batch, int p, int q, const int32_t *ixy,
+                       const int32_t *iyx, const float *gcd, float *gx, float *gy, hipStream_t s);
+
+}  // namespace a3vt

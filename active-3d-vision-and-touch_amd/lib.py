@@ -1,0 +1,90 @@
+"""ctypes binding of ``liba3vt.so`` (the C ABI declared in ``include/a3vt.h``).
+
+There is deliberately NO fallback: if the shared library is missing or a call fails, a
+``RuntimeError`` is raised.  ``build()`` compiles the HIP sources in-tree with hipcc for gfx950.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "liba3vt.so")
+SOURCES = ["capi.hip", "gcn_gemm.hip", "gcn_csr.hip", "posenc.hip", "sample.hip", "chamfer.hip"]
+
+_vp, _i, _sz, _u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_uint64
+
+# name -> (restype, argtypes); mirrors include/a3vt.h one to one.
+SIGNATURES = {
+    "a3vt_version": (_i, []),
+    "a3vt_last_error": (ctypes.c_char_p, []),
+    "a3vt_csr_validate": (_i, [_vp, _vp, _i, _i]),
+    "a3vt_gcn_stack_scratch_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "a3vt_gcn_stack_fwd": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "a3vt_gcn_stack_bwd": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i,
+                                _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "a3vt_wt_rows": (_i, [_i]),
+    "a3vt_wt_ld": (_i, [_i]),
+    "a3vt_transpose_weight": (_i, [_vp, _i, _i, _vp, _vp]),
+    "a3vt_rowgemm": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
+    "a3vt_posenc_param_count": (_sz, [_i]),
+    "a3vt_posenc_scratch_bytes": (_sz, [_i, _i]),
+    "a3vt_posenc_mask_fwd": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _vp]),
+    "a3vt_posenc_mask_bwd": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "a3vt_vertex_update": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "a3vt_face_cdf": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "a3vt_sample_points_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _u64, _u64,
+                                    _vp, _vp, _vp, _vp, _vp]),
+    "a3vt_sample_points_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "a3vt_chamfer_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "a3vt_chamfer_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "a3vt_check_finite": (_i, [_vp, _sz, _vp, _vp]),
+}
+
+_LIB = None
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -shared → liba3vt.so next to this file (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in ("common.h", "kernels.h")] + \
+        [os.path.join(_HERE, "..", "include", "a3vt.h")]
+    if not force and os.path.exists(LIB_PATH) and all(
+            os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps if os.path.exists(d)):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", *srcs, "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def load():
+    """Load the library (once).  Raises RuntimeError when it has not been built — no fallback."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"a3vt: native library {LIB_PATH} is missing. Build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). There is no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError here = header and library out of sync
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = lib
+    return _LIB
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().a3vt_last_error()
+        raise RuntimeError(f"a3vt: {what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device/host pointer of a tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())

@@ -1,0 +1,176 @@
+"""Host-side template-mesh logic: OBJ parsing, icosphere generation, sparse adjacency (CSR) construction.
+
+Mirrors the behaviour of the reference's ``pterotactyl/utility/utils.py``
+(``load_mesh_touch`` :194-200, ``calc_adj`` :134-148, ``normalize_adj`` :47-52, ``adj_fuse_touch`` :75-130,
+``adj_init`` :56-71) but never forms the dense (N,N) matrix: the row-normalised adjacency is built
+directly as CSR (plus the CSR of its transpose, needed by the backward pass because D^-1 A is not
+symmetric).  Pure numpy — this is one-time setup, not the hot path.
+"""
+import os
+
+import numpy as np
+
+CHART_VERTS = 25          # vertices of one touch chart (policies/replay.py:13 BASE_CHART_SIZE)
+CHART_CENTRE = 4          # utils.py:95 central_point
+
+
+def load_obj(path):
+    """(verts float32 (V,3), faces int64 (F,3)) from a Wavefront OBJ; 1-based -> 0-based, fan triangulation."""
+    verts, faces = [], []
+    with open(path) as f:
+        for line in f:
+            if line.startswith("v "):
+                p = line.split()
+                verts.append((float(p[1]), float(p[2]), float(p[3])))
+            elif line.startswith("f "):
+                idx = [int(tok.split("/")[0]) for tok in line.split()[1:]]
+                idx = [i - 1 if i > 0 else len(verts) + i for i in idx]
+                for k in range(1, len(idx) - 1):
+                    faces.append((idx[0], idx[k], idx[k + 1]))
+    return np.asarray(verts, dtype=np.float32), np.asarray(faces, dtype=np.int64)
+
+
+def icosphere(level=4, radius=0.25):
+    """Subdivided icosahedron: 10*4^level + 2 vertices (2562 at level 4, 10242 at level 5), 20*4^level faces.
+    The synthetic benchmark template of BASELINE.json configs[1]/[4]."""
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t),
+         (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    verts = [np.asarray(p, dtype=np.float64) / np.linalg.norm(p) for p in v]
+    faces = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2),
+             (10, 7, 6), (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5),
+             (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    for _ in range(level):
+        cache = {}
+
+        def mid(a, b):
+            key = (a, b) if a < b else (b, a)
+            if key not in cache:
+                m = verts[a] + verts[b]
+                verts.append(m / np.linalg.norm(m))
+                cache[key] = len(verts) - 1
+            return cache[key]
+
+        nf = []
+        for a, b, c in faces:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        faces = nf
+    return (np.asarray(verts) * radius).astype(np.float32), np.asarray(faces, dtype=np.int64)
+
+
+def _edges_from_faces(faces):
+    f = np.asarray(faces, dtype=np.int64)
+    a = np.concatenate([f[:, 0], f[:, 0], f[:, 1], f[:, 1], f[:, 2], f[:, 2]])
+    b = np.concatenate([f[:, 1], f[:, 2], f[:, 0], f[:, 2], f[:, 0], f[:, 1]])
+    return a, b
+
+
+def _csr_from_pairs(rows, cols, n):
+    """Binary pattern -> row-normalised CSR (rowptr int32, col int32 ascending per row, val float32 = 1/deg)."""
+    key = np.unique(rows.astype(np.int64) * n + cols.astype(np.int64))
+    r = (key // n).astype(np.int64)
+    c = (key % n).astype(np.int32)
+    counts = np.bincount(r, minlength=n)
+    rowptr = np.zeros(n + 1, dtype=np.int32)
+    rowptr[1:] = np.cumsum(counts)
+    with np.errstate(divide="ignore"):
+        r_inv = (np.float32(1.0) / counts.astype(np.float32)).astype(np.float32)  # utils.py:48-50
+    r_inv[~np.isfinite(r_inv)] = 0.0
+    return rowptr, c, r_inv[r].astype(np.float32)
+
+
+def csr_transpose(rowptr, col, val, n):
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(rowptr))
+    order = np.lexsort((rows, col))
+    t_rows = col[order].astype(np.int64)
+    t_cols = rows[order].astype(np.int32)
+    rp = np.zeros(n + 1, dtype=np.int32)
+    rp[1:] = np.cumsum(np.bincount(t_rows, minlength=n))
+    return rp, t_cols, val[order].astype(np.float32)
+
+
+def vision_pairs(faces, n):
+    """calc_adj (utils.py:134-148): self loops + undirected face edges, as (row, col) index arrays."""
+    a, b = _edges_from_faces(faces)
+    eye = np.arange(n, dtype=np.int64)
+    return np.concatenate([eye, a]), np.concatenate([eye, b])
+
+
+def fused_pairs(verts, faces, sheet_faces, num_grasps, finger, sheet_size=CHART_VERTS):
+    """adj_fuse_touch (utils.py:75-130) as index pairs.  Returns (rows, cols, n_total, faces_total)."""
+    verts = np.asarray(verts, dtype=np.float32)
+    nv = verts.shape[0]
+    fingers = 1 if finger else 4
+    k = fingers * num_grasps
+    n = nv + k * sheet_size
+    rows, cols = vision_pairs(faces, nv)
+    rr, cc = [rows], [cols]
+    sa, sb = _edges_from_faces(sheet_faces)
+    seye = np.arange(sheet_size, dtype=np.int64)
+    all_faces = [np.asarray(faces, dtype=np.int64)]
+    for i in range(k):
+        s = nv + sheet_size * i
+        rr += [seye + s, sa + s]
+        cc += [seye + s, sb + s]
+        all_faces.append(np.asarray(sheet_faces, dtype=np.int64) + nv + i * sheet_size)
+    # vertices with bit-identical float32 positions (utils.py:80-84) form seam groups
+    keys = np.ascontiguousarray(verts).view(np.dtype((np.void, 12))).ravel()
+    _, inv, counts = np.unique(keys, return_inverse=True, return_counts=True)
+    seam = np.nonzero(counts[inv] > 1)[0]
+    centres = np.asarray([CHART_CENTRE + i * sheet_size + nv for i in range(k)], dtype=np.int64)
+    order = np.argsort(inv[seam], kind="stable")
+    seam_sorted = seam[order]
+    grp = inv[seam_sorted]
+    starts = np.flatnonzero(np.r_[True, grp[1:] != grp[:-1]])
+    ends = np.r_[starts[1:], len(grp)]
+    for s0, e0 in zip(starts, ends):
+        members = seam_sorted[s0:e0]
+        rr.append(np.repeat(members, len(members)))
+        cc.append(np.tile(members, len(members)))
+    if len(seam) and k:
+        rr += [np.repeat(seam, k), np.tile(centres, len(seam))]
+        cc += [np.tile(centres, len(seam)), np.repeat(seam, k)]
+    return np.concatenate(rr), np.concatenate(cc), n, np.concatenate(all_faces)
+
+
+class CSRAdjacency:
+    """Row-normalised adjacency D^-1 A as CSR + CSR of the transpose (numpy, host)."""
+
+    def __init__(self, rowptr, col, val, n):
+        self.n = int(n)
+        self.rowptr, self.col, self.val = rowptr, col, val
+        self.t_rowptr, self.t_col, self.t_val = csr_transpose(rowptr, col, val, n)
+
+    @property
+    def nnz(self):
+        return int(self.col.shape[0])
+
+    @classmethod
+    def from_pairs(cls, rows, cols, n):
+        return cls(*_csr_from_pairs(rows, cols, n), n)
+
+    @classmethod
+    def from_dense(cls, a):
+        """From a dense, already normalised matrix (e.g. a reference-made adj_info entry)."""
+        a = np.asarray(a, dtype=np.float32)
+        r, c = np.nonzero(a)
+        n = a.shape[0]
+        rowptr = np.zeros(n + 1, dtype=np.int32)
+        rowptr[1:] = np.cumsum(np.bincount(r, minlength=n))
+        return cls(rowptr, c.astype(np.int32), a[r, c].astype(np.float32), n)
+
+    def to_dense(self):
+        out = np.zeros((self.n, self.n), dtype=np.float32)
+        rows = np.repeat(np.arange(self.n), np.diff(self.rowptr))
+        out[rows, self.col] = self.val
+        return out
+
+
+def load_asset(name):
+    """Template geometry shipped as data: ``vision_charts`` (the reference's 1824-vertex / 2304-face chart atlas,
+    ``pterotactyl/objects/vision_charts.obj``) and ``touch_chart`` (25 vertices / 32 faces,
+    ``pterotactyl/objects/touch_chart.obj``), stored as npz arrays (verts float32, faces int32)."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    z = np.load(os.path.join(here, "assets", name + ".npz"))
+    return z["verts"].astype(np.float32), z["faces"].astype(np.int64)

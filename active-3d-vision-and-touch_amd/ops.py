@@ -1,0 +1,299 @@
+"""torch.autograd wrappers over the C ABI (``include/a3vt.h``).  PyTorch is plumbing here: it owns device
+memory, the current HIP stream and autograd bookkeeping; every op below is one C call into ``liba3vt.so``.
+
+All tensors must be float32 / int32, contiguous, on a ROCm device.  There is no CPU path.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from .mesh import CSRAdjacency
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"a3vt: `{name}` must be a tensor on the GPU (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"a3vt: `{name}` must be {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+_WORKSPACES = {}
+
+
+def workspace(tag, nbytes, device):
+    """Per-device scratch buffer that only grows; all users run on the current stream, in order."""
+    key = (tag, device.index if device.index is not None else torch.cuda.current_device())
+    buf = _WORKSPACES.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.empty((nbytes + 3) // 4 + 64, dtype=torch.float32, device=device)
+        _WORKSPACES[key] = buf
+    return buf
+
+
+class DeviceCSR:
+    """Row-normalised adjacency (and its transpose) as int32/float32 device tensors."""
+
+    def __init__(self, host: CSRAdjacency, device):
+        self.n, self.nnz = host.n, host.nnz
+        L = _lib.load()
+        _lib.check(L.a3vt_csr_validate(host.rowptr.ctypes.data, host.col.ctypes.data, host.n, host.nnz), "csr_validate")
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)  # noqa: E731
+        self.rowptr, self.col, self.val = to(host.rowptr), to(host.col), to(host.val)
+        self.t_rowptr, self.t_col, self.t_val = to(host.t_rowptr), to(host.t_col), to(host.t_val)
+        self.host = host
+
+    @property
+    def device(self):
+        return self.val.device
+
+
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+class GCNStackFn(torch.autograd.Function):
+    """One GCN (reference ``GCN.forward``, vision/model.py:316-331): feats (B,N,ld) -> update (B,N,3)."""
+
+    @staticmethod
+    def forward(ctx, feats, adj, in_features, hidden, cut_len, *params):
+        L = _lib.load()
+        feats = _req(feats, "feats")
+        B, N, ld = feats.shape
+        if N != adj.n:
+            raise RuntimeError(f"a3vt: features have {N} vertices but the adjacency has {adj.n}")
+        weights = [_req(p, "weight") for p in params[0::2]]
+        biases = [_req(p, "bias") for p in params[1::2]]
+        nl = len(weights)
+        need_bwd = any(ctx.needs_input_grad)
+        M = B * N
+        acts = torch.empty((max(nl - 1, 0), M, hidden), dtype=torch.float32, device=feats.device) \
+            if (need_bwd and nl > 1) else None
+        nbytes = L.a3vt_gcn_stack_scratch_bytes(B, N, in_features, hidden, nl, cut_len, 1 if need_bwd else 0)
+        scratch = workspace("gcn", nbytes, feats.device)
+        update = torch.empty((B, N, 3), dtype=torch.float32, device=feats.device)
+        wp, bp = _ptr_array(weights), _ptr_array(biases)
+        _lib.check(L.a3vt_gcn_stack_fwd(_lib.ptr(feats), ld, in_features, wp, bp, nl, hidden, cut_len,
+                                        _lib.ptr(adj.rowptr), _lib.ptr(adj.col), _lib.ptr(adj.val), N, B,
+                                        _lib.ptr(acts), _lib.ptr(scratch), _lib.ptr(update), _stream()),
+                   "gcn_stack_fwd")
+        ctx.adj, ctx.dims = adj, (in_features, hidden, cut_len, nl)
+        ctx.acts = acts
+        ctx.save_for_backward(feats, *weights, *biases)
+        return update
+
+    @staticmethod
+    def backward(ctx, grad_update):
+        L = _lib.load()
+        in_features, hidden, cut_len, nl = ctx.dims
+        feats = ctx.saved_tensors[0]
+        weights = list(ctx.saved_tensors[1:1 + nl])
+        biases = list(ctx.saved_tensors[1 + nl:1 + 2 * nl])
+        adj = ctx.adj
+        B, N, ld = feats.shape
+        grad_update = _req(grad_update, "grad_update")
+        gw = [torch.empty_like(w) for w in weights]
+        gb = [torch.empty_like(b) for b in biases]
+        gfeats = torch.empty_like(feats)
+        nbytes = L.a3vt_gcn_stack_scratch_bytes(B, N, in_features, hidden, nl, cut_len, 1)
+        scratch = workspace("gcn", nbytes, feats.device)
+        _lib.check(L.a3vt_gcn_stack_bwd(_lib.ptr(feats), ld, in_features, _ptr_array(weights), _ptr_array(biases), nl,
+                                        hidden, cut_len, _lib.ptr(adj.rowptr), _lib.ptr(adj.col), _lib.ptr(adj.val),
+                                        _lib.ptr(adj.t_rowptr), _lib.ptr(adj.t_col), _lib.ptr(adj.t_val), N, B,
+                                        _lib.ptr(ctx.acts), _lib.ptr(grad_update), _ptr_array(gw), _ptr_array(gb),
+                                        _lib.ptr(gfeats), _lib.ptr(scratch), _stream()), "gcn_stack_bwd")
+        ctx.acts = None
+        grads = []
+        for w, b in zip(gw, gb):
+            grads += [w, b]
+        return (gfeats, None, None, None, None, *grads)
+
+
+def gcn_stack(feats, adj, in_features, hidden, cut_len, weights, biases):
+    params = []
+    for w, b in zip(weights, biases):
+        params += [w, b]
+    return GCNStackFn.apply(feats, adj, in_features, hidden, cut_len, *params)
+
+
+class PosEncMaskFn(torch.autograd.Function):
+    """Positional_Encoder + Mask_Encoder + add (vision/model.py:229-232 etc.): (B,N,3),(B,N,1) -> (B,N,ld)."""
+
+    @staticmethod
+    def forward(ctx, verts, mask, packed, input_size, ld):
+        L = _lib.load()
+        verts, mask, packed = _req(verts, "verts"), _req(mask, "mask"), _req(packed, "pe_params")
+        if packed.numel() != L.a3vt_posenc_param_count(input_size):
+            raise RuntimeError("a3vt: packed positional-encoder parameter count mismatch")
+        B, N, _ = verts.shape
+        feats = torch.empty((B, N, ld), dtype=torch.float32, device=verts.device)
+        _lib.check(L.a3vt_posenc_mask_fwd(_lib.ptr(verts), _lib.ptr(mask), B * N, input_size, _lib.ptr(packed),
+                                          _lib.ptr(feats), ld, _stream()), "posenc_mask_fwd")
+        ctx.save_for_backward(verts, mask, packed)
+        ctx.dims = (input_size, ld)
+        return feats
+
+    @staticmethod
+    def backward(ctx, gfeats):
+        L = _lib.load()
+        verts, mask, packed = ctx.saved_tensors
+        input_size, ld = ctx.dims
+        gfeats = _req(gfeats, "grad_feats")
+        B, N, _ = verts.shape
+        gverts = torch.empty_like(verts)
+        gparams = torch.empty_like(packed)
+        scratch = workspace("posenc", L.a3vt_posenc_scratch_bytes(B * N, input_size), verts.device)
+        _lib.check(L.a3vt_posenc_mask_bwd(_lib.ptr(verts), _lib.ptr(mask), B * N, input_size, _lib.ptr(packed),
+                                          _lib.ptr(gfeats), ld, _lib.ptr(gverts), _lib.ptr(gparams),
+                                          _lib.ptr(scratch), _stream()), "posenc_mask_bwd")
+        return gverts, None, gparams, None, None
+
+
+class VertexUpdateFn(torch.autograd.Function):
+    """vertices[:, :n_vision] += update[:, :n_vision] (vision/model.py:250,270,283), out of place."""
+
+    @staticmethod
+    def forward(ctx, verts, update, n_vision):
+        L = _lib.load()
+        verts, update = _req(verts, "verts"), _req(update, "update")
+        B, N, _ = verts.shape
+        out = torch.empty_like(verts)
+        _lib.check(L.a3vt_vertex_update(_lib.ptr(verts), _lib.ptr(update), B, N, n_vision, _lib.ptr(out), _stream()),
+                   "vertex_update")
+        ctx.n_vision = n_vision
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        nv = ctx.n_vision
+        if nv == g.shape[1]:
+            return g, g, None
+        gu = g.clone()
+        gu[:, nv:] = 0
+        return g, gu, None
+
+
+class SamplePointsFn(torch.autograd.Function):
+    """batch_sample (utility/utils.py:152-187) for `draws` clouds at once: verts (B,N,3) -> (draws,B,num,3)."""
+
+    @staticmethod
+    def forward(ctx, verts, faces, num, draws, seed, offset, face_idx, u, v):
+        L = _lib.load()
+        verts = _req(verts, "verts")
+        faces = _req(faces, "faces", torch.int32)
+        B, N, _ = verts.shape
+        F = faces.shape[0]
+        dev = verts.device
+        points = torch.empty((draws, B, num, 3), dtype=torch.float32, device=dev)
+        cdf = None
+        if face_idx is None:
+            cdf = torch.empty((B, F), dtype=torch.float32, device=dev)
+            _lib.check(L.a3vt_face_cdf(_lib.ptr(verts), _lib.ptr(faces), B, N, F, _lib.ptr(cdf), _stream()), "face_cdf")
+            fi = torch.empty((draws, B, num), dtype=torch.int32, device=dev)
+            uu = torch.empty((draws, B, num), dtype=torch.float32, device=dev)
+            vv = torch.empty((draws, B, num), dtype=torch.float32, device=dev)
+            _lib.check(L.a3vt_sample_points_fwd(_lib.ptr(verts), _lib.ptr(faces), _lib.ptr(cdf), B, N, F, draws, num,
+                                                None, None, None, seed, offset, _lib.ptr(points), _lib.ptr(fi),
+                                                _lib.ptr(uu), _lib.ptr(vv), _stream()), "sample_points_fwd")
+        else:
+            fi = _req(face_idx, "face_idx", torch.int32).reshape(draws, B, num)
+            uu = _req(u, "u").reshape(draws, B, num)
+            vv = _req(v, "v").reshape(draws, B, num)
+            _lib.check(L.a3vt_sample_points_fwd(_lib.ptr(verts), _lib.ptr(faces), None, B, N, F, draws, num,
+                                                _lib.ptr(fi), _lib.ptr(uu), _lib.ptr(vv), 0, 0, _lib.ptr(points),
+                                                None, None, None, _stream()), "sample_points_fwd")
+        ctx.save_for_backward(faces, fi, uu, vv)
+        ctx.dims = (B, N, F, draws, num)
+        return points
+
+    @staticmethod
+    def backward(ctx, gpoints):
+        L = _lib.load()
+        faces, fi, uu, vv = ctx.saved_tensors
+        B, N, F, draws, num = ctx.dims
+        gpoints = _req(gpoints, "grad_points")
+        gverts = torch.empty((B, N, 3), dtype=torch.float32, device=gpoints.device)
+        _lib.check(L.a3vt_sample_points_bwd(_lib.ptr(faces), B, N, F, draws, num, _lib.ptr(fi), _lib.ptr(uu),
+                                            _lib.ptr(vv), _lib.ptr(gpoints), _lib.ptr(gverts), _stream()),
+                   "sample_points_bwd")
+        return gverts, None, None, None, None, None, None, None, None
+
+
+class ChamferFn(torch.autograd.Function):
+    """pytorch3d chamfer_distance(x, y, batch_reduction=None) averaged over draws (utility/utils.py:204-217).
+    x (draws,B,P,3), y (B,Q,3) -> cd (B,)."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        L = _lib.load()
+        x, y = _req(x, "x"), _req(y, "y")
+        draws, B, P, _ = x.shape
+        Q = y.shape[1]
+        if y.shape[0] != B:
+            raise RuntimeError("a3vt: chamfer batch mismatch")
+        dev = x.device
+        dxy = torch.empty((draws, B, P), dtype=torch.float32, device=dev)
+        ixy = torch.empty((draws, B, P), dtype=torch.int32, device=dev)
+        dyx = torch.empty((draws, B, Q), dtype=torch.float32, device=dev)
+        iyx = torch.empty((draws, B, Q), dtype=torch.int32, device=dev)
+        cd = torch.empty((B,), dtype=torch.float32, device=dev)
+        _lib.check(L.a3vt_chamfer_fwd(_lib.ptr(x), _lib.ptr(y), draws, B, P, Q, _lib.ptr(dxy), _lib.ptr(ixy),
+                                      _lib.ptr(dyx), _lib.ptr(iyx), _lib.ptr(cd), _stream()), "chamfer_fwd")
+        ctx.save_for_backward(x, y, ixy, iyx)
+        ctx.aux = (dxy, dyx)
+        return cd
+
+    @staticmethod
+    def backward(ctx, gcd):
+        L = _lib.load()
+        x, y, ixy, iyx = ctx.saved_tensors
+        draws, B, P, _ = x.shape
+        Q = y.shape[1]
+        gcd = _req(gcd, "grad_cd")
+        gx = torch.empty_like(x)
+        gy = torch.empty_like(y) if ctx.needs_input_grad[1] else None
+        _lib.check(L.a3vt_chamfer_bwd(_lib.ptr(x), _lib.ptr(y), draws, B, P, Q, _lib.ptr(ixy), _lib.ptr(iyx),
+                                      _lib.ptr(gcd), _lib.ptr(gx), _lib.ptr(gy), _stream()), "chamfer_bwd")
+        return gx, gy
+
+
+def chamfer_nn(x, y):
+    """Raw nearest-neighbour outputs (dist_xy, idx_xy, dist_yx, idx_yx, cd) — used by tests and scoring."""
+    L = _lib.load()
+    x, y = _req(x, "x"), _req(y, "y")
+    draws, B, P, _ = x.shape
+    Q = y.shape[1]
+    dev = x.device
+    dxy = torch.empty((draws, B, P), dtype=torch.float32, device=dev)
+    ixy = torch.empty((draws, B, P), dtype=torch.int32, device=dev)
+    dyx = torch.empty((draws, B, Q), dtype=torch.float32, device=dev)
+    iyx = torch.empty((draws, B, Q), dtype=torch.int32, device=dev)
+    cd = torch.empty((B,), dtype=torch.float32, device=dev)
+    _lib.check(L.a3vt_chamfer_fwd(_lib.ptr(x), _lib.ptr(y), draws, B, P, Q, _lib.ptr(dxy), _lib.ptr(ixy),
+                                  _lib.ptr(dyx), _lib.ptr(iyx), _lib.ptr(cd), _stream()), "chamfer_fwd")
+    return dxy, ixy, dyx, iyx, cd
+
+
+def rowgemm(a, w):
+    """C = A @ W on the fp32 MFMA kernel (tests / bench): a (M,K) with K % 4 == 0, w (K,N) with N <= 304."""
+    L = _lib.load()
+    a, w = _req(a, "a"), _req(w, "w")
+    M, K = a.shape
+    N = w.shape[1]
+    wt = torch.empty((L.a3vt_wt_rows(N), L.a3vt_wt_ld(K)), dtype=torch.float32, device=a.device)
+    _lib.check(L.a3vt_transpose_weight(_lib.ptr(w), K, N, _lib.ptr(wt), _stream()), "transpose_weight")
+    c = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    _lib.check(L.a3vt_rowgemm(_lib.ptr(a), K, M, K, _lib.ptr(wt), N, _lib.ptr(c), N, _stream()), "rowgemm")
+    return c
+
+
+def check_finite(t, flag):
+    """Deferred NaN/Inf check: ORs 1 into `flag` (int32 device scalar) without syncing the host."""
+    L = _lib.load()
+    _lib.check(L.a3vt_check_finite(_lib.ptr(t), t.numel(), _lib.ptr(flag), _stream()), "check_finite")

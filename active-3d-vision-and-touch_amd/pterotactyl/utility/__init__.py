@@ -1,0 +1,1 @@
+"""Mirror of the reference package layout (hot-path modules only)."""

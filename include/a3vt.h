@@ -1,0 +1,156 @@
+/* a3vt.h — C ABI of the MI355X (gfx950) mesh-reconstruction hot path.
+ *
+ * Drop-in boundary for the reconstruction path of facebookresearch/Active-3D-Vision-and-Touch
+ * (`pterotactyl`).  The reference has no native/FFI layer: its boundary is the
+ * Python module API of pterotactyl.reconstruction.vision.{model,train} and pterotactyl.utility.utils,
+ * which reach third-party kernels through torch / PyTorch3D.  Every entry point below names the
+ * reference call site (file:line under /root/reference) whose arithmetic it replaces; the Python
+ * façade in active-3d-vision-and-touch_amd/pterotactyl/ binds them with ctypes.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no torch types.  Return 0 = OK, <0 = error
+ *    (a3vt_last_error() gives a thread-local message).
+ *  - All data pointers are caller-owned DEVICE pointers unless a parameter says "host".
+ *    The library never allocates or frees user tensors and never synchronises the host;
+ *    scratch memory comes from the caller (query with the *_bytes functions).
+ *  - `stream` is a hipStream_t (NULL = default stream).  Everything is fp32; indices are int32.
+ *  - Dense row-major layouts.  M = batch * n_vert rows of per-vertex data, sample-major.
+ */
+#ifndef A3VT_H
+#define A3VT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define A3VT_VERSION 100 /* 0.1.0 */
+
+int a3vt_version(void);
+const char *a3vt_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Adjacency.  Replaces the dense (N,N) float adjacency of utility/utils.py:47-52,134-148 with CSR
+ * (row-normalised, self loops included).  Host-side structural check: monotone rowptr, columns in
+ * range.  Pointers are HOST pointers.  */
+int a3vt_csr_validate(const int32_t *rowptr_host, const int32_t *col_host, int n_vert, int nnz);
+
+/* ---------------------------------------------------------------------------------------------
+ * GCN.  Replaces GCN_layer.forward, reconstruction/vision/model.py:351-363
+ *   Z = X W ;  Y[:, :c] = A Z[:, :c] + b[:c] ;  Y[:, c:] = Z[:, c:] ;  ReLU     (hidden layers, do_cut)
+ *   Y = A (X W) + b                                                              (last layer, 3 channels)
+ * and GCN.forward, model.py:316-331 (the layer loop; the NaN trap at :326 becomes a3vt_check_finite).
+ *
+ * Layer dims follow model.py:297-301: [in_features, hidden x (L-1), 3].  `weights[i]` is the
+ * reference parameter layout (1, in_i, out_i) = row-major [in_i][out_i]; `biases[i]` is [out_i].
+ * `weights`, `biases`, `grad_weights`, `grad_biases` are HOST arrays of L DEVICE pointers.
+ * `cut_len` = round(hidden * cut) (model.py:355; 99 for 300 * 0.33).
+ * csr_* is A (row-normalised), csrT_* is its transpose (A is not symmetric after normalisation).
+ *
+ * feats  : [M][ld_feats] with ld_feats >= in_features, ld_feats % 4 == 0; pad columns must be zero.
+ * acts   : saved inputs of layers 1..L-1, [L-1][M][hidden]   (needed by the backward pass)
+ * update : [M][3]
+ * Forward-only callers (policy scoring, environment.py:221-257) may pass acts = NULL: the
+ * layer outputs then ping-pong inside `scratch`. */
+size_t a3vt_gcn_stack_scratch_bytes(int batch, int n_vert, int in_features, int hidden, int num_layers,
+                                    int cut_len, int need_backward);
+
+int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features,
+                       const float *const *weights, const float *const *biases,
+                       int num_layers, int hidden, int cut_len,
+                       const int32_t *csr_rowptr, const int32_t *csr_col, const float *csr_val,
+                       int n_vert, int batch,
+                       float *acts, float *scratch, float *update, void *stream);
+
+/* Backward of the stack.  grad_update [M][3] -> grad_feats [M][ld_feats] (pad columns written as 0),
+ * grad_weights[i] [in_i][out_i], grad_biases[i] [out_i] (overwritten; channels >= cut_len of hidden
+ * biases get exact zeros: they are dead parameters in the reference, model.py:358). */
+int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features,
+                       const float *const *weights, const float *const *biases,
+                       int num_layers, int hidden, int cut_len,
+                       const int32_t *csr_rowptr, const int32_t *csr_col, const float *csr_val,
+                       const int32_t *csrT_rowptr, const int32_t *csrT_col, const float *csrT_val,
+                       int n_vert, int batch,
+                       const float *acts, const float *grad_update,
+                       float *const *grad_weights, float *const *grad_biases, float *grad_feats,
+                       float *scratch, void *stream);
+
+/* The dense per-vertex product alone (torch.matmul(features, self.weight), model.py:352) on the
+ * fp32 MFMA path: C[M][n_out] = A[M][k] * W[k][n_out], k % 4 == 0, n_out <= 304.  `wt` is W transposed
+ * and zero padded to [a3vt_wt_rows(n_out)][a3vt_wt_ld(k)] floats (a3vt_transpose_weight builds it).
+ * Used by tests and by bench.py to time the dominant kernel in isolation. */
+int a3vt_wt_rows(int n_out);
+int a3vt_wt_ld(int k);
+int a3vt_transpose_weight(const float *w, int k, int n_out, float *wt, void *stream);
+int a3vt_rowgemm(const float *a, int lda, int m, int k, const float *wt, int n_out,
+                 float *c, int ldc, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Vertex features.  Replaces Positional_Encoder.forward (model.py:381-399) + Mask_Encoder.forward
+ * (model.py:410-414) + their sum (model.py:232,240,262,275):
+ *   feats = MLP(nerf_embedding(p) ++ p) + Embedding[mask]
+ * pe_params: packed fp32 [W1 (I/4 x 63), b1, W2 (I/2 x I/4), b2, W3 (I x I/2), b3, E (4 x I)],
+ * each in torch (out,in) row-major layout (state-dict order).  Only I = 50 (the image-free model,
+ * model.py:193) is supported by the fused kernel.  feats is [M][ld_feats], pad columns zeroed. */
+size_t a3vt_posenc_param_count(int input_size);
+size_t a3vt_posenc_scratch_bytes(int m, int input_size);
+int a3vt_posenc_mask_fwd(const float *verts, const float *mask, int m, int input_size,
+                         const float *pe_params, float *feats, int ld_feats, void *stream);
+/* grad_params has a3vt_posenc_param_count floats (overwritten); grad_verts [M][3] (overwritten). */
+int a3vt_posenc_mask_bwd(const float *verts, const float *mask, int m, int input_size,
+                         const float *pe_params, const float *grad_feats, int ld_feats,
+                         float *grad_verts, float *grad_params, float *scratch, void *stream);
+
+/* Vertex update, model.py:250,270,283:  out[b][v] = in[b][v] + (v < n_vision ? update[b][v] : 0). */
+int a3vt_vertex_update(const float *verts_in, const float *update, int batch, int n_vert, int n_vision,
+                       float *verts_out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Surface sampling.  Replaces batch_sample, utility/utils.py:152-187 (PyTorch3D
+ * mesh_face_areas_normals + torch.multinomial + _rand_barycentric_coords + gathers).
+ * faces [F][3] int32 is shared by the whole batch (adj_info['faces']).
+ * a3vt_face_cdf: per-mesh inclusive CDF of p_f = |area_f / sum(area)| with the reference's NaN
+ * scrubs (utils.py:165-168): cdf [batch][F].
+ * a3vt_sample_points_fwd: `draws` independent clouds of `num` points per mesh (utils.chamfer_distance
+ * draws 3, utils.py:204-217).  If face_idx_in/u_in/v_in are non-NULL ([draws][batch][num]) they are
+ * used as the samples (parity mode); otherwise samples come from Philox4x32-10(seed, offset) through
+ * the CDF.  Outputs: points [draws][batch][num][3] and the samples actually used (face_idx/u/v out,
+ * needed by the backward pass). */
+int a3vt_face_cdf(const float *verts, const int32_t *faces, int batch, int n_vert, int n_faces,
+                  float *cdf, void *stream);
+int a3vt_sample_points_fwd(const float *verts, const int32_t *faces, const float *cdf,
+                           int batch, int n_vert, int n_faces, int draws, int num,
+                           const int32_t *face_idx_in, const float *u_in, const float *v_in,
+                           uint64_t seed, uint64_t offset,
+                           float *points, int32_t *face_idx_out, float *u_out, float *v_out, void *stream);
+/* grad_verts [batch][n_vert][3] is overwritten with the scatter-add of w_k * grad_points. */
+int a3vt_sample_points_bwd(const int32_t *faces, int batch, int n_vert, int n_faces, int draws, int num,
+                           const int32_t *face_idx, const float *u, const float *v,
+                           const float *grad_points, float *grad_verts, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Chamfer.  Replaces pytorch3d.loss.chamfer_distance(x, y, batch_reduction=None) as called at
+ * utility/utils.py:207,212 (squared-L2 K=1 nearest neighbour both ways, mean over each cloud, summed)
+ * and the mean over draws at utils.py:214-215.
+ * x [draws][batch][p][3] (predicted clouds), y [batch][q][3] (ground truth, shared by the draws).
+ * Outputs: dist_xy/idx_xy [draws][batch][p], dist_yx/idx_yx [draws][batch][q],
+ *          cd [batch] = (1/draws) sum_r ( mean_i dist_xy + mean_j dist_yx ). */
+int a3vt_chamfer_fwd(const float *x, const float *y, int draws, int batch, int p, int q,
+                     float *dist_xy, int32_t *idx_xy, float *dist_yx, int32_t *idx_yx, float *cd,
+                     void *stream);
+/* grad_cd [batch].  grad_x [draws][batch][p][3] overwritten; grad_y [batch][q][3] overwritten, may be
+ * NULL (the trainer's ground truth needs no gradient, vision/train.py:141-143). */
+int a3vt_chamfer_bwd(const float *x, const float *y, int draws, int batch, int p, int q,
+                     const int32_t *idx_xy, const int32_t *idx_yx, const float *grad_cd,
+                     float *grad_x, float *grad_y, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Deferred finite check (replaces the blocking NaN trap of model.py:326-329): sets *flag (device
+ * int32, caller-zeroed) to 1 if any of the n floats is NaN/Inf.  No host sync. */
+int a3vt_check_finite(const float *data, size_t n, int32_t *flag, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* A3VT_H */

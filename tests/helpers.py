@@ -1,0 +1,47 @@
+"""Shared builders for the parity tests (seeded inputs, oracle <-> HIP plumbing)."""
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from a3vt_amd import mesh as amesh
+
+
+def make_args(**kw):
+    d = dict(use_img=False, use_touch=False, finger=False, num_grasps=1, num_GCN_layers=20, hidden_GCN_size=300,
+             cut=0.33, number_points=1000, loss_coeff=9000.0, lr=3e-4, seed=0, num_stages=3)
+    d.update(kw)
+    return SimpleNamespace(**d)
+
+
+def template(name):
+    """(verts float32 (V,3), faces int64 (F,3)) for 'ico<level>' or 'atlas'."""
+    if name.startswith("ico"):
+        return amesh.icosphere(int(name[3:]))
+    return amesh.load_asset("vision_charts")
+
+
+def oracle_adj(verts, faces, args):
+    """CSR triple (long,long,float tensors) + faces for oracle.gcn.adj_matmul, built by the ORACLE's dense path."""
+    from oracle import mesh as omesh
+    sv, sf = amesh.load_asset("touch_chart")
+    info = omesh.adj_init(verts, faces, args.use_touch, args.num_grasps, args.finger, sv, sf)
+    rp, col, val = omesh.dense_to_csr(info["adj"])
+    return (torch.from_numpy(rp).long(), torch.from_numpy(col).long(), torch.from_numpy(val)), \
+        torch.from_numpy(info["faces"])
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def random_cloud(batch, n, seed, kind="ellipsoid"):
+    g = np.random.default_rng(seed)
+    if kind == "cube":
+        return torch.from_numpy(g.uniform(-0.16, 0.16, (batch, n, 3)).astype(np.float32))
+    d = g.normal(size=(batch, n, 3))
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    ax = g.uniform(0.05, 0.16, (batch, 1, 3))
+    return torch.from_numpy((d * ax).astype(np.float32))

@@ -1,0 +1,194 @@
+"""-m gpu: every HIP entry point against the CPU oracle on seeded inputs (fp32, tolerances stated per test)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_args, oracle_adj, random_cloud, rel_err, template
+
+pytestmark = pytest.mark.gpu
+
+
+def test_library_loads(cuda):
+    from a3vt_amd import lib
+    assert lib.load().a3vt_version() == 100
+
+
+@pytest.mark.parametrize("m,k,n", [(128, 16, 16), (1000, 52, 300), (4099, 300, 300), (300, 300, 50), (77, 300, 3)])
+def test_rowgemm_matches_fp64(cuda, m, k, n):
+    from a3vt_amd import ops
+    g = torch.Generator().manual_seed(m + k + n)
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(k, n, generator=g)
+    c = ops.rowgemm(a.to(cuda), w.to(cuda)).cpu()
+    ref = (a.double() @ w.double())
+    # fp32 fma chain over K <= 300: ~1e-6 relative to the row scale
+    assert rel_err(c, ref) < 2e-6
+
+
+def _state_to(dev, st):
+    return {k: v.to(dev) for k, v in st.items()}
+
+
+@pytest.mark.parametrize("tname,use_touch,L,H,B", [("ico2", False, 3, 32, 3), ("atlas", True, 4, 300, 2),
+                                                     ("ico3", False, 20, 300, 2), ("ico2", False, 1, 300, 2)])
+def test_gcn_stack_fwd_bwd(cuda, tname, use_touch, L, H, B):
+    from a3vt_amd import mesh as amesh, ops
+    from oracle import gcn as og
+    args = make_args(use_touch=use_touch, num_GCN_layers=L, hidden_GCN_size=H, num_grasps=1)
+    verts, faces = template(tname)
+    adj_o, _ = oracle_adj(verts, faces, args)
+    n = adj_o[0].numel() - 1
+    st = og.init_state(50, H, L, seed=3)
+    g = torch.Generator().manual_seed(11)
+    feats = torch.randn(B, n, 50, generator=g) * 0.5
+    gup = torch.randn(B, n, 3, generator=g)
+    # oracle (float64 reference of the same weights)
+    st64 = {k: v.double().requires_grad_(True) for k, v in st.items() if k.startswith("mesh_deform_1")}
+    f64 = feats.double().requires_grad_(True)
+    out_o = og.gcn(f64, st64, "mesh_deform_1", (adj_o[0], adj_o[1], adj_o[2].double()), L, 0.33)
+    (out_o * gup.double()).sum().backward()
+    # HIP
+    if use_touch:
+        sv, sf = amesh.load_asset("touch_chart")
+        r, c, nn_, _ = amesh.fused_pairs(verts, faces, sf, 1, False)
+    else:
+        r, c = amesh.vision_pairs(faces, verts.shape[0])
+        nn_ = verts.shape[0]
+    adj = ops.DeviceCSR(amesh.CSRAdjacency.from_pairs(r, c, nn_), cuda)
+    ws = [st[f"mesh_deform_1.layers.{i}.weight"].to(cuda).requires_grad_(True) for i in range(L)]
+    bs = [st[f"mesh_deform_1.layers.{i}.bias"].to(cuda).requires_grad_(True) for i in range(L)]
+    fd = torch.nn.functional.pad(feats, (0, 2)).to(cuda).requires_grad_(True)
+    out = ops.gcn_stack(fd, adj, 50, H, round(H * 0.33), ws, bs)
+    (out * gup.to(cuda)).sum().backward()
+    assert rel_err(out, out_o) < 1e-4
+    assert rel_err(fd.grad[..., :50], f64.grad) < 1e-4
+    assert fd.grad[..., 50:].abs().max().item() == 0.0
+    for i in range(L):
+        assert rel_err(ws[i].grad, st64[f"mesh_deform_1.layers.{i}.weight"].grad) < 1e-4, f"dW layer {i}"
+        assert rel_err(bs[i].grad, st64[f"mesh_deform_1.layers.{i}.bias"].grad) < 1e-4, f"db layer {i}"
+
+
+def test_posenc_mask_fwd_bwd(cuda):
+    from a3vt_amd import ops
+    from oracle import gcn as og
+    st = og.init_state(50, 8, 1, seed=5)
+    g = torch.Generator().manual_seed(2)
+    B, N = 3, 517
+    verts = (torch.rand(B, N, 3, generator=g) - 0.5) * 0.6
+    mask = torch.randint(0, 4, (B, N, 1), generator=g).float()
+    gout = torch.randn(B, N, 52, generator=g)
+    gout[..., 50:] = 0
+    names = ["positional_encoder.model.0.weight", "positional_encoder.model.0.bias",
+             "positional_encoder.model.2.weight", "positional_encoder.model.2.bias",
+             "positional_encoder.model.4.weight", "positional_encoder.model.4.bias", "mask_encoder.model.0.weight"]
+    st64 = {k: st[k].double().requires_grad_(True) for k in names}
+    v64 = verts.double().requires_grad_(True)
+    f_o = og.positional_encoder(v64, st64) + og.mask_encoder(mask, st64)
+    (f_o * gout[..., :50].double()).sum().backward()
+    packed = torch.cat([st[k].reshape(-1) for k in names]).to(cuda).requires_grad_(True)
+    vd = verts.to(cuda).requires_grad_(True)
+    f = ops.PosEncMaskFn.apply(vd, mask.to(cuda), packed, 50, 52)
+    (f * gout.to(cuda)).sum().backward()
+    assert rel_err(f[..., :50], f_o) < 1e-5
+    assert f[..., 50:].abs().max().item() == 0.0
+    assert rel_err(vd.grad, v64.grad) < 1e-4
+    g_o = torch.cat([st64[k].grad.reshape(-1) for k in names])
+    assert rel_err(packed.grad, g_o) < 1e-4
+
+
+@pytest.mark.parametrize("P,Q,B,draws", [(1, 1, 1, 1), (100, 37, 2, 3), (1000, 2176, 2, 1), (4099, 5000, 1, 2)])
+def test_chamfer_fwd_bwd(cuda, P, Q, B, draws):
+    from a3vt_amd import ops
+    from oracle import chamfer as och
+    x = random_cloud(draws * B, P, 1).reshape(draws, B, P, 3) * 1.1
+    y = random_cloud(B, Q, 2)
+    gcd = torch.rand(B) + 0.5
+    xd = x.to(cuda).requires_grad_(True)
+    yd = y.to(cuda).requires_grad_(True)
+    cd = ops.ChamferFn.apply(xd, yd)
+    (cd * gcd.to(cuda)).sum().backward()
+    x64 = x.double().requires_grad_(True)
+    y64 = y.double().requires_grad_(True)
+    cd_o = torch.stack([och.chamfer_pair(x64[r], y64) for r in range(draws)]).mean(0)
+    (cd_o * gcd.double()).sum().backward()
+    assert rel_err(cd, cd_o) < 1e-5
+    assert rel_err(xd.grad, x64.grad) < 1e-4
+    assert rel_err(yd.grad, y64.grad) < 1e-4
+    # nearest-neighbour distances bit-for-bit against the plain-C oracle (same fp32 arithmetic, fma aside)
+    dxy, ixy, dyx, iyx, _ = ops.chamfer_nn(xd.detach(), yd.detach())
+    dc, _ = och.nn_sqdist_c(x[0, 0].numpy(), y[0].numpy())
+    assert np.allclose(dxy[0, 0].cpu().numpy(), dc, rtol=1e-5, atol=1e-12)
+    # indices must point at a candidate realising the reported distance
+    yy = y[0][ixy[0, 0].cpu().long()]
+    assert np.allclose(((x[0, 0] - yy) ** 2).sum(-1).numpy(), dxy[0, 0].cpu().numpy(), rtol=1e-5, atol=1e-12)
+
+
+def test_chamfer_known_answers(cuda):
+    from a3vt_amd import ops
+    x = random_cloud(2, 300, 4).to(cuda)
+    cd = ops.ChamferFn.apply(x[None], x)
+    assert cd.abs().max().item() == 0.0                      # a cloud against itself
+    t = torch.tensor([1e-4, -2e-4, 5e-5], device=cuda)       # shift far below the point spacing -> 2|t|^2
+    cd2 = ops.ChamferFn.apply((x + t)[None], x)
+    assert abs(cd2[0].item() - 2 * (t ** 2).sum().item()) < 1e-3 * 2 * (t ** 2).sum().item()
+
+
+def test_sample_points_injected_and_grad(cuda):
+    from a3vt_amd import ops
+    from oracle import chamfer as och
+    verts, faces = template("ico2")
+    B, num, draws = 3, 500, 2
+    g = torch.Generator().manual_seed(9)
+    v = torch.from_numpy(verts)[None].repeat(B, 1, 1) + 0.02 * torch.randn(B, verts.shape[0], 3, generator=g)
+    f = torch.from_numpy(faces)
+    fi = torch.randint(0, f.shape[0], (draws, B, num), generator=g)
+    u = torch.rand(draws, B, num, generator=g)
+    w = torch.rand(draws, B, num, generator=g)
+    gp = torch.randn(draws, B, num, 3, generator=g)
+    vd = v.to(cuda).requires_grad_(True)
+    pts = ops.SamplePointsFn.apply(vd, f.to(torch.int32).to(cuda), num, draws, 0, 0, fi.to(torch.int32).to(cuda),
+                                   u.to(cuda), w.to(cuda))
+    (pts * gp.to(cuda)).sum().backward()
+    v64 = v.double().requires_grad_(True)
+    pts_o = torch.stack([och.sample_points(v64, f, fi[r], u[r].double(), w[r].double()) for r in range(draws)])
+    (pts_o * gp.double()).sum().backward()
+    assert rel_err(pts, pts_o) < 1e-6
+    assert rel_err(vd.grad, v64.grad) < 1e-5
+
+
+def test_sample_points_rng_statistics(cuda):
+    """Philox + inverse-CDF path: face histogram proportional to area, zero-area faces never drawn,
+    barycentric weights inside the triangle, points on the faces' planes."""
+    from a3vt_amd import ops
+    from oracle import chamfer as och
+    verts, faces = template("ico1")
+    v = torch.from_numpy(verts)[None].clone()
+    v[0, faces[3]] = v[0, faces[3][0]]  # collapse face 3 (and shrink its neighbours)
+    f = torch.from_numpy(faces)
+    num = 200000
+    pts = ops.SamplePointsFn.apply(v.to(cuda), f.to(torch.int32).to(cuda), num, 1, 1234, 0, None, None, None)
+    assert torch.isfinite(pts).all()
+    prob = och.face_probabilities(v, f)[0].numpy()
+    # recover the face of each sample through the saved indices of a second identical call
+    from a3vt_amd import lib
+    L = lib.load()
+    cdf = torch.empty(1, f.shape[0], device=cuda)
+    lib.check(L.a3vt_face_cdf(lib.ptr(v.to(cuda)), lib.ptr(f.to(torch.int32).to(cuda)), 1, v.shape[1], f.shape[0],
+                              lib.ptr(cdf), None), "cdf")
+    torch.cuda.synchronize()
+    assert np.allclose(cdf[0].cpu().numpy(), np.cumsum(prob), rtol=1e-5, atol=1e-6)
+    fi = torch.empty(1, 1, num, dtype=torch.int32, device=cuda)
+    uu = torch.empty(1, 1, num, device=cuda)
+    vv = torch.empty(1, 1, num, device=cuda)
+    p2 = torch.empty(1, 1, num, 3, device=cuda)
+    vdev, fdev = v.to(cuda), f.to(torch.int32).to(cuda)
+    lib.check(L.a3vt_sample_points_fwd(lib.ptr(vdev), lib.ptr(fdev), lib.ptr(cdf), 1, v.shape[1], f.shape[0], 1, num,
+                                       None, None, None, 1234, 0, lib.ptr(p2), lib.ptr(fi), lib.ptr(uu), lib.ptr(vv),
+                                       None), "sample")
+    torch.cuda.synchronize()
+    assert torch.equal(p2, pts)                               # same seed/offset -> same cloud
+    hist = np.bincount(fi.cpu().numpy().ravel(), minlength=f.shape[0]) / num
+    assert hist[prob == 0].sum() == 0
+    assert np.abs(hist - prob).max() < 4 * np.sqrt(prob.max() / num) + 1e-3
+    assert 0.0 <= uu.min().item() and uu.max().item() < 1.0 and abs(uu.mean().item() - 0.5) < 5e-3
+    assert abs(vv.mean().item() - 0.5) < 5e-3
