@@ -33,6 +33,37 @@ static const float *zero_page() {
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// ---- optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg).
+// Off by default; when on, every MFMA launch of the GCN stack is bracketed by an event pair.
+enum { PROF_GEMM_FWD = 0, PROF_GEMM_DX = 1, PROF_DW = 2, PROF_CLASSES = 3 };
+struct Prof {
+  bool on = false;
+  static constexpr int kMax = 8192;
+  hipEvent_t ev[kMax][2];
+  int cls[kMax];
+  int created = 0, used = 0;
+};
+static Prof g_prof;
+
+struct ProfScope {
+  int slot = -1;
+  hipStream_t s;
+  ProfScope(int cls, hipStream_t stream) : s(stream) {
+    if (!g_prof.on || g_prof.used >= Prof::kMax) return;
+    slot = g_prof.used++;
+    if (slot >= g_prof.created) {
+      (void)hipEventCreate(&g_prof.ev[slot][0]);
+      (void)hipEventCreate(&g_prof.ev[slot][1]);
+      g_prof.created = slot + 1;
+    }
+    g_prof.cls[slot] = cls;
+    (void)hipEventRecord(g_prof.ev[slot][0], s);
+  }
+  ~ProfScope() {
+    if (slot >= 0) (void)hipEventRecord(g_prof.ev[slot][1], s);
+  }
+};
+
 // Scratch layout of a GCN stack call (float offsets, every region 256-B aligned).
 struct StackLayout {
   size_t wt, wt_stride;  // per hidden layer: transposed (fwd) or padded (bwd) weight image
@@ -150,7 +181,10 @@ int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const 
     g.c2 = scratch + L.za;
     g.ldc2 = cpad;
     g.csplit = cut_len;
-    if (int rc = launch_rowgemm(g, EPI_FWD_HIDDEN, s)) return rc;
+    {
+      ProfScope ps(PROF_GEMM_FWD, s);
+      if (int rc = launch_rowgemm(g, EPI_FWD_HIDDEN, s)) return rc;
+    }
     if (cut_len > 0)
       if (int rc = launch_csr_fwd(scratch + L.za, cpad, biases[i], cut_len, rowptr, col, val, n_vert, batch, y, hidden, s))
         return rc;
@@ -231,7 +265,10 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
     d.m = (int)m;
     d.k_in = kin;
     d.n_out = hidden;
-    if (int rc = launch_dw(d, s)) return rc;
+    {
+      ProfScope ps(PROF_DW, s);
+      if (int rc = launch_dw(d, s)) return rc;
+    }
     if (int rc = launch_slab_reduce(scratch + L.dw_slab, dw_num_slabs(hidden), (size_t)kin * hidden,
                                     (size_t)kin * hidden, grad_weights[i], s))
       return rc;
@@ -261,7 +298,10 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
       r.ldc = hidden;
       r.mask = x;
       r.ldmask = hidden;
-      if (int rc = launch_rowgemm(r, EPI_DX_MASK, s)) return rc;
+      {
+        ProfScope ps(PROF_GEMM_DX, s);
+        if (int rc = launch_rowgemm(r, EPI_DX_MASK, s)) return rc;
+      }
       cur ^= 1;
     }
   }
@@ -352,6 +392,26 @@ int a3vt_chamfer_bwd(const float *x, const float *y, int draws, int batch, int p
   A3VT_CHECK_ARG(x && y && idx_xy && idx_yx && grad_cd && grad_x && draws > 0 && batch > 0 && p > 0 && q > 0);
   return launch_chamfer_bwd(x, y, draws, batch, p, q, idx_xy, idx_yx, grad_cd, grad_x, grad_y,
                             static_cast<hipStream_t>(stream));
+}
+
+int a3vt_profile_enable(int on) {
+  g_prof.on = on != 0;
+  g_prof.used = 0;
+  return 0;
+}
+
+int a3vt_profile_read(double *total_ms, int *count) {
+  A3VT_CHECK_ARG(total_ms && count);
+  for (int c = 0; c < PROF_CLASSES; ++c) { total_ms[c] = 0.0; count[c] = 0; }
+  for (int i = 0; i < g_prof.used; ++i) {
+    if (hipEventSynchronize(g_prof.ev[i][1]) != hipSuccess) { set_error("profile_read: event sync failed"); return -2; }
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_prof.ev[i][0], g_prof.ev[i][1]) != hipSuccess) continue;
+    total_ms[g_prof.cls[i]] += ms;
+    count[g_prof.cls[i]] += 1;
+  }
+  g_prof.used = 0;
+  return 0;
 }
 
 int a3vt_check_finite(const float *data, size_t n, int32_t *flag, void *stream) {

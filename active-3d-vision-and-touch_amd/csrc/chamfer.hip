@@ -118,7 +118,7 @@ static int launch_nn(const float *q, int nq, int q_mod, const float *c, int nc, 
                      int32_t *idx, hipStream_t s) {
   constexpr int R = 4;
   dim3 grid(cdiv(nq, 256 * R), nclouds);
-  hipLaunchKernelGGL((nn_kernel<R>), grid, dim3(256), 0, s, q, nq, q_mod, c, nc, c_mod, dist, idx);
+  A3VT_LAUNCH((nn_kernel<R>), grid, dim3(256), 0, s, q, nq, q_mod, c, nc, c_mod, dist, idx);
   A3VT_CHECK_LAUNCH();
   return 0;
 }
@@ -156,7 +156,7 @@ int launch_chamfer_fwd(const float *x, const float *y, int draws, int batch, int
   if (int rc = launch_nn(x, p, draws * batch, y, q, batch, draws * batch, dxy, ixy, s)) return rc;
   // y -> x: queries = y[b], candidates = x[r][b]
   if (int rc = launch_nn(y, q, batch, x, p, draws * batch, draws * batch, dyx, iyx, s)) return rc;
-  hipLaunchKernelGGL(chamfer_reduce_kernel, dim3(batch), dim3(256), 0, s, dxy, dyx, draws, batch, p, q, cd);
+  A3VT_LAUNCH(chamfer_reduce_kernel, dim3(batch), dim3(256), 0, s, dxy, dyx, draws, batch, p, q, cd);
   A3VT_CHECK_LAUNCH();
   return 0;
 }
@@ -211,10 +211,10 @@ int launch_chamfer_bwd(const float *x, const float *y, int draws, int batch, int
   if (gy)
     if (int rc = launch_fill_zero(gy, (size_t)batch * q * 3, s)) return rc;
   const long long tx = (long long)draws * batch * p, ty = (long long)draws * batch * q;
-  hipLaunchKernelGGL(chamfer_bwd_x_kernel, dim3(cdiv(tx, 256)), dim3(256), 0, s, x, y, draws, batch, p, q, ixy, gcd, gx,
+  A3VT_LAUNCH(chamfer_bwd_x_kernel, dim3(cdiv(tx, 256)), dim3(256), 0, s, x, y, draws, batch, p, q, ixy, gcd, gx,
                      gy);
   A3VT_CHECK_LAUNCH();
-  hipLaunchKernelGGL(chamfer_bwd_y_kernel, dim3(cdiv(ty, 256)), dim3(256), 0, s, x, y, draws, batch, p, q, iyx, gcd, gx,
+  A3VT_LAUNCH(chamfer_bwd_y_kernel, dim3(cdiv(ty, 256)), dim3(256), 0, s, x, y, draws, batch, p, q, iyx, gcd, gx,
                      gy);
   A3VT_CHECK_LAUNCH();
   return 0;

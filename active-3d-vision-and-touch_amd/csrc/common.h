@@ -16,6 +16,14 @@ void set_error(const char *fmt, ...);
     }                                                                                     \
   } while (0)
 
+// Launch after clearing any stale error left in the thread by earlier HIP calls of the host program
+// (hipGetLastError is sticky per thread; torch's own probing can leave e.g. hipErrorNoDevice behind).
+#define A3VT_LAUNCH(...)            \
+  do {                              \
+    (void)hipGetLastError();        \
+    hipLaunchKernelGGL(__VA_ARGS__); \
+  } while (0)
+
 #define A3VT_CHECK_LAUNCH()                                                               \
   do {                                                                                    \
     hipError_t e__ = hipGetLastError();                                                   \

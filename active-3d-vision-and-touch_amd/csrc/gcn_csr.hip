@@ -69,7 +69,7 @@ int launch_csr_fwd(const float *za, int ldza, const float *bias, int c, const in
     return -1;
   }
   const long long m = (long long)batch * n_vert;
-  hipLaunchKernelGGL(csr_fwd_kernel, dim3(cdiv(m, 8)), dim3(256), 0, s, za, ldza, bias, c, rowptr, col, val, n_vert, m,
+  A3VT_LAUNCH(csr_fwd_kernel, dim3(cdiv(m, 8)), dim3(256), 0, s, za, ldza, bias, c, rowptr, col, val, n_vert, m,
                      y, ldy);
   A3VT_CHECK_LAUNCH();
   return 0;
@@ -153,7 +153,7 @@ int launch_csr_bwd(const float *g, int ldg, int c, const int32_t *rowptrT, const
     return -1;
   }
   const long long m = (long long)batch * n_vert;
-  hipLaunchKernelGGL(csr_bwd_kernel, dim3(csr_bwd_num_slabs(batch, n_vert)), dim3(256), 0, s, g, ldg, c, cpad, rowptrT,
+  A3VT_LAUNCH(csr_bwd_kernel, dim3(csr_bwd_num_slabs(batch, n_vert)), dim3(256), 0, s, g, ldg, c, cpad, rowptrT,
                      colT, valT, n_vert, m, dza, lddza, db_slab);
   A3VT_CHECK_LAUNCH();
   return 0;
@@ -245,9 +245,9 @@ int launch_thin_fwd(const float *x, int ldx, int k, const float *w, const float 
   }
   const long long m = (long long)batch * n_vert;
   const int grid = (int)(cdiv(m, 16) < 4096 ? cdiv(m, 16) : 4096);
-  hipLaunchKernelGGL(thin_fwd_kernel, dim3(grid), dim3(256), 0, s, x, ldx, k, w, m, z3);
+  A3VT_LAUNCH(thin_fwd_kernel, dim3(grid), dim3(256), 0, s, x, ldx, k, w, m, z3);
   A3VT_CHECK_LAUNCH();
-  hipLaunchKernelGGL(csr3_kernel, dim3(cdiv(m, 256)), dim3(256), 0, s, z3, bias, rowptr, col, val, n_vert, m, update, 3);
+  A3VT_LAUNCH(csr3_kernel, dim3(cdiv(m, 256)), dim3(256), 0, s, z3, bias, rowptr, col, val, n_vert, m, update, 3);
   A3VT_CHECK_LAUNCH();
   return 0;
 }
@@ -354,7 +354,7 @@ __global__ void pad3to4_kernel(const float *__restrict__ in, long long m, float 
   *reinterpret_cast<f32x4 *>(out + i * 4) = f32x4{in[i * 3], in[i * 3 + 1], in[i * 3 + 2], 0.f};
 }
 static int launch_pad3to4(const float *in, long long m, float *out, hipStream_t s) {
-  hipLaunchKernelGGL(pad3to4_kernel, dim3(cdiv(m, 256)), dim3(256), 0, s, in, m, out);
+  A3VT_LAUNCH(pad3to4_kernel, dim3(cdiv(m, 256)), dim3(256), 0, s, in, m, out);
   A3VT_CHECK_LAUNCH();
   return 0;
 }
@@ -372,10 +372,10 @@ int launch_thin_bwd(const float *x, int ldx, int k, const float *w, const int32_
   float *du4 = dz3;
   float *res = dz3 + m * 4;
   if (int rc = launch_pad3to4(grad_update, m, du4, s)) return rc;
-  hipLaunchKernelGGL(csr3_kernel, dim3(cdiv(m, 256)), dim3(256), 0, s, du4, (const float *)nullptr, rowptrT, colT, valT,
+  A3VT_LAUNCH(csr3_kernel, dim3(cdiv(m, 256)), dim3(256), 0, s, du4, (const float *)nullptr, rowptrT, colT, valT,
                      n_vert, m, res, 4);
   A3VT_CHECK_LAUNCH();
-  hipLaunchKernelGGL(thin_bwd_kernel, dim3(kThinBlocks), dim3(256), 0, s, x, ldx, k, w, res, grad_update, m, apply_mask,
+  A3VT_LAUNCH(thin_bwd_kernel, dim3(kThinBlocks), dim3(256), 0, s, x, ldx, k, w, res, grad_update, m, apply_mask,
                      g_prev, ldg, n_store, dw_slab, db_slab);
   A3VT_CHECK_LAUNCH();
   return 0;
@@ -395,7 +395,7 @@ __global__ void vertex_update_kernel(const float *__restrict__ vin, const float 
 int launch_vertex_update(const float *vin, const float *upd, int batch, int n_vert, int n_vision, float *vout,
                          hipStream_t s) {
   const long long total = (long long)batch * n_vert * 3;
-  hipLaunchKernelGGL(vertex_update_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, vin, upd, total, n_vert, n_vision,
+  A3VT_LAUNCH(vertex_update_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, vin, upd, total, n_vert, n_vision,
                      vout);
   A3VT_CHECK_LAUNCH();
   return 0;
@@ -412,7 +412,7 @@ __global__ void check_finite_kernel(const float *__restrict__ d, size_t n, int32
 
 int launch_check_finite(const float *d, size_t n, int32_t *flag, hipStream_t s) {
   const int grid = (int)(cdiv((long long)n, 256) < 2048 ? cdiv((long long)n, 256) : 2048);
-  hipLaunchKernelGGL(check_finite_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, s, d, n, flag);
+  A3VT_LAUNCH(check_finite_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, s, d, n, flag);
   A3VT_CHECK_LAUNCH();
   return 0;
 }
@@ -422,7 +422,7 @@ __global__ void fill_zero_kernel(float *__restrict__ d, size_t n) {
 }
 int launch_fill_zero(float *d, size_t n, hipStream_t s) {
   const int grid = (int)(cdiv((long long)n, 256) < 2048 ? cdiv((long long)n, 256) : 2048);
-  hipLaunchKernelGGL(fill_zero_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, s, d, n);
+  A3VT_LAUNCH(fill_zero_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, s, d, n);
   A3VT_CHECK_LAUNCH();
   return 0;
 }

@@ -147,7 +147,7 @@ template <int NT, int EPI>
 static int launch_rowgemm_nt(const RowGemmArgs &a, hipStream_t s) {
   constexpr int MT = 2;
   const int grid = cdiv(a.m, 64 * MT);
-  hipLaunchKernelGGL((rowgemm_kernel<MT, NT, EPI>), dim3(grid), dim3(256), 0, s, a);
+  A3VT_LAUNCH((rowgemm_kernel<MT, NT, EPI>), dim3(grid), dim3(256), 0, s, a);
   A3VT_CHECK_LAUNCH();
   return 0;
 }
@@ -205,7 +205,7 @@ __global__ void transpose_pad_kernel(const float *__restrict__ w, int k, int n, 
 
 int launch_transpose_pad(const float *w, int k, int n, float *wt, int rows, int ld, hipStream_t s) {
   dim3 grid(cdiv(ld, 32), cdiv(rows, 32));
-  hipLaunchKernelGGL(transpose_pad_kernel, grid, dim3(32, 8), 0, s, w, k, n, wt, rows, ld);
+  A3VT_LAUNCH(transpose_pad_kernel, grid, dim3(32, 8), 0, s, w, k, n, wt, rows, ld);
   A3VT_CHECK_LAUNCH();
   return 0;
 }
@@ -220,7 +220,7 @@ __global__ void copy_pad_kernel(const float *__restrict__ w, int rows_in, int co
 }
 
 int launch_copy_pad(const float *w, int rows_in, int cols_in, float *out, int rows, int ld, hipStream_t s) {
-  hipLaunchKernelGGL(copy_pad_kernel, dim3(cdiv((long long)rows * ld, 256)), dim3(256), 0, s, w, rows_in, cols_in, out,
+  A3VT_LAUNCH(copy_pad_kernel, dim3(cdiv((long long)rows * ld, 256)), dim3(256), 0, s, w, rows_in, cols_in, out,
                      rows, ld);
   A3VT_CHECK_LAUNCH();
   return 0;
@@ -405,7 +405,7 @@ int launch_dw(const DwArgs &a, hipStream_t s) {
     (void)hipFuncSetAttribute((const void *)dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(dw_kernel, dim3(dw_num_slabs(a.n_out), dw_col_groups(a.n_out)), dim3(1024), shmem, s, a);
+  A3VT_LAUNCH(dw_kernel, dim3(dw_num_slabs(a.n_out), dw_col_groups(a.n_out)), dim3(1024), shmem, s, a);
   A3VT_CHECK_LAUNCH();
   return 0;
 }
@@ -428,7 +428,7 @@ __global__ void slab_reduce_kernel(const float *__restrict__ slab, int nslab, si
 }
 
 int launch_slab_reduce(const float *slab, int nslab, size_t stride, size_t n, float *out, hipStream_t s) {
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv((long long)n, 256)), dim3(256), 0, s, slab, nslab, stride, n, out);
+  A3VT_LAUNCH(slab_reduce_kernel, dim3(cdiv((long long)n, 256)), dim3(256), 0, s, slab, nslab, stride, n, out);
   A3VT_CHECK_LAUNCH();
   return 0;
 }

@@ -136,7 +136,7 @@ int launch_posenc_fwd(const float *verts, const float *mask, int m, int input_si
     set_error("posenc: fused kernel supports input_size == 50 only (got %d)", input_size);
     return -1;
   }
-  hipLaunchKernelGGL((posenc_fwd_kernel<50>), dim3(cdiv(m, 256)), dim3(256), 0, s, verts, mask, m, params, feats, ld);
+  A3VT_LAUNCH((posenc_fwd_kernel<50>), dim3(cdiv(m, 256)), dim3(256), 0, s, verts, mask, m, params, feats, ld);
   A3VT_CHECK_LAUNCH();
   return 0;
 }
@@ -300,7 +300,7 @@ int launch_posenc_bwd(const float *verts, const float *mask, int m, int input_si
     return -1;
   }
   const int nslab = posenc_num_slabs(m);
-  hipLaunchKernelGGL((posenc_bwd_kernel<50>), dim3(nslab), dim3(kPEBwdThreads), 0, s, verts, mask, m, params, gfeats,
+  A3VT_LAUNCH((posenc_bwd_kernel<50>), dim3(nslab), dim3(kPEBwdThreads), 0, s, verts, mask, m, params, gfeats,
                      ld, gverts, scratch);
   A3VT_CHECK_LAUNCH();
   return launch_slab_reduce(scratch, nslab, PE<50>::N, PE<50>::N, gparams, s);

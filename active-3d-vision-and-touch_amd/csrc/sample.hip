@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void face_cdf_kernel(const float *__restrict__
 
 int launch_face_cdf(const float *verts, const int32_t *faces, int batch, int n_vert, int n_faces, float *cdf,
                     hipStream_t s) {
-  hipLaunchKernelGGL(face_cdf_kernel, dim3(batch), dim3(256), 0, s, verts, faces, n_vert, n_faces, cdf);
+  A3VT_LAUNCH(face_cdf_kernel, dim3(batch), dim3(256), 0, s, verts, faces, n_vert, n_faces, cdf);
   A3VT_CHECK_LAUNCH();
   return 0;
 }
@@ -157,7 +157,7 @@ int launch_sample_fwd(const float *verts, const int32_t *faces, const float *cdf
     return -1;
   }
   const long long total = (long long)draws * batch * num;
-  hipLaunchKernelGGL(sample_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, verts, faces, cdf, batch, n_vert,
+  A3VT_LAUNCH(sample_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, verts, faces, cdf, batch, n_vert,
                      n_faces, total, num, fi_in, u_in, v_in, seed, offset, points, fi_out, u_out, v_out);
   A3VT_CHECK_LAUNCH();
   return 0;
@@ -189,7 +189,7 @@ int launch_sample_bwd(const int32_t *faces, int batch, int n_vert, int n_faces, 
   (void)n_faces;
   if (int rc = launch_fill_zero(gverts, (size_t)batch * n_vert * 3, s)) return rc;
   const long long total = (long long)draws * batch * num;
-  hipLaunchKernelGGL(sample_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, faces, batch, n_vert, total, num, fi, u,
+  A3VT_LAUNCH(sample_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, faces, batch, n_vert, total, num, fi, u,
                      v, gpoints, gverts);
   A3VT_CHECK_LAUNCH();
   return 0;

@@ -39,6 +39,8 @@ SIGNATURES = {
     "a3vt_chamfer_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "a3vt_chamfer_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "a3vt_check_finite": (_i, [_vp, _sz, _vp, _vp]),
+    "a3vt_profile_enable": (_i, [_i]),
+    "a3vt_profile_read": (_i, [_vp, _vp]),
 }
 
 _LIB = None

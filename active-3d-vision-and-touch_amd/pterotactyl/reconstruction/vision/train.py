@@ -1,0 +1,198 @@
+"""Drop-in for ``pterotactyl/reconstruction/vision/train.py`` — the vision reconstruction trainer ``Engine``.
+
+Same constructor argument (an argparse ``Namespace`` or any object with the same attributes, README.md:143-170),
+same public methods and attributes (``__call__``, ``get_loaders``, ``train``, ``validate``, ``save``, ``load``,
+``check_values``; ``encoder, optimizer, mesh_info, initial_mesh, n_vision_charts, epoch, best_loss,
+current_loss, checkpoint_dir, results_dir``), same checkpoint files (``<ckpt>/model``, ``/optim``, ``/epoch.npy``,
+``/config.json``; reference :211-267) and the same loss (``loss_coeff * chamfer.mean()`` for training :144,
+``loss_coeff * chamfer.sum()`` accumulated over examples for validation :184-200).
+
+Differences: the hot loop never blocks on the device except every ``log_interval`` iterations (the reference
+calls ``loss.item()`` every step, :151-153); tensorboard / submitit are optional; early stop raises
+``StopIteration`` instead of ``exit()`` (:284); with ``WORLD_SIZE`` > 1 gradients are averaged with one
+flat-bucket RCCL all-reduce (``a3vt_amd.distributed``).  Datasets: ``get_loaders`` uses the reference's
+``pterotactyl.utility.data_loaders`` when that package (and its downloaded data) is importable; otherwise
+pass ``loaders=(train_loader, valid_loader)`` (e.g. ``a3vt_amd.synthetic.SyntheticLoader``).
+"""
+import os
+
+import numpy as np
+import torch
+import torch.optim as optim
+
+from . import model
+from ...utility import utils
+from .... import distributed as adist
+
+try:
+    from torch.utils.tensorboard import SummaryWriter
+except Exception:  # tensorboard is optional
+    class SummaryWriter:
+        def __init__(self, *a, **k):
+            pass
+
+        def add_scalars(self, *a, **k):
+            pass
+
+
+class Engine:
+    def __init__(self, args, loaders=None, template="vision_charts"):
+        np.random.seed(args.seed)
+        torch.manual_seed(args.seed)
+        self.epoch = 0
+        self.best_loss = 10000
+        self.args = args
+        self.last_improvement = 0
+        self.vision_chart_location = template  # packaged atlas (reference: objects/vision_charts.obj) or an OBJ path
+        self._loaders = loaders
+        self.log_interval = getattr(args, "log_interval", 10)
+        self.results_dir = os.path.join("results", args.exp_type, args.exp_id)
+        os.makedirs(self.results_dir, exist_ok=True)
+        self.checkpoint_dir = os.path.join("experiments/checkpoint/", args.exp_type, args.exp_id)
+        os.makedirs(self.checkpoint_dir, exist_ok=True)
+        if not self.args.eval:
+            utils.save_config(self.checkpoint_dir, args)
+        self.rank, self.world, self.local_rank = adist.init_from_env()
+
+    def setup(self):
+        """Everything ``__call__`` does before touching data (reference :52-64)."""
+        self.mesh_info, self.initial_mesh = utils.load_mesh_vision(self.args, self.vision_chart_location)
+        self.n_vision_charts = self.initial_mesh.shape[0]
+        self.encoder = model.Deformation(self.mesh_info, self.initial_mesh, self.args).to(self.initial_mesh.device)
+        adist.broadcast_parameters(self.encoder)
+        self.bucket = None
+        if not self.args.eval:
+            params = list(self.encoder.parameters())
+            self.bucket = adist.FlatGradBucket(params)
+            try:
+                self.optimizer = optim.Adam(params, lr=self.args.lr, weight_decay=0, fused=True)
+            except (RuntimeError, TypeError):
+                self.optimizer = optim.Adam(params, lr=self.args.lr, weight_decay=0, foreach=True)
+
+    def __call__(self):
+        self.setup()
+        writer = SummaryWriter(os.path.join("experiments/tensorboard/", self.args.exp_type))
+        train_loader, valid_loaders = self.get_loaders()
+        if self.args.eval:
+            self.load()
+            with torch.no_grad():
+                self.validate(valid_loaders, writer)
+            return self.current_loss
+        self.load()
+        for epoch in range(self.epoch, self.args.epochs):
+            self.epoch = epoch
+            self.train(train_loader, writer)
+            with torch.no_grad():
+                self.validate(valid_loaders, writer)
+            self.check_values()
+        return self.best_loss
+
+    def get_loaders(self):
+        if self._loaders is not None:
+            return self._loaders
+        try:
+            from torch.utils.data import DataLoader
+            from pterotactyl.utility import data_loaders  # the reference's own datasets (needs download_data.sh)
+        except Exception as e:
+            raise RuntimeError("a3vt: the pterotactyl dataset package is not importable here; pass loaders=(train, valid) "
+                               "to Engine (e.g. a3vt_amd.synthetic.SyntheticLoader)") from e
+        train_loader = ""
+        if not self.args.eval:
+            train_data = data_loaders.mesh_loader_vision(self.args, set_type="recon_train")
+            train_loader = DataLoader(train_data, batch_size=self.args.batch_size, shuffle=True, num_workers=16,
+                                      collate_fn=train_data.collate, pin_memory=True)
+        valid_data = data_loaders.mesh_loader_vision(self.args, set_type="test" if self.args.eval else "valid")
+        valid_loader = DataLoader(valid_data, batch_size=self.args.batch_size, shuffle=False, num_workers=16,
+                                  collate_fn=valid_data.collate, pin_memory=True)
+        return train_loader, valid_loader
+
+    def train_step(self, img, charts, gt_points):
+        """One optimisation step on device tensors; returns the (device) scalar loss.  No host sync."""
+        self.bucket.zero()
+        verts = self.encoder(img, charts)[0]
+        loss = utils.chamfer_distance(verts, self.mesh_info["faces_i32"], gt_points, num=self.args.number_points)
+        loss = self.args.loss_coeff * loss.mean()
+        loss.backward()
+        self.bucket.all_reduce_mean()
+        self.optimizer.step()
+        return loss.detach()
+
+    def train(self, data, writer):
+        total_loss = torch.zeros((), device=self.initial_mesh.device)
+        iterations = 0
+        self.encoder.train()
+        dev = self.initial_mesh.device
+        for k, batch in enumerate(data):
+            img = batch["img"].to(dev, non_blocking=True)
+            gt_points = batch["gt_points"].to(dev, non_blocking=True)
+            with torch.no_grad():
+                charts = model.prepare_mesh(batch, self.initial_mesh, self.args)
+            loss = self.train_step(img, charts, gt_points)
+            total_loss += loss
+            iterations += 1
+            if self.log_interval and k % self.log_interval == 0 and self.rank == 0:
+                print(f"Train || Epoch: {self.epoch}, loss: {loss.item():.2f}, b_ptp:  {self.best_loss:.2f}")
+        if iterations:
+            writer.add_scalars("train_loss", {self.args.exp_id: total_loss.item() / iterations}, self.epoch)
+
+    def validate(self, valid_loader, writer):
+        total_loss = torch.zeros((), device=self.initial_mesh.device)
+        self.encoder.eval()
+        num_examples = 0
+        dev = self.initial_mesh.device
+        for v, batch in enumerate(valid_loader):
+            img = batch["img"].to(dev, non_blocking=True)
+            gt_points = batch["gt_points"].to(dev, non_blocking=True)
+            charts = model.prepare_mesh(batch, self.initial_mesh, self.args)
+            verts = self.encoder(img, charts)[0]
+            loss = utils.chamfer_distance(verts, self.mesh_info["faces_i32"], gt_points, num=self.args.number_points)
+            total_loss += self.args.loss_coeff * loss.sum()
+            num_examples += float(img.shape[0])
+        total = (total_loss / max(num_examples, 1.0)).item()
+        if self.rank == 0:
+            print("*******************************************************")
+            print(f"Validation Accuracy: {total}")
+            print("*******************************************************")
+        if not self.args.eval:
+            writer.add_scalars("valid_ptp", {self.args.exp_id: total}, self.epoch)
+        self.current_loss = total
+
+    def save(self):
+        if self.rank != 0:
+            return
+        torch.save(self.encoder.state_dict(), self.checkpoint_dir + "/model")
+        torch.save(self.optimizer.state_dict(), self.checkpoint_dir + "/optim")
+        np.save(self.checkpoint_dir + "/epoch.npy", np.array([self.epoch + 1]))
+
+    def load(self):
+        if self.args.eval and getattr(self.args, "pretrained", False):
+            location = getattr(self.args, "pretrained_location", None)
+            if location is None:
+                raise RuntimeError("a3vt: pretrained weights are not bundled (reference download_models.sh); set "
+                                   "args.pretrained_location to a directory holding config.json + model")
+            vision_args, _ = utils.load_model_config(location)
+            self.mesh_info, self.initial_mesh = utils.load_mesh_vision(vision_args, self.vision_chart_location)
+            self.n_vision_charts = self.initial_mesh.shape[0]
+            self.encoder = model.Deformation(self.mesh_info, self.initial_mesh, vision_args).to(self.initial_mesh.device)
+            self.encoder.load_state_dict(torch.load(os.path.join(location, "model"), map_location=self.initial_mesh.device))
+            return
+        try:
+            dev = self.initial_mesh.device
+            self.encoder.load_state_dict(torch.load(self.checkpoint_dir + "/model", map_location=dev))
+            self.optimizer.load_state_dict(torch.load(self.checkpoint_dir + "/optim", map_location=dev))
+            self.epoch = int(np.load(self.checkpoint_dir + "/epoch.npy")[0])
+        except (FileNotFoundError, AttributeError):
+            return
+
+    def check_values(self):
+        if self.best_loss >= self.current_loss:
+            improvement = self.best_loss - self.current_loss
+            if self.rank == 0:
+                print(f"Saving with {improvement:.3f} improvement in Chamfer Distance on Validation Set ")
+            self.best_loss = self.current_loss
+            self.last_improvement = 0
+            self.save()
+        else:
+            self.last_improvement += 1
+            if self.last_improvement >= self.args.patience:
+                raise StopIteration(f"Over {self.args.patience} steps since last improvement")

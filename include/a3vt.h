@@ -150,6 +150,16 @@ int a3vt_chamfer_bwd(const float *x, const float *y, int draws, int batch, int p
  * int32, caller-zeroed) to 1 if any of the n floats is NaN/Inf.  No host sync. */
 int a3vt_check_finite(const float *data, size_t n, int32_t *flag, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Measurement aid (no reference counterpart): when enabled, every fp32-MFMA launch of the GCN stack is
+ * bracketed by a HIP event pair on its launch stream.  a3vt_profile_read synchronises on those events
+ * and returns, per kernel class, the summed device time and launch count since the last read:
+ *   [0] forward product Z = X W (hidden layers, 300x300 and the first layer)
+ *   [1] backward product dX = dZ W^T (hidden layers)     [2] backward product dW = X^T dZ
+ * Only hidden x hidden launches are of the headline shape; bench.py divides by the counts it expects. */
+int a3vt_profile_enable(int on);
+int a3vt_profile_read(double *total_ms /*[3]*/, int *count /*[3]*/);
+
 #ifdef __cplusplus
 }
 #endif

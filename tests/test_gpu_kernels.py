@@ -163,7 +163,7 @@ def test_sample_points_rng_statistics(cuda):
     from oracle import chamfer as och
     verts, faces = template("ico1")
     v = torch.from_numpy(verts)[None].clone()
-    v[0, faces[3]] = v[0, faces[3][0]]  # collapse face 3 (and shrink its neighbours)
+    v[0, faces[3]] = v[0, faces[3][0]].clone()  # collapse face 3 (and shrink its neighbours)
     f = torch.from_numpy(faces)
     num = 200000
     pts = ops.SamplePointsFn.apply(v.to(cuda), f.to(torch.int32).to(cuda), num, 1, 1234, 0, None, None, None)
