@@ -72,6 +72,10 @@ def load():
             raise RuntimeError(
                 f"a3vt: native library {LIB_PATH} is missing. Build it with "
                 "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). There is no CPU fallback.")
+        # torch first: its wheel bundles its own libamdhip64.so (same SONAME as /opt/rocm's).  The process must
+        # hold ONE HIP runtime, and it has to be the one torch initialises, or device pointers / streams handed
+        # over from torch mean nothing here ("no ROCm-capable device is detected" otherwise).
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError here = header and library out of sync

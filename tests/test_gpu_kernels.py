@@ -172,16 +172,15 @@ def test_sample_points_rng_statistics(cuda):
     # recover the face of each sample through the saved indices of a second identical call
     from a3vt_amd import lib
     L = lib.load()
+    vdev, fdev = v.to(cuda), f.to(torch.int32).to(cuda)   # keep the device copies alive across the raw C calls
     cdf = torch.empty(1, f.shape[0], device=cuda)
-    lib.check(L.a3vt_face_cdf(lib.ptr(v.to(cuda)), lib.ptr(f.to(torch.int32).to(cuda)), 1, v.shape[1], f.shape[0],
-                              lib.ptr(cdf), None), "cdf")
+    lib.check(L.a3vt_face_cdf(lib.ptr(vdev), lib.ptr(fdev), 1, v.shape[1], f.shape[0], lib.ptr(cdf), None), "cdf")
     torch.cuda.synchronize()
     assert np.allclose(cdf[0].cpu().numpy(), np.cumsum(prob), rtol=1e-5, atol=1e-6)
     fi = torch.empty(1, 1, num, dtype=torch.int32, device=cuda)
     uu = torch.empty(1, 1, num, device=cuda)
     vv = torch.empty(1, 1, num, device=cuda)
     p2 = torch.empty(1, 1, num, 3, device=cuda)
-    vdev, fdev = v.to(cuda), f.to(torch.int32).to(cuda)
     lib.check(L.a3vt_sample_points_fwd(lib.ptr(vdev), lib.ptr(fdev), lib.ptr(cdf), 1, v.shape[1], f.shape[0], 1, num,
                                        None, None, None, 1234, 0, lib.ptr(p2), lib.ptr(fi), lib.ptr(uu), lib.ptr(vv),
                                        None), "sample")
