@@ -29,146 +29,298 @@ __device__ __forceinline__ void wait_vmcnt() {
 __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // ------------------------------------------------------------------------------------------------
-// rowgemm: workgroup = 4 waves; wave w owns rows [w*MT*16, (w+1)*MT*16) of a BM = 64*MT row tile and
-// all NT 16-column tiles.  K is walked in chunks of 16: per chunk the A tile [BM][16] and the Bt
-// tile [BROWS][16] are DMA'd into LDS (two stages).  A fragment read is one ds_read_b128 per
-// (m-tile, chunk): lane l holds A[row l&15][k0 + 4*(l>>4) + t], t = 0..3, and MFMA step t consumes
-// element t of both fragments — the k order inside a chunk is permuted identically for A and B,
-// which a sum over k does not see.
+// rowgemm: persistent workgroups of 8 waves (two per SIMD), one per CU.  The M rows are cut into 32-row
+// units that are dealt evenly to the workgroups; a workgroup walks its units eight at a time (one unit =
+// 2 m-tiles of 16 rows per wave, all NT 16-column tiles -> 2*NT accumulator tiles per wave).
+// K is walked in chunks of 16 through a 3-stage LDS ring filled by LDS-DMA: each wave DMAs its own A rows
+// [32][16] plus 1/8 of the shared Bt chunk [BROWS][16]; chunk t+2 is issued right after the single
+// barrier of iteration t, so two chunks are always in flight under the MFMAs (counted vmcnt, raw s_barrier).
+// A fragment read is one ds_read_b128 per (m-tile, chunk): lane l holds A[row l&15][k0 + 4*(l>>4) + t],
+// t = 0..3, and MFMA step t consumes element t of both fragments — the k order inside a chunk is permuted
+// identically for A and B, which a sum over k does not see.
 // ------------------------------------------------------------------------------------------------
-template <int MT, int NT, int EPI>
-__global__ __launch_bounds__(256, 2) void rowgemm_kernel(RowGemmArgs p) {
-  constexpr int BM = 64 * MT;
-  constexpr int BROWS = ((NT * 16 + 63) / 64) * 64;
-  constexpr int A_INSTR = MT;          // LDS-DMA wave-instructions per wave per chunk for A (16 rows each)
-  constexpr int B_INSTR = BROWS / 64;  // same for Bt
-  constexpr int STAGE = (BM + BROWS) * 16;  // floats per stage
-  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+template <int NT, int EPI>
+__global__ __launch_bounds__(512, 2) void rowgemm_kernel(RowGemmArgs p) {
+  constexpr int MT = 2;
+  constexpr int WAVES = 8;
+  constexpr int BROWS = ((NT * 16 + 127) / 128) * 128;  // Bt rows staged per chunk (multiple of 16 * WAVES)
+  constexpr int A_INSTR = MT;                            // DMA wave-instructions per wave per chunk (16 rows each)
+  constexpr int B_INSTR = BROWS / (16 * WAVES);
+  constexpr int A_FLOATS = WAVES * MT * 16 * 16;
+  constexpr int STAGE = A_FLOATS + BROWS * 16;           // floats per stage
+  constexpr int PER = A_INSTR + B_INSTR;                 // DMA instructions per wave per chunk
+  extern __shared__ __attribute__((aligned(16))) float lds[];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform (SGPR)
-  const int row0 = blockIdx.x * BM;
   const int nchunks = (p.k + 15) >> 4;
   const int l16 = lane & 15, q = lane >> 4;
-
-  // Loop-invariant per-lane source rows for the DMA (row within tile = 16*instr + lane/4, piece = lane%4).
-  const float *a0row[A_INSTR];
-  const float *a1row[A_INSTR];
-#pragma unroll
-  for (int j = 0; j < A_INSTR; ++j) {
-    int r = row0 + (wave * A_INSTR + j) * 16 + (lane >> 2);
-    r = r < p.m ? r : p.m - 1;  // ragged last tile: duplicate the last row (never stored)
-    a0row[j] = p.a0 + (size_t)r * p.lda0;
-    a1row[j] = p.a1 + (size_t)r * p.lda1;
-  }
-  const float *brow[B_INSTR];
-#pragma unroll
-  for (int j = 0; j < B_INSTR; ++j)
-    brow[j] = p.bt + (size_t)((wave * B_INSTR + j) * 16 + (lane >> 2)) * p.ldb;
   const int kpiece = (lane & 3) * 4;
 
-  f32x4 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // units of 32 rows, dealt evenly to the workgroups
+  const int units = (p.m + 31) >> 5;
+  const int ubase = units / gridDim.x, urem = units % gridDim.x;
+  const int u0 = blockIdx.x * ubase + ((int)blockIdx.x < urem ? blockIdx.x : urem);
+  const int u1 = u0 + ubase + ((int)blockIdx.x < urem ? 1 : 0);
 
-  auto issue = [&](int chunk, int buf) {
-    float *sA = lds + buf * STAGE;
-    float *sB = sA + BM * 16;
-    const int kk = chunk * 16 + kpiece;
+  const int col0 = p.col0 + blockIdx.y * (NT * 16);  // column block of this workgroup (remainder launches)
+  const float *brow[B_INSTR];
+#pragma unroll
+  for (int j = 0; j < B_INSTR; ++j) {
+    int br = col0 + (wave * B_INSTR + j) * 16 + (lane >> 2);
+    br = br < p.bt_rows ? br : p.bt_rows - 1;  // rows past the buffer are never consumed
+    brow[j] = p.bt + (size_t)br * p.ldb;
+  }
+
+  for (int ubeg = u0; ubeg < u1; ubeg += WAVES) {
+    const int unit = ubeg + wave;
+    const bool active = unit < u1;  // wave-uniform
+    const int row0 = unit * 32;
+
+    // this wave's A source rows (ragged tail: duplicate the last row, never stored)
+    const float *a0row[A_INSTR];
+    const float *a1row[A_INSTR];
 #pragma unroll
     for (int j = 0; j < A_INSTR; ++j) {
-      const float *src = kk >= p.k ? p.zeros : (kk < p.ksplit ? a0row[j] + kk : a1row[j] + kk);
-      glds16(src, sA + (wave * A_INSTR + j) * 256);
+      int r = row0 + j * 16 + (lane >> 2);
+      r = r < p.m ? r : p.m - 1;
+      a0row[j] = p.a0 + (size_t)r * p.lda0;
+      a1row[j] = p.a1 + (size_t)r * p.lda1;
     }
-#pragma unroll
-    for (int j = 0; j < B_INSTR; ++j) glds16(brow[j] + kk, sB + (wave * B_INSTR + j) * 256);
-  };
 
-  issue(0, 0);
-  for (int t = 0; t < nchunks; ++t) {
-    if (t + 1 < nchunks) {
-      issue(t + 1, (t + 1) & 1);
-      wait_vmcnt<A_INSTR + B_INSTR>();  // chunk t landed; chunk t+1 stays in flight
-    } else {
-      wait_vmcnt<0>();
-    }
-    __builtin_amdgcn_s_barrier();
-    const float *sA = lds + (t & 1) * STAGE;
-    const float *sB = sA + BM * 16;
-    f32x4 af[MT];
+    f32x4 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
-      af[i] = *reinterpret_cast<const f32x4 *>(sA + ((wave * MT + i) * 16 + l16) * 16 + q * 4);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const f32x4 bf = *reinterpret_cast<const f32x4 *>(sB + (j * 16 + l16) * 16 + q * 4);
+      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto issue = [&](int chunk, int buf) {
+      float *sA = lds + buf * STAGE + wave * (MT * 256);
+      float *sB = lds + buf * STAGE + A_FLOATS;
+      const int kk = chunk * 16 + kpiece;
+#pragma unroll
+      for (int j = 0; j < A_INSTR; ++j) {
+        const float *src = (!active || kk >= p.k) ? p.zeros : (kk < p.ksplit ? a0row[j] + kk : a1row[j] + kk);
+        glds16(src, sA + j * 256);
+      }
+#pragma unroll
+      for (int j = 0; j < B_INSTR; ++j) glds16(brow[j] + kk, sB + (wave * B_INSTR + j) * 256);
+    };
+
+    issue(0, 0);
+    if (nchunks > 1) issue(1, 1);
+    int buf = 0;
+    for (int t = 0; t < nchunks; ++t) {
+#ifdef A3VT_DBG_NODMA
+      wait_vmcnt<0>();
+#endif
+      if (t + 1 < nchunks) wait_vmcnt<PER>();  // chunk t landed; chunk t+1 may still be in flight
+      else wait_vmcnt<0>();
+#ifndef A3VT_DBG_NOBARRIER
+      __builtin_amdgcn_s_barrier();  // chunk t visible to all waves; everyone is done with chunk t-1's stage
+#endif
+#ifndef A3VT_DBG_NODMA
+      if (t + 2 < nchunks) issue(t + 2, buf >= 1 ? buf - 1 : 2);  // stage (t+2)%3 == (t-1)%3
+#endif
+      if (active) {
+        const float *sA = lds + buf * STAGE + wave * (MT * 256);
+        const float *sB = lds + buf * STAGE + A_FLOATS;
+        f32x4 af[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4 *>(sA + (i * 16 + l16) * 16 + q * 4);
+        // B fragments two n-tiles at a time, register double-buffered: the ds_reads of pair jp+1 are issued
+        // before the 16 MFMAs of pair jp, so the LDS latency hides under the matrix pipe instead of
+        // stalling it (the two waves of a SIMD run this loop in lockstep and cannot cover for each other).
+        const float *sBl = sB + l16 * 16 + q * 4;  // (non-const only for the ablation build)
+        constexpr int NP = (NT + 1) / 2;
+#ifdef A3VT_DBG_NOLDSREAD
+        if (t > 0) sBl = nullptr;
+        f32x4 bc0 = sBl ? *reinterpret_cast<const f32x4 *>(sBl) : af[0];
+        f32x4 bc1 = sBl ? *reinterpret_cast<const f32x4 *>(sBl + 256) : af[1];
+#else
+        f32x4 bc0 = *reinterpret_cast<const f32x4 *>(sBl);
+        f32x4 bc1 = NT > 1 ? *reinterpret_cast<const f32x4 *>(sBl + 256) : f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
+#pragma unroll
+        for (int jp = 0; jp < NP; ++jp) {
+          f32x4 bn0 = bc0, bn1 = bc1;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            if (s == 1) {  // prefetch the next pair one MFMA group into this block: 12 MFMAs (>= 384 cycles) of cover
+              __builtin_amdgcn_sched_barrier(0);
+#ifdef A3VT_DBG_NOLDSREAD
+              if (jp + 1 < NP && sBl) {
+#else
+              if (jp + 1 < NP) {
+#endif
+                bn0 = *reinterpret_cast<const f32x4 *>(sBl + (2 * jp + 2) * 256);
+                if (2 * jp + 3 < NT) bn1 = *reinterpret_cast<const f32x4 *>(sBl + (2 * jp + 3) * 256);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+              acc[i][2 * jp] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bc0[s], acc[i][2 * jp], 0, 0, 0);
+              if (2 * jp + 1 < NT)
+                acc[i][2 * jp + 1] =
+                    __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bc1[s], acc[i][2 * jp + 1], 0, 0, 0);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          bc0 = bn0;
+          bc1 = bn1;
+        }
+      }
+      buf = buf == 2 ? 0 : buf + 1;
+    }
+    wait_lgkm0();
+    __builtin_amdgcn_s_barrier();  // all waves finished reading the ring -> reuse it for the epilogue
+
+    // Epilogue.  C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg — a lane holds 4 rows
+    // of one column, so direct stores would be 64-byte fragments.  Each wave transposes its accumulators through
+    // a private slice of the idle ring and moves whole rows with 16-byte accesses (the ReLU-mask read of
+    // EPI_DX_MASK included): 4x fewer, fully coalesced global instructions.
+#ifdef A3VT_DBG_NOEPI
+    if (active && p.m < 0) {
+#else
+    if (active) {
+#endif
+      float *ep = lds + wave * ((3 * STAGE) / WAVES);
+      constexpr int G0 = (NT + 1) / 2;  // n-tiles in the first column group (second gets NT - G0)
+      static_assert(16 * (G0 * 16 + 4) <= (3 * STAGE) / WAVES, "epilogue slice too small");
+      const bool vec_ok = (p.ldc % 4 == 0) && (EPI != EPI_FWD_HIDDEN || p.ldc2 % 4 == 0) &&
+                          (EPI != EPI_DX_MASK || p.ldmask % 4 == 0);
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[s], acc[i][j], 0, 0, 0);
-      }
-    }
-    wait_lgkm0();
-    __builtin_amdgcn_s_barrier();  // everyone finished reading stage t&1 before it is refilled
-  }
-
-  // Epilogue. C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg.
+        for (int grp = 0; grp < 2; ++grp) {
+          const int j0 = grp == 0 ? 0 : G0;
+          const int tiles = grp == 0 ? G0 : NT - G0;
+          if (tiles == 0) continue;
+          const int ncols = tiles * 16, stride = ncols + 4, f4row = ncols / 4;
+          __builtin_amdgcn_wave_barrier();
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
+          for (int jj = 0; jj < G0; ++jj) {
+            if (jj < tiles) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = row0 + (wave * MT + i) * 16 + q * 4 + r;
-      if (row >= p.m) continue;
+              for (int r = 0; r < 4; ++r) ep[(q * 4 + r) * stride + jj * 16 + l16] = acc[i][j0 + jj][r];
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+          const int nf4 = 16 * f4row;
+          for (int f = lane; f < nf4; f += 64) {
+            const int rl = f / f4row, c4 = f - rl * f4row;
+            const int row = row0 + i * 16 + rl;
+            const int col = col0 + j0 * 16 + c4 * 4;
+            if (row >= p.m || col >= p.n_store) continue;
+            f32x4 v = *reinterpret_cast<const f32x4 *>(ep + rl * stride + c4 * 4);
+            const bool full = vec_ok && col + 3 < p.n_store;
+            if (EPI == EPI_PLAIN) {
+              float *dst = p.c + (size_t)row * p.ldc + col;
+              if (full) {
+                *reinterpret_cast<f32x4 *>(dst) = v;
+              } else {
+                for (int t = 0; t < 4; ++t)
+                  if (col + t < p.n_store) dst[t] = v[t];
+              }
+            } else if (EPI == EPI_FWD_HIDDEN) {
+              if (full && col + 3 < p.csplit) {  // aggregated channels: raw Z for the neighbour gather
+                *reinterpret_cast<f32x4 *>(p.c2 + (size_t)row * p.ldc2 + col) = v;
+              } else if (full && col >= p.csplit) {  // pass-through channels: ReLU(Z), no bias
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int col = j * 16 + l16;
-        if (col >= p.n_store) continue;
-        const float v = acc[i][j][r];
-        if (EPI == EPI_PLAIN) {
-          p.c[(size_t)row * p.ldc + col] = v;
-        } else if (EPI == EPI_FWD_HIDDEN) {
-          if (col < p.csplit)
-            p.c2[(size_t)row * p.ldc2 + col] = v;  // raw Z for the neighbour aggregation
-          else
-            p.c[(size_t)row * p.ldc + col] = v > 0.f ? v : 0.f;  // un-aggregated channels: ReLU(Z), no bias
-        } else {  // EPI_DX_MASK: gradient through the ReLU of the producing layer
-          const float y = p.mask[(size_t)row * p.ldmask + col];
-          p.c[(size_t)row * p.ldc + col] = y > 0.f ? v : 0.f;
+                for (int t = 0; t < 4; ++t) v[t] = v[t] > 0.f ? v[t] : 0.f;
+                *reinterpret_cast<f32x4 *>(p.c + (size_t)row * p.ldc + col) = v;
+              } else {
+                for (int t = 0; t < 4; ++t) {
+                  if (col + t >= p.n_store) break;
+                  if (col + t < p.csplit) p.c2[(size_t)row * p.ldc2 + col + t] = v[t];
+                  else p.c[(size_t)row * p.ldc + col + t] = v[t] > 0.f ? v[t] : 0.f;
+                }
+              }
+            } else {  // EPI_DX_MASK: gradient through the ReLU of the producing layer
+              const float *mk = p.mask + (size_t)row * p.ldmask + col;
+              float *dst = p.c + (size_t)row * p.ldc + col;
+              if (full) {
+                const f32x4 y = *reinterpret_cast<const f32x4 *>(mk);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = y[t] > 0.f ? v[t] : 0.f;
+                *reinterpret_cast<f32x4 *>(dst) = v;
+              } else {
+                for (int t = 0; t < 4; ++t)
+                  if (col + t < p.n_store) dst[t] = mk[t] > 0.f ? v[t] : 0.f;
+              }
+            }
+          }
         }
       }
     }
+    wait_lgkm0();
+    __builtin_amdgcn_s_barrier();  // epilogue slices are free again before the next super-tile's DMA
   }
 }
 
+template <int NT>
+static constexpr int rowgemm_brows() { return ((NT * 16 + 127) / 128) * 128; }
+
 template <int NT, int EPI>
-static int launch_rowgemm_nt(const RowGemmArgs &a, hipStream_t s) {
-  constexpr int MT = 2;
-  const int grid = cdiv(a.m, 64 * MT);
-  A3VT_LAUNCH((rowgemm_kernel<MT, NT, EPI>), dim3(grid), dim3(256), 0, s, a);
+static int launch_rowgemm_nt(const RowGemmArgs &a, int grid_y, hipStream_t s) {
+  constexpr size_t shmem = 3 * (size_t)(8 * 2 * 256 + rowgemm_brows<NT>() * 16) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)rowgemm_kernel<NT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)shmem);
+    attr_set = true;
+  }
+  const int units = cdiv(a.m, 32);
+  const int grid = units < 8 * 256 ? cdiv(units, 8) : 256;
+  A3VT_LAUNCH((rowgemm_kernel<NT, EPI>), dim3(grid, grid_y), dim3(512), shmem, s, a);
   A3VT_CHECK_LAUNCH();
   return 0;
 }
 
 template <int EPI>
-static int launch_rowgemm_epi(const RowGemmArgs &a, hipStream_t s) {
+static int launch_rowgemm_cols(const RowGemmArgs &a, hipStream_t s) {
   const int nt = cdiv(a.n_store, 16);
-  if (nt <= 1) return launch_rowgemm_nt<1, EPI>(a, s);
-  if (nt <= 4) return launch_rowgemm_nt<4, EPI>(a, s);
-  if (nt <= 7) return launch_rowgemm_nt<7, EPI>(a, s);
-  if (nt <= 13) return launch_rowgemm_nt<13, EPI>(a, s);
-  if (nt <= 19) return launch_rowgemm_nt<19, EPI>(a, s);
+  if (nt <= 1) return launch_rowgemm_nt<1, EPI>(a, 1, s);
+  if (nt <= 4) return launch_rowgemm_nt<4, EPI>(a, 1, s);
+  if (nt <= 8) return launch_rowgemm_nt<8, EPI>(a, 1, s);
+  if (nt <= 13) return launch_rowgemm_nt<13, EPI>(a, 1, s);
+  if (nt <= 19) return launch_rowgemm_nt<19, EPI>(a, 1, s);
   set_error("rowgemm: n_out=%d > 304 not supported yet", a.n_store);
   return -1;
+}
+
+// Load balance.  A wave owns 32-row units and the chip has 1024 wave slots doing MFMA at full rate
+// (256 CUs x 4 SIMDs), so M = 163,968 rows = 5124 units would leave 1020 SIMDs idle while 4 of them run
+// a sixth unit (+20 % time).  When such a small remainder exists, the rows that fill whole rounds go to
+// the main launch and the leftover rows are re-cut along N: one 16-column tile per workgroup.
+template <int EPI>
+static int launch_rowgemm_epi(const RowGemmArgs &a0, hipStream_t s) {
+  RowGemmArgs a = a0;
+  a.bt_rows = rowgemm_bt_rows(a.n_store);
+  a.col0 = 0;
+  const int units = cdiv(a.m, 32), nt = cdiv(a.n_store, 16);
+  const int full = units / 1024 * 1024, rem = units - full;
+  if (full == 0 || rem == 0 || rem * nt > 512 || nt < 2) return launch_rowgemm_cols<EPI>(a, s);
+  RowGemmArgs m = a;
+  m.m = full * 32;
+  if (int rc = launch_rowgemm_cols<EPI>(m, s)) return rc;
+  RowGemmArgs r = a;
+  const size_t r0 = (size_t)full * 32;
+  r.m = a.m - (int)r0;
+  r.a0 = a.a0 + r0 * a.lda0;
+  r.a1 = a.a1 + r0 * a.lda1;
+  r.c = a.c + r0 * a.ldc;
+  if (a.c2) r.c2 = a.c2 + r0 * a.ldc2;
+  if (a.mask) r.mask = a.mask + r0 * a.ldmask;
+  return launch_rowgemm_nt<1, EPI>(r, nt, s);
 }
 
 // Rows of Bt the kernel stages for a given n (must exist, zero padded, in the Bt buffer).
 int rowgemm_bt_rows(int n_store) {
   const int nt = cdiv(n_store, 16);
-  const int tnt = nt <= 1 ? 1 : nt <= 4 ? 4 : nt <= 7 ? 7 : nt <= 13 ? 13 : 19;
-  return ((tnt * 16 + 63) / 64) * 64;
+  const int tnt = nt <= 1 ? 1 : nt <= 4 ? 4 : nt <= 8 ? 8 : nt <= 13 ? 13 : 19;
+  return ((tnt * 16 + 127) / 128) * 128;
 }
 
 int launch_rowgemm(const RowGemmArgs &a, int epi, hipStream_t s) {
@@ -240,6 +392,34 @@ int launch_copy_pad(const float *w, int rows_in, int cols_in, float *out, int ro
 // ------------------------------------------------------------------------------------------------
 constexpr int DW_MAXI = 5;   // input-channel tiles per wave
 constexpr int DW_MAXO = 3;   // output-channel tiles per wave
+
+// One 16-row stage: 4 k-steps of up to NI x NO MFMAs.  NI/NO < 0 selects the guarded generic form.
+template <int NI, int NO>
+__device__ __forceinline__ void dw_stage(const float *__restrict__ sb, int ldx, int ldz0, int ldz1, int offG,
+                                         int xoff, const int (&zoff)[DW_MAXO], int q, int ni, int no,
+                                         f32x4 (&acc)[DW_MAXI][DW_MAXO]) {
+#pragma unroll 1
+  for (int ks = 0; ks < 4; ++ks) {
+    const int r = ks * 4 + q;
+    const float *xr = sb + r * ldx + xoff;
+    const int ra = r * ldz0, rg = r * ldz1;
+    float a[DW_MAXI], b[DW_MAXO];
+#pragma unroll
+    for (int i = 0; i < DW_MAXI; ++i) a[i] = (NI >= 0 ? i < NI : i < ni) ? xr[i * 16] : 0.f;
+#pragma unroll
+    for (int j = 0; j < DW_MAXO; ++j)
+      b[j] = (NO >= 0 ? j < NO : j < no) ? sb[zoff[j] + (zoff[j] < offG ? ra : rg)] : 0.f;
+#pragma unroll
+    for (int i = 0; i < DW_MAXI; ++i) {
+      if (NI >= 0 ? i < NI : i < ni) {
+#pragma unroll
+        for (int j = 0; j < DW_MAXO; ++j)
+          if (NO >= 0 ? j < NO : j < no)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+}
 
 __global__ __launch_bounds__(1024, 1) void dw_kernel(DwArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -330,38 +510,21 @@ __global__ __launch_bounds__(1024, 1) void dw_kernel(DwArgs p) {
     zoff[j] = col < p.zsplit ? offA + col : offG + col;
   }
 
+  // 3-stage ring, one barrier per 16-row stage; unit t+2 is issued right after the barrier of iteration t.
+  const int xoff = i0 * 16 + l16;
   if (nu > 0) issue(u0, 0);
+  if (nu > 1) issue(u0 + 1, 1);
+  int buf = 0;
   for (int t = 0; t < nu; ++t) {
-    if (t + 1 < nu) {
-      issue(u0 + t + 1, (t + 1) & 1);
-      wait_vmcnt<3>();
-    } else {
-      wait_vmcnt<0>();
-    }
+    if (t + 1 < nu) wait_vmcnt<3>();
+    else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    const float *sb = lds + (t & 1) * stage;
-#pragma unroll 1
-    for (int ks = 0; ks < 4; ++ks) {
-      const int r = ks * 4 + q;
-      const float *xr = sb + r * p.ldx + i0 * 16 + l16;
-      const int ra = r * p.ldz0, rg = r * p.ldz1;
-      float a[DW_MAXI], b[DW_MAXO];
-#pragma unroll
-      for (int i = 0; i < DW_MAXI; ++i) a[i] = i < ni ? xr[i * 16] : 0.f;
-#pragma unroll
-      for (int j = 0; j < DW_MAXO; ++j) b[j] = j < no ? sb[zoff[j] + (zoff[j] < offG ? ra : rg)] : 0.f;
-#pragma unroll
-      for (int i = 0; i < DW_MAXI; ++i) {
-        if (i < ni) {
-#pragma unroll
-          for (int j = 0; j < DW_MAXO; ++j)
-            if (j < no) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-      }
-    }
-    wait_lgkm0();
-    __builtin_amdgcn_s_barrier();
+    if (t + 2 < nu) issue(u0 + t + 2, buf >= 1 ? buf - 1 : 2);
+    const float *sb = lds + buf * stage;
+    dw_stage<-1, -1>(sb, p.ldx, p.ldz0, p.ldz1, offG, xoff, zoff, q, ni, no, acc);
+    buf = buf == 2 ? 0 : buf + 1;
   }
+  wait_lgkm0();
 
   // Partial -> slab[blockIdx][k_in][n_out]  (row = input channel, col = output channel)
   float *slab = p.slab + (size_t)blockIdx.x * p.k_in * p.n_out;
@@ -399,7 +562,11 @@ int launch_dw(const DwArgs &a, hipStream_t s) {
     set_error("dw: rows too wide (%d + %d + %d floats)", a.ldx, a.ldz0, a.ldz1);
     return -1;
   }
-  const size_t shmem = 2 * (size_t)((xin + ain + gin) * 256 + 256) * sizeof(float);
+  const size_t shmem = 3 * (size_t)((xin + ain + gin) * 256 + 256) * sizeof(float);
+  if (shmem > 160 * 1024) {
+    set_error("dw: rows too wide for the 3-stage ring (%zu B)", shmem);
+    return -1;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void *)dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -410,25 +577,32 @@ int launch_dw(const DwArgs &a, hipStream_t s) {
   return 0;
 }
 
-// out[i] = sum_s slab[s][i]   (fixed order -> bitwise reproducible)
-__global__ void slab_reduce_kernel(const float *__restrict__ slab, int nslab, size_t stride, size_t n,
-                                   float *__restrict__ out) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int s = 0;
-  for (; s + 3 < nslab; s += 4) {
-    s0 += slab[(size_t)s * stride + i];
-    s1 += slab[(size_t)(s + 1) * stride + i];
-    s2 += slab[(size_t)(s + 2) * stride + i];
-    s3 += slab[(size_t)(s + 3) * stride + i];
+// out[i] = sum_s slab[s * stride + i]   (fixed summation order -> bitwise reproducible).
+// Workgroup = 64 consecutive outputs x 4 slab groups: each thread sums a quarter of the slabs with 8 loads
+// in flight, then the four partials are combined through LDS in a fixed order.
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slab, int nslab, size_t stride,
+                                                          size_t n, float *__restrict__ out) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const size_t i = (size_t)blockIdx.x * 64 + lane;
+  const int per = (nslab + 3) / 4;
+  const int s0 = grp * per, s1 = min(s0 + per, nslab);
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (i < n) {
+    int s = s0;
+    for (; s + 7 < s1; s += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += slab[(size_t)(s + u) * stride + i];
+    }
+    for (; s < s1; ++s) a[0] += slab[(size_t)s * stride + i];
   }
-  for (; s < nslab; ++s) s0 += slab[(size_t)s * stride + i];
-  out[i] = (s0 + s1) + (s2 + s3);
+  part[grp][lane] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  if (grp == 0 && i < n) out[i] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
 int launch_slab_reduce(const float *slab, int nslab, size_t stride, size_t n, float *out, hipStream_t s) {
-  A3VT_LAUNCH(slab_reduce_kernel, dim3(cdiv((long long)n, 256)), dim3(256), 0, s, slab, nslab, stride, n, out);
+  A3VT_LAUNCH(slab_reduce_kernel, dim3(cdiv((long long)n, 64)), dim3(256), 0, s, slab, nslab, stride, n, out);
   A3VT_CHECK_LAUNCH();
   return 0;
 }

@@ -18,6 +18,8 @@ struct RowGemmArgs {
   float *c;            // main output [M][ldc]
   float *c2;           // EPI_FWD_HIDDEN: raw output for cols < csplit, [M][ldc2]
   int lda0, lda1, ksplit, ldb;
+  int bt_rows;  // rows present in the Bt buffer (set by launch_rowgemm)
+  int col0;     // first output column handled by blockIdx.y == 0 (set by launch_rowgemm)
   int m, k, n_store;
   int ldc, ldc2, csplit, ldmask;
 };

@@ -142,8 +142,10 @@ int launch_posenc_fwd(const float *verts, const float *mask, int m, int input_si
 }
 
 // ------------------------------------------------------------------------------------------------
-// Backward.  Workgroup = 128 vertices.  Three LDS phases reduce the outer products over the
-// workgroup's vertices:  (gout, h2) -> dW3, db3, dE ;  (dh2, h1) -> dW2, db2 ;  (dh1, e) -> dW1, db1.
+// Backward.  Workgroup = 128 vertices, one per thread.  Every per-vertex vector the weight-gradient outer
+// products need (e, gout, h2, dh2, h1, dh1) is parked in LDS rows; the thread keeps only the small hidden
+// vectors in registers and walks the long ones with rolled loops (no spills).  After one barrier the
+// workgroup reduces the outer products over its 128 vertices and writes one slab of partial gradients.
 // ------------------------------------------------------------------------------------------------
 constexpr int kPEBwdThreads = 128;
 
@@ -159,10 +161,16 @@ __global__ __launch_bounds__(kPEBwdThreads) void posenc_bwd_kernel(const float *
   using P = PE<I>;
   using L = PELds<I>;
   constexpr int T = kPEBwdThreads;
-  __shared__ float sp[L::N];
-  __shared__ float sa[T * 63];  // "left" vectors of the phase:  gout[I] / dh2[H2] / dh1[H1]   (row stride = width)
-  __shared__ float sb[T * 63];  // "right" vectors:              h2[H2]  / h1[H1]  / e[63]
-  __shared__ int stok[T];
+  constexpr int H1 = P::H1, H2 = P::H2;
+  extern __shared__ float smem[];
+  float *sp = smem;                  // parameters (transposed image)
+  float *sE = sp + L::N;             // [T][63]
+  float *sG = sE + T * 63;           // [T][I]   gout
+  float *sH2 = sG + T * I;           // [T][H2]
+  float *sD2 = sH2 + T * H2;         // [T][H2]  dh2
+  float *sH1 = sD2 + T * H2;         // [T][H1]
+  float *sD1 = sH1 + T * H1;         // [T][H1]  dh1
+  int *stok = reinterpret_cast<int *>(sD1 + T * H1);
   pe_load_params<I>(params, sp);
   __syncthreads();
   const int t = threadIdx.x;
@@ -176,40 +184,120 @@ __global__ __launch_bounds__(kPEBwdThreads) void posenc_bwd_kernel(const float *
     p[1] = verts[3 * (long long)v + 1];
     p[2] = verts[3 * (long long)v + 2];
   }
-  float e[63], h1[P::H1], h2[P::H2];
-  pe_embed<I>(p, e);
-  pe_mlp<I>(sp, e, h1, h2);
+  // ---- forward recompute: e -> LDS, h1 / h2 in registers
+  float *myE = sE + t * 63;
+#pragma unroll 1
+  for (int i = 0; i < 10; ++i) {
+    const float f = pe_freq(i);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      myE[6 * i + c] = sinf(f * p[c]);
+      myE[6 * i + 3 + c] = cosf(f * p[c]);
+    }
+  }
+  myE[60] = p[0];
+  myE[61] = p[1];
+  myE[62] = p[2];
+  float h1[H1], h2[H2];
+#pragma unroll
+  for (int j = 0; j < H1; ++j) h1[j] = sp[L::ob1 + j];
+#pragma unroll 1
+  for (int k = 0; k < 63; ++k) {
+    const float ek = myE[k];
+#pragma unroll
+    for (int j = 0; j < H1; ++j) h1[j] += sp[L::oW1t + k * H1 + j] * ek;
+  }
+#pragma unroll
+  for (int j = 0; j < H1; ++j) {
+    h1[j] = h1[j] > 0.f ? h1[j] : 0.f;
+    sH1[t * H1 + j] = h1[j];
+  }
+#pragma unroll
+  for (int j = 0; j < H2; ++j) h2[j] = sp[L::ob2 + j];
+#pragma unroll
+  for (int k = 0; k < H1; ++k)
+#pragma unroll
+    for (int j = 0; j < H2; ++j) h2[j] += sp[L::oW2t + k * H2 + j] * h1[k];
+#pragma unroll
+  for (int j = 0; j < H2; ++j) {
+    h2[j] = h2[j] > 0.f ? h2[j] : 0.f;
+    sH2[t * H2 + j] = h2[j];
+  }
   int tok = live ? (int)mask[v] : 0;
   tok = tok < 0 ? 0 : (tok > 3 ? 3 : tok);
   stok[t] = live ? tok : -1;
 
-  // ---- phase A: gout (I) x h2 (H2)
-  float dh2[P::H2];
+  // ---- backward through the MLP
+  float dh2[H2];
 #pragma unroll
-  for (int k = 0; k < P::H2; ++k) dh2[k] = 0.f;
-#pragma unroll
+  for (int k = 0; k < H2; ++k) dh2[k] = 0.f;
+#pragma unroll 1
   for (int o = 0; o < I; ++o) {
     const float g = live ? gfeats[(long long)v * ld + o] : 0.f;
-    sa[t * I + o] = g;
+    sG[t * I + o] = g;
 #pragma unroll
-    for (int k = 0; k < P::H2; ++k) dh2[k] += sp[L::oW3t + k * I + o] * g;
+    for (int k = 0; k < H2; ++k) dh2[k] += sp[L::oW3t + k * I + o] * g;
   }
 #pragma unroll
-  for (int k = 0; k < P::H2; ++k) {
-    sb[t * P::H2 + k] = h2[k];
+  for (int k = 0; k < H2; ++k) {
     dh2[k] = h2[k] > 0.f ? dh2[k] : 0.f;
+    sD2[t * H2 + k] = dh2[k];
+  }
+  float dh1[H1];
+#pragma unroll
+  for (int k = 0; k < H1; ++k) dh1[k] = 0.f;
+#pragma unroll
+  for (int j = 0; j < H2; ++j)
+#pragma unroll
+    for (int k = 0; k < H1; ++k) dh1[k] += sp[L::oW2t + k * H2 + j] * dh2[j];
+#pragma unroll
+  for (int k = 0; k < H1; ++k) {
+    dh1[k] = h1[k] > 0.f ? dh1[k] : 0.f;
+    sD1[t * H1 + k] = dh1[k];
+  }
+  // gradient w.r.t. the position: de_k = sum_j W1[j][k] dh1[j];
+  // d sin(f p)/dp = f cos(f p) = f e[6i+3+c],  d cos(f p)/dp = -f sin(f p) = -f e[6i+c]
+  float gp[3] = {0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int i = 0; i < 10; ++i) {
+    const float f = pe_freq(i);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float ds = 0.f, dc = 0.f;
+#pragma unroll
+      for (int j = 0; j < H1; ++j) {
+        ds += sp[L::oW1t + (6 * i + c) * H1 + j] * dh1[j];
+        dc += sp[L::oW1t + (6 * i + 3 + c) * H1 + j] * dh1[j];
+      }
+      gp[c] += f * (myE[6 * i + 3 + c] * ds - myE[6 * i + c] * dc);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float d = 0.f;
+#pragma unroll
+    for (int j = 0; j < H1; ++j) d += sp[L::oW1t + (60 + c) * H1 + j] * dh1[j];
+    gp[c] += d;
+  }
+  if (live) {
+    gverts[3 * (long long)v + 0] = gp[0];
+    gverts[3 * (long long)v + 1] = gp[1];
+    gverts[3 * (long long)v + 2] = gp[2];
   }
   __syncthreads();
-  for (int idx = t; idx < I * P::H2; idx += T) {  // dW3[o][k]
-    const int o = idx / P::H2, k = idx % P::H2;
+
+  // ---- workgroup reductions of the outer products (fixed order over the 128 vertices)
+  for (int idx = t; idx < I * H2; idx += T) {  // dW3[o][k] = sum_v gout[v][o] h2[v][k]
+    const int o = idx / H2, k = idx % H2;
     float s = 0.f;
-    for (int r = 0; r < T; ++r) s += sa[r * I + o] * sb[r * P::H2 + k];
+#pragma unroll 8
+    for (int r = 0; r < T; ++r) s += sG[r * I + o] * sH2[r * H2 + k];
     out[P::oW3 + idx] = s;
   }
   for (int o = t; o < I; o += T) {  // db3, dE
     float s = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     for (int r = 0; r < T; ++r) {
-      const float g = sa[r * I + o];
+      const float g = sG[r * I + o];
       const int tk = stok[r];
       s += g;
       s0 += tk == 0 ? g : 0.f;
@@ -223,74 +311,37 @@ __global__ __launch_bounds__(kPEBwdThreads) void posenc_bwd_kernel(const float *
     out[P::oE + 2 * I + o] = s2;
     out[P::oE + 3 * I + o] = s3;
   }
-  __syncthreads();
-
-  // ---- phase B: dh2 (H2) x h1 (H1)
-  float dh1[P::H1];
-#pragma unroll
-  for (int k = 0; k < P::H1; ++k) dh1[k] = 0.f;
-#pragma unroll
-  for (int j = 0; j < P::H2; ++j) {
-    sa[t * P::H2 + j] = dh2[j];
-#pragma unroll
-    for (int k = 0; k < P::H1; ++k) dh1[k] += sp[L::oW2t + k * P::H2 + j] * dh2[j];
-  }
-#pragma unroll
-  for (int k = 0; k < P::H1; ++k) {
-    sb[t * P::H1 + k] = h1[k];
-    dh1[k] = h1[k] > 0.f ? dh1[k] : 0.f;
-  }
-  __syncthreads();
-  for (int idx = t; idx < P::H2 * P::H1; idx += T) {  // dW2[j][k]
-    const int j = idx / P::H1, k = idx % P::H1;
+  for (int idx = t; idx < H2 * H1; idx += T) {  // dW2[j][k] = sum_v dh2[v][j] h1[v][k]
+    const int j = idx / H1, k = idx % H1;
     float s = 0.f;
-    for (int r = 0; r < T; ++r) s += sa[r * P::H2 + j] * sb[r * P::H1 + k];
+#pragma unroll 8
+    for (int r = 0; r < T; ++r) s += sD2[r * H2 + j] * sH1[r * H1 + k];
     out[P::oW2 + idx] = s;
   }
-  for (int j = t; j < P::H2; j += T) {
+  for (int j = t; j < H2; j += T) {
     float s = 0.f;
-    for (int r = 0; r < T; ++r) s += sa[r * P::H2 + j];
+    for (int r = 0; r < T; ++r) s += sD2[r * H2 + j];
     out[P::ob2 + j] = s;
   }
-  __syncthreads();
-
-  // ---- phase C: dh1 (H1) x e (63), and the gradient w.r.t. the position
-  float de[63];
-#pragma unroll
-  for (int k = 0; k < 63; ++k) de[k] = 0.f;
-#pragma unroll
-  for (int j = 0; j < P::H1; ++j) {
-    sa[t * P::H1 + j] = dh1[j];
-#pragma unroll
-    for (int k = 0; k < 63; ++k) de[k] += sp[L::oW1t + k * P::H1 + j] * dh1[j];
-  }
-#pragma unroll
-  for (int k = 0; k < 63; ++k) sb[t * 63 + k] = e[k];
-  __syncthreads();
-  for (int idx = t; idx < P::H1 * 63; idx += T) {  // dW1[j][k]
+  for (int idx = t; idx < H1 * 63; idx += T) {  // dW1[j][k] = sum_v dh1[v][j] e[v][k]
     const int j = idx / 63, k = idx % 63;
     float s = 0.f;
-    for (int r = 0; r < T; ++r) s += sa[r * P::H1 + j] * sb[r * 63 + k];
+#pragma unroll 8
+    for (int r = 0; r < T; ++r) s += sD1[r * H1 + j] * sE[r * 63 + k];
     out[P::oW1 + idx] = s;
   }
-  for (int j = t; j < P::H1; j += T) {
+  for (int j = t; j < H1; j += T) {
     float s = 0.f;
-    for (int r = 0; r < T; ++r) s += sa[r * P::H1 + j];
+    for (int r = 0; r < T; ++r) s += sD1[r * H1 + j];
     out[P::ob1 + j] = s;
   }
-  if (live) {
-    // d sin(f p)/dp = f cos(f p) = f * e[6i+3+c];  d cos(f p)/dp = -f sin(f p) = -f * e[6i+c]
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      float g = de[60 + c];
-#pragma unroll
-      for (int i = 0; i < 10; ++i) {
-        const float f = pe_freq(i);
-        g += f * (e[6 * i + 3 + c] * de[6 * i + c] - e[6 * i + c] * de[6 * i + 3 + c]);
-      }
-      gverts[3 * (long long)v + c] = g;
-    }
-  }
+}
+
+template <int I>
+static size_t posenc_bwd_smem() {
+  using P = PE<I>;
+  constexpr int T = kPEBwdThreads;
+  return (size_t)(PELds<I>::N + T * (63 + I + 2 * P::H2 + 2 * P::H1)) * sizeof(float) + T * sizeof(int);
 }
 
 int launch_posenc_bwd(const float *verts, const float *mask, int m, int input_size, const float *params,
@@ -300,8 +351,14 @@ int launch_posenc_bwd(const float *verts, const float *mask, int m, int input_si
     return -1;
   }
   const int nslab = posenc_num_slabs(m);
-  A3VT_LAUNCH((posenc_bwd_kernel<50>), dim3(nslab), dim3(kPEBwdThreads), 0, s, verts, mask, m, params, gfeats,
-                     ld, gverts, scratch);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)posenc_bwd_kernel<50>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)posenc_bwd_smem<50>());
+    attr_set = true;
+  }
+  A3VT_LAUNCH((posenc_bwd_kernel<50>), dim3(nslab), dim3(kPEBwdThreads), posenc_bwd_smem<50>(), s, verts, mask, m,
+              params, gfeats, ld, gverts, scratch);
   A3VT_CHECK_LAUNCH();
   return launch_slab_reduce(scratch, nslab, PE<50>::N, PE<50>::N, gparams, s);
 }

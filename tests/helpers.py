@@ -37,6 +37,15 @@ def rel_err(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
+def rel_l2(a, b):
+    """Relative L2 error.  Used for GRADIENTS through ReLU layers: a pre-activation within rounding of 0 can
+    switch sign between two correct fp32/fp64 evaluations, which flips that unit's gradient (a jump, not a
+    rounding error) for a handful of rows at large M; the max-norm then measures the kink, the L2 norm does not."""
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
 def random_cloud(batch, n, seed, kind="ellipsoid"):
     g = np.random.default_rng(seed)
     if kind == "cube":

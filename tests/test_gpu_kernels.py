@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import make_args, oracle_adj, random_cloud, rel_err, template
+from helpers import make_args, oracle_adj, random_cloud, rel_err, rel_l2, template
 
 pytestmark = pytest.mark.gpu
 
@@ -13,7 +13,8 @@ def test_library_loads(cuda):
     assert lib.load().a3vt_version() == 100
 
 
-@pytest.mark.parametrize("m,k,n", [(128, 16, 16), (1000, 52, 300), (4099, 300, 300), (300, 300, 50), (77, 300, 3)])
+@pytest.mark.parametrize("m,k,n", [(128, 16, 16), (1000, 52, 300), (4099, 300, 300), (300, 300, 50), (77, 300, 3),
+                                   (32868, 300, 300), (33000, 52, 100)])  # the last two take the main + N-split remainder path
 def test_rowgemm_matches_fp64(cuda, m, k, n):
     from a3vt_amd import ops
     g = torch.Generator().manual_seed(m + k + n)
@@ -30,7 +31,8 @@ def _state_to(dev, st):
 
 
 @pytest.mark.parametrize("tname,use_touch,L,H,B", [("ico2", False, 3, 32, 3), ("atlas", True, 4, 300, 2),
-                                                     ("ico3", False, 20, 300, 2), ("ico2", False, 1, 300, 2)])
+                                                     ("ico3", False, 20, 300, 2), ("ico2", False, 1, 300, 2),
+                                                     ("ico4", False, 3, 300, 13)])  # 33306 rows: split launches
 def test_gcn_stack_fwd_bwd(cuda, tname, use_touch, L, H, B):
     from a3vt_amd import mesh as amesh, ops
     from oracle import gcn as og
@@ -61,11 +63,14 @@ def test_gcn_stack_fwd_bwd(cuda, tname, use_touch, L, H, B):
     out = ops.gcn_stack(fd, adj, 50, H, round(H * 0.33), ws, bs)
     (out * gup.to(cuda)).sum().backward()
     assert rel_err(out, out_o) < 1e-4
-    assert rel_err(fd.grad[..., :50], f64.grad) < 1e-4
+    # gradients: L2-relative 1e-5 (see helpers.rel_l2 for why not max-norm), max-norm only loosely
+    assert rel_l2(fd.grad[..., :50], f64.grad) < 1e-5
+    assert rel_err(fd.grad[..., :50], f64.grad) < 1e-2
     assert fd.grad[..., 50:].abs().max().item() == 0.0
     for i in range(L):
-        assert rel_err(ws[i].grad, st64[f"mesh_deform_1.layers.{i}.weight"].grad) < 1e-4, f"dW layer {i}"
-        assert rel_err(bs[i].grad, st64[f"mesh_deform_1.layers.{i}.bias"].grad) < 1e-4, f"db layer {i}"
+        assert rel_l2(ws[i].grad, st64[f"mesh_deform_1.layers.{i}.weight"].grad) < 1e-5, f"dW layer {i}"
+        assert rel_l2(bs[i].grad, st64[f"mesh_deform_1.layers.{i}.bias"].grad) < 1e-5, f"db layer {i}"
+        assert rel_err(ws[i].grad, st64[f"mesh_deform_1.layers.{i}.weight"].grad) < 1e-2, f"dW layer {i}"
 
 
 def test_posenc_mask_fwd_bwd(cuda):

@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""Micro-benchmark of one GCN stack (fwd+bwd) at the headline shape; prints the mean device time per MFMA launch
+class (HIP events via a3vt_profile_*).  Development aid:  python tools/stack_bench.py [--layers 8] [--reps 5]"""
+import argparse
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+
+p = argparse.ArgumentParser()
+p.add_argument("--layers", type=int, default=8)
+p.add_argument("--hidden", type=int, default=300)
+p.add_argument("--batch", type=int, default=64)
+p.add_argument("--level", type=int, default=4)
+p.add_argument("--reps", type=int, default=5)
+a = p.parse_args()
+
+from a3vt_amd import lib, mesh as amesh, ops  # noqa: E402
+from oracle import gcn as og  # noqa: E402
+
+dev = torch.device("cuda", 0)
+verts, faces = amesh.icosphere(a.level)
+r, c = amesh.vision_pairs(faces, verts.shape[0])
+adj = ops.DeviceCSR(amesh.CSRAdjacency.from_pairs(r, c, verts.shape[0]), dev)
+st = og.init_state(50, a.hidden, a.layers, seed=0)
+ws = [st[f"mesh_deform_1.layers.{i}.weight"].to(dev).requires_grad_(True) for i in range(a.layers)]
+bs = [st[f"mesh_deform_1.layers.{i}.bias"].to(dev).requires_grad_(True) for i in range(a.layers)]
+feats = torch.zeros(a.batch, verts.shape[0], 52, device=dev)
+feats[..., :50] = torch.randn(a.batch, verts.shape[0], 50, device=dev) * 0.5
+feats.requires_grad_(True)
+gup = torch.randn(a.batch, verts.shape[0], 3, device=dev)
+L = lib.load()
+
+
+def run():
+    out = ops.gcn_stack(feats, adj, 50, a.hidden, round(a.hidden * 0.33), ws, bs)
+    out.backward(gup)
+
+
+run()
+torch.cuda.synchronize()
+L.a3vt_profile_enable(1)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(a.reps):
+    run()
+e1.record()
+torch.cuda.synchronize()
+tot = (ctypes.c_double * 3)()
+cnt = (ctypes.c_int * 3)()
+lib.check(L.a3vt_profile_read(tot, cnt), "profile_read")
+M = a.batch * verts.shape[0]
+flop = 2.0 * M * a.hidden * a.hidden
+for name, i in (("fwd Z=XW", 0), ("bwd dX", 1), ("bwd dW", 2)):
+    ms = tot[i] / max(cnt[i], 1)
+    print(f"{name:10s} launches {cnt[i]:4d}  mean {ms * 1e3:8.1f} us   {flop / (ms * 1e-3) / 1e12 if ms else 0:6.1f} TFLOP/s (hidden x hidden launches dominate)")
+print(f"stack fwd+bwd: {e0.elapsed_time(e1) / a.reps:.2f} ms per call  (MFMA classes: {sum(tot) / a.reps:.2f} ms)")
