@@ -94,17 +94,22 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(RowGemmArgs p) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto issue = [&](int chunk, int buf) {
-      float *sA = lds + buf * STAGE + wave * (MT * 256);
-      float *sB = lds + buf * STAGE + A_FLOATS;
+    // One DMA wave-instruction of a chunk: pieces [0, A_INSTR) are this wave's A rows, the rest its share of Bt.
+    auto issue_piece = [&](int chunk, int buf, int piece) {
       const int kk = chunk * 16 + kpiece;
-#pragma unroll
-      for (int j = 0; j < A_INSTR; ++j) {
-        const float *src = (!active || kk >= p.k) ? p.zeros : (kk < p.ksplit ? a0row[j] + kk : a1row[j] + kk);
-        glds16(src, sA + j * 256);
+      if (piece < A_INSTR) {
+        float *sA = lds + buf * STAGE + wave * (MT * 256);
+        const float *src = (!active || kk >= p.k) ? p.zeros : (kk < p.ksplit ? a0row[piece] + kk : a1row[piece] + kk);
+        glds16(src, sA + piece * 256);
+      } else {
+        const int j = piece - A_INSTR;
+        float *sB = lds + buf * STAGE + A_FLOATS;
+        glds16(brow[j] + kk, sB + (wave * B_INSTR + j) * 256);
       }
+    };
+    auto issue = [&](int chunk, int buf) {
 #pragma unroll
-      for (int j = 0; j < B_INSTR; ++j) glds16(brow[j] + kk, sB + (wave * B_INSTR + j) * 256);
+      for (int pc = 0; pc < PER; ++pc) issue_piece(chunk, buf, pc);
     };
 
     issue(0, 0);
@@ -119,8 +124,15 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(RowGemmArgs p) {
 #ifndef A3VT_DBG_NOBARRIER
       __builtin_amdgcn_s_barrier();  // chunk t visible to all waves; everyone is done with chunk t-1's stage
 #endif
+      // Chunk t+2 goes to stage (t+2)%3 == (t-1)%3, free since the barrier above.  Its DMA instructions are
+      // spread through the MFMA stream below (one per pair of n-tiles) so their issue cost hides under the
+      // matrix pipe instead of stalling both waves of the SIMD at the top of the iteration.
+      constexpr int NPAIR = (NT + 1) / 2;
+      constexpr bool SPREAD = NPAIR >= 2 * PER;
+      const bool prefetch = t + 2 < nchunks;
+      const int nbuf = buf >= 1 ? buf - 1 : 2;
 #ifndef A3VT_DBG_NODMA
-      if (t + 2 < nchunks) issue(t + 2, buf >= 1 ? buf - 1 : 2);  // stage (t+2)%3 == (t-1)%3
+      if (prefetch && (!SPREAD || !active)) issue(t + 2, nbuf);
 #endif
       if (active) {
         const float *sA = lds + buf * STAGE + wave * (MT * 256);
@@ -167,6 +179,12 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(RowGemmArgs p) {
             }
           }
           __builtin_amdgcn_sched_barrier(0);
+#ifndef A3VT_DBG_NODMA
+          if (SPREAD && (jp & 1) && (jp >> 1) < PER) {
+            if (prefetch) issue_piece(t + 2, nbuf, jp >> 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#endif
           bc0 = bn0;
           bc1 = bn1;
         }
@@ -404,11 +422,19 @@ __device__ __forceinline__ void dw_stage(const float *__restrict__ sb, int ldx, 
     const float *xr = sb + r * ldx + xoff;
     const int ra = r * ldz0, rg = r * ldz1;
     float a[DW_MAXI], b[DW_MAXO];
+#ifdef A3VT_DBG_NOLDSREAD
+#pragma unroll
+    for (int i = 0; i < DW_MAXI; ++i) a[i] = (float)(r + i);
+#pragma unroll
+    for (int j = 0; j < DW_MAXO; ++j) b[j] = (float)(ra + j);
+    (void)xr; (void)rg;
+#else
 #pragma unroll
     for (int i = 0; i < DW_MAXI; ++i) a[i] = (NI >= 0 ? i < NI : i < ni) ? xr[i * 16] : 0.f;
 #pragma unroll
     for (int j = 0; j < DW_MAXO; ++j)
       b[j] = (NO >= 0 ? j < NO : j < no) ? sb[zoff[j] + (zoff[j] < offG ? ra : rg)] : 0.f;
+#endif
 #pragma unroll
     for (int i = 0; i < DW_MAXI; ++i) {
       if (NI >= 0 ? i < NI : i < ni) {
@@ -518,8 +544,12 @@ __global__ __launch_bounds__(1024, 1) void dw_kernel(DwArgs p) {
   for (int t = 0; t < nu; ++t) {
     if (t + 1 < nu) wait_vmcnt<3>();
     else wait_vmcnt<0>();
+#ifndef A3VT_DBG_NOBARRIER
     __builtin_amdgcn_s_barrier();
+#endif
+#ifndef A3VT_DBG_NODMA
     if (t + 2 < nu) issue(u0 + t + 2, buf >= 1 ? buf - 1 : 2);
+#endif
     const float *sb = lds + buf * stage;
     dw_stage<-1, -1>(sb, p.ldx, p.ldz0, p.ldz1, offG, xoff, zoff, q, ni, no, acc);
     buf = buf == 2 ? 0 : buf + 1;

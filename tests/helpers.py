@@ -46,6 +46,18 @@ def rel_l2(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
 
+def assert_grad_close(a, b, what="", tol=1e-4, outlier_frac=1e-3, l2_tol=1e-3):
+    """Gradient check robust to ReLU kinks: all but a fraction `outlier_frac` of the elements within
+    `tol` * max|b|, and the whole tensor within `l2_tol` in relative L2."""
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    scale = b.abs().max().clamp_min(1e-30)
+    bad = ((a - b).abs() > tol * scale).double().mean().item()
+    assert bad <= outlier_frac, f"{what}: {bad:.2e} of the elements differ by more than {tol} (relative to max)"
+    l2 = ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+    assert l2 < l2_tol, f"{what}: relative L2 error {l2:.2e}"
+
+
 def random_cloud(batch, n, seed, kind="ellipsoid"):
     g = np.random.default_rng(seed)
     if kind == "cube":

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import make_args, oracle_adj, random_cloud, rel_err, rel_l2, template
+from helpers import assert_grad_close, make_args, oracle_adj, random_cloud, rel_err, template
 
 pytestmark = pytest.mark.gpu
 
@@ -63,14 +63,12 @@ def test_gcn_stack_fwd_bwd(cuda, tname, use_touch, L, H, B):
     out = ops.gcn_stack(fd, adj, 50, H, round(H * 0.33), ws, bs)
     (out * gup.to(cuda)).sum().backward()
     assert rel_err(out, out_o) < 1e-4
-    # gradients: L2-relative 1e-5 (see helpers.rel_l2 for why not max-norm), max-norm only loosely
-    assert rel_l2(fd.grad[..., :50], f64.grad) < 1e-5
-    assert rel_err(fd.grad[..., :50], f64.grad) < 1e-2
+    # gradients: tolerant of the rare ReLU-kink flips (helpers.assert_grad_close)
+    assert_grad_close(fd.grad[..., :50], f64.grad, "grad_feats")
     assert fd.grad[..., 50:].abs().max().item() == 0.0
     for i in range(L):
-        assert rel_l2(ws[i].grad, st64[f"mesh_deform_1.layers.{i}.weight"].grad) < 1e-5, f"dW layer {i}"
-        assert rel_l2(bs[i].grad, st64[f"mesh_deform_1.layers.{i}.bias"].grad) < 1e-5, f"db layer {i}"
-        assert rel_err(ws[i].grad, st64[f"mesh_deform_1.layers.{i}.weight"].grad) < 1e-2, f"dW layer {i}"
+        assert_grad_close(ws[i].grad, st64[f"mesh_deform_1.layers.{i}.weight"].grad, f"dW layer {i}")
+        assert_grad_close(bs[i].grad, st64[f"mesh_deform_1.layers.{i}.bias"].grad, f"db layer {i}")
 
 
 def test_posenc_mask_fwd_bwd(cuda):

@@ -1,0 +1,119 @@
+"""CPU: host-side logic of the product (no GPU, no compute calls into the library)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import a3vt_amd
+from a3vt_amd import lib, mesh as amesh
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_icosphere_sizes_and_topology():
+    for level, nv, nf, nnz in ((0, 12, 20, 72), (4, 2562, 5120, 17922), (5, 10242, 20480, 71682)):
+        v, f = amesh.icosphere(level)
+        assert v.shape == (nv, 3) and f.shape == (nf, 3)
+        assert np.allclose(np.linalg.norm(v, axis=1), 0.25, atol=1e-6)
+        A = amesh.CSRAdjacency.from_pairs(*amesh.vision_pairs(f, nv), nv)
+        assert A.nnz == nnz                                     # nnz incl. self loops
+        deg = np.diff(A.rowptr)
+        assert deg.min() == 6 and deg.max() == (6 if level == 0 else 7) and (deg == 6).sum() == 12   # 12 five-valent verts
+
+
+def test_csr_rows_sum_to_one_and_transpose():
+    v, f = amesh.load_asset("vision_charts")
+    sv, sf = amesh.load_asset("touch_chart")
+    r, c, n, faces = amesh.fused_pairs(v, f, sf, 5, False)
+    A = amesh.CSRAdjacency.from_pairs(r, c, n)
+    assert n == 2324 and A.nnz == 60726 and faces.shape == (2944, 3)
+    rows = np.repeat(np.arange(n), np.diff(A.rowptr))
+    assert np.allclose(np.bincount(rows, weights=A.val, minlength=n), 1.0, atol=1e-6)
+    assert np.diff(A.rowptr).max() == 1153                      # chart-centre hub rows
+    T = amesh.CSRAdjacency(A.t_rowptr, A.t_col, A.t_val, n)
+    assert np.array_equal(T.to_dense(), A.to_dense().T)
+    assert np.array_equal(amesh.CSRAdjacency.from_dense(A.to_dense()).col, A.col)
+
+
+def test_obj_roundtrip(tmp_path):
+    p = tmp_path / "t.obj"
+    p.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nvt 0 0\nf 1/1/1 2/1/1 3/1/1\nf 2 4 3\nf 1 2 4 3\n")
+    v, f = amesh.load_obj(str(p))
+    assert v.shape == (4, 3) and f.tolist() == [[0, 1, 2], [1, 3, 2], [0, 1, 3], [0, 3, 2]]
+
+
+def test_header_symbols_all_bound_and_exported():
+    """Every function declared in include/a3vt.h has a ctypes signature and is exported by liba3vt.so."""
+    hdr = open(os.path.join(ROOT, "include", "a3vt.h")).read()
+    declared = set(re.findall(r"\b(a3vt_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
+    if not os.path.exists(lib.LIB_PATH):
+        pytest.skip("library not built (run __graft_entry__.build())")
+    dll = ctypes.CDLL(lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(dll, name), name
+    L = lib.load()
+    assert L.a3vt_version() == 100
+    assert L.a3vt_posenc_param_count(50) == 12 * 63 + 12 + 25 * 12 + 25 + 50 * 25 + 50 + 200
+    assert L.a3vt_wt_rows(300) >= 304 and L.a3vt_wt_ld(300) == 304
+    # host-only entry point: CSR validation
+    rp = np.array([0, 1, 3], dtype=np.int32)
+    col = np.array([0, 0, 1], dtype=np.int32)
+    assert L.a3vt_csr_validate(rp.ctypes.data, col.ctypes.data, 2, 3) == 0
+    col[2] = 7
+    assert L.a3vt_csr_validate(rp.ctypes.data, col.ctypes.data, 2, 3) != 0
+    assert b"out of range" in L.a3vt_last_error()
+
+
+def test_no_cpu_fallback():
+    """The product fails loudly without a GPU / without the native library."""
+    from a3vt_amd import ops
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.ChamferFn.apply(torch.zeros(1, 1, 4, 3), torch.zeros(1, 4, 3))
+    import importlib
+    src = open(os.path.join(ROOT, "active-3d-vision-and-touch_amd", "ops.py")).read() + \
+        open(os.path.join(ROOT, "active-3d-vision-and-touch_amd", "lib.py")).read()
+    assert "oracle" not in src.replace("no CPU", "")          # the product never imports the checker
+    assert importlib.util.find_spec("a3vt_amd.oracle") is None
+
+
+def test_state_dict_layout_matches_reference():
+    from helpers import make_args
+    from a3vt_amd.pterotactyl.reconstruction.vision import model
+    net = model.Deformation({}, torch.zeros(4, 3), make_args())
+    sd = net.state_dict()
+    assert sd["positional_encoder.model.0.weight"].shape == (12, 63)
+    assert sd["positional_encoder.model.4.bias"].shape == (50,)
+    assert sd["mask_encoder.model.0.weight"].shape == (4, 50)
+    assert sd["mesh_deform_1.layers.0.weight"].shape == (1, 50, 300)
+    assert sd["mesh_deform_2.layers.19.weight"].shape == (1, 300, 3) and sd["mesh_deform_2.layers.19.bias"].shape == (3,)
+    with pytest.raises(NotImplementedError):
+        model.Deformation({}, torch.zeros(4, 3), make_args(use_img=True))
+
+
+def test_config_roundtrip(tmp_path):
+    from argparse import Namespace
+    from a3vt_amd.pterotactyl.utility import utils
+    a = Namespace(lr=3e-4, num_GCN_layers=20, exp_id="x")
+    utils.save_config(str(tmp_path), a)
+    cfg, w = utils.load_model_config(str(tmp_path))
+    assert cfg.lr == 3e-4 and cfg.num_GCN_layers == 20 and w == str(tmp_path) + "/model"
+
+
+def test_synthetic_batches_have_loader_format():
+    from helpers import make_args
+    from a3vt_amd.synthetic import SyntheticLoader
+    a = make_args(use_touch=True, num_grasps=2, number_points=64)
+    b = next(iter(SyntheticLoader(a, 2, 3)))
+    assert b["gt_points"].shape == (3, 64, 3) and b["touch_charts"].shape == (3, 2, 4, 25, 4) and len(b["names"]) == 3
+    assert a3vt_amd.__version__
+
+
+def test_shard_range_partitions_batch():
+    from a3vt_amd.distributed import shard_range
+    for gb, w in ((512, 8), (10, 3), (7, 8)):
+        spans = [shard_range(gb, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == gb and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))

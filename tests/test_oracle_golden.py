@@ -1,0 +1,154 @@
+"""CPU: the oracle restatement against the committed golden vectors (outputs of the real reference,
+tests/golden/make_golden.py).  Fixtures with pytorch3d_restated=True cross the un-vendored PyTorch3D
+boundary: they pin the reference's own arithmetic around it, not PyTorch3D itself (parity unpinned there)."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import csr_from, g7_cloud, grads_from, load, state_from
+from oracle import chamfer as och, gcn as og, mesh as omesh
+
+
+def test_g1_adjacency_matches_reference():
+    z = load("g1_adjacency.npz")
+    from a3vt_amd import mesh as amesh
+    v, f = amesh.load_asset("vision_charts")
+    sv, sf = amesh.load_asset("touch_chart")
+    assert np.array_equal(v, z["verts"])
+    for tag, kw in (("vision", dict(use_touch=False)), ("t_p", dict(use_touch=True, finger=True, num_grasps=5)),
+                    ("t_g", dict(use_touch=True, finger=False, num_grasps=5))):
+        info = omesh.adj_init(v, f, kw["use_touch"], kw.get("num_grasps", 1), kw.get("finger", False), sv, sf)
+        for key in ("origional", "adj"):
+            rp, col, val = omesh.dense_to_csr(info[key])
+            assert np.array_equal(rp, z[f"{tag}_{key}_rowptr"])
+            assert np.array_equal(col, z[f"{tag}_{key}_col"].astype(np.int32))
+            assert np.array_equal(val, z[f"{tag}_{key}_val"])           # bit-exact
+        assert np.array_equal(info["faces"], z[f"{tag}_faces"].astype(np.int64))
+    nnz = {t: int(z[f"{t}_adj_rowptr"][-1]) for t in ("vision", "t_p", "t_g")}
+    assert nnz == {"vision": 9888, "t_p": 24291, "t_g": 60726}       # SURVEY §8 probe values
+
+
+@pytest.mark.parametrize("tag,use_touch", [("vision", False), ("touch", True)])
+def test_g3_small_deformation_fwd_bwd(tag, use_touch):
+    z = load(f"g3_small_{tag}.npz")
+    g1 = load("g1_adjacency.npz")
+    st = {k: v.requires_grad_(True) for k, v in state_from(z).items()}
+    verts = torch.from_numpy(g1["verts"])
+    # dense adjacency (the reference's own formulation) -> the forward is reproduced bit for bit
+    from a3vt_amd import mesh as amesh
+    sv, sf = amesh.load_asset("touch_chart")
+    info = omesh.adj_init(g1["verts"], amesh.load_asset("vision_charts")[1], use_touch, 1, False, sv, sf)
+    adj, faces = torch.from_numpy(info["adj"]), torch.from_numpy(info["faces"])
+    ch = og.prepare_mesh(torch.from_numpy(z["touch_charts"]), verts, 2, use_touch)
+    out, mask = og.deformation_forward(st, {"adj": adj}, ch, use_touch, 3, 0.33)
+    assert np.array_equal(mask.numpy(), z["mask"])
+    np.testing.assert_array_equal(out.detach().numpy(), z["verts_out"])
+    samples = [(torch.from_numpy(z["face_idx"][r].astype(np.int64)), torch.from_numpy(z["u"][r]), torch.from_numpy(z["v"][r]))
+               for r in range(3)]
+    cd = och.chamfer_distance(out, faces, torch.from_numpy(z["gt"]), num=300, samples=samples)
+    np.testing.assert_allclose(cd.detach().numpy(), z["cd"], rtol=2e-6)
+    (9000.0 * cd.mean()).backward()
+    for k, g in grads_from(z).items():
+        np.testing.assert_allclose(st[k].grad.numpy(), g.numpy(), rtol=0, atol=2e-5 * max(1.0, float(g.abs().max())), err_msg=k)
+
+
+def test_g5_sampling():
+    z = load("g5_sampling.npz")
+    g1 = load("g1_adjacency.npz")
+    from a3vt_amd import mesh as amesh
+    sv, sf = amesh.load_asset("touch_chart")
+    info = omesh.adj_init(g1["verts"], amesh.load_asset("vision_charts")[1], True, 1, False, sv, sf)
+    faces = torch.from_numpy(info["faces"])
+    V = torch.from_numpy(z["verts"])
+    np.testing.assert_array_equal(och.face_probabilities(V, faces).numpy(), z["prob"])
+    pts = och.sample_points(V, faces, torch.from_numpy(z["face_idx"].astype(np.int64)), torch.from_numpy(z["u"]),
+                            torch.from_numpy(z["v"]))
+    np.testing.assert_allclose(pts.numpy(), z["points"], rtol=0, atol=1e-7)
+    torch.manual_seed(123)                                   # the reference's own RNG path, same call order
+    np.testing.assert_allclose(och.batch_sample(V, faces, num=500).numpy(), z["points_rng_seed123"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(z["prob"].sum(1), 1.0, atol=1e-5)
+
+
+def test_g6_chamfer_and_gradient():
+    z = load("g6_chamfer.npz")
+    x = torch.from_numpy(z["x"]).requires_grad_(True)
+    y = torch.from_numpy(z["y"])
+    cd = och.chamfer_pair(x, y)
+    np.testing.assert_allclose(cd.detach().numpy(), z["cd"], rtol=1e-6)
+    (cd * torch.tensor([1.0, 2.0])).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), z["grad_x"], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(och.chamfer_grad_x(x.detach(), y, torch.tensor([1.0, 2.0])).numpy(), z["grad_x"], rtol=0, atol=1e-8)
+    # plain-C nearest neighbour agrees with the torch one
+    d_c, i_c = och.nn_sqdist_c(z["x"][0], z["y"][0])
+    d_t, i_t = och.nn_sqdist(torch.from_numpy(z["x"][0]), y[0])
+    np.testing.assert_allclose(d_c, d_t.numpy(), rtol=1e-6)
+    assert (i_c == i_t.numpy()).mean() > 0.999
+
+
+def test_g6_abc_object_score():
+    """Undeformed t_g template (empty touch slots at the origin) against the bundled ABC object's cloud."""
+    z = load("g6_chamfer.npz")
+    g1 = load("g1_adjacency.npz")
+    cloud = torch.from_numpy(z["abc_cloud"])
+    assert cloud.shape == (2176, 3)
+    V = torch.cat((torch.from_numpy(g1["verts"])[None].repeat(2, 1, 1), torch.zeros(2, 500, 3)), dim=1)
+    faces = torch.from_numpy(g1["t_g_faces"].astype(np.int64))
+    samples = [(torch.from_numpy(z["abc_face_idx"][r].astype(np.int64)), torch.from_numpy(z["abc_u"][r]),
+                torch.from_numpy(z["abc_v"][r])) for r in range(3)]
+    score = 9000.0 * och.chamfer_distance(V, faces, cloud[None].repeat(2, 1, 1), num=2000, samples=samples)
+    np.testing.assert_allclose(score.numpy(), z["abc_score"], rtol=2e-6)
+
+
+def test_g4_full_size_forward():
+    """L=20, H=300 forward, weights re-derived from torch.manual_seed(0) by the PRODUCT's constructor (same RNG
+    call order as the reference's), evaluated by the oracle on the CPU."""
+    import hashlib
+    from helpers import make_args
+    from a3vt_amd.pterotactyl.reconstruction.vision import model
+    z = load("g4_full_forward.npz")
+    g1 = load("g1_adjacency.npz")
+    torch.manual_seed(0)
+    net = model.Deformation({}, torch.from_numpy(g1["verts"]), make_args())
+    sd = net.state_dict()
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode())
+        h.update(sd[k].detach().cpu().numpy().tobytes())
+    assert np.array_equal(np.frombuffer(h.digest(), dtype=np.uint8), z["weight_sha256"]), "init differs from the reference"
+    assert len(sd) == 87 and sum(v.numel() for v in sd.values()) == 3285799
+    ch = {"vision_charts": torch.from_numpy(z["verts_in"]), "vision_masks": 3 * torch.ones(2, 1824, 1)}
+    with torch.no_grad():
+        out, _ = og.deformation_forward(sd, {"adj": csr_from(g1, "vision", "adj")}, ch, False, 20, 0.33)
+    np.testing.assert_allclose(out.numpy(), z["verts_out"], rtol=0, atol=5e-7)
+
+
+@pytest.mark.parametrize("stages", [3, 1])
+def test_g7_train_step(stages):
+    """BASELINE.json configs[0]: bs=2, 10k Chamfer points, reference trainer arithmetic (loss_coeff*mean, Adam 3e-4)."""
+    from helpers import make_args
+    from a3vt_amd.pterotactyl.reconstruction.vision import model
+    z = load("g7_train_step.npz")
+    g1 = load("g1_adjacency.npz")
+    verts = torch.from_numpy(g1["verts"])
+    faces = torch.from_numpy(g1["vision_faces"].astype(np.int64))
+    adj = csr_from(g1, "vision", "adj")
+    torch.manual_seed(0)
+    net = model.Deformation({}, verts, make_args())
+    st = {k: p.detach().clone().requires_grad_(True) for k, p in net.named_parameters()}
+    opt = torch.optim.Adam(list(st.values()), lr=3e-4, weight_decay=0)
+    gt = g7_cloud()
+    losses = []
+    for it in range(2):
+        torch.manual_seed(1000 + it)
+        opt.zero_grad()
+        ch = og.prepare_mesh(None, verts, 2, False)
+        out, _ = og.deformation_forward(st, {"adj": adj}, ch, False, 20, 0.33, num_stages=stages)
+        loss = 9000.0 * och.chamfer_distance(out, faces, gt, num=10000, use_c=True).mean()
+        losses.append(loss.item())
+        if it == 0:
+            loss.backward()
+            opt.step()
+    assert abs(losses[0] - float(z[f"loss_before_s{stages}"])) < 1e-4 * abs(losses[0])
+    assert abs(losses[1] - float(z[f"loss_after_s{stages}"])) < 1e-3 * abs(losses[1])
+    w = st["mesh_deform_1.layers.19.weight"].detach().numpy()[0, :16]
+    np.testing.assert_allclose(w, z[f"w_after_sample_s{stages}"], rtol=0, atol=2e-6)
