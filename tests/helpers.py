@@ -46,7 +46,7 @@ def rel_l2(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
 
-def assert_grad_close(a, b, what="", tol=1e-4, outlier_frac=1e-3, l2_tol=1e-3):
+def assert_grad_close(a, b, what="", tol=1e-3, outlier_frac=1e-3, l2_tol=1e-3):
     """Gradient check robust to ReLU kinks: all but a fraction `outlier_frac` of the elements within
     `tol` * max|b|, and the whole tensor within `l2_tol` in relative L2."""
     a = a.detach().double().cpu()

@@ -1,0 +1,74 @@
+"""-m gpu: BASELINE.json configs[1] sizes (2562-vertex template, bs=64, 10k-point Chamfer, L=20 x H=300), checked
+through size-independent properties (the oracle needs minutes per iteration at this size)."""
+import pytest
+import torch
+
+from helpers import make_args, random_cloud, template
+
+pytestmark = pytest.mark.gpu
+
+
+def test_chamfer_fullsize_properties(cuda):
+    from a3vt_amd import ops
+    x = random_cloud(64, 10000, 7).to(cuda)
+    cd = ops.ChamferFn.apply(x[None].repeat(3, 1, 1, 1), x)
+    assert cd.abs().max().item() == 0.0                                  # every cloud against itself, 3 draws
+    y = random_cloud(64, 10000, 8).to(cuda)
+    a = ops.ChamferFn.apply(x[None], y)
+    b = ops.ChamferFn.apply(y[None], x)                                  # symmetric in its arguments
+    assert torch.allclose(a, b, rtol=1e-6, atol=0)
+    t = torch.tensor([0.3, -0.2, 0.1], device=cuda)                      # translation invariance
+    c = ops.ChamferFn.apply((x + t)[None], y + t)
+    assert torch.allclose(a, c, rtol=1e-4)
+    dxy, ixy, dyx, iyx, _ = ops.chamfer_nn(x[None], y)                   # indices realise the distances
+    nn = torch.gather(y, 1, ixy[0].long()[..., None].expand(-1, -1, 3))
+    assert torch.allclose(((x - nn) ** 2).sum(-1), dxy[0], rtol=1e-5, atol=1e-12)
+    assert (dxy[0] <= ((x - y) ** 2).sum(-1) * (1 + 1e-5)).all()         # never worse than the same-index pairing
+
+
+def test_rowgemm_fullsize_linearity(cuda):
+    from a3vt_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(0)
+    a1 = torch.randn(64 * 2562, 300, device=cuda, generator=g)
+    a2 = torch.randn(64 * 2562, 300, device=cuda, generator=g)
+    w = torch.randn(300, 300, device=cuda, generator=g)
+    c1, c2, c12 = ops.rowgemm(a1, w), ops.rowgemm(a2, w), ops.rowgemm(a1 + a2, w)
+    assert ((c12 - (c1 + c2)).abs().max() / c12.abs().max()).item() < 5e-6
+    idx = torch.randint(0, a1.shape[0], (512,), device=cuda)
+    ref = a1[idx].double() @ w.double()                                  # spot rows in fp64
+    assert ((c1[idx].double() - ref).abs().max() / ref.abs().max()).item() < 2e-6
+    assert torch.equal(ops.rowgemm(a1, w), c1)                           # bitwise repeatable
+
+
+def test_training_step_fullsize_is_finite_and_repeatable(cuda):
+    from a3vt_amd.pterotactyl.reconstruction.vision import model
+    from a3vt_amd.pterotactyl.utility import utils
+    args = make_args()
+    v, f = template("ico4")
+    vt, ft = torch.from_numpy(v).to(cuda), torch.from_numpy(f).to(cuda)
+    info = utils.adj_init(vt, ft, args)
+    torch.manual_seed(0)
+    net = model.Deformation(info, vt, args).to(cuda)
+    flag = torch.zeros((), dtype=torch.int32, device=cuda)
+    net.finite_flag = flag
+    B, P = 64, 10000
+    charts = model.prepare_mesh({"img": torch.zeros(B, 1)}, vt, args)
+    gt = random_cloud(B, P, 3).to(cuda)
+    g = torch.Generator().manual_seed(1)
+    samples = (torch.randint(0, f.shape[0], (3, B, P), generator=g).to(torch.int32).to(cuda),
+               torch.rand(3, B, P, generator=g).to(cuda), torch.rand(3, B, P, generator=g).to(cuda))
+    outs = []
+    for _ in range(2):
+        net.zero_grad()
+        out = net(torch.zeros(B, 1), charts)[0]
+        loss = 9000.0 * utils.chamfer_distance(out, info["faces"], gt, num=P, samples=samples).mean()
+        loss.backward()
+        outs.append((out.detach().clone(), loss.item(), net.mesh_deform_2.layers[5].weight.grad.clone()))
+    assert flag.item() == 0 and all(torch.isfinite(p.grad).all() for p in net.parameters())
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]          # forward + loss bitwise repeatable
+    # weight gradients: the GCN backward is deterministic (slab reductions); only the sampling / Chamfer scatter
+    # use float atomics, which perturbs the incoming gradient in the last bits
+    rel = ((outs[0][2] - outs[1][2]).abs().max() / outs[0][2].abs().max()).item()
+    assert rel < 1e-4
+    # only the first N_vision vertices move and the mask is the vision token
+    assert torch.equal(net(torch.zeros(B, 1), charts)[1], 3 * torch.ones(B, v.shape[0], 1, device=cuda))

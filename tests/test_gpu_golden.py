@@ -1,0 +1,106 @@
+"""-m gpu: the HIP path (through the pterotactyl facade and the C ABI) against the committed golden vectors,
+i.e. against outputs of the real reference.  Tolerance: 1e-4 relative on vertex positions and Chamfer loss
+(BASELINE.json north_star); gradients via helpers.assert_grad_close."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import g7_cloud, grads_from, load, state_from
+from helpers import assert_grad_close, make_args, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _facade():
+    from a3vt_amd.pterotactyl.reconstruction.vision import model
+    from a3vt_amd.pterotactyl.utility import utils
+    return model, utils
+
+
+@pytest.mark.parametrize("tag,use_touch", [("vision", False), ("touch", True)])
+def test_g3_small_deformation(cuda, tag, use_touch):
+    model, utils = _facade()
+    z = load(f"g3_small_{tag}.npz")
+    args = make_args(use_touch=use_touch, num_grasps=1, finger=False, num_GCN_layers=3, hidden_GCN_size=32)
+    info, verts = utils.load_mesh_vision(args, "vision_charts")
+    net = model.Deformation(info, verts, args).to(cuda)
+    net.load_state_dict(state_from(z))
+    batch = {"img": torch.zeros(2, 1), "touch_charts": torch.from_numpy(z["touch_charts"])}
+    out, mask = net(batch["img"], model.prepare_mesh(batch, verts, args))
+    assert np.array_equal(mask.cpu().numpy(), z["mask"])
+    assert rel_err(out, torch.from_numpy(z["verts_out"])) < 1e-4
+    samples = tuple(torch.from_numpy(z[k].astype(np.int32) if k == "face_idx" else z[k]).to(cuda) for k in ("face_idx", "u", "v"))
+    cd = utils.chamfer_distance(out, info["faces"], torch.from_numpy(z["gt"]).to(cuda), num=300, samples=samples)
+    assert rel_err(cd, torch.from_numpy(z["cd"])) < 1e-4
+    (9000.0 * cd.mean()).backward()
+    ref = grads_from(z)
+    for k, p in net.named_parameters():
+        assert_grad_close(p.grad, ref[k], k)
+
+
+def test_g4_full_size_forward(cuda):
+    model, utils = _facade()
+    z = load("g4_full_forward.npz")
+    args = make_args()
+    info, verts = utils.load_mesh_vision(args, "vision_charts")
+    torch.manual_seed(0)                                        # same RNG order as the reference constructor
+    net = model.Deformation(info, verts, args).to(cuda)
+    assert np.allclose(net.mesh_deform_1.layers[0].weight.detach().cpu().numpy()[0, :4, :8], z["w_first"], atol=0)
+    charts = {"vision_charts": torch.from_numpy(z["verts_in"]).to(cuda), "vision_masks": 3 * torch.ones(2, 1824, 1, device=cuda)}
+    with torch.no_grad():
+        out, _ = net(torch.zeros(2, 1), charts)
+    assert rel_err(out, torch.from_numpy(z["verts_out"])) < 1e-4
+    assert not torch.equal(charts["vision_charts"], out)        # inputs are not mutated (reference clones them)
+    assert torch.equal(charts["vision_charts"].cpu(), torch.from_numpy(z["verts_in"]))
+
+
+def test_g6_chamfer(cuda):
+    from a3vt_amd import ops
+    _, utils = _facade()
+    z = load("g6_chamfer.npz")
+    x = torch.from_numpy(z["x"]).to(cuda).requires_grad_(True)
+    cd = ops.ChamferFn.apply(x[None], torch.from_numpy(z["y"]).to(cuda))
+    assert rel_err(cd, torch.from_numpy(z["cd"])) < 1e-5
+    (cd * torch.tensor([1.0, 2.0], device=cuda)).sum().backward()
+    assert rel_err(x.grad, torch.from_numpy(z["grad_x"])) < 1e-4
+    # bundled ABC object vs the undeformed t_g template
+    args = make_args(use_touch=True, num_grasps=5, finger=False)
+    info, verts = utils.load_mesh_vision(args, "vision_charts")
+    V = torch.cat((verts[None].repeat(2, 1, 1), torch.zeros(2, 500, 3, device=cuda)), dim=1)
+    samples = tuple(torch.from_numpy(z[k].astype(np.int32) if "face" in k else z[k]).to(cuda) for k in ("abc_face_idx", "abc_u", "abc_v"))
+    gt = torch.from_numpy(z["abc_cloud"]).to(cuda)[None].repeat(2, 1, 1)
+    score = 9000.0 * utils.chamfer_distance(V, info["faces"], gt, num=2000, samples=samples)
+    assert rel_err(score, torch.from_numpy(z["abc_score"])) < 1e-4
+
+
+@pytest.mark.parametrize("stages", [3, 1])
+def test_g7_train_step(cuda, stages):
+    """BASELINE.json configs[0] on the GPU: bs=2, 10k-point Chamfer, one Adam step; losses vs the reference's."""
+    from oracle import chamfer as och
+    model, utils = _facade()
+    z = load("g7_train_step.npz")
+    args = make_args(num_stages=stages)
+    info, verts = utils.load_mesh_vision(args, "vision_charts")
+    torch.manual_seed(0)
+    net = model.Deformation(info, verts, args).to(cuda)
+    opt = torch.optim.Adam(net.parameters(), lr=3e-4, weight_decay=0)
+    gt = g7_cloud().to(cuda)
+    faces_cpu = info["faces"].cpu()
+    losses = []
+    for it in range(2):
+        opt.zero_grad()
+        out = net(torch.zeros(2, 1), model.prepare_mesh({"img": torch.zeros(2, 1)}, verts, args))[0]
+        # the reference's draws for this evaluation: same torch CPU generator calls, in the reference's order
+        torch.manual_seed(1000 + it)
+        draws = [och.draw_samples(och.face_probabilities(out.detach().cpu(), faces_cpu), 10000) for _ in range(3)]
+        samples = (torch.stack([d[0] for d in draws]).to(torch.int32).to(cuda), torch.stack([d[1] for d in draws]).to(cuda),
+                   torch.stack([d[2] for d in draws]).to(cuda))
+        loss = 9000.0 * utils.chamfer_distance(out, info["faces"], gt, num=10000, samples=samples).mean()
+        losses.append(loss.item())
+        if it == 0:
+            loss.backward()
+            opt.step()
+    assert abs(losses[0] - float(z[f"loss_before_s{stages}"])) < 1e-4 * abs(losses[0])
+    assert abs(losses[1] - float(z[f"loss_after_s{stages}"])) < 1e-3 * abs(losses[1])
+    w = net.mesh_deform_1.layers[19].weight.detach().cpu().numpy()[0, :16]
+    np.testing.assert_allclose(w, z[f"w_after_sample_s{stages}"], rtol=0, atol=5e-6)
