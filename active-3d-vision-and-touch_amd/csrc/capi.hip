@@ -139,6 +139,15 @@ int a3vt_csr_validate(const int32_t *rowptr, const int32_t *col, int n_vert, int
   return 0;
 }
 
+// ReLU-sign bytes saved by the forward pass for the backward pass: [num_layers-1][pad32(M)][mld],
+// mld = pad4(cut_len)/4 + ceil(hidden/4).
+static inline int mask_ld(int hidden, int cut_len) { return pad4(cut_len) / 4 + (hidden + 3) / 4; }
+size_t a3vt_gcn_stack_mask_bytes(int batch, int n_vert, int hidden, int num_layers, int cut_len) {
+  if (num_layers < 2) return 0;
+  const size_t mpad = ((size_t)batch * n_vert + 31) / 32 * 32;
+  return (size_t)(num_layers - 1) * mpad * mask_ld(hidden, cut_len);
+}
+
 size_t a3vt_gcn_stack_scratch_bytes(int batch, int n_vert, int in_features, int hidden, int num_layers, int cut_len,
                                     int need_backward) {
   return stack_layout(batch, n_vert, in_features, hidden, num_layers, cut_len, need_backward).total * sizeof(float);
@@ -147,8 +156,9 @@ size_t a3vt_gcn_stack_scratch_bytes(int batch, int n_vert, int in_features, int 
 int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const float *const *weights,
                        const float *const *biases, int num_layers, int hidden, int cut_len,
                        const int32_t *rowptr, const int32_t *col, const float *val, int n_vert, int batch,
-                       float *acts, float *scratch, float *update, void *stream) {
+                       float *acts, uint8_t *masks, float *scratch, float *update, void *stream) {
   A3VT_CHECK_ARG(feats && weights && biases && rowptr && col && val && scratch && update);
+  A3VT_CHECK_ARG((acts == nullptr) == (masks == nullptr) || num_layers < 2);
   A3VT_CHECK_ARG(n_vert > 0 && batch > 0);
   if (int rc = check_stack_dims(ld_feats, in_features, num_layers, hidden, cut_len)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -157,6 +167,8 @@ int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const 
   const StackLayout L = stack_layout(batch, n_vert, in_features, hidden, num_layers, cut_len, 0);
   const size_t m = (size_t)batch * n_vert;
   const int cpad = pad4(cut_len);
+  const int mld = mask_ld(hidden, cut_len);
+  const size_t mpad = (m + 31) / 32 * 32;
 
   const float *x = feats;
   int ldx = ld_feats;
@@ -181,12 +193,16 @@ int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const 
     g.c2 = scratch + L.za;
     g.ldc2 = cpad;
     g.csplit = cut_len;
+    uint8_t *mk = masks ? masks + (size_t)i * mpad * mld : nullptr;
+    g.maskb = mk;
+    g.mld = mld;
+    g.moff = cpad / 4;
     {
       ProfScope ps(PROF_GEMM_FWD, s);
       if (int rc = launch_rowgemm(g, EPI_FWD_HIDDEN, s)) return rc;
     }
     if (cut_len > 0)
-      if (int rc = launch_csr_fwd(scratch + L.za, cpad, biases[i], cut_len, rowptr, col, val, n_vert, batch, y, hidden, s))
+      if (int rc = launch_csr_fwd(scratch + L.za, cpad, biases[i], cut_len, rowptr, col, val, n_vert, batch, y, hidden, mk, mld, s))
         return rc;
     x = y;
     ldx = hidden;
@@ -200,12 +216,13 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
                        const float *const *biases, int num_layers, int hidden, int cut_len,
                        const int32_t *rowptr, const int32_t *col, const float *val, const int32_t *rowptrT,
                        const int32_t *colT, const float *valT, int n_vert, int batch, const float *acts,
-                       const float *grad_update, float *const *grad_weights, float *const *grad_biases,
+                       const uint8_t *masks, const float *grad_update, float *const *grad_weights, float *const *grad_biases,
                        float *grad_feats, float *scratch, void *stream) {
   (void)biases; (void)rowptr; (void)col; (void)val;
   A3VT_CHECK_ARG(feats && weights && rowptrT && colT && valT && grad_update && grad_weights && grad_biases);
   A3VT_CHECK_ARG(grad_feats && scratch && n_vert > 0 && batch > 0);
   A3VT_CHECK_ARG(num_layers == 1 || acts != nullptr);
+  A3VT_CHECK_ARG(num_layers <= 2 || masks != nullptr);
   if (int rc = check_stack_dims(ld_feats, in_features, num_layers, hidden, cut_len)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const float *zeros = zero_page();
@@ -213,6 +230,8 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
   const StackLayout L = stack_layout(batch, n_vert, in_features, hidden, num_layers, cut_len, 1);
   const size_t m = (size_t)batch * n_vert;
   const int cpad = pad4(cut_len);
+  const int mld = mask_ld(hidden, cut_len);
+  const size_t mpad = (m + 31) / 32 * 32;
   const int last = num_layers - 1;
 
   // ---- output layer
@@ -296,8 +315,11 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
     } else {
       r.c = scratch + L.ping[cur ^ 1];
       r.ldc = hidden;
-      r.mask = x;
-      r.ldmask = hidden;
+      // X_i is the output of layer i-1: its ReLU signs were saved by that layer's forward launches
+      r.maskb = const_cast<uint8_t *>(masks) + (size_t)(i - 1) * mpad * mld;
+      r.mld = mld;
+      r.moff = cpad / 4;
+      r.csplit = cut_len;
       {
         ProfScope ps(PROF_GEMM_DX, s);
         if (int rc = launch_rowgemm(r, EPI_DX_MASK, s)) return rc;

@@ -22,7 +22,8 @@ __global__ __launch_bounds__(256) void csr_fwd_kernel(const float *__restrict__ 
                                                       const int32_t *__restrict__ rowptr,
                                                       const int32_t *__restrict__ colidx,
                                                       const float *__restrict__ val, int n_vert, long long m,
-                                                      float *__restrict__ y, int ldy) {
+                                                      float *__restrict__ y, int ldy,
+                                                      uint8_t *__restrict__ maskb, int mld) {
   const int hl = threadIdx.x & 31;
   const long long row = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
   if (row >= m) return;
@@ -52,25 +53,28 @@ __global__ __launch_bounds__(256) void csr_fwd_kernel(const float *__restrict__ 
       acc += val[e] * r0;
     }
     float *yo = y + row * ldy + ch;
+    unsigned bits = 0;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       if (ch + t < c) {
         const float o = acc[t] + bias[ch + t];
         yo[t] = o > 0.f ? o : 0.f;
+        bits |= (o > 0.f ? 1u : 0u) << t;
       }
     }
+    if (maskb) maskb[row * mld + (ch >> 2)] = (uint8_t)bits;  // ReLU sign of the aggregated channels
   }
 }
 
 int launch_csr_fwd(const float *za, int ldza, const float *bias, int c, const int32_t *rowptr, const int32_t *col,
-                   const float *val, int n_vert, int batch, float *y, int ldy, hipStream_t s) {
+                   const float *val, int n_vert, int batch, float *y, int ldy, uint8_t *maskb, int mld, hipStream_t s) {
   if (ldza % 4 != 0 || ldza < pad4(c)) {
     set_error("csr_fwd: ldza=%d must be a multiple of 4 and >= pad4(c=%d)", ldza, c);
     return -1;
   }
   const long long m = (long long)batch * n_vert;
   A3VT_LAUNCH(csr_fwd_kernel, dim3(cdiv(m, 8)), dim3(256), 0, s, za, ldza, bias, c, rowptr, col, val, n_vert, m,
-                     y, ldy);
+              y, ldy, maskb, mld);
   A3VT_CHECK_LAUNCH();
   return 0;
 }

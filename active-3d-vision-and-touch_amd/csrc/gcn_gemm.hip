@@ -49,6 +49,7 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(RowGemmArgs p) {
   constexpr int A_FLOATS = WAVES * MT * 16 * 16;
   constexpr int STAGE = A_FLOATS + BROWS * 16;           // floats per stage
   constexpr int PER = A_INSTR + B_INSTR;                 // DMA instructions per wave per chunk
+  constexpr int MSLOT = 1024;                            // floats (4 KiB) of ReLU-sign bytes per wave (EPI_DX_MASK)
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
   const int lane = threadIdx.x & 63;
@@ -112,6 +113,18 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(RowGemmArgs p) {
       for (int pc = 0; pc < PER; ++pc) issue_piece(chunk, buf, pc);
     };
 
+    if (EPI == EPI_DX_MASK) {
+      // This unit's ReLU-sign bytes (32 rows x mld contiguous bytes) ride along with the first chunks: issued
+      // before them, so the first counted wait of the K loop also covers them.
+      float *ms = lds + 3 * STAGE + wave * MSLOT;
+      const uint8_t *src0 = p.maskb + (size_t)row0 * p.mld;
+      const int nbytes = 32 * p.mld;
+      for (int o = 0; o < nbytes; o += 1024) {
+        const int b = o + lane * 16;
+        const void *src = (active && b < nbytes) ? (const void *)(src0 + b) : (const void *)p.zeros;
+        glds16(reinterpret_cast<const float *>(src), ms + o / 4);
+      }
+    }
     issue(0, 0);
     if (nchunks > 1) issue(1, 1);
     int buf = 0;
@@ -206,8 +219,8 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(RowGemmArgs p) {
       float *ep = lds + wave * ((3 * STAGE) / WAVES);
       constexpr int G0 = (NT + 1) / 2;  // n-tiles in the first column group (second gets NT - G0)
       static_assert(16 * (G0 * 16 + 4) <= (3 * STAGE) / WAVES, "epilogue slice too small");
-      const bool vec_ok = (p.ldc % 4 == 0) && (EPI != EPI_FWD_HIDDEN || p.ldc2 % 4 == 0) &&
-                          (EPI != EPI_DX_MASK || p.ldmask % 4 == 0);
+      const bool vec_ok = (p.ldc % 4 == 0) && (EPI != EPI_FWD_HIDDEN || p.ldc2 % 4 == 0);
+      const uint8_t *mslot = reinterpret_cast<const uint8_t *>(lds + 3 * STAGE + wave * MSLOT);
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -242,6 +255,13 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(RowGemmArgs p) {
                   if (col + t < p.n_store) dst[t] = v[t];
               }
             } else if (EPI == EPI_FWD_HIDDEN) {
+              if (p.maskb && col + 3 >= p.csplit) {  // ReLU sign of the pass-through channels, 1 byte per 4 columns
+                unsigned bits = 0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                  bits |= ((col + t >= p.csplit && col + t < p.n_store && v[t] > 0.f) ? 1u : 0u) << t;
+                p.maskb[(size_t)row * p.mld + p.moff + (col >> 2)] = (uint8_t)bits;
+              }
               if (full && col + 3 < p.csplit) {  // aggregated channels: raw Z for the neighbour gather
                 *reinterpret_cast<f32x4 *>(p.c2 + (size_t)row * p.ldc2 + col) = v;
               } else if (full && col >= p.csplit) {  // pass-through channels: ReLU(Z), no bias
@@ -255,17 +275,21 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(RowGemmArgs p) {
                   else p.c[(size_t)row * p.ldc + col + t] = v[t] > 0.f ? v[t] : 0.f;
                 }
               }
-            } else {  // EPI_DX_MASK: gradient through the ReLU of the producing layer
-              const float *mk = p.mask + (size_t)row * p.ldmask + col;
+            } else {  // EPI_DX_MASK: gradient through the ReLU of the producing layer (sign bytes from LDS)
+              const int ur = i * 16 + rl;  // row inside the unit
+              const unsigned ba = mslot[ur * p.mld + (col >> 2)];
+              const unsigned bb = mslot[ur * p.mld + p.moff + (col >> 2)];
               float *dst = p.c + (size_t)row * p.ldc + col;
-              if (full) {
-                const f32x4 y = *reinterpret_cast<const f32x4 *>(mk);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) v[t] = y[t] > 0.f ? v[t] : 0.f;
+              for (int t = 0; t < 4; ++t) {
+                const unsigned bit = ((col + t < p.csplit ? ba : bb) >> t) & 1u;
+                v[t] = bit ? v[t] : 0.f;
+              }
+              if (full) {
                 *reinterpret_cast<f32x4 *>(dst) = v;
               } else {
                 for (int t = 0; t < 4; ++t)
-                  if (col + t < p.n_store) dst[t] = mk[t] > 0.f ? v[t] : 0.f;
+                  if (col + t < p.n_store) dst[t] = v[t];
               }
             }
           }
@@ -282,7 +306,7 @@ static constexpr int rowgemm_brows() { return ((NT * 16 + 127) / 128) * 128; }
 
 template <int NT, int EPI>
 static int launch_rowgemm_nt(const RowGemmArgs &a, int grid_y, hipStream_t s) {
-  constexpr size_t shmem = 3 * (size_t)(8 * 2 * 256 + rowgemm_brows<NT>() * 16) * sizeof(float);
+  constexpr size_t shmem = (3 * (size_t)(8 * 2 * 256 + rowgemm_brows<NT>() * 16) + (EPI == EPI_DX_MASK ? 8 * 1024 : 0)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void *)rowgemm_kernel<NT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -330,7 +354,7 @@ static int launch_rowgemm_epi(const RowGemmArgs &a0, hipStream_t s) {
   r.a1 = a.a1 + r0 * a.lda1;
   r.c = a.c + r0 * a.ldc;
   if (a.c2) r.c2 = a.c2 + r0 * a.ldc2;
-  if (a.mask) r.mask = a.mask + r0 * a.ldmask;
+  if (a.maskb) r.maskb = a.maskb + r0 * a.mld;
   return launch_rowgemm_nt<1, EPI>(r, nt, s);
 }
 
@@ -342,6 +366,10 @@ int rowgemm_bt_rows(int n_store) {
 }
 
 int launch_rowgemm(const RowGemmArgs &a, int epi, hipStream_t s) {
+  if (epi == EPI_DX_MASK && (a.maskb == nullptr || 32 * a.mld > 4096)) {
+    set_error("rowgemm: EPI_DX_MASK needs sign bytes with 32*mld <= 4096 (mld=%d)", a.mld);
+    return -1;
+  }
   if (a.k % 4 != 0 || a.ksplit % 4 != 0 || a.ldb < pad16(a.k)) {
     set_error("rowgemm: k=%d ksplit=%d ldb=%d violate alignment rules", a.k, a.ksplit, a.ldb);
     return -1;
@@ -447,6 +475,52 @@ __device__ __forceinline__ void dw_stage(const float *__restrict__ sb, int ldx, 
   }
 }
 
+// Common shape (ni in {4,5}, no in {2,3} — e.g. 19 x 10 tiles over 4 x 4 waves): the 4 x 2 core block runs
+// unconditionally, the 5th row / 3rd column / corner behind three wave-uniform branches, and the operand
+// reads of k-step ks+1 are issued before the MFMAs of k-step ks (register double buffer).
+__device__ __forceinline__ void dw_stage_fast(const float *__restrict__ sb, int ldx, int ldz0, int ldz1, int offG,
+                                              int xoff, const int (&zoff)[DW_MAXO], int q, bool row5, bool col3,
+                                              f32x4 (&acc)[DW_MAXI][DW_MAXO]) {
+  float a[DW_MAXI], b[DW_MAXO], an[DW_MAXI], bn[DW_MAXO];
+  auto load = [&](int ks, float (&av)[DW_MAXI], float (&bv)[DW_MAXO]) {
+    const int r = ks * 4 + q;
+    const float *xr = sb + r * ldx + xoff;
+    const int ra = r * ldz0, rg = r * ldz1;
+#pragma unroll
+    for (int i = 0; i < DW_MAXI; ++i) av[i] = xr[(i < 4 || row5 ? i : 3) * 16];
+#pragma unroll
+    for (int j = 0; j < DW_MAXO; ++j) {
+      const int zo = zoff[j < 2 || col3 ? j : 1];
+      bv[j] = sb[zo + (zo < offG ? ra : rg)];
+    }
+  };
+  load(0, a, b);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    if (ks < 3) load(ks + 1, an, bn);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    if (row5) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[4][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4], b[j], acc[4][j], 0, 0, 0);
+    }
+    if (col3) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[2], acc[i][2], 0, 0, 0);
+      if (row5) acc[4][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4], b[2], acc[4][2], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < DW_MAXI; ++i) a[i] = an[i];
+#pragma unroll
+    for (int j = 0; j < DW_MAXO; ++j) b[j] = bn[j];
+  }
+}
+
+template <bool FAST>
 __global__ __launch_bounds__(1024, 1) void dw_kernel(DwArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63;
@@ -551,7 +625,8 @@ __global__ __launch_bounds__(1024, 1) void dw_kernel(DwArgs p) {
     if (t + 2 < nu) issue(u0 + t + 2, buf >= 1 ? buf - 1 : 2);
 #endif
     const float *sb = lds + buf * stage;
-    dw_stage<-1, -1>(sb, p.ldx, p.ldz0, p.ldz1, offG, xoff, zoff, q, ni, no, acc);
+    if (FAST) dw_stage_fast(sb, p.ldx, p.ldz0, p.ldz1, offG, xoff, zoff, q, ni == 5, no == 3, acc);
+    else dw_stage<-1, -1>(sb, p.ldx, p.ldz0, p.ldz1, offG, xoff, zoff, q, ni, no, acc);
     buf = buf == 2 ? 0 : buf + 1;
   }
   wait_lgkm0();
@@ -599,10 +674,16 @@ int launch_dw(const DwArgs &a, hipStream_t s) {
   }
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)dw_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)dw_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  A3VT_LAUNCH(dw_kernel, dim3(dw_num_slabs(a.n_out), dw_col_groups(a.n_out)), dim3(1024), shmem, s, a);
+  // fast path: every wave owns 4-5 input tiles and 2-3 output tiles (true for 300 x 300)
+  const int tin = cdiv(a.k_in, 16), tout = cdiv(a.n_out, 16), groups = dw_col_groups(a.n_out);
+  const bool fast = tin / 4 >= 4 && tin <= 20 && (tout / groups) / 4 >= 2 && cdiv(tout, groups) <= 12;
+  const dim3 grid(dw_num_slabs(a.n_out), groups);
+  if (fast) A3VT_LAUNCH(dw_kernel<true>, grid, dim3(1024), shmem, s, a);
+  else A3VT_LAUNCH(dw_kernel<false>, grid, dim3(1024), shmem, s, a);
   A3VT_CHECK_LAUNCH();
   return 0;
 }

@@ -14,14 +14,17 @@ struct RowGemmArgs {
   const float *a1;
   const float *bt;     // [rowgemm_bt_rows(n_store)][ldb], zero padded (rows >= n_out, cols >= k)
   const float *zeros;  // >= 16 B of zeros
-  const float *mask;   // EPI_DX_MASK: [M][ldmask]
+  // ReLU sign bytes, one per (row, 4 columns): [Mpad32][mld]; bytes [0, moff) cover the aggregated channels
+  // (written by csr_fwd), bytes [moff, mld) all channels (written by the EPI_FWD_HIDDEN epilogue for columns
+  // >= csplit).  EPI_FWD_HIDDEN writes them, EPI_DX_MASK reads them (instead of re-reading the 197 MB activation).
+  uint8_t *maskb;
   float *c;            // main output [M][ldc]
   float *c2;           // EPI_FWD_HIDDEN: raw output for cols < csplit, [M][ldc2]
   int lda0, lda1, ksplit, ldb;
   int bt_rows;  // rows present in the Bt buffer (set by launch_rowgemm)
   int col0;     // first output column handled by blockIdx.y == 0 (set by launch_rowgemm)
   int m, k, n_store;
-  int ldc, ldc2, csplit, ldmask;
+  int ldc, ldc2, csplit, mld, moff;
 };
 int rowgemm_bt_rows(int n_store);
 int launch_rowgemm(const RowGemmArgs &a, int epi, hipStream_t s);
@@ -44,7 +47,7 @@ int launch_slab_reduce(const float *slab, int nslab, size_t stride, size_t n, fl
 
 // CSR neighbour aggregation on the first c channels (+ bias + ReLU), model.py:356-358,363.
 int launch_csr_fwd(const float *za, int ldza, const float *bias, int c, const int32_t *rowptr, const int32_t *col,
-                   const float *val, int n_vert, int batch, float *y, int ldy, hipStream_t s);
+                   const float *val, int n_vert, int batch, float *y, int ldy, uint8_t *maskb, int mld, hipStream_t s);
 // dZa[:, :c] = A^T G[:, :c];  dZa[:, c:cpad] = G[:, c:cpad];  db partial sums of G[:, :c] -> slab [nslab][cpad].
 int csr_bwd_num_slabs(int batch, int n_vert);
 int launch_csr_bwd(const float *g, int ldg, int c, const int32_t *rowptrT, const int32_t *colT, const float *valT,

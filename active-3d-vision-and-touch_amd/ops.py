@@ -73,18 +73,21 @@ class GCNStackFn(torch.autograd.Function):
         nl = len(weights)
         need_bwd = any(ctx.needs_input_grad)
         M = B * N
-        acts = torch.empty((max(nl - 1, 0), M, hidden), dtype=torch.float32, device=feats.device) \
-            if (need_bwd and nl > 1) else None
+        acts = masks = None
+        if need_bwd and nl > 1:
+            acts = torch.empty((nl - 1, M, hidden), dtype=torch.float32, device=feats.device)
+            masks = torch.empty(L.a3vt_gcn_stack_mask_bytes(B, N, hidden, nl, cut_len), dtype=torch.uint8,
+                                device=feats.device)
         nbytes = L.a3vt_gcn_stack_scratch_bytes(B, N, in_features, hidden, nl, cut_len, 1 if need_bwd else 0)
         scratch = workspace("gcn", nbytes, feats.device)
         update = torch.empty((B, N, 3), dtype=torch.float32, device=feats.device)
         wp, bp = _ptr_array(weights), _ptr_array(biases)
         _lib.check(L.a3vt_gcn_stack_fwd(_lib.ptr(feats), ld, in_features, wp, bp, nl, hidden, cut_len,
                                         _lib.ptr(adj.rowptr), _lib.ptr(adj.col), _lib.ptr(adj.val), N, B,
-                                        _lib.ptr(acts), _lib.ptr(scratch), _lib.ptr(update), _stream()),
+                                        _lib.ptr(acts), _lib.ptr(masks), _lib.ptr(scratch), _lib.ptr(update), _stream()),
                    "gcn_stack_fwd")
         ctx.adj, ctx.dims = adj, (in_features, hidden, cut_len, nl)
-        ctx.acts = acts
+        ctx.acts, ctx.masks = acts, masks
         ctx.save_for_backward(feats, *weights, *biases)
         return update
 
@@ -106,9 +109,10 @@ class GCNStackFn(torch.autograd.Function):
         _lib.check(L.a3vt_gcn_stack_bwd(_lib.ptr(feats), ld, in_features, _ptr_array(weights), _ptr_array(biases), nl,
                                         hidden, cut_len, _lib.ptr(adj.rowptr), _lib.ptr(adj.col), _lib.ptr(adj.val),
                                         _lib.ptr(adj.t_rowptr), _lib.ptr(adj.t_col), _lib.ptr(adj.t_val), N, B,
-                                        _lib.ptr(ctx.acts), _lib.ptr(grad_update), _ptr_array(gw), _ptr_array(gb),
+                                        _lib.ptr(ctx.acts), _lib.ptr(ctx.masks), _lib.ptr(grad_update), _ptr_array(gw),
+                                        _ptr_array(gb),
                                         _lib.ptr(gfeats), _lib.ptr(scratch), _stream()), "gcn_stack_bwd")
-        ctx.acts = None
+        ctx.acts = ctx.masks = None
         grads = []
         for w, b in zip(gw, gb):
             grads += [w, b]

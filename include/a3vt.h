@@ -50,18 +50,21 @@ int a3vt_csr_validate(const int32_t *rowptr_host, const int32_t *col_host, int n
  *
  * feats  : [M][ld_feats] with ld_feats >= in_features, ld_feats % 4 == 0; pad columns must be zero.
  * acts   : saved inputs of layers 1..L-1, [L-1][M][hidden]   (needed by the backward pass)
+ * masks  : ReLU sign bytes of those activations (1 byte per 4 channels), a3vt_gcn_stack_mask_bytes() bytes;
+ *          the backward pass reads these 16 MB per layer instead of re-reading the 197 MB activation
  * update : [M][3]
- * Forward-only callers (policy scoring, environment.py:221-257) may pass acts = NULL: the
+ * Forward-only callers (policy scoring, environment.py:221-257) may pass acts = masks = NULL: the
  * layer outputs then ping-pong inside `scratch`. */
 size_t a3vt_gcn_stack_scratch_bytes(int batch, int n_vert, int in_features, int hidden, int num_layers,
                                     int cut_len, int need_backward);
+size_t a3vt_gcn_stack_mask_bytes(int batch, int n_vert, int hidden, int num_layers, int cut_len);
 
 int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features,
                        const float *const *weights, const float *const *biases,
                        int num_layers, int hidden, int cut_len,
                        const int32_t *csr_rowptr, const int32_t *csr_col, const float *csr_val,
                        int n_vert, int batch,
-                       float *acts, float *scratch, float *update, void *stream);
+                       float *acts, uint8_t *masks, float *scratch, float *update, void *stream);
 
 /* Backward of the stack.  grad_update [M][3] -> grad_feats [M][ld_feats] (pad columns written as 0),
  * grad_weights[i] [in_i][out_i], grad_biases[i] [out_i] (overwritten; channels >= cut_len of hidden
@@ -72,7 +75,7 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features,
                        const int32_t *csr_rowptr, const int32_t *csr_col, const float *csr_val,
                        const int32_t *csrT_rowptr, const int32_t *csrT_col, const float *csrT_val,
                        int n_vert, int batch,
-                       const float *acts, const float *grad_update,
+                       const float *acts, const uint8_t *masks, const float *grad_update,
                        float *const *grad_weights, float *const *grad_biases, float *grad_feats,
                        float *scratch, void *stream);
 
