@@ -12,6 +12,69 @@ namespace a3vt {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+// XCD-aware work mapping.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 names the XCD group,
+// MI355X_MICROARCH.md "Workgroup dispatch"), each XCD has a private 4 MiB L2, and a neighbour gather only
+// ever touches rows of its own mesh (<= 1 MB per mesh at 100 channels).  So mesh b is processed entirely by
+// the workgroups of XCD group b % 8: the mesh's rows are pulled into ONE L2 and every re-read (7x on the
+// icosphere) hits there, instead of every L2 thrashing over every mesh and falling through to the Infinity
+// Cache.  Placement only affects speed, never correctness.
+struct XcdWalk {
+  int xcd, nloc, stride;       // this workgroup's XCD group, its index inside the group, workgroups per group
+  long long ngroups;           // 8-vertex groups owned by the XCD group
+  int gps, nmesh;              // groups per mesh, meshes owned
+  __device__ XcdWalk(int batch, int n_vert) {
+    xcd = blockIdx.x & 7;
+    nloc = blockIdx.x >> 3;
+    stride = (gridDim.x + 7 - xcd) >> 3;  // workgroups with this blockIdx % 8
+    gps = (n_vert + 7) >> 3;
+    nmesh = batch > xcd ? (batch - xcd + 7) >> 3 : 0;
+    ngroups = (long long)nmesh * gps;
+  }
+  // vertex handled by sub-group `sub` (0..7) of group g; returns false past the mesh end
+  __device__ bool locate(long long g, int sub, int n_vert, long long &b, int &v) const {
+    b = xcd + 8 * (g / gps);
+    v = (int)(g % gps) * 8 + sub;
+    return v < n_vert;
+  }
+};
+
+// Weighted sum of neighbour rows for one vertex, computed by a half-wave (32 lanes): the row's column
+// indices and weights are fetched 32 at a time with ONE coalesced load each and handed around with
+// shuffles, so the only dependent memory round trip per neighbour is the 16-byte row gather itself.
+__device__ __forceinline__ f32x4 gather_row(const float *__restrict__ base, long long ld, int ch, bool lane_on,
+                                            int e0, int e1, int hl, const int32_t *__restrict__ colidx,
+                                            const float *__restrict__ val) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int eb = e0; eb < e1; eb += 32) {
+    const int n = min(32, e1 - eb);
+    const int myc = hl < n ? colidx[eb + hl] : 0;
+    const float myw = hl < n ? val[eb + hl] : 0.f;
+    int j = 0;
+    for (; j + 3 < n; j += 4) {  // 4 neighbour rows in flight (8 costs occupancy and loses)
+      const int c0 = __shfl(myc, j, 32), c1 = __shfl(myc, j + 1, 32), c2 = __shfl(myc, j + 2, 32),
+                c3 = __shfl(myc, j + 3, 32);
+      const float w0 = __shfl(myw, j, 32), w1 = __shfl(myw, j + 1, 32), w2 = __shfl(myw, j + 2, 32),
+                  w3 = __shfl(myw, j + 3, 32);
+      if (lane_on) {
+        const f32x4 r0 = *reinterpret_cast<const f32x4 *>(base + c0 * ld + ch);
+        const f32x4 r1 = *reinterpret_cast<const f32x4 *>(base + c1 * ld + ch);
+        const f32x4 r2 = *reinterpret_cast<const f32x4 *>(base + c2 * ld + ch);
+        const f32x4 r3 = *reinterpret_cast<const f32x4 *>(base + c3 * ld + ch);
+        acc += w0 * r0;
+        acc += w1 * r1;
+        acc += w2 * r2;
+        acc += w3 * r3;
+      }
+    }
+    for (; j < n; ++j) {
+      const int c0 = __shfl(myc, j, 32);
+      const float w0 = __shfl(myw, j, 32);
+      if (lane_on) acc += w0 * *reinterpret_cast<const f32x4 *>(base + c0 * ld + ch);
+    }
+  }
+  return acc;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Forward: Y[m][ch] = relu( sum_e val[e] * Za[b][col[e]][ch] + bias[ch] ), ch < c.
 // A half-wave (32 lanes) owns one vertex; lane l handles channels 4l..4l+3 (16-byte loads of the
@@ -25,44 +88,43 @@ __global__ __launch_bounds__(256) void csr_fwd_kernel(const float *__restrict__ 
                                                       float *__restrict__ y, int ldy,
                                                       uint8_t *__restrict__ maskb, int mld) {
   const int hl = threadIdx.x & 31;
-  const long long row = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
-  if (row >= m) return;
-  const long long b = row / n_vert;
-  const int v = (int)(row - b * n_vert);
-  const float *zb = za + b * n_vert * (long long)ldza;
-  const int e0 = rowptr[v], e1 = rowptr[v + 1];
-  for (int ch0 = 0; ch0 < c; ch0 += 128) {
-    const int ch = ch0 + hl * 4;
-    if (ch >= c) continue;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    int e = e0;
-    for (; e + 3 < e1; e += 4) {  // 4 neighbour rows in flight
-      const int n0 = colidx[e], n1 = colidx[e + 1], n2 = colidx[e + 2], n3 = colidx[e + 3];
-      const float w0 = val[e], w1 = val[e + 1], w2 = val[e + 2], w3 = val[e + 3];
-      const f32x4 r0 = *reinterpret_cast<const f32x4 *>(zb + (long long)n0 * ldza + ch);
-      const f32x4 r1 = *reinterpret_cast<const f32x4 *>(zb + (long long)n1 * ldza + ch);
-      const f32x4 r2 = *reinterpret_cast<const f32x4 *>(zb + (long long)n2 * ldza + ch);
-      const f32x4 r3 = *reinterpret_cast<const f32x4 *>(zb + (long long)n3 * ldza + ch);
-      acc += w0 * r0;
-      acc += w1 * r1;
-      acc += w2 * r2;
-      acc += w3 * r3;
-    }
-    for (; e < e1; ++e) {
-      const f32x4 r0 = *reinterpret_cast<const f32x4 *>(zb + (long long)colidx[e] * ldza + ch);
-      acc += val[e] * r0;
-    }
-    float *yo = y + row * ldy + ch;
-    unsigned bits = 0;
+  const XcdWalk w((int)(m / n_vert), n_vert);
+  float bsv[4] = {0.f, 0.f, 0.f, 0.f};  // bias of this lane's 4 channels (c <= 128: one pass)
+  if (c <= 128) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      if (ch + t < c) {
-        const float o = acc[t] + bias[ch + t];
-        yo[t] = o > 0.f ? o : 0.f;
-        bits |= (o > 0.f ? 1u : 0u) << t;
+    for (int t = 0; t < 4; ++t)
+      if (hl * 4 + t < c) bsv[t] = bias[hl * 4 + t];
+  }
+  for (long long g = w.nloc; g < w.ngroups; g += w.stride) {
+    long long b;
+    int v;
+    if (!w.locate(g, threadIdx.x >> 5, n_vert, b, v)) continue;  // uniform per half-wave
+    const long long row = b * n_vert + v;
+    const float *zb = za + b * n_vert * (long long)ldza;
+    const int e0 = rowptr[v], e1 = rowptr[v + 1];
+    for (int ch0 = 0; ch0 < c; ch0 += 128) {
+      const int ch = ch0 + hl * 4;
+      const bool on = ch < c;
+      const f32x4 acc = gather_row(zb, ldza, ch, on, e0, e1, hl, colidx, val);
+      if (!on) continue;
+      float *yo = y + row * ldy + ch;
+      unsigned bits = 0;
+      f32x4 o;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float pre = ch + t < c ? acc[t] + (c <= 128 ? bsv[t] : bias[ch + t]) : 0.f;
+        o[t] = pre > 0.f ? pre : 0.f;
+        bits |= (pre > 0.f ? 1u : 0u) << t;
       }
+      if (ch + 3 < c && (ldy & 3) == 0) {
+        *reinterpret_cast<f32x4 *>(yo) = o;
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          if (ch + t < c) yo[t] = o[t];
+      }
+      if (maskb) maskb[row * mld + (ch >> 2)] = (uint8_t)bits;  // ReLU sign of the aggregated channels
     }
-    if (maskb) maskb[row * mld + (ch >> 2)] = (uint8_t)bits;  // ReLU sign of the aggregated channels
   }
 }
 
@@ -73,8 +135,9 @@ int launch_csr_fwd(const float *za, int ldza, const float *bias, int c, const in
     return -1;
   }
   const long long m = (long long)batch * n_vert;
-  A3VT_LAUNCH(csr_fwd_kernel, dim3(cdiv(m, 8)), dim3(256), 0, s, za, ldza, bias, c, rowptr, col, val, n_vert, m,
-              y, ldy, maskb, mld);
+  const int grid = (int)(cdiv(m, 8) < 4096 ? (cdiv(m, 8) + 7) / 8 * 8 : 4096);  // multiple of 8: whole XCD groups
+  A3VT_LAUNCH(csr_fwd_kernel, dim3(grid), dim3(256), 0, s, za, ldza, bias, c, rowptr, col, val, n_vert, m, y, ldy,
+              maskb, mld);
   A3VT_CHECK_LAUNCH();
   return 0;
 }
@@ -98,32 +161,20 @@ __global__ __launch_bounds__(256) void csr_bwd_kernel(const float *__restrict__ 
   for (int ch0 = 0; ch0 < cpad; ch0 += 128) {
     const int ch = ch0 + hl * 4;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
-    if (ch < cpad) {
-      for (long long row = (long long)blockIdx.x * 8 + grp; row < m; row += (long long)gridDim.x * 8) {
-        const long long b = row / n_vert;
-        const int v = (int)(row - b * n_vert);
-        const float *gb = g + b * n_vert * (long long)ldg;
-        const f32x4 own = *reinterpret_cast<const f32x4 *>(gb + (long long)v * ldg + ch);
-        bsum += own;
-        const int e0 = rowptr[v], e1 = rowptr[v + 1];
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        int e = e0;
-        for (; e + 3 < e1; e += 4) {
-          const int n0 = colidx[e], n1 = colidx[e + 1], n2 = colidx[e + 2], n3 = colidx[e + 3];
-          const float w0 = val[e], w1 = val[e + 1], w2 = val[e + 2], w3 = val[e + 3];
-          const f32x4 r0 = *reinterpret_cast<const f32x4 *>(gb + (long long)n0 * ldg + ch);
-          const f32x4 r1 = *reinterpret_cast<const f32x4 *>(gb + (long long)n1 * ldg + ch);
-          const f32x4 r2 = *reinterpret_cast<const f32x4 *>(gb + (long long)n2 * ldg + ch);
-          const f32x4 r3 = *reinterpret_cast<const f32x4 *>(gb + (long long)n3 * ldg + ch);
-          acc += w0 * r0;
-          acc += w1 * r1;
-          acc += w2 * r2;
-          acc += w3 * r3;
-        }
-        for (; e < e1; ++e) {
-          const f32x4 r0 = *reinterpret_cast<const f32x4 *>(gb + (long long)colidx[e] * ldg + ch);
-          acc += val[e] * r0;
-        }
+    const bool on = ch < cpad;  // all 32 lanes of the half-wave stay in the loop: gather_row shuffles across them
+    const XcdWalk w((int)(m / n_vert), n_vert);
+    for (long long gi = w.nloc; gi < w.ngroups; gi += w.stride) {
+      long long b;
+      int v;
+      if (!w.locate(gi, grp, n_vert, b, v)) continue;  // uniform per half-wave
+      const long long row = b * n_vert + v;
+      const float *gb = g + b * n_vert * (long long)ldg;
+      f32x4 own = {0.f, 0.f, 0.f, 0.f};
+      if (on) own = *reinterpret_cast<const f32x4 *>(gb + (long long)v * ldg + ch);
+      bsum += own;
+      const int e0 = rowptr[v], e1 = rowptr[v + 1];
+      const f32x4 acc = gather_row(gb, ldg, ch, on, e0, e1, hl, colidx, val);
+      if (on) {
         f32x4 out;
 #pragma unroll
         for (int t = 0; t < 4; ++t) out[t] = ch + t < c ? acc[t] : own[t];
@@ -146,7 +197,7 @@ __global__ __launch_bounds__(256) void csr_bwd_kernel(const float *__restrict__ 
 
 int csr_bwd_num_slabs(int batch, int n_vert) {
   const long long groups = ((long long)batch * n_vert + 7) / 8;
-  return (int)(groups < kCsrBwdMaxBlocks ? groups : kCsrBwdMaxBlocks);
+  return (int)(groups < kCsrBwdMaxBlocks ? (groups + 7) / 8 * 8 : kCsrBwdMaxBlocks);  // multiple of 8 (XCD groups)
 }
 
 int launch_csr_bwd(const float *g, int ldg, int c, const int32_t *rowptrT, const int32_t *colT, const float *valT,
