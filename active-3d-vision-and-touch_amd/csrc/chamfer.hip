@@ -116,9 +116,17 @@ __global__ __launch_bounds__(256) void nn_kernel(const float *__restrict__ q, in
 
 static int launch_nn(const float *q, int nq, int q_mod, const float *c, int nc, int c_mod, int nclouds, float *dist,
                      int32_t *idx, hipStream_t s) {
-  constexpr int R = 4;
-  dim3 grid(cdiv(nq, 256 * R), nclouds);
-  A3VT_LAUNCH((nn_kernel<R>), grid, dim3(256), 0, s, q, nq, q_mod, c, nc, c_mod, dist, idx);
+  // 8 queries per lane when the cloud is large (fewer, fatter workgroups: all resident in one round, LDS reads
+  // amortised over more VALU work); 4 for small clouds so the grid still fills the chip.
+  if (nq >= 4096) {
+    constexpr int R = 8;
+    dim3 grid(cdiv(nq, 256 * R), nclouds);
+    A3VT_LAUNCH((nn_kernel<R>), grid, dim3(256), 0, s, q, nq, q_mod, c, nc, c_mod, dist, idx);
+  } else {
+    constexpr int R = 4;
+    dim3 grid(cdiv(nq, 256 * R), nclouds);
+    A3VT_LAUNCH((nn_kernel<R>), grid, dim3(256), 0, s, q, nq, q_mod, c, nc, c_mod, dist, idx);
+  }
   A3VT_CHECK_LAUNCH();
   return 0;
 }
