@@ -73,6 +73,20 @@ def cpu_baseline(level, layers, hidden, points, seed=0):
                       f"CSR aggregation + plain-C brute-force NN, torch CPU fp32"}
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC collection (tools/collect_traffic.sh:
+    separate --pmc passes; FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM": it reports half of a wide coalesced
+    stream on gfx950; WRITE_SIZE exact).  None when the summary is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_summary.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        k = next(v for name, v in d.items() if "rowgemm_kernel<19, 2>" in name)
+        return (2.0 * k["FETCH_SIZE_KiB_max"] + k["WRITE_SIZE_KiB_max"]) * 1024.0
+    except Exception:
+        return None
+
+
 def main():
     a = parse()
     from a3vt_amd import distributed as adist, lib
@@ -155,8 +169,9 @@ def main():
         # dominant kernel = rowgemm (forward + dX launches share the kernel); dX launches are all hidden x hidden
         t_ms = tot[1] / max(n_dx, 1)
         achieved = flop / (t_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "rowgemm_kernel<2,19> (fp32 MFMA 16x16x4, M x 300 x 300)",
-                "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3, "traffic": None,
+        roof = {"bound": "mfma", "kernel": "rowgemm_kernel<19,EPI_DX_MASK> (fp32 MFMA 16x16x4, M x 300 x 300, dX = dZ W^T)",
+                "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3,
+                "traffic": pmc_traffic(),
                 "avg_launch_ms": t_ms, "launches": n_dx, "flop_per_launch": flop,
                 "other_mfma_ms": per,
                 "mfma_ms_per_step": (tot[0] + tot[1] + tot[2]) / a.profile_steps}
