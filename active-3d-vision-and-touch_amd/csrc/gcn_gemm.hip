@@ -689,14 +689,15 @@ int launch_dw(const DwArgs &a, hipStream_t s) {
 }
 
 // out[i] = sum_s slab[s * stride + i]   (fixed summation order -> bitwise reproducible).
-// Workgroup = 64 consecutive outputs x 4 slab groups: each thread sums a quarter of the slabs with 8 loads
-// in flight, then the four partials are combined through LDS in a fixed order.
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slab, int nslab, size_t stride,
-                                                          size_t n, float *__restrict__ out) {
-  __shared__ float part[4][64];
+// Workgroup = 64 consecutive outputs x 16 slab groups (1024 threads): each thread sums its 1/16 of the slabs with
+// every load in flight at once (the reduce is latency-bound: 128 slabs x 360 KB per layer), then the sixteen
+// partials are combined through LDS in a fixed order.
+__global__ __launch_bounds__(1024) void slab_reduce_kernel(const float *__restrict__ slab, int nslab, size_t stride,
+                                                           size_t n, float *__restrict__ out) {
+  __shared__ float part[16][64];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const size_t i = (size_t)blockIdx.x * 64 + lane;
-  const int per = (nslab + 3) / 4;
+  const int per = (nslab + 15) / 16;
   const int s0 = grp * per, s1 = min(s0 + per, nslab);
   float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (i < n) {
@@ -709,11 +710,16 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
   }
   part[grp][lane] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   __syncthreads();
-  if (grp == 0 && i < n) out[i] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+  if (grp == 0 && i < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += part[g][lane];
+    out[i] = t;
+  }
 }
 
 int launch_slab_reduce(const float *slab, int nslab, size_t stride, size_t n, float *out, hipStream_t s) {
-  A3VT_LAUNCH(slab_reduce_kernel, dim3(cdiv((long long)n, 64)), dim3(256), 0, s, slab, nslab, stride, n, out);
+  A3VT_LAUNCH(slab_reduce_kernel, dim3(cdiv((long long)n, 64)), dim3(1024), 0, s, slab, nslab, stride, n, out);
   A3VT_CHECK_LAUNCH();
   return 0;
 }
