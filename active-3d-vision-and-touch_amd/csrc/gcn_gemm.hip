@@ -9,6 +9,8 @@
 // Both use v_mfma_f32_16x16x4_f32 (exact fp32 fma chain, 64 FLOP/clk/SIMD — MI355X_MICROARCH.md
 // "Matrix cores"), operands staged HBM/L2 -> LDS with LDS-DMA (global_load_lds_dwordx4), counted
 // vmcnt waits and raw s_barrier so the next chunk's DMA stays in flight under the MFMAs.
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -29,27 +31,34 @@ __device__ __forceinline__ void wait_vmcnt() {
 __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // ------------------------------------------------------------------------------------------------
-// rowgemm: persistent workgroups of 8 waves (two per SIMD), one per CU.  The M rows are cut into 32-row
-// units that are dealt evenly to the workgroups; a workgroup walks its units eight at a time (one unit =
-// 2 m-tiles of 16 rows per wave, all NT 16-column tiles -> 2*NT accumulator tiles per wave).
-// K is walked in chunks of 16 through a 3-stage LDS ring filled by LDS-DMA: each wave DMAs its own A rows
-// [32][16] plus 1/8 of the shared Bt chunk [BROWS][16]; chunk t+2 is issued right after the single
-// barrier of iteration t, so two chunks are always in flight under the MFMAs (counted vmcnt, raw s_barrier).
+// rowgemm: persistent workgroups; the M rows are cut into 16-row tiles that are dealt evenly to the
+// workgroups, and inside a workgroup to its waves, two tiles per wave per round (a wave's round =
+// 2 x NT accumulator tiles of 16 x 16, 152 VGPRs at NT = 19).  The last, partial round of a workgroup gives
+// every wave one tile instead of half the waves two, so all four SIMDs stay equally loaded.
+// K is walked in chunks of 16 through an NSTAGE-deep LDS ring filled by LDS-DMA: each wave DMAs its own A rows
+// [32][16] plus its share of the Bt chunk [BROWS][16]; chunk t+NSTAGE-1 is issued right after the single
+// barrier of iteration t (counted vmcnt, raw s_barrier).
 // A fragment read is one ds_read_b128 per (m-tile, chunk): lane l holds A[row l&15][k0 + 4*(l>>4) + t],
 // t = 0..3, and MFMA step t consumes element t of both fragments — the k order inside a chunk is permuted
 // identically for A and B, which a sum over k does not see.
+//
+// Geometry (RowGemmCfg) is a template choice: WAVES waves per workgroup, NSTAGE ring stages.  One 8-wave
+// workgroup per CU with a 3-stage ring is the fastest measured; the single-tile remainder launches use a
+// deeper ring because a handful of MFMAs per chunk cannot cover a DMA round trip.  Known cost: the epilogue is
+// bound by the CU's store path (~7-10 B/clk: 770 KB per CU per launch = 30-45 us) and is not overlapped.
 // ------------------------------------------------------------------------------------------------
-template <int NT, int EPI>
-__global__ __launch_bounds__(512, 2) void rowgemm_kernel(RowGemmArgs p) {
+template <int NT, int EPI, int NSTAGE, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
   constexpr int MT = 2;
-  constexpr int WAVES = 8;
-  constexpr int BROWS = ((NT * 16 + 127) / 128) * 128;  // Bt rows staged per chunk (multiple of 16 * WAVES)
-  constexpr int A_INSTR = MT;                            // DMA wave-instructions per wave per chunk (16 rows each)
+  constexpr int BROWS = ((NT * 16 + 16 * WAVES - 1) / (16 * WAVES)) * (16 * WAVES);  // Bt rows staged per chunk
+  constexpr int A_INSTR = MT;                   // DMA wave-instructions per wave per chunk (16 rows each)
   constexpr int B_INSTR = BROWS / (16 * WAVES);
   constexpr int A_FLOATS = WAVES * MT * 16 * 16;
-  constexpr int STAGE = A_FLOATS + BROWS * 16;           // floats per stage
-  constexpr int PER = A_INSTR + B_INSTR;                 // DMA instructions per wave per chunk
-  constexpr int MSLOT = 1024;                            // floats (4 KiB) of ReLU-sign bytes per wave (EPI_DX_MASK)
+  constexpr int STAGE = A_FLOATS + BROWS * 16;  // floats per stage
+  constexpr int PER = A_INSTR + B_INSTR;        // DMA instructions per wave per chunk
+  constexpr int DIST = NSTAGE - 1;              // chunks issued ahead of the one being consumed
+  constexpr int MSLOT = 1024;                   // floats (4 KiB) of ReLU-sign bytes per wave (EPI_DX_MASK)
+  static_assert((DIST - 1) * PER <= 63, "vmcnt immediate");
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
   const int lane = threadIdx.x & 63;
@@ -58,11 +67,11 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(RowGemmArgs p) {
   const int l16 = lane & 15, q = lane >> 4;
   const int kpiece = (lane & 3) * 4;
 
-  // units of 32 rows, dealt evenly to the workgroups
-  const int units = (p.m + 31) >> 5;
-  const int ubase = units / gridDim.x, urem = units % gridDim.x;
-  const int u0 = blockIdx.x * ubase + ((int)blockIdx.x < urem ? blockIdx.x : urem);
-  const int u1 = u0 + ubase + ((int)blockIdx.x < urem ? 1 : 0);
+  // 16-row tiles, dealt evenly to the workgroups
+  const int tiles = (p.m + 15) >> 4;
+  const int tbase = tiles / gridDim.x, trem = tiles % gridDim.x;
+  const int t0 = blockIdx.x * tbase + ((int)blockIdx.x < trem ? blockIdx.x : trem);
+  const int t1 = t0 + tbase + ((int)blockIdx.x < trem ? 1 : 0);
 
   const int col0 = p.col0 + blockIdx.y * (NT * 16);  // column block of this workgroup (remainder launches)
   const float *brow[B_INSTR];
@@ -73,10 +82,14 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(RowGemmArgs p) {
     brow[j] = p.bt + (size_t)br * p.ldb;
   }
 
-  for (int ubeg = u0; ubeg < u1; ubeg += WAVES) {
-    const int unit = ubeg + wave;
-    const bool active = unit < u1;  // wave-uniform
-    const int row0 = unit * 32;
+  for (int tb = t0; tb < t1; tb += MT * WAVES) {
+    // tiles of this round for this wave: two each when the round is full, an even split otherwise
+    const int cnt = t1 - tb < MT * WAVES ? t1 - tb : MT * WAVES;
+    const int base = cnt / WAVES, extra = cnt % WAVES;
+    const int nm = base + (wave < extra ? 1 : 0);  // 0..2, wave-uniform
+    const int first = tb + wave * base + (wave < extra ? wave : extra);
+    const bool active = nm > 0;
+    const int row0 = first * 16;
 
     // this wave's A source rows (ragged tail: duplicate the last row, never stored)
     const float *a0row[A_INSTR];
@@ -95,12 +108,13 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(RowGemmArgs p) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // One DMA wave-instruction of a chunk: pieces [0, A_INSTR) are this wave's A rows, the rest its share of Bt.
+    // One DMA wave-instruction of a chunk: pieces [0, A_INSTR) are this wave's A tiles, the rest its share of Bt.
     auto issue_piece = [&](int chunk, int buf, int piece) {
       const int kk = chunk * 16 + kpiece;
       if (piece < A_INSTR) {
         float *sA = lds + buf * STAGE + wave * (MT * 256);
-        const float *src = (!active || kk >= p.k) ? p.zeros : (kk < p.ksplit ? a0row[piece] + kk : a1row[piece] + kk);
+        const float *src =
+            (piece >= nm || kk >= p.k) ? p.zeros : (kk < p.ksplit ? a0row[piece] + kk : a1row[piece] + kk);
         glds16(src, sA + piece * 256);
       } else {
         const int j = piece - A_INSTR;
@@ -114,125 +128,113 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(RowGemmArgs p) {
     };
 
     if (EPI == EPI_DX_MASK) {
-      // This unit's ReLU-sign bytes (32 rows x mld contiguous bytes) ride along with the first chunks: issued
+      // This round's ReLU-sign bytes (16*nm rows x mld contiguous bytes) ride along with the first chunks: issued
       // before them, so the first counted wait of the K loop also covers them.
-      float *ms = lds + 3 * STAGE + wave * MSLOT;
+      float *ms = lds + NSTAGE * STAGE + wave * MSLOT;
       const uint8_t *src0 = p.maskb + (size_t)row0 * p.mld;
-      const int nbytes = 32 * p.mld;
-      for (int o = 0; o < nbytes; o += 1024) {
+      const int nbytes = 16 * nm * p.mld;
+      for (int o = 0; o < 32 * p.mld; o += 1024) {
         const int b = o + lane * 16;
-        const void *src = (active && b < nbytes) ? (const void *)(src0 + b) : (const void *)p.zeros;
+        const void *src = b < nbytes ? (const void *)(src0 + b) : (const void *)p.zeros;
         glds16(reinterpret_cast<const float *>(src), ms + o / 4);
       }
     }
-    issue(0, 0);
-    if (nchunks > 1) issue(1, 1);
+#pragma unroll
+    for (int d = 0; d < DIST; ++d)
+      if (d < nchunks) issue(d, d);
     int buf = 0;
     for (int t = 0; t < nchunks; ++t) {
-#ifdef A3VT_DBG_NODMA
-      wait_vmcnt<0>();
-#endif
-      if (t + 1 < nchunks) wait_vmcnt<PER>();  // chunk t landed; chunk t+1 may still be in flight
+      // chunk t landed; up to DIST-1 younger chunks may still be in flight
+      const int younger = nchunks - 1 - t < DIST - 1 ? nchunks - 1 - t : DIST - 1;
+      if (younger >= 4) wait_vmcnt<(DIST > 4 ? 4 : 0) * PER>();
+      else if (younger == 3) wait_vmcnt<(DIST > 3 ? 3 : 0) * PER>();
+      else if (younger == 2) wait_vmcnt<(DIST > 2 ? 2 : 0) * PER>();
+      else if (younger == 1) wait_vmcnt<(DIST > 1 ? 1 : 0) * PER>();
       else wait_vmcnt<0>();
-#ifndef A3VT_DBG_NOBARRIER
       __builtin_amdgcn_s_barrier();  // chunk t visible to all waves; everyone is done with chunk t-1's stage
-#endif
-      // Chunk t+2 goes to stage (t+2)%3 == (t-1)%3, free since the barrier above.  Its DMA instructions are
-      // spread through the MFMA stream below (one per pair of n-tiles) so their issue cost hides under the
-      // matrix pipe instead of stalling both waves of the SIMD at the top of the iteration.
+      // Chunk t+DIST goes to stage (t-1) % NSTAGE, free since the barrier above.  With enough n-tile pairs its DMA
+      // instructions are spread through the MFMA stream below so their issue cost hides under the matrix pipe.
       constexpr int NPAIR = (NT + 1) / 2;
       constexpr bool SPREAD = NPAIR >= 2 * PER;
-      const bool prefetch = t + 2 < nchunks;
-      const int nbuf = buf >= 1 ? buf - 1 : 2;
-#ifndef A3VT_DBG_NODMA
-      if (prefetch && (!SPREAD || !active)) issue(t + 2, nbuf);
-#endif
+      const bool prefetch = t + DIST < nchunks;
+      const int nbuf = buf >= 1 ? buf - 1 : NSTAGE - 1;
+      if (prefetch && (!SPREAD || !active)) issue(t + DIST, nbuf);
       if (active) {
         const float *sA = lds + buf * STAGE + wave * (MT * 256);
         const float *sB = lds + buf * STAGE + A_FLOATS;
         f32x4 af[MT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4 *>(sA + (i * 16 + l16) * 16 + q * 4);
-        // B fragments two n-tiles at a time, register double-buffered: the ds_reads of pair jp+1 are issued
-        // before the 16 MFMAs of pair jp, so the LDS latency hides under the matrix pipe instead of
-        // stalling it (the two waves of a SIMD run this loop in lockstep and cannot cover for each other).
-        const float *sBl = sB + l16 * 16 + q * 4;  // (non-const only for the ablation build)
+        // B fragments two n-tiles at a time, register double-buffered: the ds_reads of pair jp+1 are issued one
+        // MFMA group into pair jp, so the LDS latency hides under the matrix pipe.
+        const float *sBl = sB + l16 * 16 + q * 4;
         constexpr int NP = (NT + 1) / 2;
-#ifdef A3VT_DBG_NOLDSREAD
-        if (t > 0) sBl = nullptr;
-        f32x4 bc0 = sBl ? *reinterpret_cast<const f32x4 *>(sBl) : af[0];
-        f32x4 bc1 = sBl ? *reinterpret_cast<const f32x4 *>(sBl + 256) : af[1];
-#else
         f32x4 bc0 = *reinterpret_cast<const f32x4 *>(sBl);
         f32x4 bc1 = NT > 1 ? *reinterpret_cast<const f32x4 *>(sBl + 256) : f32x4{0.f, 0.f, 0.f, 0.f};
-#endif
 #pragma unroll
         for (int jp = 0; jp < NP; ++jp) {
           f32x4 bn0 = bc0, bn1 = bc1;
+          // first m-tile: 8 MFMAs over two accumulators (dependent distance 2 = 64 cycles > the 40-cycle latency)
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            if (s == 1) {  // prefetch the next pair one MFMA group into this block: 12 MFMAs (>= 384 cycles) of cover
+            if (s == 1) {
               __builtin_amdgcn_sched_barrier(0);
-#ifdef A3VT_DBG_NOLDSREAD
-              if (jp + 1 < NP && sBl) {
-#else
               if (jp + 1 < NP) {
-#endif
                 bn0 = *reinterpret_cast<const f32x4 *>(sBl + (2 * jp + 2) * 256);
                 if (2 * jp + 3 < NT) bn1 = *reinterpret_cast<const f32x4 *>(sBl + (2 * jp + 3) * 256);
               }
               __builtin_amdgcn_sched_barrier(0);
             }
+            acc[0][2 * jp] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][s], bc0[s], acc[0][2 * jp], 0, 0, 0);
+            if (2 * jp + 1 < NT)
+              acc[0][2 * jp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][s], bc1[s], acc[0][2 * jp + 1], 0, 0, 0);
+          }
+          if (nm > 1) {  // wave-uniform: the second m-tile is absent in a partial round
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-              acc[i][2 * jp] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bc0[s], acc[i][2 * jp], 0, 0, 0);
+            for (int s = 0; s < 4; ++s) {
+              acc[1][2 * jp] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][s], bc0[s], acc[1][2 * jp], 0, 0, 0);
               if (2 * jp + 1 < NT)
-                acc[i][2 * jp + 1] =
-                    __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bc1[s], acc[i][2 * jp + 1], 0, 0, 0);
+                acc[1][2 * jp + 1] =
+                    __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][s], bc1[s], acc[1][2 * jp + 1], 0, 0, 0);
             }
           }
           __builtin_amdgcn_sched_barrier(0);
-#ifndef A3VT_DBG_NODMA
           if (SPREAD && (jp & 1) && (jp >> 1) < PER) {
-            if (prefetch) issue_piece(t + 2, nbuf, jp >> 1);
+            if (prefetch) issue_piece(t + DIST, nbuf, jp >> 1);
             __builtin_amdgcn_sched_barrier(0);
           }
-#endif
           bc0 = bn0;
           bc1 = bn1;
         }
       }
-      buf = buf == 2 ? 0 : buf + 1;
+      buf = buf == NSTAGE - 1 ? 0 : buf + 1;
     }
     wait_lgkm0();
     __builtin_amdgcn_s_barrier();  // all waves finished reading the ring -> reuse it for the epilogue
 
     // Epilogue.  C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg — a lane holds 4 rows
     // of one column, so direct stores would be 64-byte fragments.  Each wave transposes its accumulators through
-    // a private slice of the idle ring and moves whole rows with 16-byte accesses (the ReLU-mask read of
-    // EPI_DX_MASK included): 4x fewer, fully coalesced global instructions.
-#ifdef A3VT_DBG_NOEPI
-    if (active && p.m < 0) {
-#else
+    // a private slice of the idle ring and moves whole rows with 16-byte accesses; the fused ReLU / raw-Z split
+    // (forward) and the ReLU-sign multiply (backward, bytes already in LDS) happen on the way out.
     if (active) {
-#endif
-      float *ep = lds + wave * ((3 * STAGE) / WAVES);
+      float *ep = lds + wave * ((NSTAGE * STAGE) / WAVES);
       constexpr int G0 = (NT + 1) / 2;  // n-tiles in the first column group (second gets NT - G0)
-      static_assert(16 * (G0 * 16 + 4) <= (3 * STAGE) / WAVES, "epilogue slice too small");
+      static_assert(16 * (G0 * 16 + 4) <= (NSTAGE * STAGE) / WAVES, "epilogue slice too small");
       const bool vec_ok = (p.ldc % 4 == 0) && (EPI != EPI_FWD_HIDDEN || p.ldc2 % 4 == 0);
-      const uint8_t *mslot = reinterpret_cast<const uint8_t *>(lds + 3 * STAGE + wave * MSLOT);
+      const uint8_t *mslot = reinterpret_cast<const uint8_t *>(lds + NSTAGE * STAGE + wave * MSLOT);
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
+        if (i >= nm) continue;
 #pragma unroll
         for (int grp = 0; grp < 2; ++grp) {
           const int j0 = grp == 0 ? 0 : G0;
-          const int tiles = grp == 0 ? G0 : NT - G0;
-          if (tiles == 0) continue;
-          const int ncols = tiles * 16, stride = ncols + 4, f4row = ncols / 4;
+          const int tiles_g = grp == 0 ? G0 : NT - G0;
+          if (tiles_g == 0) continue;
+          const int ncols = tiles_g * 16, stride = ncols + 4, f4row = ncols / 4;
           __builtin_amdgcn_wave_barrier();
 #pragma unroll
           for (int jj = 0; jj < G0; ++jj) {
-            if (jj < tiles) {
+            if (jj < tiles_g) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) ep[(q * 4 + r) * stride + jj * 16 + l16] = acc[i][j0 + jj][r];
             }
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(RowGemmArgs p) {
                 }
               }
             } else {  // EPI_DX_MASK: gradient through the ReLU of the producing layer (sign bytes from LDS)
-              const int ur = i * 16 + rl;  // row inside the unit
+              const int ur = i * 16 + rl;  // row inside this wave's round
               const unsigned ba = mslot[ur * p.mld + (col >> 2)];
               const unsigned bb = mslot[ur * p.mld + p.moff + (col >> 2)];
               float *dst = p.c + (size_t)row * p.ldc + col;
@@ -297,25 +299,36 @@ __global__ __launch_bounds__(512, 2) void rowgemm_kernel(RowGemmArgs p) {
       }
     }
     wait_lgkm0();
-    __builtin_amdgcn_s_barrier();  // epilogue slices are free again before the next super-tile's DMA
+    __builtin_amdgcn_s_barrier();  // epilogue slices are free again before the next round's DMA
   }
 }
 
 template <int NT>
-static constexpr int rowgemm_brows() { return ((NT * 16 + 127) / 128) * 128; }
+struct RowGemmCfg {
+  // Measured at M = 163,968, 300 x 300 (r01): one 8-wave workgroup per CU with a 3-stage ring 277-290 us per launch;
+  // two 4-wave workgroups per CU with 2-stage rings 297-321 us (twice the Bt staging, shallower prefetch).
+  static constexpr int WAVES = 8;
+  static constexpr int NSTAGE = NT == 1 ? 5 : 3;
+  static constexpr int WG_PER_CU = 1;
+  static constexpr int BROWS = ((NT * 16 + 16 * WAVES - 1) / (16 * WAVES)) * (16 * WAVES);
+};
 
 template <int NT, int EPI>
 static int launch_rowgemm_nt(const RowGemmArgs &a, int grid_y, hipStream_t s) {
-  constexpr size_t shmem = (3 * (size_t)(8 * 2 * 256 + rowgemm_brows<NT>() * 16) + (EPI == EPI_DX_MASK ? 8 * 1024 : 0)) * sizeof(float);
+  using C = RowGemmCfg<NT>;
+  constexpr size_t shmem = (C::NSTAGE * (size_t)(C::WAVES * 2 * 256 + C::BROWS * 16) +
+                            (EPI == EPI_DX_MASK ? C::WAVES * 1024 : 0)) * sizeof(float);
+  static_assert(shmem * C::WG_PER_CU <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)rowgemm_kernel<NT, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)shmem);
+    (void)hipFuncSetAttribute((const void *)rowgemm_kernel<NT, EPI, C::NSTAGE, C::WAVES>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     attr_set = true;
   }
-  const int units = cdiv(a.m, 32);
-  const int grid = units < 8 * 256 ? cdiv(units, 8) : 256;
-  A3VT_LAUNCH((rowgemm_kernel<NT, EPI>), dim3(grid, grid_y), dim3(512), shmem, s, a);
+  const int tiles = cdiv(a.m, 16);
+  const int max_wg = 256 * C::WG_PER_CU;
+  const int grid = tiles < 2 * C::WAVES * max_wg ? cdiv(tiles, 2 * C::WAVES) : max_wg;
+  A3VT_LAUNCH((rowgemm_kernel<NT, EPI, C::NSTAGE, C::WAVES>), dim3(grid, grid_y), dim3(64 * C::WAVES), shmem, s, a);
   A3VT_CHECK_LAUNCH();
   return 0;
 }
@@ -332,23 +345,23 @@ static int launch_rowgemm_cols(const RowGemmArgs &a, hipStream_t s) {
   return -1;
 }
 
-// Load balance.  A wave owns 32-row units and the chip has 1024 wave slots doing MFMA at full rate
-// (256 CUs x 4 SIMDs), so M = 163,968 rows = 5124 units would leave 1020 SIMDs idle while 4 of them run
-// a sixth unit (+20 % time).  When such a small remainder exists, the rows that fill whole rounds go to
-// the main launch and the leftover rows are re-cut along N: one 16-column tile per workgroup.
+// Load balance.  The chip runs 2048 waves of this kernel at once (256 CUs x 4 SIMDs x 2), each owning 16-row
+// tiles in pairs; M = 163,968 rows = 10,248 tiles would leave almost every SIMD idle while a few run a sixth
+// tile pair (+20 % time).  When such a small remainder exists, the tiles that fill whole rounds go to the main
+// launch and the leftover rows are re-cut along N: one 16-column tile per workgroup.
 template <int EPI>
 static int launch_rowgemm_epi(const RowGemmArgs &a0, hipStream_t s) {
   RowGemmArgs a = a0;
   a.bt_rows = rowgemm_bt_rows(a.n_store);
   a.col0 = 0;
-  const int units = cdiv(a.m, 32), nt = cdiv(a.n_store, 16);
-  const int full = units / 1024 * 1024, rem = units - full;
-  if (full == 0 || rem == 0 || rem * nt > 512 || nt < 2) return launch_rowgemm_cols<EPI>(a, s);
+  const int tiles = cdiv(a.m, 16), nt = cdiv(a.n_store, 16);
+  const int full = tiles / 2048 * 2048, rem = tiles - full;
+  if (full == 0 || rem == 0 || rem * nt > 1024 || nt < 2) return launch_rowgemm_cols<EPI>(a, s);
   RowGemmArgs m = a;
-  m.m = full * 32;
+  m.m = full * 16;
   if (int rc = launch_rowgemm_cols<EPI>(m, s)) return rc;
   RowGemmArgs r = a;
-  const size_t r0 = (size_t)full * 32;
+  const size_t r0 = (size_t)full * 16;
   r.m = a.m - (int)r0;
   r.a0 = a.a0 + r0 * a.lda0;
   r.a1 = a.a1 + r0 * a.lda1;
