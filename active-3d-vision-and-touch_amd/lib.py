@@ -11,6 +11,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("A3VT_LIB", os.path.join(_HERE, "liba3vt.so"))  # A3VT_LIB: developer override (variant builds)
 SOURCES = ["capi.hip", "gcn_gemm.hip", "gcn_csr.hip", "posenc.hip", "sample.hip", "chamfer.hip"]
+# Per-file extra flags (none at present; sample.hip / gcn_csr.hip rely on IEEE NaN semantics — the reference's NaN
+# scrubs, a3vt_check_finite — so fast-math style flags must never be applied globally).
+EXTRA_FLAGS = {}
 
 _vp, _i, _sz, _u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_uint64
 
@@ -58,7 +61,22 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", *srcs, "-o", LIB_PATH]
+    common = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
+    objdir = os.path.join(_HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    procs = []
+    for name in SOURCES:
+        obj = os.path.join(objdir, name.replace(".hip", ".o"))
+        cmd = [hipcc, *common, *EXTRA_FLAGS.get(name, []), "-c", os.path.join(CSRC, name), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd), obj))
+    objs = []
+    for cmd, pr, obj in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+        objs.append(obj)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
