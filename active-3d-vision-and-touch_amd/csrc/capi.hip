@@ -113,7 +113,8 @@ static int check_stack_dims(int ld_feats, int in_features, int num_layers, int h
     set_error("gcn_stack: hidden=%d (must be a multiple of 4, <= 304) cut_len=%d unsupported", hidden, cut_len);
     return -1;
   }
-  if (ld_feats > 304) { set_error("gcn_stack: in_features=%d > 304 unsupported", in_features); return -1; }
+  if (ld_feats > 600) { set_error("gcn_stack: in_features=%d > 600 unsupported", in_features); return -1; }
+  if (num_layers == 1 && ld_feats > 320) { set_error("gcn_stack: single-layer stack with %d inputs unsupported", in_features); return -1; }
   return 0;
 }
 
@@ -270,27 +271,42 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
         return rc;
     }
 
-    // dW_i = X_i^T dZ
-    DwArgs d{};
-    d.x = x;
-    d.ldx = ldx;
-    d.z0 = dza;
-    d.ldz0 = cpad > 0 ? cpad : 4;
-    d.z1 = g;
-    d.ldz1 = hidden;
-    d.zsplit = cpad;
-    d.zeros = zeros;
-    d.slab = scratch + L.dw_slab;
-    d.m = (int)m;
-    d.k_in = kin;
-    d.n_out = hidden;
-    {
-      ProfScope ps(PROF_DW, s);
-      if (int rc = launch_dw(d, s)) return rc;
+    // dW_i = X_i^T dZ.  The kernel covers up to 304 input channels per pass; wider inputs (the 448-wide image
+    // model's first layer) go in column blocks of <= 300, each first copied into a contiguous panel (the free
+    // gradient ping buffer).
+    for (int c0 = 0; c0 < kin; c0 += 300) {
+      const int w = kin - c0 < 300 ? kin - c0 : 300;
+      const float *xs = x;
+      int ldxs = ldx;
+      if (kin > 304) {
+        float *panel = scratch + L.ping[cur ^ 1];
+        const int wp = pad4(w);
+        if (wp != w) { set_error("gcn_stack: in_features=%d needs a multiple of 4 past 300", kin); return -1; }
+        if (int rc = launch_copy_cols(x, ldx, c0, w, panel, (long long)m, s)) return rc;
+        xs = panel;
+        ldxs = w;
+      }
+      DwArgs d{};
+      d.x = xs;
+      d.ldx = ldxs;
+      d.z0 = dza;
+      d.ldz0 = cpad > 0 ? cpad : 4;
+      d.z1 = g;
+      d.ldz1 = hidden;
+      d.zsplit = cpad;
+      d.zeros = zeros;
+      d.slab = scratch + L.dw_slab;
+      d.m = (int)m;
+      d.k_in = w;
+      d.n_out = hidden;
+      {
+        ProfScope ps(PROF_DW, s);
+        if (int rc = launch_dw(d, s)) return rc;
+      }
+      if (int rc = launch_slab_reduce(scratch + L.dw_slab, dw_num_slabs(hidden), (size_t)w * hidden, (size_t)w * hidden,
+                                      grad_weights[i] + (size_t)c0 * hidden, s))
+        return rc;
     }
-    if (int rc = launch_slab_reduce(scratch + L.dw_slab, dw_num_slabs(hidden), (size_t)kin * hidden,
-                                    (size_t)kin * hidden, grad_weights[i], s))
-      return rc;
 
     // dX_i = dZ W_i^T  (masked by the ReLU of layer i-1, whose output is X_i)
     const int n_store = i == 0 ? ld_feats : hidden;

@@ -340,9 +340,8 @@ static int launch_rowgemm_cols(const RowGemmArgs &a, hipStream_t s) {
   if (nt <= 4) return launch_rowgemm_nt<4, EPI>(a, 1, s);
   if (nt <= 8) return launch_rowgemm_nt<8, EPI>(a, 1, s);
   if (nt <= 13) return launch_rowgemm_nt<13, EPI>(a, 1, s);
-  if (nt <= 19) return launch_rowgemm_nt<19, EPI>(a, 1, s);
-  set_error("rowgemm: n_out=%d > 304 not supported yet", a.n_store);
-  return -1;
+  // wider outputs: column blocks of 19 tiles (blockIdx.y), A re-read once per block
+  return launch_rowgemm_nt<19, EPI>(a, cdiv(nt, 19), s);
 }
 
 // Load balance.  The chip runs 2048 waves of this kernel at once (256 CUs x 4 SIMDs x 2), each owning 16-row
@@ -374,6 +373,7 @@ static int launch_rowgemm_epi(const RowGemmArgs &a0, hipStream_t s) {
 // Rows of Bt the kernel stages for a given n (must exist, zero padded, in the Bt buffer).
 int rowgemm_bt_rows(int n_store) {
   const int nt = cdiv(n_store, 16);
+  if (nt > 19) return ((n_store + 127) / 128) * 128;
   const int tnt = nt <= 1 ? 1 : nt <= 4 ? 4 : nt <= 8 ? 8 : nt <= 13 ? 13 : 19;
   return ((tnt * 16 + 127) / 128) * 128;
 }
@@ -433,6 +433,23 @@ __global__ void copy_pad_kernel(const float *__restrict__ w, int rows_in, int co
 int launch_copy_pad(const float *w, int rows_in, int cols_in, float *out, int rows, int ld, hipStream_t s) {
   A3VT_LAUNCH(copy_pad_kernel, dim3(cdiv((long long)rows * ld, 256)), dim3(256), 0, s, w, rows_in, cols_in, out,
                      rows, ld);
+  A3VT_CHECK_LAUNCH();
+  return 0;
+}
+
+// dst[m][0..w) = src[m][c0..c0+w)   (w % 4 == 0, both 16-byte aligned): contiguous column block for dw_kernel
+__global__ void copy_cols_kernel(const float *__restrict__ src, int ld_src, int c0, int w, float *__restrict__ dst,
+                                 long long m) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int w4 = w >> 2;
+  if (i >= m * w4) return;
+  const long long r = i / w4;
+  const int c = (int)(i - r * w4) * 4;
+  *reinterpret_cast<f32x4 *>(dst + r * w + c) = *reinterpret_cast<const f32x4 *>(src + r * ld_src + c0 + c);
+}
+
+int launch_copy_cols(const float *src, int ld_src, int c0, int w, float *dst, long long m, hipStream_t s) {
+  A3VT_LAUNCH(copy_cols_kernel, dim3(cdiv(m * (w >> 2), 256)), dim3(256), 0, s, src, ld_src, c0, w, dst, m);
   A3VT_CHECK_LAUNCH();
   return 0;
 }

@@ -43,6 +43,7 @@ struct DwArgs {
 };
 int dw_num_slabs(int n_out);
 int launch_dw(const DwArgs &a, hipStream_t s);
+int launch_copy_cols(const float *src, int ld_src, int c0, int w, float *dst, long long m, hipStream_t s);
 int launch_slab_reduce(const float *slab, int nslab, size_t stride, size_t n, float *out, hipStream_t s);
 
 // CSR neighbour aggregation on the first c channels (+ bias + ReLU), model.py:356-358,363.

@@ -12,13 +12,17 @@ per-vertex products + CSR neighbour aggregation, activations saved for backward)
 encoder + mask embedding is one fused kernel, and nothing synchronises the host (the reference's NaN
 trap at :326-329 becomes an optional deferred flag, ``Deformation.finite_flag``).
 
-Not covered this round: ``use_img=True`` (``Image_Encoder`` :27-164 — the CNN stays a torch/MIOpen
-concern and needs a 448-wide first GCN layer) — constructing with it raises.
+``use_img=True``: ``Image_Encoder`` (:27-164) is a plain torch module here — its convolutions run on
+MIOpen, the per-vertex bilinear pooling on ``grid_sample`` (not hand-written) — and the
+448-wide vertex features go through the same HIP GCN stack; only the tiny positional/mask encoders fall back
+from the fused kernel (built for I = 50) to torch ops on the GPU.
 """
 import math
 
+import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 from torch.nn.parameter import Parameter
 
 from .... import ops as _ops
@@ -41,6 +45,76 @@ def _csr_of(adj_info, key):
     except TypeError:
         pass
     return csr
+
+
+def _cnn_block(f_in, f_out, k, stride=1, simple=False, padding=1):
+    """BN -> ReLU -> Conv (or a bare Conv when ``simple``): same Sequential indices as the reference (:15-23), so
+    state-dict keys read ``layers.<n>.0.*`` (BN or the bare conv) and ``layers.<n>.2.*`` (conv)."""
+    mods = [] if simple else [nn.BatchNorm2d(int(f_in)), nn.ReLU(inplace=True)]
+    mods.append(nn.Conv2d(int(f_in), int(f_out), kernel_size=k, padding=padding, stride=stride))
+    return nn.Sequential(*mods)
+
+
+# camera of the rendered dataset images (reference :50-64): intrinsics f = 221.7025, c = (128, 128)
+_CAM_RT = [[-7.587616579485257e-08, -1.0000001192092896, 0.0, -2.2762851159541242e-08],
+           [-0.7071068286895752, 7.587616579485257e-08, -0.7071068286895752, 0.0],
+           [0.7071068286895752, 0.0, -0.7071067690849304, 0.4242640733718872]]
+_CAM_F = 221.7025
+
+
+class Image_Encoder(nn.Module):
+    """Image pyramid + per-vertex feature pooling (reference :27-103).  Runs on torch ops (MIOpen convolutions,
+    ``grid_sample``): SURVEY §2b K13/K14 keep these off the hand-written path."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        k = args.CNN_ker_size
+        blocks = [_cnn_block(3, 3, k, stride=1, simple=True)]
+        cur, nxt = 3, 16
+        for _ in range(args.num_CNN_blocks):
+            blocks.append(_cnn_block(cur, nxt, k, stride=2))
+            cur, nxt = nxt, nxt * 2
+            blocks += [_cnn_block(cur, cur, k) for _ in range(args.layers_per_block - 1)]
+        self.layers = nn.ModuleList(blocks)
+        K = np.array([[_CAM_F, 0, 128.0], [0, _CAM_F, 128.0], [0, 0, 1]])
+        self.register_buffer("matrix", torch.FloatTensor(K.dot(np.array(_CAM_RT))), persistent=False)
+
+    def forward(self, img):
+        """Feature maps of the three layers ``layers_per_block`` apart from the end, plus the last map reached
+        before the spatial size drops below the kernel size (:147-164)."""
+        n = len(self.layers)
+        picks = {n - 1 - (i + 1) * self.args.layers_per_block for i in range(3)}
+        x, maps = img, []
+        for e, layer in enumerate(self.layers):
+            if x.shape[-1] < self.args.CNN_ker_size:
+                break
+            x = layer(x)
+            if e in picks:
+                maps.append(x)
+        maps.append(x)
+        return maps
+
+    def pooling(self, blocks, verts_pos):
+        """Project vertices with K.RT, bilinear-sample every map at the projected pixel, concatenate (:70-103)."""
+        ones = torch.ones_like(verts_pos[..., :1])
+        proj = torch.matmul(torch.cat((verts_pos, ones), dim=-1), self.matrix.to(verts_pos.device).t())
+        z = torch.where(proj[..., 2] == 0, torch.full_like(proj[..., 2], 0.1), proj[..., 2])
+        xs = proj[..., 1] / z / 256.0
+        ys = proj[..., 0] / z / 256.0
+        xs = torch.where(torch.isinf(xs), torch.full_like(xs, 0.5), xs)
+        ys = torch.where(torch.isinf(ys), torch.full_like(ys, 0.5), ys)
+        grid = torch.stack((ys, xs), dim=-1).unsqueeze(2) * 2 - 1            # (B,N,1,2), x-coordinate first = ys
+        feats = [F.grid_sample(b, grid, align_corners=True)[..., 0] for b in blocks]   # each (B,C,N)
+        return torch.cat(feats, dim=1).permute(0, 2, 1)
+
+
+def _nerf_embedding(p):
+    out = []
+    for i in range(10):
+        f = np.pi if i == 0 else np.pi * 2 * i
+        out += [torch.sin(f * p), torch.cos(f * p)]
+    return torch.cat(out, dim=-1)
 
 
 class GCN_layer(nn.Module):
@@ -105,7 +179,10 @@ class Positional_Encoder(nn.Module):
         return [m[0].weight, m[0].bias, m[2].weight, m[2].bias, m[4].weight, m[4].bias]
 
     def forward(self, positions):
-        raise NotImplementedError("a3vt: Positional_Encoder runs fused with Mask_Encoder inside Deformation")
+        """torch-op path (GPU); Deformation uses the fused HIP kernel instead when input_size == 50."""
+        shape = positions.shape
+        p = positions.contiguous().view(shape[0] * shape[1], -1)
+        return self.model(torch.cat((_nerf_embedding(p), p), dim=-1)).view(shape[0], shape[1], -1)
 
 
 class Mask_Encoder(nn.Module):
@@ -114,27 +191,33 @@ class Mask_Encoder(nn.Module):
         self.model = nn.Sequential(nn.Embedding(4, input_size))
 
     def forward(self, mask):
-        raise NotImplementedError("a3vt: Mask_Encoder runs fused with Positional_Encoder inside Deformation")
+        shape = mask.shape
+        return self.model(mask.contiguous().view(-1, 1).long()).view(shape[0], shape[1], -1)
 
 
 class Deformation(nn.Module):
     def __init__(self, adj_info, inital_positions, args, return_img=False, pass_img=False):
         super().__init__()
-        if getattr(args, "use_img", False):
-            raise NotImplementedError("a3vt: use_img=True (Image_Encoder + 448-wide GCN input) is not built yet")
         self.adj_info = adj_info
         self.initial_positions = inital_positions
         self.args = args
         self.return_img = return_img
         self.pass_img = pass_img
         self.num_stages = getattr(args, "num_stages", 3)  # new knob; the reference always runs 3 (:216-283)
-        input_size = 50  # :193
+        # construction order = reference order (:180-201) so seeds reproduce the reference init
+        if getattr(args, "use_img", False):
+            self.img_encoder_global = Image_Encoder(args)
+            self.img_encoder_local = Image_Encoder(args)
+            with torch.no_grad():  # feature width = channels of the maps a 256x256 image yields (:183-190; 448 by default)
+                maps = self.img_encoder_global(torch.zeros(1, 3, 256, 256))
+                input_size = sum(m.shape[1] for m in maps)
+        else:
+            input_size = 50  # :193
         self.input_size = input_size
         self.ld_feats = (input_size + 3) // 4 * 4
-        # construction order = reference order (:196-201) so seeds reproduce the reference init
         self.positional_encoder = Positional_Encoder(input_size)
         self.mask_encoder = Mask_Encoder(input_size)
-        self.mesh_deform_1 = GCN(input_size, args, ignore_touch_matrix=args.use_img)
+        self.mesh_deform_1 = GCN(input_size, args, ignore_touch_matrix=getattr(args, "use_img", False))
         self.mesh_deform_2 = GCN(input_size, args)
         self.finite_flag = None  # set to an int32 device scalar to enable the deferred NaN/Inf check
 
@@ -142,26 +225,48 @@ class Deformation(nn.Module):
         return torch.cat([p.reshape(-1) for p in self.positional_encoder.packed()] +
                          [self.mask_encoder.model[0].weight.reshape(-1)])
 
-    def forward(self, img, charts, img_features=None):
-        vc = charts["vision_charts"].shape[1]
-        if self.args.use_touch:
-            vertices = torch.cat((charts["vision_charts"], charts["touch_charts"]), dim=1)
-            mask = torch.cat((charts["vision_masks"], charts["touch_masks"]), dim=1)
-        else:
-            vertices = charts["vision_charts"]
-            mask = charts["vision_masks"]
-        vertices = vertices.to(torch.float32).contiguous()
-        mask = mask.to(torch.float32).contiguous()
-        packed = self._packed_encoder_params()
-        for stage in range(self.num_stages):
-            gcn = self.mesh_deform_1 if stage == 0 else self.mesh_deform_2  # stages 2 and 3 share weights (:268,281)
+    def _vertex_features(self, vertices, mask, packed, img_maps):
+        if self.input_size == 50:
             feats = _ops.PosEncMaskFn.apply(vertices, mask, packed, self.input_size, self.ld_feats)
+        else:  # image model (I = 448): small torch ops on the GPU, padded to the 4-float row granule
+            feats = self.positional_encoder(vertices) + self.mask_encoder(mask)
+            if img_maps is not None:
+                feats = feats + self.img_encoder_global.pooling(img_maps, vertices)   # always the global encoder's
+            if self.ld_feats != self.input_size:                                      # projection (:243,265,277)
+                feats = F.pad(feats, (0, self.ld_feats - self.input_size))
+        return feats.contiguous()
+
+    def forward(self, img, charts, img_features=None):
+        use_img, use_touch = getattr(self.args, "use_img", False), self.args.use_touch
+        vc = charts["vision_charts"].shape[1]
+        if self.pass_img and img_features is not None:
+            global_maps, local_maps = img_features
+        elif use_img:
+            img = img.to(charts["vision_charts"].device)
+            global_maps, local_maps = self.img_encoder_global(img), self.img_encoder_local(img)
+        else:
+            global_maps, local_maps = [], []
+        f32 = lambda t: t.to(torch.float32).contiguous()  # noqa: E731
+        touch_in_stage1 = use_touch and not use_img       # touch-only models see the touch charts immediately (:218)
+        if touch_in_stage1:
+            vertices = f32(torch.cat((charts["vision_charts"], charts["touch_charts"]), dim=1))
+            mask = f32(torch.cat((charts["vision_masks"], charts["touch_masks"]), dim=1))
+        else:
+            vertices, mask = f32(charts["vision_charts"]), f32(charts["vision_masks"])
+        packed = self._packed_encoder_params() if self.input_size == 50 else None
+        for stage in range(self.num_stages):
+            if stage == 1 and use_touch and use_img:      # vision+touch models add the touch charts now (:254-259)
+                vertices = f32(torch.cat((vertices, charts["touch_charts"]), dim=1))
+                mask = f32(torch.cat((charts["vision_masks"], charts["touch_masks"]), dim=1))
+            gcn = self.mesh_deform_1 if stage == 0 else self.mesh_deform_2  # stages 2 and 3 share weights (:268,281)
+            maps = (global_maps if stage == 0 else local_maps) if use_img else None
+            feats = self._vertex_features(vertices, mask, packed, maps)
             update = gcn(feats, self.adj_info)
             vertices = _ops.VertexUpdateFn.apply(vertices, update, vc)
             if self.finite_flag is not None:
                 _ops.check_finite(update, self.finite_flag)
         if self.return_img:
-            return vertices, mask, [[], []]
+            return vertices, mask, [global_maps, local_maps]
         return vertices, mask
 
 

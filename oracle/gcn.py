@@ -87,6 +87,82 @@ def mask_encoder(mask, state, prefix="mask_encoder"):
     return state[f"{prefix}.model.0.weight"][idx].view(shape[0], shape[1], -1)
 
 
+# camera used by Image_Encoder.pooling (model.py:50-67): K.RT with f = 221.7025, c = (128, 128)
+CAMERA_RT = [[-7.587616579485257e-08, -1.0000001192092896, 0.0, -2.2762851159541242e-08],
+             [-0.7071068286895752, 7.587616579485257e-08, -0.7071068286895752, 0.0],
+             [0.7071068286895752, 0.0, -0.7071067690849304, 0.4242640733718872]]
+
+
+def projection_matrix():
+    K = np.array([[221.7025, 0, 128.0], [0, 221.7025, 128.0], [0, 0, 1]])
+    return torch.FloatTensor(K.dot(np.array(CAMERA_RT)))
+
+
+def image_encoder(img, state, prefix, ker=5, num_blocks=6, layers_per_block=3, training=False):
+    """Image_Encoder.forward (model.py:147-164) over the layer list built at :36-48: layer 0 is a bare conv, every
+    other layer BN -> ReLU -> conv; the first layer of each block has stride 2; all convs pad 1.  Collects the maps of
+    the layers ``len-1-(i+1)*layers_per_block`` (i=0..2) and the last map reached before the size drops below ``ker``."""
+    F = torch.nn.functional
+    n = 1 + num_blocks * layers_per_block
+    picks = {n - 1 - (i + 1) * layers_per_block for i in range(3)}
+    x, maps = img, []
+    for e in range(n):
+        if x.shape[-1] < ker:
+            break
+        if e == 0:
+            x = F.conv2d(x, state[f"{prefix}.layers.0.0.weight"], state[f"{prefix}.layers.0.0.bias"], stride=1, padding=1)
+        else:
+            k = f"{prefix}.layers.{e}"
+            x = F.batch_norm(x, state[f"{k}.0.running_mean"], state[f"{k}.0.running_var"], state[f"{k}.0.weight"],
+                             state[f"{k}.0.bias"], training, 0.1, 1e-5)
+            x = torch.relu(x)
+            stride = 2 if (e - 1) % layers_per_block == 0 else 1
+            x = F.conv2d(x, state[f"{k}.2.weight"], state[f"{k}.2.bias"], stride=stride, padding=1)
+        if e in picks:
+            maps.append(x)
+    maps.append(x)
+    return maps
+
+
+def image_pooling(maps, verts):
+    """Image_Encoder.pooling (model.py:70-103)."""
+    ext = torch.cat((verts, torch.ones_like(verts[..., :1])), dim=-1)
+    ext = torch.matmul(ext, projection_matrix().to(verts.dtype).permute(1, 0)).clone()
+    ext[:, :, 2][ext[:, :, 2] == 0] = 0.1
+    xs = ext[:, :, 1] / ext[:, :, 2] / 256.0
+    xs[torch.isinf(xs)] = 0.5
+    ys = ext[:, :, 0] / ext[:, :, 2] / 256.0
+    ys[torch.isinf(ys)] = 0.5
+    grid = torch.cat([ys.unsqueeze(2).unsqueeze(3), xs.unsqueeze(2).unsqueeze(3)], 3) * 2 - 1
+    feats = [torch.nn.functional.grid_sample(m.to(verts.dtype), grid, align_corners=True) for m in maps]
+    return torch.cat(feats, dim=1)[:, :, :, 0].permute(0, 2, 1)
+
+
+def deformation_forward_img(state, adj_info, charts, img, use_touch, num_layers=20, cut=0.33, cnn=(5, 6, 3),
+                            training=False):
+    """model.py:203-286 for ``use_img=True``: stage 1 on the vision charts with the vision-only adjacency
+    ('origional', :198-200,317-318) and the global encoder's maps; touch charts join in stage 2 (:254-259); stages 2-3
+    use the local encoder's maps (pooled with the global encoder's projection, :265,277) and the fused adjacency."""
+    vc = charts["vision_charts"].shape[1]
+    gmaps = image_encoder(img, state, "img_encoder_global", *cnn, training=training)
+    lmaps = image_encoder(img, state, "img_encoder_local", *cnn, training=training)
+    vertices = charts["vision_charts"].clone()
+    mask = charts["vision_masks"].clone()
+    mask_features = mask_encoder(mask, state)
+    feats = positional_encoder(vertices, state) + mask_features + image_pooling(gmaps, vertices)
+    update = gcn(feats, state, "mesh_deform_1", adj_info["origional"], num_layers, cut)
+    vertices = vertices + update[:, :vc]
+    if use_touch:
+        vertices = torch.cat((vertices, charts["touch_charts"].clone()), dim=1)
+        mask = torch.cat((charts["vision_masks"].clone(), charts["touch_masks"].clone()), dim=1)
+        mask_features = mask_encoder(mask, state)
+    for _ in range(2):
+        feats = positional_encoder(vertices, state) + mask_features + image_pooling(lmaps, vertices)
+        update = gcn(feats, state, "mesh_deform_2", adj_info["adj"], num_layers, cut)
+        vertices = torch.cat((vertices[:, :vc] + update[:, :vc], vertices[:, vc:]), dim=1)
+    return vertices, mask
+
+
 def deformation_forward(state, adj_info, charts, use_touch, num_layers=20, cut=0.33, num_stages=3):
     """model.py:203-286 for ``use_img=False``.  ``adj_info`` holds 'adj' (dense tensor or CSR triple).
     Returns (vertices (B,N,3), mask (B,N,1)).  ``num_stages`` < 3 truncates after that many

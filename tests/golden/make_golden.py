@@ -265,7 +265,48 @@ def g7():
     save("g7_train_step.npz", **out)
 
 
+def g8():
+    """use_img modes (vision-only and vision+touch): default CNN (k=5, 6 blocks x 3 layers -> 448-wide features),
+    reduced GCN (L=3, H=300).  Weights are NOT stored (44 M): tests re-derive them from torch.manual_seed(0) with the
+    product's constructor and check the SHA-256."""
+    for tag, kw in (("vision", dict(use_touch=False)), ("touch", dict(use_touch=True, num_grasps=1, finger=False))):
+        a = args_of(use_img=True, num_GCN_layers=3, hidden_GCN_size=300, CNN_ker_size=5, num_CNN_blocks=6,
+                    layers_per_block=3, **kw)
+        torch.manual_seed(0)
+        info, verts = ref.utils.load_mesh_vision(a, OBJ)
+        net = ref.model.Deformation(info, verts, a)
+        B, P = 2, 300
+        g = torch.Generator().manual_seed(17)
+        img = torch.rand(B, 3, 256, 256, generator=g)
+        batch = {"img": img, "touch_charts": touch_batch(B, a, 3)}
+        out = {"weight_sha256": state_checksum(net.state_dict()), "touch_charts": batch["touch_charts"].numpy(),
+               "img_seed": np.int64(17), "pytorch3d_restated": np.bool_(True)}
+        gt = (torch.rand(B, 400, 3, generator=g) - 0.5) * 0.3
+        samples = injected(B, info["faces"].shape[0], P, 11)
+        out["gt"] = gt.numpy()
+        out["face_idx"] = torch.stack([s_[0] for s_ in samples]).numpy().astype(np.int16)
+        out["u"] = torch.stack([s_[1] for s_ in samples]).numpy()
+        out["v"] = torch.stack([s_[2] for s_ in samples]).numpy()
+        for mode in ("eval", "train"):
+            net.train(mode == "train")
+            net.zero_grad()
+            verts_out, mask = net(batch["img"], ref.model.prepare_mesh(batch, verts, a))
+            cd = ref_chamfer_injected(verts_out, info["faces"], gt, samples)
+            loss = 9000.0 * cd.mean()
+            out[f"verts_out_{mode}"] = verts_out.detach().numpy()
+            out[f"cd_{mode}"] = cd.detach().numpy()
+            if mode == "train":
+                loss.backward()
+                for k in ("mesh_deform_1.layers.0.weight", "mesh_deform_2.layers.2.weight", "mesh_deform_2.layers.0.bias",
+                          "img_encoder_global.layers.0.0.weight", "img_encoder_local.layers.9.2.bias",
+                          "positional_encoder.model.4.bias", "mask_encoder.model.0.weight"):
+                    gk = dict(net.named_parameters())[k].grad
+                    out["g:" + k] = gk.numpy() if gk.numel() < 40000 else gk.numpy()[..., ::7, ::11]
+                out["mask"] = mask.numpy()
+        save(f"g8_image_{tag}.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7", "g8"]
     for w in which:
         globals()[w]()

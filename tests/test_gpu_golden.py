@@ -104,3 +104,33 @@ def test_g7_train_step(cuda, stages):
     assert abs(losses[1] - float(z[f"loss_after_s{stages}"])) < 1e-3 * abs(losses[1])
     w = net.mesh_deform_1.layers[19].weight.detach().cpu().numpy()[0, :16]
     np.testing.assert_allclose(w, z[f"w_after_sample_s{stages}"], rtol=0, atol=5e-6)
+
+
+@pytest.mark.parametrize("tag,use_touch", [("vision", False), ("touch", True)])
+def test_g8_image_modes(cuda, tag, use_touch):
+    """use_img=True through the facade: torch/MIOpen image encoders + the HIP GCN stack at 448 input features."""
+    from test_oracle_golden import _image_setup
+    model, utils = _facade()
+    z, args, net_cpu, img, v, f = _image_setup(tag, use_touch)
+    info, verts = utils.load_mesh_vision(args, "vision_charts")
+    net = model.Deformation(info, verts, args).to(cuda)
+    net.load_state_dict(net_cpu.state_dict())
+    batch = {"img": img, "touch_charts": torch.from_numpy(z["touch_charts"])}
+    samples = tuple(torch.from_numpy(z[k].astype(np.int32) if k == "face_idx" else z[k]).to(cuda) for k in ("face_idx", "u", "v"))
+    gt = torch.from_numpy(z["gt"]).to(cuda)
+    net.eval()
+    with torch.no_grad():
+        out, _ = net(img.to(cuda), model.prepare_mesh(batch, verts, args))
+    assert rel_err(out, torch.from_numpy(z["verts_out_eval"])) < 1e-4
+    net.train()
+    out, mask = net(img.to(cuda), model.prepare_mesh(batch, verts, args))
+    assert rel_err(out, torch.from_numpy(z["verts_out_train"])) < 1e-4
+    assert np.array_equal(mask.cpu().numpy(), z["mask"])
+    cd = utils.chamfer_distance(out, info["faces"], gt, num=300, samples=samples)
+    assert rel_err(cd, torch.from_numpy(z["cd_train"])) < 1e-4
+    (9000.0 * cd.mean()).backward()
+    params = dict(net.named_parameters())
+    for key in [k for k in z.files if k.startswith("g:")]:
+        gk = params[key[2:]].grad
+        got = gk if gk.numel() < 40000 else gk[..., ::7, ::11]
+        assert_grad_close(got, torch.from_numpy(z[key]), key)

@@ -152,3 +152,60 @@ def test_g7_train_step(stages):
     assert abs(losses[1] - float(z[f"loss_after_s{stages}"])) < 1e-3 * abs(losses[1])
     w = st["mesh_deform_1.layers.19.weight"].detach().numpy()[0, :16]
     np.testing.assert_allclose(w, z[f"w_after_sample_s{stages}"], rtol=0, atol=2e-6)
+
+
+def _image_setup(tag, use_touch):
+    """Shared by the CPU and GPU image-mode tests: args, weights re-derived from seed 0, inputs from the fixture."""
+    import hashlib
+    from helpers import make_args
+    from a3vt_amd import mesh as amesh
+    from a3vt_amd.pterotactyl.reconstruction.vision import model
+    z = load(f"g8_image_{tag}.npz")
+    args = make_args(use_img=True, use_touch=use_touch, num_grasps=1, finger=False, num_GCN_layers=3,
+                     hidden_GCN_size=300, CNN_ker_size=5, num_CNN_blocks=6, layers_per_block=3)
+    v, f = amesh.load_asset("vision_charts")
+    torch.manual_seed(0)
+    net = model.Deformation({}, torch.from_numpy(v), args)      # same RNG call order as the reference constructor
+    sd = net.state_dict()
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode())
+        h.update(sd[k].detach().cpu().numpy().tobytes())
+    assert np.array_equal(np.frombuffer(h.digest(), dtype=np.uint8), z["weight_sha256"]), "init differs from the reference"
+    g = torch.Generator().manual_seed(int(z["img_seed"]))
+    img = torch.rand(2, 3, 256, 256, generator=g)
+    return z, args, net, img, v, f
+
+
+@pytest.mark.parametrize("tag,use_touch", [("vision", False), ("touch", True)])
+def test_g8_image_modes(tag, use_touch):
+    """use_img=True (vision-only and vision+touch): oracle vs the reference's outputs, eval and train (BN batch stats)."""
+    from a3vt_amd import mesh as amesh
+    z, args, net, img, v, f = _image_setup(tag, use_touch)
+    sv, sf = amesh.load_asset("touch_chart")
+    info = omesh.adj_init(v, f, use_touch, 1, False, sv, sf)
+    adj = {"origional": torch.from_numpy(info["origional"]), "adj": torch.from_numpy(info["adj"])}
+    faces = torch.from_numpy(info["faces"])
+    verts = torch.from_numpy(v)
+    ch = og.prepare_mesh(torch.from_numpy(z["touch_charts"]), verts, 2, use_touch)
+    samples = [(torch.from_numpy(z["face_idx"][r].astype(np.int64)), torch.from_numpy(z["u"][r]), torch.from_numpy(z["v"][r]))
+               for r in range(3)]
+    gt = torch.from_numpy(z["gt"])
+    st = {k: t.clone() for k, t in net.state_dict().items()}
+    with torch.no_grad():
+        out, _ = og.deformation_forward_img(st, adj, ch, img, use_touch, 3, 0.33, training=False)
+    np.testing.assert_allclose(out.numpy(), z["verts_out_eval"], rtol=0, atol=1e-6)
+    for k in st:
+        if st[k].is_floating_point():
+            st[k].requires_grad_(not k.endswith(("running_mean", "running_var")))
+    out, mask = og.deformation_forward_img(st, adj, ch, img, use_touch, 3, 0.33, training=True)
+    np.testing.assert_allclose(out.detach().numpy(), z["verts_out_train"], rtol=0, atol=1e-6)
+    assert np.array_equal(mask.numpy(), z["mask"])
+    cd = och.chamfer_distance(out, faces, gt, num=300, samples=samples)
+    np.testing.assert_allclose(cd.detach().numpy(), z["cd_train"], rtol=1e-5)
+    (9000.0 * cd.mean()).backward()
+    for key in [k for k in z.files if k.startswith("g:")]:
+        gk = st[key[2:]].grad
+        got = gk.numpy() if gk.numel() < 40000 else gk.numpy()[..., ::7, ::11]
+        scale = max(1.0, float(np.abs(z[key]).max()))
+        np.testing.assert_allclose(got, z[key], rtol=0, atol=2e-4 * scale, err_msg=key)
