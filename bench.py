@@ -81,7 +81,7 @@ def pmc_traffic():
     try:
         with open(path) as f:
             d = json.load(f)
-        k = next(v for name, v in d.items() if "rowgemm_kernel<19, 2>" in name)
+        k = next(v for name, v in d.items() if "rowgemm_kernel<19, 2" in name)
         return (2.0 * k["FETCH_SIZE_KiB_max"] + k["WRITE_SIZE_KiB_max"]) * 1024.0
     except Exception:
         return None
