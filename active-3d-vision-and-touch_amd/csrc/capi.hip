@@ -203,7 +203,7 @@ int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const 
       if (int rc = launch_rowgemm(g, EPI_FWD_HIDDEN, s)) return rc;
     }
     if (cut_len > 0)
-      if (int rc = launch_csr_fwd(scratch + L.za, cpad, biases[i], cut_len, rowptr, col, val, n_vert, batch, y, hidden, mk, mld, s))
+      if (int rc = launch_csr_fwd(scratch + L.za, cpad, biases[i], cut_len, rowptr, col, val, n_vert, batch, y, hidden, mk, mld, 1, s))
         return rc;
     x = y;
     ldx = hidden;
@@ -344,6 +344,172 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
     }
   }
   return 0;
+}
+
+// ---- one layer on its own (GCN_layer.forward for the auto-encoder / DDQN layer loops)
+namespace {
+struct LayerLayout {
+  size_t wt, za, ga, dz, panel, dw_slab, db_slab, total;
+};
+LayerLayout layer_layout(int batch, int n_vert, int ld_x, int n_out, int cut_len, int need_backward) {
+  LayerLayout L{};
+  const size_t m = (size_t)batch * n_vert;
+  const int cpad = pad4(cut_len), npad = pad4(n_out);
+  size_t off = 0;
+  auto take = [&](size_t nfloats) {
+    const size_t o = off;
+    off = align_up(off + nfloats, 64);
+    return o;
+  };
+  const size_t wt_fwd = (size_t)rowgemm_bt_rows(n_out) * pad16(ld_x);
+  const size_t wt_bwd = (size_t)rowgemm_bt_rows(ld_x) * pad16(npad);
+  L.wt = take(wt_fwd > wt_bwd ? wt_fwd : wt_bwd);
+  L.za = take(m * (cpad > 4 ? cpad : 4));  // forward: raw Z of the aggregated channels; backward: 4-float dummy rows
+  if (need_backward) {
+    L.ga = take(m * (cpad > 4 ? cpad : 4));
+    L.dz = take(m * npad);
+    L.panel = take(ld_x > 304 ? m * 300 : 0);
+    const int kin = ld_x > 304 ? 300 : ld_x;
+    L.dw_slab = take((size_t)dw_num_slabs(n_out) * kin * n_out);
+    L.db_slab = take((size_t)csr_bwd_num_slabs(batch, n_vert) * (cpad > 4 ? cpad : 4));
+  }
+  L.total = off;
+  return L;
+}
+int check_layer_dims(int ld_x, int in_features, int n_out, int cut_len) {
+  if (ld_x % 4 != 0 || ld_x < in_features || ld_x > 600 || in_features < 1) {
+    set_error("gcn_layer: ld_x=%d must be a multiple of 4, >= in_features=%d and <= 600", ld_x, in_features);
+    return -1;
+  }
+  if (n_out < 1 || n_out > 304 || cut_len < 0 || cut_len > n_out) {
+    set_error("gcn_layer: out_features=%d (1..304) cut_len=%d unsupported", n_out, cut_len);
+    return -1;
+  }
+  if (in_features > 304 && in_features % 4 != 0) {
+    set_error("gcn_layer: in_features=%d > 304 must be a multiple of 4", in_features);
+    return -1;
+  }
+  return 0;
+}
+}  // namespace
+
+size_t a3vt_gcn_layer_scratch_bytes(int batch, int n_vert, int ld_x, int out_features, int cut_len, int need_backward) {
+  return layer_layout(batch, n_vert, ld_x, out_features, cut_len, need_backward).total * sizeof(float);
+}
+
+int a3vt_gcn_layer_fwd(const float *x, int ld_x, int in_features, const float *weight, const float *bias,
+                       int out_features, int cut_len, int relu, const int32_t *rowptr, const int32_t *col,
+                       const float *val, int n_vert, int batch, float *y, int ld_y, float *scratch, void *stream) {
+  A3VT_CHECK_ARG(x && weight && bias && rowptr && col && val && y && scratch && n_vert > 0 && batch > 0);
+  if (int rc = check_layer_dims(ld_x, in_features, out_features, cut_len)) return rc;
+  A3VT_CHECK_ARG(ld_y % 4 == 0 && ld_y >= out_features);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const float *zeros = zero_page();
+  A3VT_CHECK_ARG(zeros != nullptr);
+  const LayerLayout L = layer_layout(batch, n_vert, ld_x, out_features, cut_len, 0);
+  const size_t m = (size_t)batch * n_vert;
+  const int cpad = pad4(cut_len);
+  float *wt = scratch + L.wt;
+  if (int rc = launch_transpose_pad(weight, in_features, out_features, wt, rowgemm_bt_rows(out_features), pad16(ld_x), s))
+    return rc;
+  RowGemmArgs g{};
+  g.a0 = g.a1 = x;
+  g.lda0 = g.lda1 = ld_x;
+  g.ksplit = ld_x;
+  g.bt = wt;
+  g.ldb = pad16(ld_x);
+  g.zeros = zeros;
+  g.m = (int)m;
+  g.k = ld_x;
+  g.n_store = out_features;
+  g.c = y;
+  g.ldc = ld_y;
+  g.c2 = scratch + L.za;
+  g.ldc2 = cpad > 4 ? cpad : 4;
+  g.csplit = cut_len;
+  g.no_relu = relu ? 0 : 1;
+  if (int rc = launch_rowgemm(g, EPI_FWD_HIDDEN, s)) return rc;
+  if (cut_len > 0)
+    if (int rc = launch_csr_fwd(scratch + L.za, g.ldc2, bias, cut_len, rowptr, col, val, n_vert, batch, y, ld_y, nullptr,
+                                0, relu ? 1 : 0, s))
+      return rc;
+  return 0;
+}
+
+int a3vt_gcn_layer_bwd(const float *x, int ld_x, int in_features, const float *weight, int out_features, int cut_len,
+                       int relu, const int32_t *rowptrT, const int32_t *colT, const float *valT, int n_vert, int batch,
+                       const float *y, int ld_y, const float *grad_y, int ld_gy, float *grad_weight, float *grad_bias,
+                       float *grad_x, float *scratch, void *stream) {
+  A3VT_CHECK_ARG(x && weight && rowptrT && colT && valT && grad_y && grad_weight && grad_bias && grad_x && scratch);
+  A3VT_CHECK_ARG(n_vert > 0 && batch > 0 && ld_gy >= out_features && (!relu || (y && ld_y >= out_features)));
+  if (int rc = check_layer_dims(ld_x, in_features, out_features, cut_len)) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const float *zeros = zero_page();
+  A3VT_CHECK_ARG(zeros != nullptr);
+  const LayerLayout L = layer_layout(batch, n_vert, ld_x, out_features, cut_len, 1);
+  const size_t m = (size_t)batch * n_vert;
+  const int cpad = pad4(cut_len), npad = pad4(out_features);
+  float *ga = scratch + L.ga, *dz = scratch + L.dz;
+
+  // gradient through the activation; aggregated columns to `ga`, the rest straight into the merged dZ rows
+  if (int rc = launch_relu_split(grad_y, ld_gy, y, ld_y, relu ? 1 : 0, out_features, cpad, npad, (long long)m, ga, dz, s))
+    return rc;
+  if (int rc = launch_fill_zero(grad_bias, out_features, s)) return rc;
+  if (cut_len > 0) {
+    // dZ[:, :c] = A^T G[:, :c] (columns c..cpad pass through), bias gradient = column sums of G[:, :c]
+    if (int rc = launch_csr_bwd(ga, cpad, cut_len, rowptrT, colT, valT, n_vert, batch, dz, npad, scratch + L.db_slab, s))
+      return rc;
+    if (int rc = launch_slab_reduce(scratch + L.db_slab, csr_bwd_num_slabs(batch, n_vert), cpad, cut_len, grad_bias, s))
+      return rc;
+  }
+  // dW = X^T dZ, in column panels of <= 300 input channels when the input is wider than the kernel covers
+  for (int c0 = 0; c0 < in_features; c0 += 300) {
+    const int w = in_features > 304 ? (in_features - c0 < 300 ? in_features - c0 : 300) : in_features;
+    const float *xs = x;
+    int ldxs = ld_x;
+    if (in_features > 304) {
+      float *panel = scratch + L.panel;
+      if (int rc = launch_copy_cols(x, ld_x, c0, w, panel, (long long)m, s)) return rc;
+      xs = panel;
+      ldxs = w;
+    }
+    DwArgs d{};
+    d.x = xs;
+    d.ldx = ldxs;
+    d.z0 = scratch + L.za;  // zsplit = 0: never consumed, only staged
+    d.ldz0 = 4;
+    d.z1 = dz;
+    d.ldz1 = npad;
+    d.zsplit = 0;
+    d.zeros = zeros;
+    d.slab = scratch + L.dw_slab;
+    d.m = (int)m;
+    d.k_in = w;
+    d.n_out = out_features;
+    if (int rc = launch_dw(d, s)) return rc;
+    if (int rc = launch_slab_reduce(scratch + L.dw_slab, dw_num_slabs(out_features), (size_t)w * out_features,
+                                    (size_t)w * out_features, grad_weight + (size_t)c0 * out_features, s))
+      return rc;
+    if (in_features <= 304) break;
+  }
+  // dX = dZ W^T
+  float *wp = scratch + L.wt;
+  if (int rc = launch_copy_pad(weight, in_features, out_features, wp, rowgemm_bt_rows(ld_x), pad16(npad), s)) return rc;
+  RowGemmArgs r{};
+  r.a0 = scratch + L.za;
+  r.lda0 = 4;
+  r.ksplit = 0;
+  r.a1 = dz;
+  r.lda1 = npad;
+  r.bt = wp;
+  r.ldb = pad16(npad);
+  r.zeros = zeros;
+  r.m = (int)m;
+  r.k = npad;
+  r.n_store = ld_x;
+  r.c = grad_x;
+  r.ldc = ld_x;
+  return launch_rowgemm(r, EPI_PLAIN, s);
 }
 
 int a3vt_wt_rows(int n_out) { return rowgemm_bt_rows(n_out); }

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void csr_fwd_kernel(const float *__restrict__ 
                                                       const int32_t *__restrict__ colidx,
                                                       const float *__restrict__ val, int n_vert, long long m,
                                                       float *__restrict__ y, int ldy,
-                                                      uint8_t *__restrict__ maskb, int mld) {
+                                                      uint8_t *__restrict__ maskb, int mld, int relu) {
   const int hl = threadIdx.x & 31;
   const XcdWalk w((int)(m / n_vert), n_vert);
   float bsv[4] = {0.f, 0.f, 0.f, 0.f};  // bias of this lane's 4 channels (c <= 128: one pass)
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void csr_fwd_kernel(const float *__restrict__ 
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const float pre = ch + t < c ? acc[t] + (c <= 128 ? bsv[t] : bias[ch + t]) : 0.f;
-        o[t] = pre > 0.f ? pre : 0.f;
+        o[t] = (pre > 0.f || !relu) ? pre : 0.f;
         bits |= (pre > 0.f ? 1u : 0u) << t;
       }
       if (ch + 3 < c && (ldy & 3) == 0) {
@@ -129,7 +129,8 @@ __global__ __launch_bounds__(256) void csr_fwd_kernel(const float *__restrict__ 
 }
 
 int launch_csr_fwd(const float *za, int ldza, const float *bias, int c, const int32_t *rowptr, const int32_t *col,
-                   const float *val, int n_vert, int batch, float *y, int ldy, uint8_t *maskb, int mld, hipStream_t s) {
+                   const float *val, int n_vert, int batch, float *y, int ldy, uint8_t *maskb, int mld, int relu,
+                   hipStream_t s) {
   if (ldza % 4 != 0 || ldza < pad4(c)) {
     set_error("csr_fwd: ldza=%d must be a multiple of 4 and >= pad4(c=%d)", ldza, c);
     return -1;
@@ -137,7 +138,7 @@ int launch_csr_fwd(const float *za, int ldza, const float *bias, int c, const in
   const long long m = (long long)batch * n_vert;
   const int grid = (int)(cdiv(m, 8) < 4096 ? (cdiv(m, 8) + 7) / 8 * 8 : 4096);  // multiple of 8: whole XCD groups
   A3VT_LAUNCH(csr_fwd_kernel, dim3(grid), dim3(256), 0, s, za, ldza, bias, c, rowptr, col, val, n_vert, m, y, ldy,
-              maskb, mld);
+              maskb, mld, relu);
   A3VT_CHECK_LAUNCH();
   return 0;
 }
@@ -468,6 +469,30 @@ __global__ void check_finite_kernel(const float *__restrict__ d, size_t n, int32
 int launch_check_finite(const float *d, size_t n, int32_t *flag, hipStream_t s) {
   const int grid = (int)(cdiv((long long)n, 256) < 2048 ? cdiv((long long)n, 256) : 2048);
   A3VT_LAUNCH(check_finite_kernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, s, d, n, flag);
+  A3VT_CHECK_LAUNCH();
+  return 0;
+}
+
+// Stand-alone layer backward: gradient through the activation, split into the gather input and the merged dZ rows.
+__global__ void relu_split_kernel(const float *__restrict__ gy, int ldgy, const float *__restrict__ y, int ldy,
+                                  int relu, int n_out, int cpad, int npad, long long m, float *__restrict__ ga,
+                                  float *__restrict__ dz) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m * npad) return;
+  const long long r = i / npad;
+  const int c = (int)(i - r * npad);
+  float v = 0.f;
+  if (c < n_out) {
+    v = gy[r * ldgy + c];
+    if (relu && !(y[r * ldy + c] > 0.f)) v = 0.f;
+  }
+  if (c < cpad) ga[r * cpad + c] = v;
+  else dz[r * npad + c] = v;
+}
+int launch_relu_split(const float *gy, int ldgy, const float *y, int ldy, int relu, int n_out, int cpad, int npad,
+                      long long m, float *ga, float *dz, hipStream_t s) {
+  A3VT_LAUNCH(relu_split_kernel, dim3((unsigned)cdiv(m * npad, 256)), dim3(256), 0, s, gy, ldgy, y, ldy, relu, n_out,
+              cpad, npad, m, ga, dz);
   A3VT_CHECK_LAUNCH();
   return 0;
 }

@@ -268,13 +268,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
                 *reinterpret_cast<f32x4 *>(p.c2 + (size_t)row * p.ldc2 + col) = v;
               } else if (full && col >= p.csplit) {  // pass-through channels: ReLU(Z), no bias
 #pragma unroll
-                for (int t = 0; t < 4; ++t) v[t] = v[t] > 0.f ? v[t] : 0.f;
+                for (int t = 0; t < 4; ++t) v[t] = (v[t] > 0.f || p.no_relu) ? v[t] : 0.f;
                 *reinterpret_cast<f32x4 *>(p.c + (size_t)row * p.ldc + col) = v;
               } else {
                 for (int t = 0; t < 4; ++t) {
                   if (col + t >= p.n_store) break;
                   if (col + t < p.csplit) p.c2[(size_t)row * p.ldc2 + col + t] = v[t];
-                  else p.c[(size_t)row * p.ldc + col + t] = v[t] > 0.f ? v[t] : 0.f;
+                  else p.c[(size_t)row * p.ldc + col + t] = (v[t] > 0.f || p.no_relu) ? v[t] : 0.f;
                 }
               }
             } else {  // EPI_DX_MASK: gradient through the ReLU of the producing layer (sign bytes from LDS)

@@ -25,6 +25,7 @@ struct RowGemmArgs {
   int col0;     // first output column handled by blockIdx.y == 0 (set by launch_rowgemm)
   int m, k, n_store;
   int ldc, ldc2, csplit, mld, moff;
+  int no_relu;  // EPI_FWD_HIDDEN: store the pass-through channels without the ReLU (identity activation)
 };
 int rowgemm_bt_rows(int n_store);
 int launch_rowgemm(const RowGemmArgs &a, int epi, hipStream_t s);
@@ -48,7 +49,12 @@ int launch_slab_reduce(const float *slab, int nslab, size_t stride, size_t n, fl
 
 // CSR neighbour aggregation on the first c channels (+ bias + ReLU), model.py:356-358,363.
 int launch_csr_fwd(const float *za, int ldza, const float *bias, int c, const int32_t *rowptr, const int32_t *col,
-                   const float *val, int n_vert, int batch, float *y, int ldy, uint8_t *maskb, int mld, hipStream_t s);
+                   const float *val, int n_vert, int batch, float *y, int ldy, uint8_t *maskb, int mld, int relu,
+                   hipStream_t s);
+// Stand-alone layer backward entry: G = grad_y (* (y > 0) when relu); columns [0, cpad) -> ga [M][cpad] (input of the
+// A^T gather), columns [cpad, npad) -> dz [M][npad] (pad columns zero).
+int launch_relu_split(const float *gy, int ldgy, const float *y, int ldy, int relu, int n_out, int cpad, int npad,
+                      long long m, float *ga, float *dz, hipStream_t s);
 // dZa[:, :c] = A^T G[:, :c];  dZa[:, c:cpad] = G[:, c:cpad];  db partial sums of G[:, :c] -> slab [nslab][cpad].
 int csr_bwd_num_slabs(int batch, int n_vert);
 int launch_csr_bwd(const float *g, int ldg, int c, const int32_t *rowptrT, const int32_t *colT, const float *valT,

@@ -126,6 +126,54 @@ def gcn_stack(feats, adj, in_features, hidden, cut_len, weights, biases):
     return GCNStackFn.apply(feats, adj, in_features, hidden, cut_len, *params)
 
 
+class GCNLayerFn(torch.autograd.Function):
+    """One GCN layer (reference ``GCN_layer.forward``, vision/model.py:351-363) for callers with their own layer loop:
+    x (B,N,ld) -> y (B,N,out).  ``cut_len`` = out for a layer without the cut."""
+
+    @staticmethod
+    def forward(ctx, x, adj, weight, bias, cut_len, relu):
+        L = _lib.load()
+        x = _req(x, "features")
+        weight, bias = _req(weight, "weight"), _req(bias, "bias")
+        B, N, ld = x.shape
+        if N != adj.n:
+            raise RuntimeError(f"a3vt: features have {N} vertices but the adjacency has {adj.n}")
+        kin, nout = weight.shape[-2], weight.shape[-1]
+        if ld % 4 != 0 or ld < kin:
+            raise RuntimeError(f"a3vt: feature row length {ld} must be a multiple of 4 and >= in_features={kin}")
+        need_bwd = any(ctx.needs_input_grad)
+        ldy = (nout + 3) // 4 * 4
+        y = torch.empty((B, N, ldy), dtype=torch.float32, device=x.device)
+        scratch = workspace("gcn", L.a3vt_gcn_layer_scratch_bytes(B, N, ld, nout, cut_len, 1 if need_bwd else 0),
+                            x.device)
+        _lib.check(L.a3vt_gcn_layer_fwd(_lib.ptr(x), ld, kin, _lib.ptr(weight), _lib.ptr(bias), nout, cut_len,
+                                        1 if relu else 0, _lib.ptr(adj.rowptr), _lib.ptr(adj.col), _lib.ptr(adj.val),
+                                        N, B, _lib.ptr(y), ldy, _lib.ptr(scratch), _stream()), "gcn_layer_fwd")
+        ctx.adj, ctx.dims = adj, (kin, nout, cut_len, bool(relu), ldy)
+        ctx.save_for_backward(x, weight, y)
+        return y[..., :nout] if ldy != nout else y
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = _lib.load()
+        kin, nout, cut_len, relu, ldy = ctx.dims
+        x, weight, y = ctx.saved_tensors
+        adj = ctx.adj
+        B, N, ld = x.shape
+        gy = _req(gy, "grad_output")
+        gw, gb, gx = torch.empty_like(weight), torch.empty(nout, dtype=torch.float32, device=x.device), torch.empty_like(x)
+        scratch = workspace("gcn", L.a3vt_gcn_layer_scratch_bytes(B, N, ld, nout, cut_len, 1), x.device)
+        _lib.check(L.a3vt_gcn_layer_bwd(_lib.ptr(x), ld, kin, _lib.ptr(weight), nout, cut_len, 1 if relu else 0,
+                                        _lib.ptr(adj.t_rowptr), _lib.ptr(adj.t_col), _lib.ptr(adj.t_val), N, B,
+                                        _lib.ptr(y), ldy, _lib.ptr(gy), gy.shape[-1], _lib.ptr(gw), _lib.ptr(gb),
+                                        _lib.ptr(gx), _lib.ptr(scratch), _stream()), "gcn_layer_bwd")
+        return gx, None, gw, gb, None, None
+
+
+def gcn_layer(x, adj, weight, bias, cut_len, relu):
+    return GCNLayerFn.apply(x, adj, weight, bias, cut_len, relu)
+
+
 class PosEncMaskFn(torch.autograd.Function):
     """Positional_Encoder + Mask_Encoder + add (vision/model.py:229-232 etc.): (B,N,3),(B,N,1) -> (B,N,ld)."""
 

@@ -18,6 +18,7 @@ MIOpen, the per-vertex bilinear pooling on ``grid_sample`` (SURVEY §2b K13/K14:
 from the fused kernel (built for I = 50) to torch ops on the GPU.
 """
 import math
+import weakref
 
 import numpy as np
 import torch
@@ -44,6 +45,25 @@ def _csr_of(adj_info, key):
         adj_info[ck] = csr
     except TypeError:
         pass
+    return csr
+
+
+_DENSE_CSR_CACHE = {}
+
+
+def _csr_from_arg(adj):
+    """``GCN_layer.forward`` takes the adjacency as an argument: accept a CSR handle or a dense tensor."""
+    if isinstance(adj, _ops.DeviceCSR):
+        return adj
+    if not isinstance(adj, torch.Tensor) or adj.dim() != 2 or adj.shape[0] != adj.shape[1]:
+        raise RuntimeError("a3vt: GCN_layer needs a dense (N,N) adjacency tensor or an ops.DeviceCSR handle")
+    ent = _DENSE_CSR_CACHE.get(id(adj))
+    if ent is not None and ent[0]() is adj and ent[1] == adj._version:
+        return ent[2]
+    for k in [k for k, e in _DENSE_CSR_CACHE.items() if e[0]() is None]:  # drop entries of dead tensors
+        del _DENSE_CSR_CACHE[k]
+    csr = _ops.DeviceCSR(CSRAdjacency.from_dense(adj.detach().cpu().numpy()), adj.device)
+    _DENSE_CSR_CACHE[id(adj)] = (weakref.ref(adj), adj._version, csr)
     return csr
 
 
@@ -136,9 +156,18 @@ class GCN_layer(nn.Module):
         self.bias.data.uniform_(-0.1, 0.1)
 
     def forward(self, features, adj, activation):
-        raise NotImplementedError(
-            "a3vt: a stand-alone GCN_layer call is not on the round-1 hot path; call the enclosing GCN "
-            "(SURVEY §8f-3 lists the auto-encoder / DDQN consumers as the next row)")
+        """The reference's layer call (:351-363) for callers with their own layer loop (the auto-encoder encoder,
+        the DDQN graph model).  ``adj`` is a dense row-normalised (N,N) tensor — converted to CSR once and cached — or
+        an ``ops.DeviceCSR`` handle.  ReLU is fused; any other ``activation`` is applied to the layer output."""
+        csr = _csr_from_arg(adj)
+        nout = self.weight.shape[-1]
+        c = _cut_len(nout, self.cut_size) if self.do_cut else nout
+        relu = activation is F.relu or activation is torch.relu
+        pad = (-features.shape[-1]) % 4
+        if pad:
+            features = F.pad(features, (0, pad))
+        y = _ops.gcn_layer(features, csr, self.weight, self.bias, c, relu)
+        return y if relu else activation(y)
 
 
 class GCN(nn.Module):

@@ -79,6 +79,29 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features,
                        float *const *grad_weights, float *const *grad_biases, float *grad_feats,
                        float *scratch, void *stream);
 
+/* One GCN layer on its own — GCN_layer.forward(features, adj, activation), model.py:351-363, for callers
+ * that run their own layer loop (the copies in reconstruction/autoencoder/model.py:96-137 and
+ * policies/DDQN/model.py:132-168 have layer shapes the stack entry points do not cover:
+ * hidden -> hidden without the cut, hidden_dim -> num_actions).
+ *   Z = X W ;  Y[:, :c] = A Z[:, :c] + b[:c] ;  Y[:, c:] = Z[:, c:] ;  Y = relu ? max(Y, 0) : Y
+ * c = cut_len = round(out * cut) when the layer cuts (do_cut), c = out_features otherwise (all channels
+ * aggregated, bias on all).  in_features <= ld_x <= 600, out_features <= 304.
+ * x [M][ld_x] (ld_x % 4 == 0, pad columns zero), weight [in_features][out_features] (reference layout
+ * (1,in,out)), bias [out_features], y [M][ld_y] (ld_y % 4 == 0, ld_y >= out_features; pad columns untouched).
+ * Backward: grad_y [M][ld_gy] and the forward output y (the ReLU mask is y > 0) -> grad_x [M][ld_x] (pad
+ * columns zero), grad_weight [in][out], grad_bias [out] (all overwritten; bias channels >= c get zeros). */
+size_t a3vt_gcn_layer_scratch_bytes(int batch, int n_vert, int ld_x, int out_features, int cut_len,
+                                    int need_backward);
+int a3vt_gcn_layer_fwd(const float *x, int ld_x, int in_features, const float *weight, const float *bias,
+                       int out_features, int cut_len, int relu,
+                       const int32_t *csr_rowptr, const int32_t *csr_col, const float *csr_val,
+                       int n_vert, int batch, float *y, int ld_y, float *scratch, void *stream);
+int a3vt_gcn_layer_bwd(const float *x, int ld_x, int in_features, const float *weight,
+                       int out_features, int cut_len, int relu,
+                       const int32_t *csrT_rowptr, const int32_t *csrT_col, const float *csrT_val,
+                       int n_vert, int batch, const float *y, int ld_y, const float *grad_y, int ld_gy,
+                       float *grad_weight, float *grad_bias, float *grad_x, float *scratch, void *stream);
+
 /* The dense per-vertex product alone (torch.matmul(features, self.weight), model.py:352) on the
  * fp32 MFMA path: C[M][n_out] = A[M][k] * W[k][n_out], k % 4 == 0, n_out <= 304.  `wt` is W transposed
  * and zero padded to [a3vt_wt_rows(n_out)][a3vt_wt_ld(k)] floats (a3vt_transpose_weight builds it).

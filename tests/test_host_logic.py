@@ -90,8 +90,13 @@ def test_state_dict_layout_matches_reference():
     assert sd["mask_encoder.model.0.weight"].shape == (4, 50)
     assert sd["mesh_deform_1.layers.0.weight"].shape == (1, 50, 300)
     assert sd["mesh_deform_2.layers.19.weight"].shape == (1, 300, 3) and sd["mesh_deform_2.layers.19.bias"].shape == (3,)
-    with pytest.raises(NotImplementedError):
-        model.Deformation({}, torch.zeros(4, 3), make_args(use_img=True))
+    # image model (47 349 642 parameters; encoder keys layers.<k>.{0|2}.*)
+    net = model.Deformation({}, torch.zeros(4, 3), make_args(use_img=True, CNN_ker_size=5, num_CNN_blocks=6,
+                                                              layers_per_block=3))
+    assert sum(p.numel() for p in net.parameters()) == 47349642
+    sd = net.state_dict()
+    assert sd["mesh_deform_1.layers.0.weight"].shape == (1, 448, 300)
+    assert "img_encoder_global.layers.0.0.weight" in sd and "img_encoder_local.layers.1.2.weight" in sd
 
 
 def test_config_roundtrip(tmp_path):
