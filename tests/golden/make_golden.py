@@ -9,11 +9,16 @@ Chamfer / sampling boundary is marked ``pytorch3d_restated=True``: parity unpinn
 
 Fixtures (names follow SURVEY §8c):
   g1_adjacency.npz     CSR of the reference's row-normalised adjacency for the atlas: vision-only, t_p, t_g
+  g2_gcn_layer.npz     GCN_layer fwd + grads (B=2, N=1824, 50->300 with the cut; 300->300 without), atlas adjacency
   g3_small_<mode>.npz  reduced Deformation (L=3,H=32): weights, inputs, verts, loss (injected samples), all grads
   g4_full_forward.npz  full-size Deformation (L=20,H=300, seed-0 init) forward verts for B=2 + weight checksum
   g5_sampling.npz      batch_sample probabilities + points for injected (face, u, v)
   g6_chamfer.npz       chamfer_distance + d/dx on random clouds and on the bundled ABC object's cloud
   g7_train_step.npz    one trainer step (bs=2, P=10000, 3 stages, and the 1-stage variant): loss before / after Adam
+  g8_image_<mode>.npz  use_img models (default CNN, reduced GCN): verts (eval + train mode), loss, selected grads
+  g9_autoencoder.npz   reconstruction/autoencoder AutoEncoder (L=3, H=300): latent, folded points, Chamfer loss with
+                       the gradient on the SECOND cloud (autoencoder/train.py:145-150), selected grads
+  g10_graph_model.npz  policies/DDQN Graph_Model (3 layers, 300 -> 200 -> 200 -> 50): Q values + selected grads
 """
 import hashlib
 import os
@@ -306,7 +311,93 @@ def g8():
         save(f"g8_image_{tag}.npz", **out)
 
 
+def g2():
+    """the reference layer itself, on the real atlas adjacency (dense, as the reference holds it)."""
+    info, verts = ref.utils.load_mesh_vision(args_of(), OBJ)
+    adj = info["adj"]
+    n = adj.shape[0]
+    out = {}
+    for tag, (kin, nout, do_cut, relu) in (("cut", (50, 300, True, True)), ("nocut", (300, 300, False, False))):
+        torch.manual_seed(21)
+        layer = ref.model.GCN_layer(kin, nout, 0.33, do_cut)
+        g = torch.Generator().manual_seed(kin)
+        x = (torch.randn(2, n, kin, generator=g) * 0.5).requires_grad_(True)
+        gy = torch.randn(2, n, nout, generator=g)
+        y = layer(x, adj, torch.nn.functional.relu if relu else (lambda t: t))
+        (y * gy).sum().backward()
+        out[f"{tag}_weight_sha256"] = state_checksum(layer.state_dict())   # tests re-derive the weights from seed 21
+        out[f"{tag}_x_seed"] = np.int64(kin)
+        out[f"{tag}_y"] = y.detach().numpy()[:, ::32]              # every 32nd vertex
+        out[f"{tag}_y_sum"] = y.detach().double().sum(dim=(0, 1)).numpy()  # per-channel checksum over all vertices
+        out[f"{tag}_gx"] = x.grad.numpy()[:, ::32]
+        out[f"{tag}_gw"], out[f"{tag}_gb"] = layer.weight.grad.numpy()[0, ::3, ::5], layer.bias.grad.numpy()
+    save("g2_gcn_layer.npz", **out)
+
+
+def g9():
+    import importlib
+    am = importlib.import_module("pterotactyl.reconstruction.autoencoder.model")
+    a = args_of(use_touch=True, num_grasps=1, finger=False, num_GCN_layers=3, hidden_GCN_size=300, encoding_size=200)
+    torch.manual_seed(0)
+    info, verts = ref.utils.load_mesh_vision(a, OBJ)
+    net = am.AutoEncoder(info, verts, a)
+    B, P = 2, 300
+    batch = {"img": torch.zeros(B, 1), "touch_charts": touch_batch(B, a, 3)}
+    charts = ref.model.prepare_mesh(batch, verts, a)
+    g = torch.Generator().manual_seed(23)
+    v_in = torch.cat((charts["vision_charts"], charts["touch_charts"]), dim=1)
+    v_in = v_in + 0.01 * torch.randn(v_in.shape, generator=g)
+    mask = torch.cat((charts["vision_masks"], charts["touch_masks"]), dim=1)
+    pred, latent = net(v_in, mask)
+    samples = injected(B, info["faces"].shape[0], P, 11)
+    cd = ref_chamfer_injected(v_in, info["faces"], pred, samples)   # grad flows to the second cloud only
+    loss = 9000.0 * cd.mean()
+    loss.backward()
+    out = {"weight_sha256": state_checksum(net.state_dict()), "verts_in": v_in.numpy(), "mask": mask.numpy(),
+           "latent": latent.detach().numpy(), "pred_points": pred.detach().numpy()[:, ::16], "cd": cd.detach().numpy(),
+           "face_idx": torch.stack([s_[0] for s_ in samples]).numpy().astype(np.int16),
+           "u": torch.stack([s_[1] for s_ in samples]).numpy(), "v": torch.stack([s_[2] for s_ in samples]).numpy(),
+           "pytorch3d_restated": np.bool_(True)}
+    params = dict(net.named_parameters())
+    for k in ("encoder.layers.0.weight", "encoder.layers.2.bias", "encoder.layers.1.bias", "encoder.mlp.3.0.bias",
+              "decoder.initial.bias", "decoder.model.fold2.conv3.weight", "positional_encoder.model.4.bias",
+              "mask_encoder.model.0.weight"):
+        out["g:" + k] = params[k].grad.numpy()
+    out["g:encoder.layers.2.weight"] = params["encoder.layers.2.weight"].grad.numpy()[..., ::7, ::11]
+    save("g9_autoencoder.npz", **out)
+
+
+def g10():
+    import importlib
+    dm = importlib.import_module("pterotactyl.policies.DDQN.model")
+    a = args_of(use_touch=True, num_grasps=5, finger=True, layers=3, hidden_dim=200, num_actions=50)
+    torch.manual_seed(0)
+    info, verts = ref.utils.load_mesh_vision(a, OBJ)
+    net = dm.Graph_Model(a, info)
+    B = 3
+    g = torch.Generator().manual_seed(29)
+    n = info["adj"].shape[0]
+    mesh = torch.zeros(B, n, 4)
+    mesh[:, :verts.shape[0], :3] = verts + 0.01 * torch.randn(B, verts.shape[0], 3, generator=g)
+    mesh[:, :verts.shape[0], 3] = 3
+    mesh[:, verts.shape[0]:, :3] = (torch.rand(B, n - verts.shape[0], 3, generator=g) - 0.5) * 0.3
+    mesh[:, verts.shape[0]:, 3] = torch.randint(0, 3, (B, n - verts.shape[0]), generator=g).float()
+    done = (torch.rand(B, 50, generator=g) < 0.2).float()
+    obs = {"mesh": mesh, "mask": done}
+    q = net(obs)
+    gq = torch.randn(q.shape, generator=g)
+    (q * gq).sum().backward()
+    out = {"weight_sha256": state_checksum(net.state_dict()), "mesh": mesh.numpy(), "mask": done.numpy(),
+           "q": q.detach().numpy(), "gq": gq.numpy()}
+    params = dict(net.named_parameters())
+    for k in ("layers.0.bias", "layers.1.weight", "layers.2.weight", "layers.2.bias", "action_model.2.0.bias",
+              "positional_embedding.model.4.bias", "mask_embedding.model.0.weight"):
+        out["g:" + k] = params[k].grad.numpy()
+    out["g:layers.0.weight"] = params["layers.0.weight"].grad.numpy()[..., ::3, ::5]
+    save("g10_graph_model.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     for w in which:
         globals()[w]()

@@ -1,4 +1,5 @@
 """Helpers shared by the golden-vector tests: load fixtures, rebuild the reference's inputs from seeds."""
+import hashlib
 import os
 
 import numpy as np
@@ -29,3 +30,12 @@ def g7_cloud(B=2, P=10000, seed=99):
     g = torch.Generator().manual_seed(seed)
     d = torch.randn(B, P, 3, generator=g)
     return d / d.norm(dim=-1, keepdim=True) * (0.05 + 0.11 * torch.rand(B, 1, 3, generator=g))
+
+
+def state_sha256(sd):
+    """SHA-256 over sorted (key, raw bytes) of a state dict — make_golden.state_checksum."""
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode())
+        h.update(sd[k].detach().cpu().numpy().tobytes())
+    return np.frombuffer(h.digest(), dtype=np.uint8)

@@ -134,3 +134,86 @@ def test_g8_image_modes(cuda, tag, use_touch):
         gk = params[key[2:]].grad
         got = gk if gk.numel() < 40000 else gk[..., ::7, ::11]
         assert_grad_close(got, torch.from_numpy(z[key]), key)
+
+
+@pytest.mark.parametrize("tag,kin,nout,do_cut,relu", [("cut", 50, 300, True, True), ("nocut", 300, 300, False, False)])
+def test_g2_gcn_layer(cuda, tag, kin, nout, do_cut, relu):
+    """Stand-alone HIP layer vs the reference layer's own output/gradients (dense adjacency argument, as the reference
+    passes it)."""
+    from golden_util import state_sha256
+    model, utils = _facade()
+    z = load("g2_gcn_layer.npz")
+    info, _ = utils.load_mesh_vision(make_args(), "vision_charts")
+    torch.manual_seed(21)
+    layer = model.GCN_layer(kin, nout, 0.33, do_cut)
+    assert np.array_equal(state_sha256(layer.state_dict()), z[f"{tag}_weight_sha256"])
+    layer = layer.to(cuda)
+    g = torch.Generator().manual_seed(int(z[f"{tag}_x_seed"]))
+    x = (torch.randn(2, 1824, kin, generator=g) * 0.5).to(cuda).requires_grad_(True)
+    gy = torch.randn(2, 1824, nout, generator=g).to(cuda)
+    y = layer(x, info["adj"], torch.nn.functional.relu if relu else (lambda t: t))
+    (y * gy).sum().backward()
+    assert rel_err(y[:, ::32], torch.from_numpy(z[f"{tag}_y"])) < 1e-4
+    assert rel_err(y.double().sum(dim=(0, 1)), torch.from_numpy(z[f"{tag}_y_sum"])) < 1e-4
+    assert_grad_close(x.grad[:, ::32], torch.from_numpy(z[f"{tag}_gx"]), "grad_x")
+    assert_grad_close(layer.weight.grad[0, ::3, ::5], torch.from_numpy(z[f"{tag}_gw"]), "grad_weight")
+    assert_grad_close(layer.bias.grad, torch.from_numpy(z[f"{tag}_gb"]), "grad_bias")
+
+
+def _samples_of(z, cuda):
+    return tuple(torch.from_numpy(z[k].astype(np.int32) if k == "face_idx" else z[k]).to(cuda) for k in ("face_idx", "u", "v"))
+
+
+def test_g9_autoencoder(cuda):
+    """Consumer: the auto-encoder on the HIP layer / encoder / Chamfer kernels vs the reference
+    AutoEncoder — latent, folded points, and the loss of autoencoder/train.py:145-150 (gradient on the second cloud)."""
+    from golden_util import state_sha256
+    from a3vt_amd.pterotactyl.reconstruction.autoencoder import model as am
+    _, utils = _facade()
+    z = load("g9_autoencoder.npz")
+    args = make_args(use_touch=True, num_grasps=1, finger=False, num_GCN_layers=3, hidden_GCN_size=300, encoding_size=200)
+    info, verts = utils.load_mesh_vision(args, "vision_charts")
+    torch.manual_seed(0)
+    net = am.AutoEncoder(info, verts, args)
+    assert np.array_equal(state_sha256(net.state_dict()), z["weight_sha256"]), "init differs from the reference"
+    net = net.to(cuda)
+    v_in, mask = torch.from_numpy(z["verts_in"]).to(cuda), torch.from_numpy(z["mask"]).to(cuda)
+    pred, latent = net(v_in, mask)
+    assert pred.shape == (2, 6400, 3)
+    assert rel_err(latent, torch.from_numpy(z["latent"])) < 1e-4
+    assert rel_err(pred[:, ::16], torch.from_numpy(z["pred_points"])) < 1e-4
+    cd = utils.chamfer_distance(v_in, info["faces"], pred, num=300, samples=_samples_of(z, cuda))
+    assert rel_err(cd, torch.from_numpy(z["cd"])) < 1e-4
+    (9000.0 * cd.mean()).backward()
+    params = dict(net.named_parameters())
+    for key in [k for k in z.files if k.startswith("g:")]:
+        gk = params[key[2:]].grad
+        got = gk[..., ::7, ::11] if key == "g:encoder.layers.2.weight" else gk
+        assert_grad_close(got, torch.from_numpy(z[key]), key)
+    with torch.no_grad():
+        assert rel_err(net(v_in, mask, only_encode=True), torch.from_numpy(z["latent"])) < 1e-4
+
+
+def test_g10_ddqn_graph_model(cuda):
+    """Consumer: the DDQN graph Q-network (300 -> 200 -> 200 -> 50, hub-heavy t_p adjacency) vs the
+    reference Graph_Model."""
+    from golden_util import state_sha256
+    from a3vt_amd.pterotactyl.policies.DDQN import model as dm
+    _, utils = _facade()
+    z = load("g10_graph_model.npz")
+    args = make_args(use_touch=True, num_grasps=5, finger=True, layers=3, hidden_dim=200, num_actions=50)
+    info, verts = utils.load_mesh_vision(args, "vision_charts")
+    torch.manual_seed(0)
+    net = dm.Graph_Model(args, info)
+    assert np.array_equal(state_sha256(net.state_dict()), z["weight_sha256"]), "init differs from the reference"
+    net = net.to(cuda)
+    obs = {"mesh": torch.from_numpy(z["mesh"]), "mask": torch.from_numpy(z["mask"])}
+    q = net(obs)
+    assert q.shape == (3, 50)
+    assert rel_err(q, torch.from_numpy(z["q"])) < 1e-4
+    (q * torch.from_numpy(z["gq"]).to(cuda)).sum().backward()
+    params = dict(net.named_parameters())
+    for key in [k for k in z.files if k.startswith("g:")]:
+        gk = params[key[2:]].grad
+        got = gk[..., ::3, ::5] if key == "g:layers.0.weight" else gk
+        assert_grad_close(got, torch.from_numpy(z[key]), key)
