@@ -266,8 +266,7 @@ class Deformation(nn.Module):
         return feats.contiguous()
 
     def forward(self, img, charts, img_features=None):
-        use_img, use_touch = getattr(self.args, "use_img", False), self.args.use_touch
-        vc = charts["vision_charts"].shape[1]
+        use_img = getattr(self.args, "use_img", False)
         if self.pass_img and img_features is not None:
             global_maps, local_maps = img_features
         elif use_img:
@@ -275,6 +274,17 @@ class Deformation(nn.Module):
             global_maps, local_maps = self.img_encoder_global(img), self.img_encoder_local(img)
         else:
             global_maps, local_maps = [], []
+        vertices, mask = self.deform_with_maps(charts, global_maps, local_maps)
+        if self.return_img:
+            return vertices, mask, [global_maps, local_maps]
+        return vertices, mask
+
+    def deform_with_maps(self, charts, global_maps, local_maps):
+        """The three refinement stages (:216-283) on already computed image feature maps (empty lists without
+        ``use_img``).  Split out so a caller scoring many candidate touches of the same images (policies/scoring.py)
+        runs the image encoders once."""
+        use_img, use_touch = getattr(self.args, "use_img", False), self.args.use_touch
+        vc = charts["vision_charts"].shape[1]
         f32 = lambda t: t.to(torch.float32).contiguous()  # noqa: E731
         touch_in_stage1 = use_touch and not use_img       # touch-only models see the touch charts immediately (:218)
         if touch_in_stage1:
@@ -294,8 +304,6 @@ class Deformation(nn.Module):
             vertices = _ops.VertexUpdateFn.apply(vertices, update, vc)
             if self.finite_flag is not None:
                 _ops.check_finite(update, self.finite_flag)
-        if self.return_img:
-            return vertices, mask, [global_maps, local_maps]
         return vertices, mask
 
 

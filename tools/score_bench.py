@@ -1,0 +1,74 @@
+#!/usr/bin/env python
+"""Candidate-touch scoring throughput: the reference's sequential loop (one compute_obs per candidate,
+policies/environment.py:174-180) vs one batched call (a3vt_amd ... policies/scoring.py), both on the HIP kernels.
+Atlas + 5 finger charts (N = 1949), reference hyper-parameters (L=20, H=300), P = 10 000, E env elements, K candidates."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--env", type=int, default=3)
+    p.add_argument("--candidates", type=int, default=50)
+    p.add_argument("--points", type=int, default=10000)
+    p.add_argument("--reps", type=int, default=3)
+    a = p.parse_args()
+    from helpers import make_args, random_cloud
+    from a3vt_amd.pterotactyl.policies import scoring
+    from a3vt_amd.pterotactyl.reconstruction.vision import model
+    from a3vt_amd.pterotactyl.utility import utils
+    dev = torch.device("cuda", 0)
+    args = make_args(use_touch=True, finger=True, num_grasps=5, number_points=a.points)
+    info, verts = utils.load_mesh_vision(args, "vision_charts")
+    torch.manual_seed(0)
+    net = model.Deformation(info, verts, args).to(dev).eval()
+    E, K = a.env, a.candidates
+    g = torch.Generator().manual_seed(1)
+    img = torch.zeros(E, 1)
+    gt = random_cloud(E, a.points, 3).to(dev)
+    charts_list = []
+    for k in range(K):
+        tc = torch.zeros(E, 5, 25, 4)
+        tc[..., :3] = (torch.rand(E, 5, 25, 3, generator=g) - 0.5) * 0.3
+        tc[..., 3] = 2
+        charts_list.append(model.prepare_mesh({"img": img, "touch_charts": tc}, verts, args))
+
+    def sequential():
+        out = []
+        for c in charts_list:
+            with torch.no_grad():
+                v, m = net(img, c)
+                s = args.loss_coeff * utils.chamfer_distance(v, info["faces"], gt, num=a.points)
+            out.append((s.cpu(), torch.cat((v, m), dim=-1).cpu()))   # the D2H copies compute_obs makes
+        return out
+
+    def batched():
+        s, v, m = scoring.score_actions(net, img, charts_list, gt, info["faces"], a.points, args.loss_coeff)
+        return s.cpu(), torch.cat((v, m), dim=-1).cpu()
+
+    res = {}
+    for name, fn in (("sequential", sequential), ("batched", batched)):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.reps):
+            fn()
+        torch.cuda.synchronize()
+        res[name + "_ms"] = 1e3 * (time.perf_counter() - t0) / a.reps
+    res.update({"env": E, "candidates": K, "points": a.points, "n_vert": 1949,
+                "candidates_per_s_batched": 1e3 * E * K / res["batched_ms"],
+                "speedup": res["sequential_ms"] / res["batched_ms"]})
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
