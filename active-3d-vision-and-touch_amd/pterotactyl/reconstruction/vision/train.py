@@ -10,9 +10,10 @@ current_loss, checkpoint_dir, results_dir``), same checkpoint files (``<ckpt>/mo
 Differences: the hot loop never blocks on the device except every ``log_interval`` iterations (the reference
 calls ``loss.item()`` every step, :151-153); tensorboard / submitit are optional; early stop raises
 ``StopIteration`` instead of ``exit()`` (:284); with ``WORLD_SIZE`` > 1 gradients are averaged with one
-flat-bucket RCCL all-reduce (``a3vt_amd.distributed``).  Datasets: ``get_loaders`` uses the reference's
-``pterotactyl.utility.data_loaders`` when that package (and its downloaded data) is importable; otherwise
-pass ``loaders=(train_loader, valid_loader)`` (e.g. ``a3vt_amd.synthetic.SyntheticLoader``).
+flat-bucket RCCL all-reduce (``a3vt_amd.distributed``).  Datasets: ``get_loaders`` reads the reference's on-disk
+layout through ``utility/data_loaders.py`` (``args.data_root`` / ``PTEROTACTYL_DATA``; worker count ``args.num_workers``,
+default 16 as the reference); or pass ``loaders=(train_loader, valid_loader)`` (e.g. ``a3vt_amd.synthetic.SyntheticLoader``).
+Batches are uploaded one step ahead on a copy stream (``data_loaders.DevicePrefetcher``).
 """
 import os
 
@@ -21,7 +22,7 @@ import torch
 import torch.optim as optim
 
 from . import model
-from ...utility import utils
+from ...utility import data_loaders, utils
 from .... import distributed as adist
 
 try:
@@ -90,19 +91,14 @@ class Engine:
     def get_loaders(self):
         if self._loaders is not None:
             return self._loaders
-        try:
-            from torch.utils.data import DataLoader
-            from pterotactyl.utility import data_loaders  # the reference's own datasets (needs download_data.sh)
-        except Exception as e:
-            raise RuntimeError("a3vt: the pterotactyl dataset package is not importable here; pass loaders=(train, valid) "
-                               "to Engine (e.g. a3vt_amd.synthetic.SyntheticLoader)") from e
+        from torch.utils.data import DataLoader   # dataset classes: utility/data_loaders.py on args.data_root
         train_loader = ""
         if not self.args.eval:
             train_data = data_loaders.mesh_loader_vision(self.args, set_type="recon_train")
-            train_loader = DataLoader(train_data, batch_size=self.args.batch_size, shuffle=True, num_workers=16,
+            train_loader = DataLoader(train_data, batch_size=self.args.batch_size, shuffle=True, num_workers=getattr(self.args, "num_workers", 16),
                                       collate_fn=train_data.collate, pin_memory=True)
         valid_data = data_loaders.mesh_loader_vision(self.args, set_type="test" if self.args.eval else "valid")
-        valid_loader = DataLoader(valid_data, batch_size=self.args.batch_size, shuffle=False, num_workers=16,
+        valid_loader = DataLoader(valid_data, batch_size=self.args.batch_size, shuffle=False, num_workers=getattr(self.args, "num_workers", 16),
                                   collate_fn=valid_data.collate, pin_memory=True)
         return train_loader, valid_loader
 
@@ -122,7 +118,7 @@ class Engine:
         iterations = 0
         self.encoder.train()
         dev = self.initial_mesh.device
-        for k, batch in enumerate(data):
+        for k, batch in enumerate(data_loaders.DevicePrefetcher(data, dev)):
             img = batch["img"].to(dev, non_blocking=True)
             gt_points = batch["gt_points"].to(dev, non_blocking=True)
             with torch.no_grad():
@@ -140,7 +136,7 @@ class Engine:
         self.encoder.eval()
         num_examples = 0
         dev = self.initial_mesh.device
-        for v, batch in enumerate(valid_loader):
+        for v, batch in enumerate(data_loaders.DevicePrefetcher(valid_loader, dev)):
             img = batch["img"].to(dev, non_blocking=True)
             gt_points = batch["gt_points"].to(dev, non_blocking=True)
             charts = model.prepare_mesh(batch, self.initial_mesh, self.args)

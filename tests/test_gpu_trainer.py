@@ -119,3 +119,26 @@ def test_batched_scoring(cuda, use_img):
     # production sampling (Philox draws) also runs batched
     s2, _, _ = scoring.score_actions(net, img, charts_list, gt, info["faces"], P, args.loss_coeff)
     assert s2.shape == (K, E) and torch.isfinite(s2).all()
+
+
+def test_engine_on_disk_dataset_and_prefetcher(cuda, tmp_path):
+    """the trainer on the reference's on-disk dataset layout (written here in miniature), batches uploaded
+    one step ahead by the DevicePrefetcher; the prefetched tensors equal the loader's."""
+    from test_host_logic import _write_dataset
+    from a3vt_amd.pterotactyl.reconstruction.vision import train
+    from a3vt_amd.pterotactyl.utility import data_loaders
+    from a3vt_amd.synthetic import SyntheticLoader
+    root = os.path.join(str(tmp_path), "data")
+    _write_dataset(root, list(range(10)), np.random.default_rng(1))
+    args = _args(tmp_path, use_touch=True, num_grasps=2, data_root=root, num_workers=0, limit_data=False, val_grasps=-1)
+    args.epochs = 1
+    eng = train.Engine(args)
+    best = eng()
+    assert np.isfinite(best) and eng.epoch == 0 and os.path.exists(os.path.join(eng.checkpoint_dir, "model"))
+    # prefetcher: same batches, on the device, in order
+    loader = SyntheticLoader(args, 5, 3, seed=4)
+    got = list(data_loaders.DevicePrefetcher(loader, cuda))
+    assert len(got) == 5
+    for a, b in zip(loader, got):
+        assert b["gt_points"].is_cuda and torch.equal(a["gt_points"], b["gt_points"].cpu())
+        assert torch.equal(a["touch_charts"], b["touch_charts"].cpu()) and a["names"] == b["names"]

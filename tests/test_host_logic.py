@@ -138,3 +138,52 @@ def test_shard_range_partitions_batch():
     for gb, w in ((512, 8), (10, 3), (7, 8)):
         spans = [shard_range(gb, r, w) for r in range(w)]
         assert spans[0][0] == 0 and spans[-1][1] == gb and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def _write_dataset(root, ids, rng):
+    """A miniature dataset in the reference's on-disk layout (utility/data_loaders.py:18-29)."""
+    for sub in ("point_cloud_info", "images_colourful", "touch_charts", "object_info"):
+        os.makedirs(os.path.join(root, sub), exist_ok=True)
+    for i in ids:
+        np.save(os.path.join(root, "point_cloud_info", f"{i}.npy"), rng.standard_normal((3000, 3)).astype(np.float64))
+        np.save(os.path.join(root, "images_colourful", f"{i}.npy"), rng.integers(0, 256, (256, 256, 3), dtype=np.uint8))
+        os.makedirs(os.path.join(root, "touch_charts", str(i)), exist_ok=True)
+        tc = rng.standard_normal((50, 4, 25, 4)).astype(np.float32)
+        tc[..., 3] = rng.integers(0, 3, (50, 4, 1))
+        np.save(os.path.join(root, "touch_charts", str(i), "touch_charts.npy"), tc.reshape(50, 4, 100))
+    np.save(os.path.join(root, "data_split.npy"),
+            {"recon_train": [str(i) for i in ids[:4]], "valid": [str(i) for i in ids[4:]], "test": [], "auto_train": []})
+
+
+@pytest.mark.parametrize("finger", [False, True])
+def test_dataset_wire_format(tmp_path, finger):
+    from helpers import make_args
+    from a3vt_amd.pterotactyl.reconstruction.vision import model
+    from a3vt_amd.pterotactyl.utility import data_loaders
+    _write_dataset(str(tmp_path), list(range(6)), np.random.default_rng(0))
+    args = make_args(use_touch=True, use_img=True, finger=finger, num_grasps=3, number_points=500, eval=False,
+                     data_root=str(tmp_path), limit_data=False, val_grasps=-1)
+    train = data_loaders.mesh_loader_vision(args, set_type="recon_train")
+    valid = data_loaders.mesh_loader_vision(args, set_type="valid")
+    assert len(train) == 4 and len(valid) == 2 * 5            # validation objects x 5 grasp subsets (:160-170)
+    batch = valid.collate([valid[i] for i in range(3)])
+    assert batch["gt_points"].shape == (3, 500, 3) and batch["gt_points"].dtype == torch.float32
+    assert batch["img"].shape == (3, 3, 256, 256) and 0.0 <= batch["img"].min() and batch["img"].max() <= 1.0
+    assert batch["touch_charts"].shape == ((3, 3, 25, 4) if finger else (3, 3, 4, 25, 4))
+    name, grasps = batch["names"][0]
+    assert name.endswith("object_info/4") and len(grasps) <= 3
+    # validation instances are deterministic (seeded by position), unused grasp slots are all-zero charts
+    again = valid[0]
+    assert again["names"][1] == valid[0]["names"][1]
+    assert torch.equal(batch["touch_charts"][0][len(grasps):], torch.zeros_like(batch["touch_charts"][0][len(grasps):]))
+    raw = np.load(os.path.join(str(tmp_path), "touch_charts", "4", "touch_charts.npy")).reshape(50, 4, 25, 4)
+    if grasps:
+        want = raw[grasps[0]][1] if finger else raw[grasps[0]]
+        assert np.array_equal(batch["touch_charts"][0][0].numpy(), want)
+    # the batch feeds prepare_mesh exactly as the synthetic loader's does
+    charts = model.prepare_mesh(batch, torch.zeros(7, 3), args)
+    assert charts["touch_charts"].shape == (3, 3 * (1 if finger else 4) * 25, 3) and charts["vision_charts"].shape == (3, 7, 3)
+    args.use_img = args.use_touch = False
+    plain = data_loaders.mesh_loader_vision(args, set_type="recon_train")
+    b = plain.collate([plain[0], plain[1]])
+    assert b["img"].shape == (2, 1) and b["touch_charts"].shape == (2, 1)
