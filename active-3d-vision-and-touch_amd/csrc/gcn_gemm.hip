@@ -65,7 +65,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform (SGPR)
   const int nchunks = (p.k + 15) >> 4;
   const int l16 = lane & 15, q = lane >> 4;
-  const int kpiece = (lane & 3) * 4;
+  // LDS bank swizzle.  A staged row is 16 floats (64 B), so rows r and r+4 share banks, and the 16-lane groups a
+  // ds_read_b128 is served in ({0-3,12-15,20-27}, ... MI355X_MICROARCH.md "LDS") pair exactly such rows: a 2-way
+  // conflict on every fragment read (SQ_LDS_BANK_CONFLICT = 45 % of the LDS cycles).  Rows with bit 2 set keep
+  // their four 16-B k-quads in the order 2,3,0,1: the DMA lane fetches quad (slot ^ 2), the reader of quad q
+  // looks in slot (q ^ 2).  Conflict-free, and free: both are per-lane constants.
+  const int kpiece = ((lane & 3) ^ ((lane >> 3) & 2)) * 4;
+  const int qs = q ^ ((l16 >> 1) & 2);
 
   // 16-row tiles, dealt evenly to the workgroups
   const int tiles = (p.m + 15) >> 4;
@@ -164,10 +170,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
         const float *sB = lds + buf * STAGE + A_FLOATS;
         f32x4 af[MT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4 *>(sA + (i * 16 + l16) * 16 + q * 4);
+        for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4 *>(sA + (i * 16 + l16) * 16 + qs * 4);
         // B fragments two n-tiles at a time, register double-buffered: the ds_reads of pair jp+1 are issued one
         // MFMA group into pair jp, so the LDS latency hides under the matrix pipe.
-        const float *sBl = sB + l16 * 16 + q * 4;
+        const float *sBl = sB + l16 * 16 + qs * 4;
         constexpr int NP = (NT + 1) / 2;
         f32x4 bc0 = *reinterpret_cast<const f32x4 *>(sBl);
         f32x4 bc1 = NT > 1 ? *reinterpret_cast<const f32x4 *>(sBl + 256) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -476,7 +482,7 @@ __device__ __forceinline__ void dw_stage(const float *__restrict__ sb, int ldx, 
                                          f32x4 (&acc)[DW_MAXI][DW_MAXO]) {
 #pragma unroll 1
   for (int ks = 0; ks < 4; ++ks) {
-    const int r = ks * 4 + q;
+    const int r = q * 4 + ks;  // see dw_stage_fast
     const float *xr = sb + r * ldx + xoff;
     const int ra = r * ldz0, rg = r * ldz1;
     float a[DW_MAXI], b[DW_MAXO];
@@ -513,7 +519,11 @@ __device__ __forceinline__ void dw_stage_fast(const float *__restrict__ sb, int 
                                               f32x4 (&acc)[DW_MAXI][DW_MAXO]) {
   float a[DW_MAXI], b[DW_MAXO], an[DW_MAXI], bn[DW_MAXO];
   auto load = [&](int ks, float (&av)[DW_MAXI], float (&bv)[DW_MAXO]) {
-    const int r = ks * 4 + q;
+    // k-step ks takes rows {ks, 4+ks, 8+ks, 12+ks} of the stage (lane group q reads row 4q+ks) rather than four
+    // adjacent rows: a ds_read_b32 is served 32 lanes at a time (two q groups), and rows 4 apart sit 4*ld floats
+    // apart = 16 banks off for every ld = 4 mod 8 (300, 100, 52, 148) -> the two 16-lane runs never share a bank.
+    // Adjacent rows (ld mod 32 = 12 or 4) overlapped: 2-way conflicts on every operand read.
+    const int r = q * 4 + ks;
     const float *xr = sb + r * ldx + xoff;
     const int ra = r * ldz0, rg = r * ldz1;
 #pragma unroll
