@@ -142,3 +142,28 @@ def test_engine_on_disk_dataset_and_prefetcher(cuda, tmp_path):
     for a, b in zip(loader, got):
         assert b["gt_points"].is_cuda and torch.equal(a["gt_points"], b["gt_points"].cpu())
         assert torch.equal(a["touch_charts"], b["touch_charts"].cpu()) and a["names"] == b["names"]
+
+
+def test_rccl_backend_single_rank(cuda):
+    """The multi-GPU path's transport on this image: torch.distributed 'nccl' (= RCCL) initialises on the GPU box and
+    reduces / broadcasts the flat gradient bucket.  (N > 1 ranks are covered on CPU by tests/test_distributed_gloo.py and
+    run by the driver's scaling bench.)"""
+    import torch.distributed as dist
+    from a3vt_amd import distributed as adist
+    if dist.is_initialized():
+        pytest.skip("a process group is already up in this process")
+    dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1)
+    try:
+        net = torch.nn.Linear(64, 32).to(cuda)
+        bucket = adist.FlatGradBucket(list(net.parameters()))
+        net(torch.randn(8, 64, device=cuda)).square().mean().backward()
+        want = bucket.flat.clone()
+        dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM)      # one rank: the sum is the value itself
+        assert torch.equal(bucket.flat, want) and net.weight.grad.data_ptr() == bucket.flat.data_ptr()
+        flat = torch.arange(10, device=cuda, dtype=torch.float32)
+        dist.broadcast(flat, 0)
+        dist.barrier()
+        torch.cuda.synchronize()
+        assert flat[9].item() == 9.0
+    finally:
+        dist.destroy_process_group()
