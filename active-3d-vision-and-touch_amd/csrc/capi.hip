@@ -171,13 +171,32 @@ int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const 
   const int mld = mask_ld(hidden, cut_len);
   const size_t mpad = (m + 31) / 32 * 32;
 
+  // transposed, zero-padded weight images of all hidden layers (one launch)
+  const bool batched_images = num_layers - 1 <= kMaxImages;
+  if (batched_images && num_layers > 1) {
+    WeightImages wi{};
+    for (int i = 0; i + 1 < num_layers; ++i) {
+      wi.w[i] = weights[i];
+      wi.k[i] = i == 0 ? in_features : hidden;
+      wi.rows[i] = rowgemm_bt_rows(hidden);
+      wi.ld[i] = pad16(i == 0 ? ld_feats : hidden);
+    }
+    wi.dst = scratch + L.wt;
+    wi.dst_stride = L.wt_stride;
+    wi.n = hidden;
+    wi.count = num_layers - 1;
+    wi.transpose = 1;
+    if (int rc = launch_weight_images(wi, rowgemm_bt_rows(hidden), pad16(ld_feats > hidden ? ld_feats : hidden), s)) return rc;
+  }
+
   const float *x = feats;
   int ldx = ld_feats;
   for (int i = 0; i + 1 < num_layers; ++i) {
     const int k = i == 0 ? ld_feats : hidden;       // K walked by the kernel (pad columns of feats are zero)
     const int kin = i == 0 ? in_features : hidden;  // rows of W_i
     float *wt = scratch + L.wt + L.wt_stride * i;
-    if (int rc = launch_transpose_pad(weights[i], kin, hidden, wt, rowgemm_bt_rows(hidden), pad16(k), s)) return rc;
+    if (!batched_images)
+      if (int rc = launch_transpose_pad(weights[i], kin, hidden, wt, rowgemm_bt_rows(hidden), pad16(k), s)) return rc;
     float *y = acts ? acts + (size_t)i * m * hidden : scratch + L.ping[i & 1];
     RowGemmArgs g{};
     g.a0 = g.a1 = x;
@@ -251,6 +270,26 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
     if (int rc = launch_slab_reduce(scratch + L.thin_db_slab, thin_num_slabs(), 3, 3, grad_biases[last], s)) return rc;
   }
 
+  // zero-padded weight images (Bt = W_i for dX) of all hidden layers, one launch
+  const bool batched_images = num_layers - 1 <= kMaxImages;
+  if (batched_images && num_layers > 1) {
+    WeightImages wi{};
+    int max_rows = 0;
+    for (int i = 0; i < last; ++i) {
+      wi.w[i] = weights[i];
+      wi.k[i] = i == 0 ? in_features : hidden;
+      wi.rows[i] = rowgemm_bt_rows(i == 0 ? ld_feats : hidden);
+      wi.ld[i] = pad16(hidden);
+      max_rows = wi.rows[i] > max_rows ? wi.rows[i] : max_rows;
+    }
+    wi.dst = scratch + L.wt;
+    wi.dst_stride = L.wt_stride;
+    wi.n = hidden;
+    wi.count = last;
+    wi.transpose = 0;
+    if (int rc = launch_weight_images(wi, max_rows, pad16(hidden), s)) return rc;
+  }
+
   // ---- hidden layers, last to first.  g = dL/dY_i already multiplied by the ReLU mask of layer i.
   int cur = 0;
   for (int i = last - 1; i >= 0; --i) {
@@ -261,14 +300,16 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
     const int kin = i == 0 ? in_features : hidden;
 
     // bias gradient + A^T gather on the aggregated channels
-    if (int rc = launch_fill_zero(grad_biases[i], hidden, s)) return rc;
     if (cut_len > 0) {
       if (int rc = launch_csr_bwd(g, hidden, cut_len, rowptrT, colT, valT, n_vert, batch, dza, cpad,
                                   scratch + L.db_slab, s))
         return rc;
-      if (int rc = launch_slab_reduce(scratch + L.db_slab, csr_bwd_num_slabs(batch, n_vert), cpad, cut_len,
-                                      grad_biases[i], s))
+      // channels >= cut_len are dead bias parameters (model.py:358): written as exact zeros by the same launch
+      if (int rc = launch_slab_reduce_z(scratch + L.db_slab, csr_bwd_num_slabs(batch, n_vert), cpad, cut_len, hidden,
+                                        grad_biases[i], s))
         return rc;
+    } else {
+      if (int rc = launch_fill_zero(grad_biases[i], hidden, s)) return rc;
     }
 
     // dW_i = X_i^T dZ.  The kernel covers up to 304 input channels per pass; wider inputs (the 448-wide image
@@ -311,7 +352,8 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
     // dX_i = dZ W_i^T  (masked by the ReLU of layer i-1, whose output is X_i)
     const int n_store = i == 0 ? ld_feats : hidden;
     float *wp = scratch + L.wt + L.wt_stride * i;
-    if (int rc = launch_copy_pad(weights[i], kin, hidden, wp, rowgemm_bt_rows(n_store), pad16(hidden), s)) return rc;
+    if (!batched_images)
+      if (int rc = launch_copy_pad(weights[i], kin, hidden, wp, rowgemm_bt_rows(n_store), pad16(hidden), s)) return rc;
     RowGemmArgs r{};
     r.a0 = dza;
     r.lda0 = cpad > 0 ? cpad : 4;

@@ -31,6 +31,17 @@ int rowgemm_bt_rows(int n_store);
 int launch_rowgemm(const RowGemmArgs &a, int epi, hipStream_t s);
 int launch_transpose_pad(const float *w, int k, int n, float *wt, int rows, int ld, hipStream_t s);
 int launch_copy_pad(const float *w, int rows_in, int cols_in, float *out, int rows, int ld, hipStream_t s);
+// Weight images of up to kMaxImages layers in one launch.  transpose = 1: dst_l [rows_l][ld_l] = W_l^T (W_l is
+// [k_l][n]); transpose = 0: dst_l [rows_l][ld_l] = W_l zero padded.  dst_l = dst + l * dst_stride.
+constexpr int kMaxImages = 32;
+struct WeightImages {
+  const float *w[kMaxImages];
+  float *dst;
+  size_t dst_stride;
+  int k[kMaxImages], rows[kMaxImages], ld[kMaxImages];
+  int n, count, transpose;
+};
+int launch_weight_images(const WeightImages &w, int max_rows, int max_ld, hipStream_t s);
 
 // slab[wg][k_in][n_out] = X[rows of wg]^T * dZ[rows of wg];  dZ cols [0,zsplit) from z0, rest from z1.
 struct DwArgs {
@@ -46,6 +57,8 @@ int dw_num_slabs(int n_out);
 int launch_dw(const DwArgs &a, hipStream_t s);
 int launch_copy_cols(const float *src, int ld_src, int c0, int w, float *dst, long long m, hipStream_t s);
 int launch_slab_reduce(const float *slab, int nslab, size_t stride, size_t n, float *out, hipStream_t s);
+// same, and out[n .. n_out) = 0
+int launch_slab_reduce_z(const float *slab, int nslab, size_t stride, size_t n, size_t n_out, float *out, hipStream_t s);
 
 // CSR neighbour aggregation on the first c channels (+ bias + ReLU), model.py:356-358,363.
 int launch_csr_fwd(const float *za, int ldza, const float *bias, int c, const int32_t *rowptr, const int32_t *col,

@@ -184,10 +184,62 @@ __global__ __launch_bounds__(256) void sample_bwd_kernel(const int32_t *__restri
   }
 }
 
+// Same scatter with the vertex gradient of ONE mesh accumulated in LDS (n_vert * 12 bytes; 30 KB for 2562 vertices):
+// the ~9 float atomics per sample hit LDS (ds_add_f32) instead of L2, and each workgroup then adds its slice of the
+// mesh's samples to global memory with one coalesced pass.  grid = (batch, kSampleSplits).
+constexpr int kSampleSplits = 4;
+__global__ __launch_bounds__(1024) void sample_bwd_lds_kernel(const int32_t *__restrict__ faces, int batch, int n_vert,
+                                                              int draws, int num, const int32_t *__restrict__ fi,
+                                                              const float *__restrict__ u, const float *__restrict__ v,
+                                                              const float *__restrict__ gp, float *__restrict__ gverts) {
+  extern __shared__ float acc[];
+  const int b = blockIdx.x;
+  const int nf = n_vert * 3;
+  for (int i = threadIdx.x; i < nf; i += blockDim.x) acc[i] = 0.f;
+  __syncthreads();
+  const int per = (num + gridDim.y - 1) / gridDim.y;
+  const int j0 = blockIdx.y * per, j1 = min(num, j0 + per);
+  for (int d = 0; d < draws; ++d) {
+    const long long base = ((long long)d * batch + b) * num;
+    for (int j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
+      const long long i = base + j;
+      const float su = sqrtf(u[i]);
+      const float w[3] = {1.0f - su, su * (1.0f - v[i]), su * v[i]};
+      const int32_t *fc = faces + 3 * (long long)fi[i];
+      const float g0 = gp[i * 3], g1 = gp[i * 3 + 1], g2 = gp[i * 3 + 2];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float *dst = acc + 3 * fc[k];
+        atomicAdd(dst + 0, w[k] * g0);
+        atomicAdd(dst + 1, w[k] * g1);
+        atomicAdd(dst + 2, w[k] * g2);
+      }
+    }
+  }
+  __syncthreads();
+  float *gb = gverts + (long long)b * nf;
+  for (int i = threadIdx.x; i < nf; i += blockDim.x) {
+    const float a = acc[i];
+    if (a != 0.f) atomicAdd(gb + i, a);
+  }
+}
+
 int launch_sample_bwd(const int32_t *faces, int batch, int n_vert, int n_faces, int draws, int num, const int32_t *fi,
                       const float *u, const float *v, const float *gpoints, float *gverts, hipStream_t s) {
   (void)n_faces;
   if (int rc = launch_fill_zero(gverts, (size_t)batch * n_vert * 3, s)) return rc;
+  const size_t shmem = (size_t)n_vert * 3 * sizeof(float);
+  if (shmem <= 144 * 1024) {  // up to 12 288 vertices per mesh (icosphere-5: 10 242)
+    static size_t attr = 64 * 1024;
+    if (shmem > attr) {
+      (void)hipFuncSetAttribute((const void *)sample_bwd_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+      attr = 144 * 1024;
+    }
+    A3VT_LAUNCH(sample_bwd_lds_kernel, dim3(batch, kSampleSplits), dim3(1024), shmem, s, faces, batch, n_vert, draws, num,
+                fi, u, v, gpoints, gverts);
+    A3VT_CHECK_LAUNCH();
+    return 0;
+  }
   const long long total = (long long)draws * batch * num;
   A3VT_LAUNCH(sample_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, faces, batch, n_vert, total, num, fi, u,
                      v, gpoints, gverts);
