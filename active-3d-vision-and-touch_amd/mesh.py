@@ -30,9 +30,10 @@ def load_obj(path):
     return np.asarray(verts, dtype=np.float32), np.asarray(faces, dtype=np.int64)
 
 
-def icosphere(level=4, radius=0.25):
+def icosphere(level=4, radius=0.25, spatial_order=True):
     """Subdivided icosahedron: 10*4^level + 2 vertices (2562 at level 4, 10242 at level 5), 20*4^level faces.
-    The synthetic benchmark template of BASELINE.json configs[1]/[4]."""
+    The synthetic benchmark template of BASELINE.json configs[1]/[4].  Vertices are numbered along a
+    space-filling curve by default (``reorder_spatially``); ``spatial_order=False`` keeps subdivision order."""
     t = (1.0 + 5.0 ** 0.5) / 2.0
     v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t),
          (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
@@ -56,7 +57,32 @@ def icosphere(level=4, radius=0.25):
             ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
             nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
         faces = nf
-    return (np.asarray(verts) * radius).astype(np.float32), np.asarray(faces, dtype=np.int64)
+    verts, faces = np.asarray(verts), np.asarray(faces, dtype=np.int64)
+    if spatial_order:
+        verts, faces = reorder_spatially(verts, faces)
+    return (verts * radius).astype(np.float32), faces
+
+
+def reorder_spatially(verts, faces):
+    """Renumber vertices along a Morton (Z-order) curve of their positions: neighbours in the mesh get nearby indices, so
+    the rows a neighbour gather touches are the rows the same workgroup touched a moment ago (L1/L2 locality of the
+    CSR aggregation).  Subdivision order scatters them: a level-4 vertex sits thousands of rows from its level-0
+    neighbours.  Pure relabelling — geometry and topology are unchanged."""
+    v = np.asarray(verts, dtype=np.float64)
+    lo, hi = v.min(axis=0), v.max(axis=0)
+    q = np.minimum(((v - lo) / np.maximum(hi - lo, 1e-30) * 1024).astype(np.int64), 1023)
+
+    def spread(x):                      # 10 bits -> every third bit
+        x = (x | (x << 16)) & 0x030000FF
+        x = (x | (x << 8)) & 0x0300F00F
+        x = (x | (x << 4)) & 0x030C30C3
+        return (x | (x << 2)) & 0x09249249
+
+    code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+    order = np.argsort(code, kind="stable")
+    new_index = np.empty(len(order), dtype=np.int64)
+    new_index[order] = np.arange(len(order))
+    return v[order].astype(np.asarray(verts).dtype), new_index[np.asarray(faces, dtype=np.int64)]
 
 
 def _edges_from_faces(faces):

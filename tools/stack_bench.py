@@ -17,13 +17,14 @@ p.add_argument("--hidden", type=int, default=300)
 p.add_argument("--batch", type=int, default=64)
 p.add_argument("--level", type=int, default=4)
 p.add_argument("--reps", type=int, default=5)
+p.add_argument("--subdivision-order", action="store_true", help="icosphere vertices in subdivision order (poor locality)")
 a = p.parse_args()
 
 from a3vt_amd import lib, mesh as amesh, ops  # noqa: E402
 from oracle import gcn as og  # noqa: E402
 
 dev = torch.device("cuda", 0)
-verts, faces = amesh.icosphere(a.level)
+verts, faces = amesh.icosphere(a.level, spatial_order=not a.subdivision_order)
 r, c = amesh.vision_pairs(faces, verts.shape[0])
 adj = ops.DeviceCSR(amesh.CSRAdjacency.from_pairs(r, c, verts.shape[0]), dev)
 st = og.init_state(50, a.hidden, a.layers, seed=0)
@@ -58,4 +59,4 @@ flop = 2.0 * M * a.hidden * a.hidden
 for name, i in (("fwd Z=XW", 0), ("bwd dX", 1), ("bwd dW", 2)):
     ms = tot[i] / max(cnt[i], 1)
     print(f"{name:10s} launches {cnt[i]:4d}  mean {ms * 1e3:8.1f} us   {flop / (ms * 1e-3) / 1e12 if ms else 0:6.1f} TFLOP/s (hidden x hidden launches dominate)")
-print(f"stack fwd+bwd: {e0.elapsed_time(e1) / a.reps:.2f} ms per call  (MFMA classes: {sum(tot) / a.reps:.2f} ms)")
+print(f"stack fwd+bwd: {e0.elapsed_time(e1) / a.reps:.2f} ms per call  (MFMA classes: {sum(tot) / a.reps:.2f} ms, rest {e0.elapsed_time(e1) / a.reps - sum(tot) / a.reps:.2f} ms)")
