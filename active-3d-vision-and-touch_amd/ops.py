@@ -277,6 +277,27 @@ class SamplePointsFn(torch.autograd.Function):
         return gverts, None, None, None, None, None, None, None, None
 
 
+def sample_points(verts, faces, num, draws, seed=0, offset=0, return_samples=False):
+    """Forward-only area-weighted sampling on the Philox path; with ``return_samples`` also the draws themselves
+    (face_idx int32, u, v — each (draws,B,num)), e.g. to re-inject them into another call."""
+    L = _lib.load()
+    verts = _req(verts, "verts")
+    faces = _req(faces, "faces", torch.int32)
+    B, N, _ = verts.shape
+    F = faces.shape[0]
+    dev = verts.device
+    points = torch.empty((draws, B, num, 3), dtype=torch.float32, device=dev)
+    cdf = torch.empty((B, F), dtype=torch.float32, device=dev)
+    fi = torch.empty((draws, B, num), dtype=torch.int32, device=dev)
+    uu = torch.empty((draws, B, num), dtype=torch.float32, device=dev)
+    vv = torch.empty((draws, B, num), dtype=torch.float32, device=dev)
+    _lib.check(L.a3vt_face_cdf(_lib.ptr(verts), _lib.ptr(faces), B, N, F, _lib.ptr(cdf), _stream()), "face_cdf")
+    _lib.check(L.a3vt_sample_points_fwd(_lib.ptr(verts), _lib.ptr(faces), _lib.ptr(cdf), B, N, F, draws, num, None, None,
+                                        None, seed, offset, _lib.ptr(points), _lib.ptr(fi), _lib.ptr(uu), _lib.ptr(vv),
+                                        _stream()), "sample_points_fwd")
+    return (points, fi, uu, vv) if return_samples else points
+
+
 class ChamferFn(torch.autograd.Function):
     """pytorch3d chamfer_distance(x, y, batch_reduction=None) averaged over draws (utility/utils.py:204-217).
     x (draws,B,P,3), y (B,Q,3) -> cd (B,)."""
