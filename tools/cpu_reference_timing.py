@@ -1,0 +1,63 @@
+#!/usr/bin/env python
+"""Build-container only: time the ACTUAL reference (imported from /root/reference through oracle.ref_shim) next to the
+oracle restatement on BASELINE configs[0] (atlas template N=1824, bs=2, L=20, H=300, 10k-point Chamfer x3, CPU fp32),
+so that bench.py's `cpu_baseline` (the oracle, kind "port") is tied to the reference's own speed.
+The PyTorch3D calls inside the reference run through the shim's restatement (brute-force cdist-style NN)."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+
+from oracle import chamfer as och, gcn as og, ref_shim  # noqa: E402
+
+
+def main():
+    from helpers import make_args, oracle_adj
+    from a3vt_amd import mesh as amesh
+    from a3vt_amd.synthetic import gt_cloud
+    ref = ref_shim.load_reference()
+    assert ref is not None, "needs /root/reference"
+    torch.set_num_threads(8)
+    bs, P = 2, 10000
+    args = make_args(number_points=P)
+    gt = gt_cloud(bs, P, 0)
+    res = {"config": "atlas N=1824, bs=2, L=20, H=300, 10k-pt Chamfer x3, fp32 CPU", "threads": torch.get_num_threads()}
+    # the reference itself
+    info, verts = ref.utils.load_mesh_vision(args, os.path.join(ref.objects_dir, "vision_charts.obj"))
+    torch.manual_seed(0)
+    net = ref.model.Deformation(info, verts, args)
+    batch = {"img": torch.zeros(bs, 1)}
+    times = []
+    for it in range(2):
+        t0 = time.perf_counter()
+        out, _ = net(batch["img"], ref.model.prepare_mesh(batch, verts, args))
+        loss = 9000.0 * ref.utils.chamfer_distance(out, info["faces"], gt, num=P).mean()
+        net.zero_grad()
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+    res["reference_s_per_iter"] = min(times)
+    # the oracle (CSR aggregation + C nearest neighbour), same weights
+    v, f = amesh.load_asset("vision_charts")
+    adj_o, faces_o = oracle_adj(v, f, args)
+    st = {k: t.detach().clone().requires_grad_(True) for k, t in net.state_dict().items()}
+    ch = og.prepare_mesh(None, torch.from_numpy(v), bs, False)
+    times = []
+    for it in range(2):
+        t0 = time.perf_counter()
+        out, _ = og.deformation_forward(st, {"adj": adj_o}, ch, False, 20, 0.33)
+        loss = 9000.0 * och.chamfer_distance(out, faces_o, gt, num=P, use_c=True).mean()
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+    res["oracle_s_per_iter"] = min(times)
+    res["oracle_speedup_over_reference"] = res["reference_s_per_iter"] / res["oracle_s_per_iter"]
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
