@@ -176,6 +176,7 @@ def main():
                 "other_mfma_ms": per,
                 "mfma_ms_per_step": (tot[0] + tot[1] + tot[2]) / a.profile_steps}
 
+    default_cfg = (a.level, a.batch, a.points, a.layers, a.hidden) == (4, 64, 10000, 20, 300)
     out = {
         "metric": "mesh-recon iters/sec (fwd+bwd, 2562-vert GCN + 10k-pt Chamfer) at bs=64",
         "value": world * a.steps / dt, "unit": "iters/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -183,7 +184,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"icosphere-{a.level} template ({vt.shape[0]} verts, {ft.shape[0]} faces), 3-stage GCN "
                                f"{a.layers}x{a.hidden} cut 0.33, bs={a.batch}/GPU, {a.points}-pt Chamfer x3 draws, "
-                               f"Adam, {a.cloud} clouds (BASELINE.json configs[1])",
+                               f"Adam, {a.cloud} clouds" + (" (BASELINE.json configs[1])" if default_cfg else " (custom sizes)"),
                    "global_batch": a.batch * world, "parallelism": f"dp{world}", "final_loss": final_loss},
     }
     if roof is not None:
