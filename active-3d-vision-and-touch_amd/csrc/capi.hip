@@ -640,6 +640,55 @@ int a3vt_chamfer_bwd(const float *x, const float *y, int draws, int batch, int p
                             static_cast<hipStream_t>(stream));
 }
 
+static int fill_pool_args(PoolArgs &a, const float *verts, int batch, int n_vert, const float *proj, int n_maps,
+                          const float *const *maps, const int *chans, const int *heights, const int *widths, int ld) {
+  A3VT_CHECK_ARG(verts && proj && maps && chans && heights && widths && batch > 0 && n_vert > 0);
+  A3VT_CHECK_ARG(n_maps >= 1 && n_maps <= kMaxMaps);
+  a.verts = verts;
+  for (int i = 0; i < 12; ++i) a.proj[i] = proj[i];
+  a.batch = batch;
+  a.n_vert = n_vert;
+  a.n_maps = n_maps;
+  int off = 0;
+  for (int k = 0; k < n_maps; ++k) {
+    A3VT_CHECK_ARG(maps[k] != nullptr);
+    a.maps[k] = maps[k];
+    a.C[k] = chans[k];
+    a.H[k] = heights[k];
+    a.W[k] = widths[k];
+    a.off[k] = off;
+    off += chans[k];
+  }
+  a.ld = ld;
+  return 0;
+}
+
+int a3vt_image_pool_fwd(const float *verts, int batch, int n_vert, const float *proj, int n_maps,
+                        const float *const *maps, const int *chans, const int *heights, const int *widths,
+                        float *feats, int ld_feats, void *stream) {
+  PoolArgs a{};
+  if (int rc = fill_pool_args(a, verts, batch, n_vert, proj, n_maps, maps, chans, heights, widths, ld_feats)) return rc;
+  A3VT_CHECK_ARG(feats != nullptr);
+  a.feats = feats;
+  return launch_pool_fwd(a, static_cast<hipStream_t>(stream));
+}
+
+int a3vt_image_pool_bwd(const float *verts, int batch, int n_vert, const float *proj, int n_maps,
+                        const float *const *maps, const int *chans, const int *heights, const int *widths,
+                        const float *grad_feats, int ld_feats, float *const *grad_maps, float *grad_verts,
+                        void *stream) {
+  PoolArgs a{};
+  if (int rc = fill_pool_args(a, verts, batch, n_vert, proj, n_maps, maps, chans, heights, widths, ld_feats)) return rc;
+  A3VT_CHECK_ARG(grad_feats && grad_maps && grad_verts);
+  for (int k = 0; k < n_maps; ++k) {
+    A3VT_CHECK_ARG(grad_maps[k] != nullptr);
+    a.gmaps[k] = grad_maps[k];
+  }
+  a.gfeats = grad_feats;
+  a.gverts = grad_verts;
+  return launch_pool_bwd(a, static_cast<hipStream_t>(stream));
+}
+
 int a3vt_profile_enable(int on) {
   g_prof.on = on != 0;
   g_prof.used = 0;

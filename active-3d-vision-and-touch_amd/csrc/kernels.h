@@ -107,6 +107,23 @@ int launch_sample_bwd(const int32_t *faces, int batch, int n_vert, int n_faces, 
                       const int32_t *fi, const float *u, const float *v, const float *gpoints, float *gverts,
                       hipStream_t s);
 
+// pooling.hip — Image_Encoder.pooling (model.py:70-103): projection + bilinear gather from channels-last maps
+constexpr int kMaxMaps = 4;
+struct PoolArgs {
+  const float *verts;   // [B][N][3]
+  float proj[12];       // K.RT, row-major 3 x 4
+  int batch, n_vert, n_maps;
+  const float *maps[kMaxMaps];   // channels-last [B][H][W][C]
+  float *gmaps[kMaxMaps];        // backward: gradient of the maps, same layout (overwritten)
+  int C[kMaxMaps], H[kMaxMaps], W[kMaxMaps], off[kMaxMaps];  // off = first output channel of the map
+  float *feats;         // fwd out  [B*N][ld]
+  const float *gfeats;  // bwd in   [B*N][ld]
+  int ld;
+  float *gverts;        // bwd out  [B*N][3]
+};
+int launch_pool_fwd(PoolArgs a, hipStream_t s);
+int launch_pool_bwd(PoolArgs a, hipStream_t s);
+
 // chamfer.hip
 int launch_chamfer_fwd(const float *x, const float *y, int draws, int batch, int p, int q, float *dxy, int32_t *ixy,
                        float *dyx, int32_t *iyx, float *cd, hipStream_t s);

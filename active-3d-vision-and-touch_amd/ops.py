@@ -207,6 +207,51 @@ class PosEncMaskFn(torch.autograd.Function):
         return gverts, None, gparams, None, None
 
 
+class ImagePoolFn(torch.autograd.Function):
+    """Image_Encoder.pooling (vision/model.py:70-103): verts (B,N,3) + feature maps (B,C_k,H_k,W_k) -> (B,N,sum C_k).
+    Maps are consumed in torch's channels_last memory format (converted here if they are not already)."""
+
+    @staticmethod
+    def forward(ctx, verts, matrix, *maps):
+        L = _lib.load()
+        verts = _req(verts, "verts")
+        B, N, _ = verts.shape
+        cl = [m.contiguous(memory_format=torch.channels_last) for m in maps]
+        for m in cl:
+            if not m.is_cuda or m.dtype != torch.float32 or m.shape[0] != B:
+                raise RuntimeError("a3vt: feature maps must be float32 (B,C,H,W) tensors on the GPU")
+        chans = [int(m.shape[1]) for m in cl]
+        ld = sum(chans)                                     # every C_k is a multiple of 4 (checked by the library)
+        feats = torch.empty((B, N, ld), dtype=torch.float32, device=verts.device)
+        if isinstance(matrix, torch.Tensor):               # host copy of the 3 x 4 camera matrix (a device tensor costs a sync)
+            matrix = matrix.detach().cpu().reshape(-1).tolist()
+        proj = (ctypes.c_float * 12)(*[float(x) for x in matrix])
+        ints = lambda xs: (ctypes.c_int * len(xs))(*xs)  # noqa: E731
+        geo = (ints(chans), ints([int(m.shape[2]) for m in cl]), ints([int(m.shape[3]) for m in cl]))
+        _lib.check(L.a3vt_image_pool_fwd(_lib.ptr(verts), B, N, proj, len(cl), _ptr_array(cl), *geo, _lib.ptr(feats), ld,
+                                         _stream()), "image_pool_fwd")
+        ctx.save_for_backward(verts, *cl)
+        ctx.proj, ctx.geo = proj, geo
+        return feats
+
+    @staticmethod
+    def backward(ctx, gfeats):
+        L = _lib.load()
+        verts, *cl = ctx.saved_tensors
+        B, N, _ = verts.shape
+        gfeats = _req(gfeats, "grad_feats")
+        gmaps = [torch.empty_like(m) for m in cl]          # keeps the channels_last strides
+        gverts = torch.empty_like(verts)
+        _lib.check(L.a3vt_image_pool_bwd(_lib.ptr(verts), B, N, ctx.proj, len(cl), _ptr_array(cl), *ctx.geo,
+                                         _lib.ptr(gfeats), gfeats.shape[-1], _ptr_array(gmaps), _lib.ptr(gverts),
+                                         _stream()), "image_pool_bwd")
+        return (gverts, None, *gmaps)
+
+
+def image_pool(verts, matrix, maps):
+    return ImagePoolFn.apply(verts, matrix, *maps)
+
+
 class VertexUpdateFn(torch.autograd.Function):
     """vertices[:, :n_vision] += update[:, :n_vision] (vision/model.py:250,270,283), out of place."""
 

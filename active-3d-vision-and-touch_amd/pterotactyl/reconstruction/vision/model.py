@@ -83,8 +83,8 @@ _CAM_F = 221.7025
 
 
 class Image_Encoder(nn.Module):
-    """Image pyramid + per-vertex feature pooling (reference :27-103).  Runs on torch ops (MIOpen convolutions,
-    ``grid_sample``): SURVEY §2b K13/K14 keep these off the hand-written path."""
+    """Image pyramid + per-vertex feature pooling (reference :27-103).  The convolutions run on torch ops (MIOpen,
+    SURVEY §2b K13); the pooling is the fused HIP kernel of csrc/pooling.hip."""
 
     def __init__(self, args):
         super().__init__()
@@ -99,6 +99,7 @@ class Image_Encoder(nn.Module):
         self.layers = nn.ModuleList(blocks)
         K = np.array([[_CAM_F, 0, 128.0], [0, _CAM_F, 128.0], [0, 0, 1]])
         self.register_buffer("matrix", torch.FloatTensor(K.dot(np.array(_CAM_RT))), persistent=False)
+        self._matrix_host = [float(x) for x in self.matrix.reshape(-1).tolist()]   # fp32 values, no device sync later
 
     def forward(self, img):
         """Feature maps of the three layers ``layers_per_block`` apart from the end, plus the last map reached
@@ -116,17 +117,9 @@ class Image_Encoder(nn.Module):
         return maps
 
     def pooling(self, blocks, verts_pos):
-        """Project vertices with K.RT, bilinear-sample every map at the projected pixel, concatenate (:70-103)."""
-        ones = torch.ones_like(verts_pos[..., :1])
-        proj = torch.matmul(torch.cat((verts_pos, ones), dim=-1), self.matrix.to(verts_pos.device).t())
-        z = torch.where(proj[..., 2] == 0, torch.full_like(proj[..., 2], 0.1), proj[..., 2])
-        xs = proj[..., 1] / z / 256.0
-        ys = proj[..., 0] / z / 256.0
-        xs = torch.where(torch.isinf(xs), torch.full_like(xs, 0.5), xs)
-        ys = torch.where(torch.isinf(ys), torch.full_like(ys, 0.5), ys)
-        grid = torch.stack((ys, xs), dim=-1).unsqueeze(2) * 2 - 1            # (B,N,1,2), x-coordinate first = ys
-        feats = [F.grid_sample(b, grid, align_corners=True)[..., 0] for b in blocks]   # each (B,C,N)
-        return torch.cat(feats, dim=1).permute(0, 2, 1)
+        """Project vertices with K.RT, bilinear-sample every map at the projected pixel, concatenate (:70-103) — one
+        fused HIP kernel (``a3vt_image_pool_fwd/bwd``) instead of three ``grid_sample`` calls and the concatenations."""
+        return _ops.image_pool(verts_pos.to(torch.float32), self._matrix_host, list(blocks))
 
 
 def _nerf_embedding(p):

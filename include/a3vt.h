@@ -128,6 +128,23 @@ int a3vt_posenc_mask_bwd(const float *verts, const float *mask, int m, int input
                          const float *pe_params, const float *grad_feats, int ld_feats,
                          float *grad_verts, float *grad_params, float *scratch, void *stream);
 
+/* Per-vertex image features.  Replaces Image_Encoder.pooling (model.py:70-103): project the vertices with the fixed
+ * camera matrix `proj` = K.RT (row-major 3 x 4, model.py:50-67; HOST pointer), z == 0 -> 0.1,
+ * xs = P1/P2/256, ys = P0/P2/256, inf -> 0.5, then grid_sample(bilinear, zeros, align_corners=True) of every map at
+ * (2 ys - 1, 2 xs - 1) and concatenation:  feats[b][v][off_k + c] for map k, channel c.
+ * maps[k] is CHANNELS-LAST, [B][H_k][W_k][C_k] (torch channels_last memory of a (B,C,H,W) tensor), C_k % 4 == 0;
+ * `maps`, `chans`, `heights`, `widths`, `grad_maps` are HOST arrays of n_maps (<= 4) entries.
+ * feats / grad_feats are [B*N][ld_feats], ld_feats % 4 == 0, ld_feats >= sum C_k (other columns untouched).
+ * Backward overwrites grad_maps[k] (same layout as maps[k]) and grad_verts [B*N][3] (the reference's autograd
+ * reaches the vertex positions through the sampling grid; its in-place patches cut the gradient where they fire). */
+int a3vt_image_pool_fwd(const float *verts, int batch, int n_vert, const float *proj_host, int n_maps,
+                        const float *const *maps, const int *chans, const int *heights, const int *widths,
+                        float *feats, int ld_feats, void *stream);
+int a3vt_image_pool_bwd(const float *verts, int batch, int n_vert, const float *proj_host, int n_maps,
+                        const float *const *maps, const int *chans, const int *heights, const int *widths,
+                        const float *grad_feats, int ld_feats, float *const *grad_maps, float *grad_verts,
+                        void *stream);
+
 /* Vertex update, model.py:250,270,283:  out[b][v] = in[b][v] + (v < n_vision ? update[b][v] : 0). */
 int a3vt_vertex_update(const float *verts_in, const float *update, int batch, int n_vert, int n_vision,
                        float *verts_out, void *stream);

@@ -120,6 +120,39 @@ def test_gcn_layer_standalone(cuda, tname, use_touch, B, kin, nout, cut, do_cut,
             assert layer.bias.grad[round(nout * cut):].abs().max().item() == 0.0
 
 
+def test_image_pool_fwd_bwd(cuda):
+    """Fused projection + bilinear pooling (a3vt_image_pool_fwd/bwd) vs the oracle's restatement of
+    Image_Encoder.pooling (model.py:70-103) in float64: default pyramid sizes (64x23x23, 128x7x7, 256x3x3), vertices
+    inside the image, on its border and projected outside it (zero padding)."""
+    from a3vt_amd import ops
+    from oracle import gcn as og
+    B, N = 3, 700
+    g = torch.Generator().manual_seed(12)
+    verts = (torch.rand(B, N, 3, generator=g) - 0.5) * 0.5
+    verts[:, :40] *= 6.0                                     # far off-screen: all four corners out of range
+    maps = [torch.randn(B, c, h, h, generator=g) for c, h in ((64, 23), (128, 7), (256, 3))]
+    gout = torch.randn(B, N, 448, generator=g)
+    matrix = og.projection_matrix().float()
+    v64 = verts.double().requires_grad_(True)
+    m64 = [m.double().requires_grad_(True) for m in maps]
+    f_o = og.image_pooling(m64, v64)
+    (f_o * gout.double()).sum().backward()
+    vd = verts.to(cuda).requires_grad_(True)
+    md = [m.to(cuda).requires_grad_(True) for m in maps]
+    f = ops.image_pool(vd, matrix, md)
+    assert f.shape == (B, N, 448)
+    (f * gout.to(cuda)).sum().backward()
+    assert rel_err(f, f_o) < 1e-5
+    assert (f[:, :40].abs().sum(-1) == 0).float().mean() > 0.5          # most far vertices sample nothing
+    for k in range(3):
+        assert md[k].grad.shape == maps[k].shape and rel_err(md[k].grad, m64[k].grad) < 1e-5
+    # position gradient: piecewise-smooth in the position (kinks at pixel boundaries) -> L2 + outlier tolerant check
+    assert_grad_close(vd.grad, v64.grad, "grad_verts")
+    # channels_last input is consumed as is, and the result does not depend on the input memory format
+    f2 = ops.image_pool(vd.detach(), matrix, [m.detach().contiguous(memory_format=torch.channels_last) for m in md])
+    assert torch.equal(f2, f.detach())
+
+
 def test_posenc_mask_fwd_bwd(cuda):
     from a3vt_amd import ops
     from oracle import gcn as og
