@@ -145,7 +145,7 @@ def _write_dataset(root, ids, rng):
     for sub in ("point_cloud_info", "images_colourful", "touch_charts", "object_info"):
         os.makedirs(os.path.join(root, sub), exist_ok=True)
     for i in ids:
-        np.save(os.path.join(root, "point_cloud_info", f"{i}.npy"), rng.standard_normal((3000, 3)).astype(np.float64))
+        np.save(os.path.join(root, "point_cloud_info", f"{i}.npy"), (0.1 * rng.standard_normal((3000, 3))).astype(np.float64))
         np.save(os.path.join(root, "images_colourful", f"{i}.npy"), rng.integers(0, 256, (256, 256, 3), dtype=np.uint8))
         os.makedirs(os.path.join(root, "touch_charts", str(i)), exist_ok=True)
         tc = rng.standard_normal((50, 4, 25, 4)).astype(np.float32)
