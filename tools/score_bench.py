@@ -64,6 +64,26 @@ def main():
             fn()
         torch.cuda.synchronize()
         res[name + "_ms"] = 1e3 * (time.perf_counter() - t0) / a.reps
+    # one forward pass of E meshes: eager launches vs one HIP-graph replay (launch-bound at this size)
+    static = {k: v.clone() for k, v in charts_list[0].items()}
+    with torch.no_grad():
+        net(img, static)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            net(img, static)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            net(img, static)
+        for name, fn in (("forward_eager_ms", lambda: net(img, static)), ("forward_graph_ms", graph.replay)):
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize()
+            res[name] = 1e3 * (time.perf_counter() - t0) / 20
     res.update({"env": E, "candidates": K, "points": a.points, "n_vert": 1949,
                 "candidates_per_s_batched": 1e3 * E * K / res["batched_ms"],
                 "speedup": res["sequential_ms"] / res["batched_ms"]})
