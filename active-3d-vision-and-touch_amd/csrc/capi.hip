@@ -71,6 +71,7 @@ struct StackLayout {
   size_t z3;             // [2][M][4]
   size_t ping[2];        // [M][hidden] each (fwd without acts: layer outputs; bwd: gradients)
   size_t dw_slab, db_slab, thin_dw_slab, thin_db_slab;
+  size_t heavy;          // int32 list of hub rows (csr_heavy_scratch_ints)
   size_t total;
 };
 
@@ -92,6 +93,7 @@ static StackLayout stack_layout(int batch, int n_vert, int in_features, int hidd
   L.z3 = take(2 * m * 4);
   L.ping[0] = take(m * hidden);
   L.ping[1] = take(m * hidden);
+  L.heavy = take(csr_heavy_scratch_ints(n_vert));
   if (need_backward) {
     const size_t kin = kmax;
     L.dw_slab = take((size_t)dw_num_slabs(hidden) * kin * hidden);
@@ -156,8 +158,8 @@ size_t a3vt_gcn_stack_scratch_bytes(int batch, int n_vert, int in_features, int 
 
 int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const float *const *weights,
                        const float *const *biases, int num_layers, int hidden, int cut_len,
-                       const int32_t *rowptr, const int32_t *col, const float *val, int n_vert, int batch,
-                       float *acts, uint8_t *masks, float *scratch, float *update, void *stream) {
+                       const int32_t *rowptr, const int32_t *col, const float *val, int max_degree, int n_vert,
+                       int batch, float *acts, uint8_t *masks, float *scratch, float *update, void *stream) {
   A3VT_CHECK_ARG(feats && weights && biases && rowptr && col && val && scratch && update);
   A3VT_CHECK_ARG((acts == nullptr) == (masks == nullptr) || num_layers < 2);
   A3VT_CHECK_ARG(n_vert > 0 && batch > 0);
@@ -171,6 +173,12 @@ int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const 
   const int mld = mask_ld(hidden, cut_len);
   const size_t mpad = (m + 31) / 32 * 32;
 
+  // hub rows (if any): listed once, then every layer's aggregation hands them to whole workgroups
+  int32_t *heavy = nullptr;
+  if (max_degree <= 0 || max_degree > csr_heavy_degree()) {
+    heavy = reinterpret_cast<int32_t *>(scratch + L.heavy);
+    if (int rc = launch_csr_heavy_list(rowptr, n_vert, heavy, s)) return rc;
+  }
   // transposed, zero-padded weight images of all hidden layers (one launch)
   const bool batched_images = num_layers - 1 <= kMaxImages;
   if (batched_images && num_layers > 1) {
@@ -222,20 +230,20 @@ int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const 
       if (int rc = launch_rowgemm(g, EPI_FWD_HIDDEN, s)) return rc;
     }
     if (cut_len > 0)
-      if (int rc = launch_csr_fwd(scratch + L.za, cpad, biases[i], cut_len, rowptr, col, val, n_vert, batch, y, hidden, mk, mld, 1, s))
+      if (int rc = launch_csr_fwd(scratch + L.za, cpad, biases[i], cut_len, rowptr, col, val, heavy, n_vert, batch, y, hidden, mk, mld, 1, s))
         return rc;
     x = y;
     ldx = hidden;
   }
   const int klast = num_layers == 1 ? in_features : hidden;
-  return launch_thin_fwd(x, ldx, klast, weights[num_layers - 1], biases[num_layers - 1], rowptr, col, val, n_vert,
+  return launch_thin_fwd(x, ldx, klast, weights[num_layers - 1], biases[num_layers - 1], rowptr, col, val, heavy, n_vert,
                          batch, scratch + L.z3, update, s);
 }
 
 int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const float *const *weights,
                        const float *const *biases, int num_layers, int hidden, int cut_len,
                        const int32_t *rowptr, const int32_t *col, const float *val, const int32_t *rowptrT,
-                       const int32_t *colT, const float *valT, int n_vert, int batch, const float *acts,
+                       const int32_t *colT, const float *valT, int max_degreeT, int n_vert, int batch, const float *acts,
                        const uint8_t *masks, const float *grad_update, float *const *grad_weights, float *const *grad_biases,
                        float *grad_feats, float *scratch, void *stream) {
   (void)biases; (void)rowptr; (void)col; (void)val;
@@ -254,13 +262,20 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
   const size_t mpad = (m + 31) / 32 * 32;
   const int last = num_layers - 1;
 
+  // hub rows of A^T (if any): listed once for every aggregation of this call
+  int32_t *heavyT = nullptr;
+  if (max_degreeT <= 0 || max_degreeT > csr_heavy_degree()) {
+    heavyT = reinterpret_cast<int32_t *>(scratch + L.heavy);
+    if (int rc = launch_csr_heavy_list(rowptrT, n_vert, heavyT, s)) return rc;
+  }
+
   // ---- output layer
   {
     const float *x = num_layers == 1 ? feats : acts + (size_t)(last - 1) * m * hidden;
     const int ldx = num_layers == 1 ? ld_feats : hidden;
     const int k = num_layers == 1 ? in_features : hidden;
     float *gprev = num_layers == 1 ? grad_feats : scratch + L.ping[0];
-    if (int rc = launch_thin_bwd(x, ldx, k, weights[last], rowptrT, colT, valT, n_vert, batch, grad_update,
+    if (int rc = launch_thin_bwd(x, ldx, k, weights[last], rowptrT, colT, valT, heavyT, n_vert, batch, grad_update,
                                  scratch + L.z3, num_layers > 1, gprev, ldx, ldx, scratch + L.thin_dw_slab,
                                  scratch + L.thin_db_slab, s))
       return rc;
@@ -301,7 +316,7 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
 
     // bias gradient + A^T gather on the aggregated channels
     if (cut_len > 0) {
-      if (int rc = launch_csr_bwd(g, hidden, cut_len, rowptrT, colT, valT, n_vert, batch, dza, cpad,
+      if (int rc = launch_csr_bwd(g, hidden, cut_len, rowptrT, colT, valT, heavyT, n_vert, batch, dza, cpad,
                                   scratch + L.db_slab, s))
         return rc;
       // channels >= cut_len are dead bias parameters (model.py:358): written as exact zeros by the same launch
@@ -391,7 +406,7 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
 // ---- one layer on its own (GCN_layer.forward for the auto-encoder / DDQN layer loops)
 namespace {
 struct LayerLayout {
-  size_t wt, za, ga, dz, panel, dw_slab, db_slab, total;
+  size_t wt, za, ga, dz, panel, dw_slab, db_slab, heavy, total;
 };
 LayerLayout layer_layout(int batch, int n_vert, int ld_x, int n_out, int cut_len, int need_backward) {
   LayerLayout L{};
@@ -407,6 +422,7 @@ LayerLayout layer_layout(int batch, int n_vert, int ld_x, int n_out, int cut_len
   const size_t wt_bwd = (size_t)rowgemm_bt_rows(ld_x) * pad16(npad);
   L.wt = take(wt_fwd > wt_bwd ? wt_fwd : wt_bwd);
   L.za = take(m * (cpad > 4 ? cpad : 4));  // forward: raw Z of the aggregated channels; backward: 4-float dummy rows
+  L.heavy = take(csr_heavy_scratch_ints(n_vert));
   if (need_backward) {
     L.ga = take(m * (cpad > 4 ? cpad : 4));
     L.dz = take(m * npad);
@@ -441,7 +457,8 @@ size_t a3vt_gcn_layer_scratch_bytes(int batch, int n_vert, int ld_x, int out_fea
 
 int a3vt_gcn_layer_fwd(const float *x, int ld_x, int in_features, const float *weight, const float *bias,
                        int out_features, int cut_len, int relu, const int32_t *rowptr, const int32_t *col,
-                       const float *val, int n_vert, int batch, float *y, int ld_y, float *scratch, void *stream) {
+                       const float *val, int max_degree, int n_vert, int batch, float *y, int ld_y, float *scratch,
+                       void *stream) {
   A3VT_CHECK_ARG(x && weight && bias && rowptr && col && val && y && scratch && n_vert > 0 && batch > 0);
   if (int rc = check_layer_dims(ld_x, in_features, out_features, cut_len)) return rc;
   A3VT_CHECK_ARG(ld_y % 4 == 0 && ld_y >= out_features);
@@ -471,17 +488,23 @@ int a3vt_gcn_layer_fwd(const float *x, int ld_x, int in_features, const float *w
   g.csplit = cut_len;
   g.no_relu = relu ? 0 : 1;
   if (int rc = launch_rowgemm(g, EPI_FWD_HIDDEN, s)) return rc;
-  if (cut_len > 0)
-    if (int rc = launch_csr_fwd(scratch + L.za, g.ldc2, bias, cut_len, rowptr, col, val, n_vert, batch, y, ld_y, nullptr,
-                                0, relu ? 1 : 0, s))
+  if (cut_len > 0) {
+    int32_t *heavy = nullptr;
+    if (max_degree <= 0 || max_degree > csr_heavy_degree()) {
+      heavy = reinterpret_cast<int32_t *>(scratch + L.heavy);
+      if (int rc = launch_csr_heavy_list(rowptr, n_vert, heavy, s)) return rc;
+    }
+    if (int rc = launch_csr_fwd(scratch + L.za, g.ldc2, bias, cut_len, rowptr, col, val, heavy, n_vert, batch, y, ld_y,
+                                nullptr, 0, relu ? 1 : 0, s))
       return rc;
+  }
   return 0;
 }
 
 int a3vt_gcn_layer_bwd(const float *x, int ld_x, int in_features, const float *weight, int out_features, int cut_len,
-                       int relu, const int32_t *rowptrT, const int32_t *colT, const float *valT, int n_vert, int batch,
-                       const float *y, int ld_y, const float *grad_y, int ld_gy, float *grad_weight, float *grad_bias,
-                       float *grad_x, float *scratch, void *stream) {
+                       int relu, const int32_t *rowptrT, const int32_t *colT, const float *valT, int max_degreeT,
+                       int n_vert, int batch, const float *y, int ld_y, const float *grad_y, int ld_gy,
+                       float *grad_weight, float *grad_bias, float *grad_x, float *scratch, void *stream) {
   A3VT_CHECK_ARG(x && weight && rowptrT && colT && valT && grad_y && grad_weight && grad_bias && grad_x && scratch);
   A3VT_CHECK_ARG(n_vert > 0 && batch > 0 && ld_gy >= out_features && (!relu || (y && ld_y >= out_features)));
   if (int rc = check_layer_dims(ld_x, in_features, out_features, cut_len)) return rc;
@@ -499,7 +522,13 @@ int a3vt_gcn_layer_bwd(const float *x, int ld_x, int in_features, const float *w
   if (int rc = launch_fill_zero(grad_bias, out_features, s)) return rc;
   if (cut_len > 0) {
     // dZ[:, :c] = A^T G[:, :c] (columns c..cpad pass through), bias gradient = column sums of G[:, :c]
-    if (int rc = launch_csr_bwd(ga, cpad, cut_len, rowptrT, colT, valT, n_vert, batch, dz, npad, scratch + L.db_slab, s))
+    int32_t *heavyT = nullptr;
+    if (max_degreeT <= 0 || max_degreeT > csr_heavy_degree()) {
+      heavyT = reinterpret_cast<int32_t *>(scratch + L.heavy);
+      if (int rc = launch_csr_heavy_list(rowptrT, n_vert, heavyT, s)) return rc;
+    }
+    if (int rc = launch_csr_bwd(ga, cpad, cut_len, rowptrT, colT, valT, heavyT, n_vert, batch, dz, npad,
+                                scratch + L.db_slab, s))
       return rc;
     if (int rc = launch_slab_reduce(scratch + L.db_slab, csr_bwd_num_slabs(batch, n_vert), cpad, cut_len, grad_bias, s))
       return rc;

@@ -76,6 +76,90 @@ __device__ __forceinline__ f32x4 gather_row(const float *__restrict__ base, long
 }
 
 // ------------------------------------------------------------------------------------------------
+// Hub rows.  The fused vision + touch graphs link every seam vertex to the centre of every touch chart
+// (utility/utils.py:119-128), so a handful of rows have ~1150 neighbours while the rest have 5-25.  One half-wave
+// walking such a row serially takes ~290 us and sets the kernel time (5x the uniform-graph time).  Rows with more than
+// kHeavyDeg neighbours are therefore listed once per call (csr_heavy_list_kernel) and handled by a second launch in
+// which a whole workgroup shares one (mesh, row): its 8 half-waves take an eighth of the edge list each and the
+// partial sums are combined through LDS in a fixed order.
+// ------------------------------------------------------------------------------------------------
+constexpr int kHeavyDeg = 64;
+
+// One workgroup scans all rows (n_vert is a few thousand) and compacts the hub rows through an LDS counter: no
+// memset, no global atomics, nothing a HIP-graph capture could object to.  heavy[0] = count, heavy[64..] = rows.
+__global__ __launch_bounds__(1024) void csr_heavy_list_kernel(const int32_t *__restrict__ rowptr, int n_vert,
+                                                              int32_t *__restrict__ heavy) {
+  __shared__ int cnt;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  for (int v = threadIdx.x; v < n_vert; v += 1024)
+    if (rowptr[v + 1] - rowptr[v] > kHeavyDeg) heavy[64 + atomicAdd(&cnt, 1)] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) heavy[0] = cnt;
+}
+
+size_t csr_heavy_scratch_ints(int n_vert) { return (size_t)n_vert + 64; }
+int csr_heavy_degree() { return kHeavyDeg; }
+
+int launch_csr_heavy_list(const int32_t *rowptr, int n_vert, int32_t *heavy, hipStream_t s) {
+  A3VT_LAUNCH(csr_heavy_list_kernel, dim3(1), dim3(1024), 0, s, rowptr, n_vert, heavy);
+  A3VT_CHECK_LAUNCH();
+  return 0;
+}
+
+// mode 0: forward epilogue (bias, optional ReLU, sign bytes).  mode 1: backward (A^T gather; channels [c, cpad) pass
+// the row's own gradient through).
+template <int MODE>
+__global__ __launch_bounds__(256) void csr_heavy_kernel(const float *__restrict__ src, int ld_src,
+                                                        const float *__restrict__ bias, int c, int cpad,
+                                                        const int32_t *__restrict__ rowptr,
+                                                        const int32_t *__restrict__ colidx,
+                                                        const float *__restrict__ val, int n_vert, int batch,
+                                                        const int32_t *__restrict__ heavy, float *__restrict__ dst,
+                                                        int ld_dst, uint8_t *__restrict__ maskb, int mld, int relu) {
+  __shared__ f32x4 red[8][32];
+  const int hl = threadIdx.x & 31, sub = threadIdx.x >> 5;
+  const int count = heavy[0];
+  const int width = MODE == 0 ? c : cpad;
+  for (long long item = blockIdx.x; item < (long long)count * batch; item += gridDim.x) {
+    const int v = heavy[64 + (int)(item % count)];
+    const long long b = item / count, row = b * n_vert + v;
+    const float *sb = src + b * n_vert * (long long)ld_src;
+    const int e0 = rowptr[v], e1 = rowptr[v + 1];
+    const int per = ((e1 - e0 + 7) / 8 + 3) & ~3;  // edges per half-wave, a multiple of the gather's unroll
+    const int s0 = min(e1, e0 + sub * per), s1 = min(e1, s0 + per);
+    for (int ch0 = 0; ch0 < width; ch0 += 128) {
+      const int ch = ch0 + hl * 4;
+      const bool on = ch < width;
+      red[sub][hl] = gather_row(sb, ld_src, ch, on, s0, s1, hl, colidx, val);
+      __syncthreads();
+      if (sub == 0 && on) {
+        f32x4 acc = red[0][hl];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) acc += red[r][hl];
+        float *o = dst + row * ld_dst + ch;
+        if (MODE == 0) {
+          unsigned bits = 0;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float pre = ch + t < c ? acc[t] + bias[ch + t] : 0.f;
+            const float out = (pre > 0.f || !relu) ? pre : 0.f;
+            bits |= (pre > 0.f ? 1u : 0u) << t;
+            if (ch + t < c) o[t] = out;
+          }
+          if (maskb) maskb[row * mld + (ch >> 2)] = (uint8_t)bits;
+        } else {
+          const f32x4 own = *reinterpret_cast<const f32x4 *>(sb + (long long)v * ld_src + ch);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) o[t] = ch + t < c ? acc[t] : own[t];
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Forward: Y[m][ch] = relu( sum_e val[e] * Za[b][col[e]][ch] + bias[ch] ), ch < c.
 // A half-wave (32 lanes) owns one vertex; lane l handles channels 4l..4l+3 (16-byte loads of the
 // neighbour row), so up to 128 aggregated channels are covered per pass.
@@ -86,7 +170,8 @@ __global__ __launch_bounds__(256) void csr_fwd_kernel(const float *__restrict__ 
                                                       const int32_t *__restrict__ colidx,
                                                       const float *__restrict__ val, int n_vert, long long m,
                                                       float *__restrict__ y, int ldy,
-                                                      uint8_t *__restrict__ maskb, int mld, int relu) {
+                                                      uint8_t *__restrict__ maskb, int mld, int relu,
+                                                      int heavy_thresh) {
   const int hl = threadIdx.x & 31;
   const XcdWalk w((int)(m / n_vert), n_vert);
   float bsv[4] = {0.f, 0.f, 0.f, 0.f};  // bias of this lane's 4 channels (c <= 128: one pass)
@@ -102,6 +187,7 @@ __global__ __launch_bounds__(256) void csr_fwd_kernel(const float *__restrict__ 
     const long long row = b * n_vert + v;
     const float *zb = za + b * n_vert * (long long)ldza;
     const int e0 = rowptr[v], e1 = rowptr[v + 1];
+    if (e1 - e0 > heavy_thresh) continue;  // hub row: csr_heavy_kernel spreads it over a whole workgroup
     for (int ch0 = 0; ch0 < c; ch0 += 128) {
       const int ch = ch0 + hl * 4;
       const bool on = ch < c;
@@ -129,8 +215,8 @@ __global__ __launch_bounds__(256) void csr_fwd_kernel(const float *__restrict__ 
 }
 
 int launch_csr_fwd(const float *za, int ldza, const float *bias, int c, const int32_t *rowptr, const int32_t *col,
-                   const float *val, int n_vert, int batch, float *y, int ldy, uint8_t *maskb, int mld, int relu,
-                   hipStream_t s) {
+                   const float *val, const int32_t *heavy, int n_vert, int batch, float *y, int ldy, uint8_t *maskb,
+                   int mld, int relu, hipStream_t s) {
   if (ldza % 4 != 0 || ldza < pad4(c)) {
     set_error("csr_fwd: ldza=%d must be a multiple of 4 and >= pad4(c=%d)", ldza, c);
     return -1;
@@ -138,8 +224,13 @@ int launch_csr_fwd(const float *za, int ldza, const float *bias, int c, const in
   const long long m = (long long)batch * n_vert;
   const int grid = (int)(cdiv(m, 8) < 4096 ? (cdiv(m, 8) + 7) / 8 * 8 : 4096);  // multiple of 8: whole XCD groups
   A3VT_LAUNCH(csr_fwd_kernel, dim3(grid), dim3(256), 0, s, za, ldza, bias, c, rowptr, col, val, n_vert, m, y, ldy,
-              maskb, mld, relu);
+              maskb, mld, relu, heavy ? kHeavyDeg : 0x7fffffff);
   A3VT_CHECK_LAUNCH();
+  if (heavy) {
+    A3VT_LAUNCH(csr_heavy_kernel<0>, dim3(512), dim3(256), 0, s, za, ldza, bias, c, pad4(c), rowptr, col, val, n_vert,
+                batch, heavy, y, ldy, maskb, mld, relu);
+    A3VT_CHECK_LAUNCH();
+  }
   return 0;
 }
 
@@ -156,7 +247,7 @@ __global__ __launch_bounds__(256) void csr_bwd_kernel(const float *__restrict__ 
                                                       const int32_t *__restrict__ colidx,
                                                       const float *__restrict__ val, int n_vert, long long m,
                                                       float *__restrict__ dza, int lddza,
-                                                      float *__restrict__ db_slab) {
+                                                      float *__restrict__ db_slab, int heavy_thresh) {
   __shared__ float red[8][128];
   const int hl = threadIdx.x & 31, grp = threadIdx.x >> 5;
   for (int ch0 = 0; ch0 < cpad; ch0 += 128) {
@@ -174,6 +265,7 @@ __global__ __launch_bounds__(256) void csr_bwd_kernel(const float *__restrict__ 
       if (on) own = *reinterpret_cast<const f32x4 *>(gb + (long long)v * ldg + ch);
       bsum += own;
       const int e0 = rowptr[v], e1 = rowptr[v + 1];
+      if (e1 - e0 > heavy_thresh) continue;  // hub row: gathered and stored by csr_heavy_kernel (its bias share is counted above)
       const f32x4 acc = gather_row(gb, ldg, ch, on, e0, e1, hl, colidx, val);
       if (on) {
         f32x4 out;
@@ -202,7 +294,7 @@ int csr_bwd_num_slabs(int batch, int n_vert) {
 }
 
 int launch_csr_bwd(const float *g, int ldg, int c, const int32_t *rowptrT, const int32_t *colT, const float *valT,
-                   int n_vert, int batch, float *dza, int lddza, float *db_slab, hipStream_t s) {
+                   const int32_t *heavyT, int n_vert, int batch, float *dza, int lddza, float *db_slab, hipStream_t s) {
   const int cpad = pad4(c);
   if (ldg % 4 != 0 || lddza % 4 != 0 || lddza < cpad || ldg < cpad) {
     set_error("csr_bwd: ldg=%d lddza=%d c=%d violate alignment rules", ldg, lddza, c);
@@ -210,8 +302,13 @@ int launch_csr_bwd(const float *g, int ldg, int c, const int32_t *rowptrT, const
   }
   const long long m = (long long)batch * n_vert;
   A3VT_LAUNCH(csr_bwd_kernel, dim3(csr_bwd_num_slabs(batch, n_vert)), dim3(256), 0, s, g, ldg, c, cpad, rowptrT,
-                     colT, valT, n_vert, m, dza, lddza, db_slab);
+                     colT, valT, n_vert, m, dza, lddza, db_slab, heavyT ? kHeavyDeg : 0x7fffffff);
   A3VT_CHECK_LAUNCH();
+  if (heavyT) {
+    A3VT_LAUNCH(csr_heavy_kernel<1>, dim3(512), dim3(256), 0, s, g, ldg, nullptr, c, cpad, rowptrT, colT, valT, n_vert,
+                batch, heavyT, dza, lddza, nullptr, 0, 0);
+    A3VT_CHECK_LAUNCH();
+  }
   return 0;
 }
 
@@ -268,13 +365,14 @@ __global__ __launch_bounds__(256) void csr3_kernel(const float *__restrict__ z, 
                                                    const int32_t *__restrict__ rowptr,
                                                    const int32_t *__restrict__ colidx,
                                                    const float *__restrict__ val, int n_vert, long long m,
-                                                   float *__restrict__ out, int ldo) {
+                                                   float *__restrict__ out, int ldo, int heavy_thresh) {
   const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= m) return;
   const long long b = row / n_vert;
   const int v = (int)(row - b * n_vert);
   const float *zb = z + b * n_vert * 4;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (rowptr[v + 1] - rowptr[v] > heavy_thresh) return;  // hub row: csr3_heavy_kernel
   for (int e = rowptr[v]; e < rowptr[v + 1]; ++e)
     acc += val[e] * *reinterpret_cast<const f32x4 *>(zb + (long long)colidx[e] * 4);
   if (bias) {
@@ -292,9 +390,56 @@ __global__ __launch_bounds__(256) void csr3_kernel(const float *__restrict__ z, 
   }
 }
 
+// Hub rows of the 3-channel aggregation: one wave per (mesh, row), lanes stride over the edge list.
+__global__ __launch_bounds__(256) void csr3_heavy_kernel(const float *__restrict__ z, const float *__restrict__ bias,
+                                                         const int32_t *__restrict__ rowptr,
+                                                         const int32_t *__restrict__ colidx,
+                                                         const float *__restrict__ val, int n_vert, int batch,
+                                                         const int32_t *__restrict__ heavy, float *__restrict__ out,
+                                                         int ldo) {
+  const int lane = threadIdx.x & 63;
+  const int count = heavy[0];
+  for (long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); item < (long long)count * batch;
+       item += (long long)gridDim.x * 4) {
+    const int v = heavy[64 + (int)(item % count)];
+    const long long b = item / count, row = b * n_vert + v;
+    const float *zb = z + b * n_vert * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int e = rowptr[v] + lane; e < rowptr[v + 1]; e += 64)
+      acc += val[e] * *reinterpret_cast<const f32x4 *>(zb + (long long)colidx[e] * 4);
+    acc[0] = wave_sum(acc[0]);
+    acc[1] = wave_sum(acc[1]);
+    acc[2] = wave_sum(acc[2]);
+    if (lane == 0) {
+      if (bias) {
+        acc[0] += bias[0];
+        acc[1] += bias[1];
+        acc[2] += bias[2];
+      }
+      out[row * ldo + 0] = acc[0];
+      out[row * ldo + 1] = acc[1];
+      out[row * ldo + 2] = acc[2];
+      if (ldo == 4) out[row * 4 + 3] = 0.f;
+    }
+  }
+}
+
+static int launch_csr3(const float *z, const float *bias, const int32_t *rowptr, const int32_t *col, const float *val,
+                       const int32_t *heavy, int n_vert, int batch, float *out, int ldo, hipStream_t s) {
+  const long long m = (long long)batch * n_vert;
+  A3VT_LAUNCH(csr3_kernel, dim3(cdiv(m, 256)), dim3(256), 0, s, z, bias, rowptr, col, val, n_vert, m, out, ldo,
+              heavy ? kHeavyDeg : 0x7fffffff);
+  A3VT_CHECK_LAUNCH();
+  if (heavy) {
+    A3VT_LAUNCH(csr3_heavy_kernel, dim3(64), dim3(256), 0, s, z, bias, rowptr, col, val, n_vert, batch, heavy, out, ldo);
+    A3VT_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
 int launch_thin_fwd(const float *x, int ldx, int k, const float *w, const float *bias, const int32_t *rowptr,
-                    const int32_t *col, const float *val, int n_vert, int batch, float *z3, float *update,
-                    hipStream_t s) {
+                    const int32_t *col, const float *val, const int32_t *heavy, int n_vert, int batch, float *z3,
+                    float *update, hipStream_t s) {
   if (k > kThinPieces * 64 || ldx % 4 != 0) {
     set_error("thin_fwd: k=%d (max %d) ldx=%d unsupported", k, kThinPieces * 64, ldx);
     return -1;
@@ -303,9 +448,7 @@ int launch_thin_fwd(const float *x, int ldx, int k, const float *w, const float 
   const int grid = (int)(cdiv(m, 16) < 4096 ? cdiv(m, 16) : 4096);
   A3VT_LAUNCH(thin_fwd_kernel, dim3(grid), dim3(256), 0, s, x, ldx, k, w, m, z3);
   A3VT_CHECK_LAUNCH();
-  A3VT_LAUNCH(csr3_kernel, dim3(cdiv(m, 256)), dim3(256), 0, s, z3, bias, rowptr, col, val, n_vert, m, update, 3);
-  A3VT_CHECK_LAUNCH();
-  return 0;
+  return launch_csr3(z3, bias, rowptr, col, val, heavy, n_vert, batch, update, 3, s);
 }
 
 // Backward of the output layer.  dz3 = A^T dU (csr3 with the transposed CSR, no bias), then one pass over X:
@@ -416,8 +559,9 @@ static int launch_pad3to4(const float *in, long long m, float *out, hipStream_t 
 }
 
 int launch_thin_bwd(const float *x, int ldx, int k, const float *w, const int32_t *rowptrT, const int32_t *colT,
-                    const float *valT, int n_vert, int batch, const float *grad_update, float *dz3, int apply_mask,
-                    float *g_prev, int ldg, int n_store, float *dw_slab, float *db_slab, hipStream_t s) {
+                    const float *valT, const int32_t *heavyT, int n_vert, int batch, const float *grad_update,
+                    float *dz3, int apply_mask, float *g_prev, int ldg, int n_store, float *dw_slab, float *db_slab,
+                    hipStream_t s) {
   if (k > kThinPieces * 64 || ldx % 4 != 0 || ldg % 4 != 0) {
     set_error("thin_bwd: k=%d ldx=%d ldg=%d unsupported", k, ldx, ldg);
     return -1;
@@ -428,9 +572,7 @@ int launch_thin_bwd(const float *x, int ldx, int k, const float *w, const int32_
   float *du4 = dz3;
   float *res = dz3 + m * 4;
   if (int rc = launch_pad3to4(grad_update, m, du4, s)) return rc;
-  A3VT_LAUNCH(csr3_kernel, dim3(cdiv(m, 256)), dim3(256), 0, s, du4, (const float *)nullptr, rowptrT, colT, valT,
-                     n_vert, m, res, 4);
-  A3VT_CHECK_LAUNCH();
+  if (int rc = launch_csr3(du4, nullptr, rowptrT, colT, valT, heavyT, n_vert, batch, res, 4, s)) return rc;
   A3VT_LAUNCH(thin_bwd_kernel, dim3(kThinBlocks), dim3(256), 0, s, x, ldx, k, w, res, grad_update, m, apply_mask,
                      g_prev, ldg, n_store, dw_slab, db_slab);
   A3VT_CHECK_LAUNCH();

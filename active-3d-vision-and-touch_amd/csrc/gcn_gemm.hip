@@ -333,7 +333,8 @@ static int launch_rowgemm_nt(const RowGemmArgs &a, int grid_y, hipStream_t s) {
   }
   const int tiles = cdiv(a.m, 16);
   const int max_wg = 256 * C::WG_PER_CU;
-  const int grid = tiles < 2 * C::WAVES * max_wg ? cdiv(tiles, 2 * C::WAVES) : max_wg;
+  // one tile per wave until every CU has a workgroup; beyond that the kernel deals tiles evenly (two per wave per round)
+  const int grid = cdiv(tiles, C::WAVES) < max_wg ? cdiv(tiles, C::WAVES) : max_wg;
   A3VT_LAUNCH((rowgemm_kernel<NT, EPI, C::NSTAGE, C::WAVES>), dim3(grid, grid_y), dim3(64 * C::WAVES), shmem, s, a);
   A3VT_CHECK_LAUNCH();
   return 0;
@@ -342,6 +343,13 @@ static int launch_rowgemm_nt(const RowGemmArgs &a, int grid_y, hipStream_t s) {
 template <int EPI>
 static int launch_rowgemm_cols(const RowGemmArgs &a, hipStream_t s) {
   const int nt = cdiv(a.n_store, 16);
+  // Few rows (forward-only scoring of a handful of meshes: M = 2-7 k): the row tiles alone occupy a fraction of the
+  // CUs, so the output columns are cut into blocks (blockIdx.y) until ~all CUs have a workgroup.
+  const int row_wgs = cdiv(cdiv(a.m, 16), 8);
+  if (row_wgs < 96 && nt > 4) {
+    if (row_wgs * cdiv(nt, 4) >= 96) return launch_rowgemm_nt<4, EPI>(a, cdiv(nt, 4), s);
+    return launch_rowgemm_nt<1, EPI>(a, nt, s);
+  }
   if (nt <= 1) return launch_rowgemm_nt<1, EPI>(a, 1, s);
   if (nt <= 4) return launch_rowgemm_nt<4, EPI>(a, 1, s);
   if (nt <= 8) return launch_rowgemm_nt<8, EPI>(a, 1, s);

@@ -62,8 +62,13 @@ int launch_slab_reduce_z(const float *slab, int nslab, size_t stride, size_t n, 
 
 // CSR neighbour aggregation on the first c channels (+ bias + ReLU), model.py:356-358,363.
 int launch_csr_fwd(const float *za, int ldza, const float *bias, int c, const int32_t *rowptr, const int32_t *col,
-                   const float *val, int n_vert, int batch, float *y, int ldy, uint8_t *maskb, int mld, int relu,
-                   hipStream_t s);
+                   const float *val, const int32_t *heavy, int n_vert, int batch, float *y, int ldy, uint8_t *maskb,
+                   int mld, int relu, hipStream_t s);
+// Rows with many neighbours (hub rows of the fused touch graph) are listed once per call into `heavy`
+// (csr_heavy_scratch_ints(n_vert) ints of scratch) and handled by a workgroup each; launch_csr_fwd/bwd take the list.
+size_t csr_heavy_scratch_ints(int n_vert);
+int csr_heavy_degree();   // rows with more neighbours than this go to the heavy pass; heavy == nullptr disables it
+int launch_csr_heavy_list(const int32_t *rowptr, int n_vert, int32_t *heavy, hipStream_t s);
 // Stand-alone layer backward entry: G = grad_y (* (y > 0) when relu); columns [0, cpad) -> ga [M][cpad] (input of the
 // A^T gather), columns [cpad, npad) -> dz [M][npad] (pad columns zero).
 int launch_relu_split(const float *gy, int ldgy, const float *y, int ldy, int relu, int n_out, int cpad, int npad,
@@ -71,18 +76,18 @@ int launch_relu_split(const float *gy, int ldgy, const float *y, int ldy, int re
 // dZa[:, :c] = A^T G[:, :c];  dZa[:, c:cpad] = G[:, c:cpad];  db partial sums of G[:, :c] -> slab [nslab][cpad].
 int csr_bwd_num_slabs(int batch, int n_vert);
 int launch_csr_bwd(const float *g, int ldg, int c, const int32_t *rowptrT, const int32_t *colT, const float *valT,
-                   int n_vert, int batch, float *dza, int lddza, float *db_slab, hipStream_t s);
+                   const int32_t *heavyT, int n_vert, int batch, float *dza, int lddza, float *db_slab, hipStream_t s);
 
 // Last layer (out = 3 channels, all aggregated, no activation), model.py:359-361.
 int thin_num_slabs();
 int launch_thin_fwd(const float *x, int ldx, int k, const float *w /*[k][3]*/, const float *bias /*[3]*/,
-                    const int32_t *rowptr, const int32_t *col, const float *val, int n_vert, int batch,
-                    float *z3 /*[M][4] scratch*/, float *update /*[M][3]*/, hipStream_t s);
+                    const int32_t *rowptr, const int32_t *col, const float *val, const int32_t *heavy, int n_vert,
+                    int batch, float *z3 /*[M][4] scratch*/, float *update /*[M][3]*/, hipStream_t s);
 int launch_thin_bwd(const float *x, int ldx, int k, const float *w, const int32_t *rowptrT, const int32_t *colT,
-                    const float *valT, int n_vert, int batch, const float *grad_update /*[M][3]*/,
-                    float *dz3 /*[M][4] scratch*/, int apply_mask, float *g_prev /*[M][ldg]*/, int ldg, int n_store,
-                    float *dw_slab /*[thin_num_slabs()][k*3]*/, float *db_slab /*[thin_num_slabs()][3]*/,
-                    hipStream_t s);
+                    const float *valT, const int32_t *heavyT, int n_vert, int batch,
+                    const float *grad_update /*[M][3]*/, float *dz3 /*[2][M][4] scratch*/, int apply_mask,
+                    float *g_prev /*[M][ldg]*/, int ldg, int n_store, float *dw_slab /*[thin_num_slabs()][k*3]*/,
+                    float *db_slab /*[thin_num_slabs()][3]*/, hipStream_t s);
 
 int launch_vertex_update(const float *vin, const float *upd, int batch, int n_vert, int n_vision, float *vout,
                          hipStream_t s);

@@ -48,6 +48,8 @@ class DeviceCSR:
         self.rowptr, self.col, self.val = to(host.rowptr), to(host.col), to(host.val)
         self.t_rowptr, self.t_col, self.t_val = to(host.t_rowptr), to(host.t_col), to(host.t_val)
         self.host = host
+        self.max_degree = int(np.diff(host.rowptr).max()) if host.n else 0        # hub rows get their own launch
+        self.t_max_degree = int(np.diff(host.t_rowptr).max()) if host.n else 0
 
     @property
     def device(self):
@@ -83,7 +85,7 @@ class GCNStackFn(torch.autograd.Function):
         update = torch.empty((B, N, 3), dtype=torch.float32, device=feats.device)
         wp, bp = _ptr_array(weights), _ptr_array(biases)
         _lib.check(L.a3vt_gcn_stack_fwd(_lib.ptr(feats), ld, in_features, wp, bp, nl, hidden, cut_len,
-                                        _lib.ptr(adj.rowptr), _lib.ptr(adj.col), _lib.ptr(adj.val), N, B,
+                                        _lib.ptr(adj.rowptr), _lib.ptr(adj.col), _lib.ptr(adj.val), adj.max_degree, N, B,
                                         _lib.ptr(acts), _lib.ptr(masks), _lib.ptr(scratch), _lib.ptr(update), _stream()),
                    "gcn_stack_fwd")
         ctx.adj, ctx.dims = adj, (in_features, hidden, cut_len, nl)
@@ -108,7 +110,8 @@ class GCNStackFn(torch.autograd.Function):
         scratch = workspace("gcn", nbytes, feats.device)
         _lib.check(L.a3vt_gcn_stack_bwd(_lib.ptr(feats), ld, in_features, _ptr_array(weights), _ptr_array(biases), nl,
                                         hidden, cut_len, _lib.ptr(adj.rowptr), _lib.ptr(adj.col), _lib.ptr(adj.val),
-                                        _lib.ptr(adj.t_rowptr), _lib.ptr(adj.t_col), _lib.ptr(adj.t_val), N, B,
+                                        _lib.ptr(adj.t_rowptr), _lib.ptr(adj.t_col), _lib.ptr(adj.t_val),
+                                        adj.t_max_degree, N, B,
                                         _lib.ptr(ctx.acts), _lib.ptr(ctx.masks), _lib.ptr(grad_update), _ptr_array(gw),
                                         _ptr_array(gb),
                                         _lib.ptr(gfeats), _lib.ptr(scratch), _stream()), "gcn_stack_bwd")
@@ -148,7 +151,8 @@ class GCNLayerFn(torch.autograd.Function):
                             x.device)
         _lib.check(L.a3vt_gcn_layer_fwd(_lib.ptr(x), ld, kin, _lib.ptr(weight), _lib.ptr(bias), nout, cut_len,
                                         1 if relu else 0, _lib.ptr(adj.rowptr), _lib.ptr(adj.col), _lib.ptr(adj.val),
-                                        N, B, _lib.ptr(y), ldy, _lib.ptr(scratch), _stream()), "gcn_layer_fwd")
+                                        adj.max_degree, N, B, _lib.ptr(y), ldy, _lib.ptr(scratch), _stream()),
+                   "gcn_layer_fwd")
         ctx.adj, ctx.dims = adj, (kin, nout, cut_len, bool(relu), ldy)
         ctx.save_for_backward(x, weight, y)
         return y[..., :nout] if ldy != nout else y
@@ -164,7 +168,8 @@ class GCNLayerFn(torch.autograd.Function):
         gw, gb, gx = torch.empty_like(weight), torch.empty(nout, dtype=torch.float32, device=x.device), torch.empty_like(x)
         scratch = workspace("gcn", L.a3vt_gcn_layer_scratch_bytes(B, N, ld, nout, cut_len, 1), x.device)
         _lib.check(L.a3vt_gcn_layer_bwd(_lib.ptr(x), ld, kin, _lib.ptr(weight), nout, cut_len, 1 if relu else 0,
-                                        _lib.ptr(adj.t_rowptr), _lib.ptr(adj.t_col), _lib.ptr(adj.t_val), N, B,
+                                        _lib.ptr(adj.t_rowptr), _lib.ptr(adj.t_col), _lib.ptr(adj.t_val),
+                                        adj.t_max_degree, N, B,
                                         _lib.ptr(y), ldy, _lib.ptr(gy), gy.shape[-1], _lib.ptr(gw), _lib.ptr(gb),
                                         _lib.ptr(gx), _lib.ptr(scratch), _stream()), "gcn_layer_bwd")
         return gx, None, gw, gb, None, None

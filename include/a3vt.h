@@ -47,6 +47,10 @@ int a3vt_csr_validate(const int32_t *rowptr_host, const int32_t *col_host, int n
  * `weights`, `biases`, `grad_weights`, `grad_biases` are HOST arrays of L DEVICE pointers.
  * `cut_len` = round(hidden * cut) (model.py:355; 99 for 300 * 0.33).
  * csr_* is A (row-normalised), csrT_* is its transpose (A is not symmetric after normalisation).
+ * csr_max_degree / csrT_max_degree: the largest number of entries in a row of that matrix, or 0 if unknown.  The
+ * fused vision + touch graphs have hub rows (chart centres linked to every seam vertex, ~1150 entries,
+ * utility/utils.py:119-128); rows above 64 entries are aggregated by a whole workgroup in a second launch, which a
+ * known small maximum lets the library skip.  Results do not depend on the value.
  *
  * feats  : [M][ld_feats] with ld_feats >= in_features, ld_feats % 4 == 0; pad columns must be zero.
  * acts   : saved inputs of layers 1..L-1, [L-1][M][hidden]   (needed by the backward pass)
@@ -62,7 +66,7 @@ size_t a3vt_gcn_stack_mask_bytes(int batch, int n_vert, int hidden, int num_laye
 int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features,
                        const float *const *weights, const float *const *biases,
                        int num_layers, int hidden, int cut_len,
-                       const int32_t *csr_rowptr, const int32_t *csr_col, const float *csr_val,
+                       const int32_t *csr_rowptr, const int32_t *csr_col, const float *csr_val, int csr_max_degree,
                        int n_vert, int batch,
                        float *acts, uint8_t *masks, float *scratch, float *update, void *stream);
 
@@ -73,7 +77,7 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features,
                        const float *const *weights, const float *const *biases,
                        int num_layers, int hidden, int cut_len,
                        const int32_t *csr_rowptr, const int32_t *csr_col, const float *csr_val,
-                       const int32_t *csrT_rowptr, const int32_t *csrT_col, const float *csrT_val,
+                       const int32_t *csrT_rowptr, const int32_t *csrT_col, const float *csrT_val, int csrT_max_degree,
                        int n_vert, int batch,
                        const float *acts, const uint8_t *masks, const float *grad_update,
                        float *const *grad_weights, float *const *grad_biases, float *grad_feats,
@@ -94,11 +98,11 @@ size_t a3vt_gcn_layer_scratch_bytes(int batch, int n_vert, int ld_x, int out_fea
                                     int need_backward);
 int a3vt_gcn_layer_fwd(const float *x, int ld_x, int in_features, const float *weight, const float *bias,
                        int out_features, int cut_len, int relu,
-                       const int32_t *csr_rowptr, const int32_t *csr_col, const float *csr_val,
+                       const int32_t *csr_rowptr, const int32_t *csr_col, const float *csr_val, int csr_max_degree,
                        int n_vert, int batch, float *y, int ld_y, float *scratch, void *stream);
 int a3vt_gcn_layer_bwd(const float *x, int ld_x, int in_features, const float *weight,
                        int out_features, int cut_len, int relu,
-                       const int32_t *csrT_rowptr, const int32_t *csrT_col, const float *csrT_val,
+                       const int32_t *csrT_rowptr, const int32_t *csrT_col, const float *csrT_val, int csrT_max_degree,
                        int n_vert, int batch, const float *y, int ld_y, const float *grad_y, int ld_gy,
                        float *grad_weight, float *grad_bias, float *grad_x, float *scratch, void *stream);
 
