@@ -227,7 +227,7 @@ int launch_csr_fwd(const float *za, int ldza, const float *bias, int c, const in
               maskb, mld, relu, heavy ? kHeavyDeg : 0x7fffffff);
   A3VT_CHECK_LAUNCH();
   if (heavy) {
-    A3VT_LAUNCH(csr_heavy_kernel<0>, dim3(512), dim3(256), 0, s, za, ldza, bias, c, pad4(c), rowptr, col, val, n_vert,
+    A3VT_LAUNCH(csr_heavy_kernel<0>, dim3(2048), dim3(256), 0, s, za, ldza, bias, c, pad4(c), rowptr, col, val, n_vert,
                 batch, heavy, y, ldy, maskb, mld, relu);
     A3VT_CHECK_LAUNCH();
   }
@@ -305,7 +305,7 @@ int launch_csr_bwd(const float *g, int ldg, int c, const int32_t *rowptrT, const
                      colT, valT, n_vert, m, dza, lddza, db_slab, heavyT ? kHeavyDeg : 0x7fffffff);
   A3VT_CHECK_LAUNCH();
   if (heavyT) {
-    A3VT_LAUNCH(csr_heavy_kernel<1>, dim3(512), dim3(256), 0, s, g, ldg, nullptr, c, cpad, rowptrT, colT, valT, n_vert,
+    A3VT_LAUNCH(csr_heavy_kernel<1>, dim3(2048), dim3(256), 0, s, g, ldg, nullptr, c, cpad, rowptrT, colT, valT, n_vert,
                 batch, heavyT, dza, lddza, nullptr, 0, 0);
     A3VT_CHECK_LAUNCH();
   }
