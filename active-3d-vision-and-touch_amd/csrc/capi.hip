@@ -159,7 +159,8 @@ size_t a3vt_gcn_stack_scratch_bytes(int batch, int n_vert, int in_features, int 
 int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const float *const *weights,
                        const float *const *biases, int num_layers, int hidden, int cut_len,
                        const int32_t *rowptr, const int32_t *col, const float *val, int max_degree, int n_vert,
-                       int batch, float *acts, uint8_t *masks, float *scratch, float *update, void *stream) {
+                       int batch, int gemm_bf16, float *acts, uint8_t *masks, float *scratch, float *update,
+                       void *stream) {
   A3VT_CHECK_ARG(feats && weights && biases && rowptr && col && val && scratch && update);
   A3VT_CHECK_ARG((acts == nullptr) == (masks == nullptr) || num_layers < 2);
   A3VT_CHECK_ARG(n_vert > 0 && batch > 0);
@@ -225,6 +226,7 @@ int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const 
     g.maskb = mk;
     g.mld = mld;
     g.moff = cpad / 4;
+    g.bf16 = gemm_bf16 ? 1 : 0;
     {
       ProfScope ps(PROF_GEMM_FWD, s);
       if (int rc = launch_rowgemm(g, EPI_FWD_HIDDEN, s)) return rc;
@@ -243,7 +245,8 @@ int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const 
 int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const float *const *weights,
                        const float *const *biases, int num_layers, int hidden, int cut_len,
                        const int32_t *rowptr, const int32_t *col, const float *val, const int32_t *rowptrT,
-                       const int32_t *colT, const float *valT, int max_degreeT, int n_vert, int batch, const float *acts,
+                       const int32_t *colT, const float *valT, int max_degreeT, int n_vert, int batch, int gemm_bf16,
+                       const float *acts,
                        const uint8_t *masks, const float *grad_update, float *const *grad_weights, float *const *grad_biases,
                        float *grad_feats, float *scratch, void *stream) {
   (void)biases; (void)rowptr; (void)col; (void)val;
@@ -355,6 +358,7 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
       d.m = (int)m;
       d.k_in = w;
       d.n_out = hidden;
+      d.bf16 = gemm_bf16 ? 1 : 0;
       {
         ProfScope ps(PROF_DW, s);
         if (int rc = launch_dw(d, s)) return rc;
@@ -381,6 +385,7 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
     r.m = (int)m;
     r.k = hidden;
     r.n_store = n_store;
+    r.bf16 = gemm_bf16 ? 1 : 0;
     if (i == 0) {
       r.c = grad_feats;
       r.ldc = ld_feats;
@@ -457,8 +462,8 @@ size_t a3vt_gcn_layer_scratch_bytes(int batch, int n_vert, int ld_x, int out_fea
 
 int a3vt_gcn_layer_fwd(const float *x, int ld_x, int in_features, const float *weight, const float *bias,
                        int out_features, int cut_len, int relu, const int32_t *rowptr, const int32_t *col,
-                       const float *val, int max_degree, int n_vert, int batch, float *y, int ld_y, float *scratch,
-                       void *stream) {
+                       const float *val, int max_degree, int n_vert, int batch, int gemm_bf16, float *y, int ld_y,
+                       float *scratch, void *stream) {
   A3VT_CHECK_ARG(x && weight && bias && rowptr && col && val && y && scratch && n_vert > 0 && batch > 0);
   if (int rc = check_layer_dims(ld_x, in_features, out_features, cut_len)) return rc;
   A3VT_CHECK_ARG(ld_y % 4 == 0 && ld_y >= out_features);
@@ -487,6 +492,7 @@ int a3vt_gcn_layer_fwd(const float *x, int ld_x, int in_features, const float *w
   g.ldc2 = cpad > 4 ? cpad : 4;
   g.csplit = cut_len;
   g.no_relu = relu ? 0 : 1;
+  g.bf16 = gemm_bf16 ? 1 : 0;
   if (int rc = launch_rowgemm(g, EPI_FWD_HIDDEN, s)) return rc;
   if (cut_len > 0) {
     int32_t *heavy = nullptr;
@@ -503,7 +509,7 @@ int a3vt_gcn_layer_fwd(const float *x, int ld_x, int in_features, const float *w
 
 int a3vt_gcn_layer_bwd(const float *x, int ld_x, int in_features, const float *weight, int out_features, int cut_len,
                        int relu, const int32_t *rowptrT, const int32_t *colT, const float *valT, int max_degreeT,
-                       int n_vert, int batch, const float *y, int ld_y, const float *grad_y, int ld_gy,
+                       int n_vert, int batch, int gemm_bf16, const float *y, int ld_y, const float *grad_y, int ld_gy,
                        float *grad_weight, float *grad_bias, float *grad_x, float *scratch, void *stream) {
   A3VT_CHECK_ARG(x && weight && rowptrT && colT && valT && grad_y && grad_weight && grad_bias && grad_x && scratch);
   A3VT_CHECK_ARG(n_vert > 0 && batch > 0 && ld_gy >= out_features && (!relu || (y && ld_y >= out_features)));
@@ -557,6 +563,7 @@ int a3vt_gcn_layer_bwd(const float *x, int ld_x, int in_features, const float *w
     d.m = (int)m;
     d.k_in = w;
     d.n_out = out_features;
+    d.bf16 = gemm_bf16 ? 1 : 0;
     if (int rc = launch_dw(d, s)) return rc;
     if (int rc = launch_slab_reduce(scratch + L.dw_slab, dw_num_slabs(out_features), (size_t)w * out_features,
                                     (size_t)w * out_features, grad_weight + (size_t)c0 * out_features, s))
@@ -578,6 +585,7 @@ int a3vt_gcn_layer_bwd(const float *x, int ld_x, int in_features, const float *w
   r.m = (int)m;
   r.k = npad;
   r.n_store = ld_x;
+  r.bf16 = gemm_bf16 ? 1 : 0;
   r.c = grad_x;
   r.ldc = ld_x;
   return launch_rowgemm(r, EPI_PLAIN, s);
@@ -591,7 +599,8 @@ int a3vt_transpose_weight(const float *w, int k, int n_out, float *wt, void *str
   return launch_transpose_pad(w, k, n_out, wt, rowgemm_bt_rows(n_out), pad16(k), static_cast<hipStream_t>(stream));
 }
 
-int a3vt_rowgemm(const float *a, int lda, int m, int k, const float *wt, int n_out, float *c, int ldc, void *stream) {
+int a3vt_rowgemm(const float *a, int lda, int m, int k, const float *wt, int n_out, int gemm_bf16, float *c, int ldc,
+                 void *stream) {
   A3VT_CHECK_ARG(a && wt && c && m > 0 && k > 0 && k % 4 == 0 && lda >= k && ldc >= n_out && n_out <= 304);
   RowGemmArgs g{};
   g.a0 = g.a1 = a;
@@ -606,6 +615,7 @@ int a3vt_rowgemm(const float *a, int lda, int m, int k, const float *wt, int n_o
   g.n_store = n_out;
   g.c = c;
   g.ldc = ldc;
+  g.bf16 = gemm_bf16 ? 1 : 0;
   return launch_rowgemm(g, EPI_PLAIN, static_cast<hipStream_t>(stream));
 }
 

@@ -24,6 +24,21 @@ __device__ __forceinline__ void glds16(const float *gsrc, float *lds_wave_base) 
                                    (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
+// bf16 operand mode ("bf16 + MFMA feature MLP", BASELINE configs[3]/[4]): the fp32 values staged in LDS are rounded to
+// bf16 (RNE, v_cvt_pk_bf16_f32) as they are read into fragments and multiplied with v_mfma_f32_16x16x16_bf16 into the
+// same fp32 accumulators.  A lane's ds_read_b128 already holds k = 4q..4q+3 of its row — exactly the operand layout of
+// the 16x16x16 instruction — so ONE bf16 MFMA replaces the four fp32 16x16x4 steps (1/8 of the matrix-pipe time).
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using s16x4 = __attribute__((ext_vector_type(4))) short;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+__device__ __forceinline__ s16x4 cvt_bf16x4(f32x4 v) {
+  const bf16x2 lo = __builtin_convertvector((f32x2){v[0], v[1]}, bf16x2);
+  const bf16x2 hi = __builtin_convertvector((f32x2){v[2], v[3]}, bf16x2);
+  const u32x2 r = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+  return __builtin_bit_cast(s16x4, r);
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -47,7 +62,7 @@ __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0
 // deeper ring because a handful of MFMAs per chunk cannot cover a DMA round trip.  Known cost: the epilogue is
 // bound by the CU's store path (~7-10 B/clk: 770 KB per CU per launch = 30-45 us) and is not overlapped.
 // ------------------------------------------------------------------------------------------------
-template <int NT, int EPI, int NSTAGE, int WAVES>
+template <int NT, int EPI, int NSTAGE, int WAVES, bool BF16>
 __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
   constexpr int MT = 2;
   constexpr int BROWS = ((NT * 16 + 16 * WAVES - 1) / (16 * WAVES)) * (16 * WAVES);  // Bt rows staged per chunk
@@ -171,6 +186,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
         f32x4 af[MT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4 *>(sA + (i * 16 + l16) * 16 + qs * 4);
+        s16x4 abf[MT];
+        if (BF16) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i) abf[i] = cvt_bf16x4(af[i]);
+        }
         // B fragments two n-tiles at a time, register double-buffered: the ds_reads of pair jp+1 are issued one
         // MFMA group into pair jp, so the LDS latency hides under the matrix pipe.
         const float *sBl = sB + l16 * 16 + qs * 4;
@@ -180,6 +200,23 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
 #pragma unroll
         for (int jp = 0; jp < NP; ++jp) {
           f32x4 bn0 = bc0, bn1 = bc1;
+          if (BF16) {
+            const s16x4 b0 = cvt_bf16x4(bc0), b1 = cvt_bf16x4(bc1);
+            acc[0][2 * jp] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(abf[0], b0, acc[0][2 * jp], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (jp + 1 < NP) {
+              bn0 = *reinterpret_cast<const f32x4 *>(sBl + (2 * jp + 2) * 256);
+              if (2 * jp + 3 < NT) bn1 = *reinterpret_cast<const f32x4 *>(sBl + (2 * jp + 3) * 256);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (2 * jp + 1 < NT)
+              acc[0][2 * jp + 1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(abf[0], b1, acc[0][2 * jp + 1], 0, 0, 0);
+            if (nm > 1) {
+              acc[1][2 * jp] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(abf[1], b0, acc[1][2 * jp], 0, 0, 0);
+              if (2 * jp + 1 < NT)
+                acc[1][2 * jp + 1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(abf[1], b1, acc[1][2 * jp + 1], 0, 0, 0);
+            }
+          } else {
           // first m-tile: 8 MFMAs over two accumulators (dependent distance 2 = 64 cycles > the 40-cycle latency)
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
@@ -204,6 +241,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
                     __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][s], bc1[s], acc[1][2 * jp + 1], 0, 0, 0);
             }
           }
+          }  // !BF16
           __builtin_amdgcn_sched_barrier(0);
           if (SPREAD && (jp & 1) && (jp >> 1) < PER) {
             if (prefetch) issue_piece(t + DIST, nbuf, jp >> 1);
@@ -327,7 +365,9 @@ static int launch_rowgemm_nt(const RowGemmArgs &a, int grid_y, hipStream_t s) {
   static_assert(shmem * C::WG_PER_CU <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)rowgemm_kernel<NT, EPI, C::NSTAGE, C::WAVES>,
+    (void)hipFuncSetAttribute((const void *)rowgemm_kernel<NT, EPI, C::NSTAGE, C::WAVES, false>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    (void)hipFuncSetAttribute((const void *)rowgemm_kernel<NT, EPI, C::NSTAGE, C::WAVES, true>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     attr_set = true;
   }
@@ -335,7 +375,10 @@ static int launch_rowgemm_nt(const RowGemmArgs &a, int grid_y, hipStream_t s) {
   const int max_wg = 256 * C::WG_PER_CU;
   // one tile per wave until every CU has a workgroup; beyond that the kernel deals tiles evenly (two per wave per round)
   const int grid = cdiv(tiles, C::WAVES) < max_wg ? cdiv(tiles, C::WAVES) : max_wg;
-  A3VT_LAUNCH((rowgemm_kernel<NT, EPI, C::NSTAGE, C::WAVES>), dim3(grid, grid_y), dim3(64 * C::WAVES), shmem, s, a);
+  if (a.bf16)
+    A3VT_LAUNCH((rowgemm_kernel<NT, EPI, C::NSTAGE, C::WAVES, true>), dim3(grid, grid_y), dim3(64 * C::WAVES), shmem, s, a);
+  else
+    A3VT_LAUNCH((rowgemm_kernel<NT, EPI, C::NSTAGE, C::WAVES, false>), dim3(grid, grid_y), dim3(64 * C::WAVES), shmem, s, a);
   A3VT_CHECK_LAUNCH();
   return 0;
 }
@@ -604,7 +647,42 @@ __device__ __forceinline__ void dw_stage_fast(const float *__restrict__ sb, int 
   }
 }
 
-template <bool FAST>
+// bf16 operand mode: the four rows a lane owns in a 16-row stage (4q .. 4q+3) are the four k values of the
+// 16x16x16 bf16 instruction, so each (input tile, output tile) pair takes ONE MFMA per stage instead of four.
+__device__ __forceinline__ void dw_stage_bf16(const float *__restrict__ sb, int ldx, int ldz0, int ldz1, int offG,
+                                              int xoff, const int (&zoff)[DW_MAXO], int q, int ni, int no,
+                                              f32x4 (&acc)[DW_MAXI][DW_MAXO]) {
+  s16x4 a[DW_MAXI], b[DW_MAXO];
+#pragma unroll
+  for (int i = 0; i < DW_MAXI; ++i) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (i < ni) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) v[ks] = sb[(q * 4 + ks) * ldx + xoff + i * 16];
+    }
+    a[i] = cvt_bf16x4(v);
+  }
+#pragma unroll
+  for (int j = 0; j < DW_MAXO; ++j) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (j < no) {
+      const int ld = zoff[j] < offG ? ldz0 : ldz1;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) v[ks] = sb[zoff[j] + (q * 4 + ks) * ld];
+    }
+    b[j] = cvt_bf16x4(v);
+  }
+#pragma unroll
+  for (int i = 0; i < DW_MAXI; ++i) {
+    if (i < ni) {
+#pragma unroll
+      for (int j = 0; j < DW_MAXO; ++j)
+        if (j < no) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+}
+
+template <bool FAST, bool BF16>
 __global__ __launch_bounds__(1024, 1) void dw_kernel(DwArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63;
@@ -709,7 +787,8 @@ __global__ __launch_bounds__(1024, 1) void dw_kernel(DwArgs p) {
     if (t + 2 < nu) issue(u0 + t + 2, buf >= 1 ? buf - 1 : 2);
 #endif
     const float *sb = lds + buf * stage;
-    if (FAST) dw_stage_fast(sb, p.ldx, p.ldz0, p.ldz1, offG, xoff, zoff, q, ni == 5, no == 3, acc);
+    if (BF16) dw_stage_bf16(sb, p.ldx, p.ldz0, p.ldz1, offG, xoff, zoff, q, ni, no, acc);
+    else if (FAST) dw_stage_fast(sb, p.ldx, p.ldz0, p.ldz1, offG, xoff, zoff, q, ni == 5, no == 3, acc);
     else dw_stage<-1, -1>(sb, p.ldx, p.ldz0, p.ldz1, offG, xoff, zoff, q, ni, no, acc);
     buf = buf == 2 ? 0 : buf + 1;
   }
@@ -758,16 +837,18 @@ int launch_dw(const DwArgs &a, hipStream_t s) {
   }
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)dw_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)dw_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)dw_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)dw_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)dw_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   // fast path: every wave owns 4-5 input tiles and 2-3 output tiles (true for 300 x 300)
   const int tin = cdiv(a.k_in, 16), tout = cdiv(a.n_out, 16), groups = dw_col_groups(a.n_out);
   const bool fast = tin / 4 >= 4 && tin <= 20 && (tout / groups) / 4 >= 2 && cdiv(tout, groups) <= 12;
   const dim3 grid(dw_num_slabs(a.n_out), groups);
-  if (fast) A3VT_LAUNCH(dw_kernel<true>, grid, dim3(1024), shmem, s, a);
-  else A3VT_LAUNCH(dw_kernel<false>, grid, dim3(1024), shmem, s, a);
+  if (a.bf16) A3VT_LAUNCH((dw_kernel<false, true>), grid, dim3(1024), shmem, s, a);
+  else if (fast) A3VT_LAUNCH((dw_kernel<true, false>), grid, dim3(1024), shmem, s, a);
+  else A3VT_LAUNCH((dw_kernel<false, false>), grid, dim3(1024), shmem, s, a);
   A3VT_CHECK_LAUNCH();
   return 0;
 }

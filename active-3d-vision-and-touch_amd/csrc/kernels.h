@@ -26,6 +26,7 @@ struct RowGemmArgs {
   int m, k, n_store;
   int ldc, ldc2, csplit, mld, moff;
   int no_relu;  // EPI_FWD_HIDDEN: store the pass-through channels without the ReLU (identity activation)
+  int bf16;     // operands rounded to bf16, v_mfma_f32_16x16x16_bf16, fp32 accumulate (default: exact fp32 MFMA)
 };
 int rowgemm_bt_rows(int n_store);
 int launch_rowgemm(const RowGemmArgs &a, int epi, hipStream_t s);
@@ -52,6 +53,7 @@ struct DwArgs {
   float *slab;  // [dw_num_slabs(n_out)][k_in][n_out]
   int ldx, ldz0, ldz1, zsplit;
   int m, k_in, n_out;
+  int bf16;  // as RowGemmArgs::bf16
 };
 int dw_num_slabs(int n_out);
 int launch_dw(const DwArgs &a, hipStream_t s);

@@ -24,17 +24,17 @@ SIGNATURES = {
     "a3vt_csr_validate": (_i, [_vp, _vp, _i, _i]),
     "a3vt_gcn_stack_scratch_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "a3vt_gcn_stack_mask_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "a3vt_gcn_stack_fwd": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    "a3vt_gcn_stack_bwd": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i,
+    "a3vt_gcn_stack_fwd": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "a3vt_gcn_stack_bwd": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "a3vt_gcn_layer_scratch_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
-    "a3vt_gcn_layer_fwd": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp]),
-    "a3vt_gcn_layer_bwd": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i,
+    "a3vt_gcn_layer_fwd": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "a3vt_gcn_layer_bwd": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i,
                                 _vp, _vp, _vp, _vp, _vp]),
     "a3vt_wt_rows": (_i, [_i]),
     "a3vt_wt_ld": (_i, [_i]),
     "a3vt_transpose_weight": (_i, [_vp, _i, _i, _vp, _vp]),
-    "a3vt_rowgemm": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
+    "a3vt_rowgemm": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp]),
     "a3vt_posenc_param_count": (_sz, [_i]),
     "a3vt_posenc_scratch_bytes": (_sz, [_i, _i]),
     "a3vt_posenc_mask_fwd": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _vp]),

@@ -64,7 +64,7 @@ class GCNStackFn(torch.autograd.Function):
     """One GCN (reference ``GCN.forward``, vision/model.py:316-331): feats (B,N,ld) -> update (B,N,3)."""
 
     @staticmethod
-    def forward(ctx, feats, adj, in_features, hidden, cut_len, *params):
+    def forward(ctx, feats, adj, in_features, hidden, cut_len, bf16, *params):
         L = _lib.load()
         feats = _req(feats, "feats")
         B, N, ld = feats.shape
@@ -86,9 +86,10 @@ class GCNStackFn(torch.autograd.Function):
         wp, bp = _ptr_array(weights), _ptr_array(biases)
         _lib.check(L.a3vt_gcn_stack_fwd(_lib.ptr(feats), ld, in_features, wp, bp, nl, hidden, cut_len,
                                         _lib.ptr(adj.rowptr), _lib.ptr(adj.col), _lib.ptr(adj.val), adj.max_degree, N, B,
+                                        1 if bf16 else 0,
                                         _lib.ptr(acts), _lib.ptr(masks), _lib.ptr(scratch), _lib.ptr(update), _stream()),
                    "gcn_stack_fwd")
-        ctx.adj, ctx.dims = adj, (in_features, hidden, cut_len, nl)
+        ctx.adj, ctx.dims, ctx.bf16 = adj, (in_features, hidden, cut_len, nl), bool(bf16)
         ctx.acts, ctx.masks = acts, masks
         ctx.save_for_backward(feats, *weights, *biases)
         return update
@@ -111,7 +112,7 @@ class GCNStackFn(torch.autograd.Function):
         _lib.check(L.a3vt_gcn_stack_bwd(_lib.ptr(feats), ld, in_features, _ptr_array(weights), _ptr_array(biases), nl,
                                         hidden, cut_len, _lib.ptr(adj.rowptr), _lib.ptr(adj.col), _lib.ptr(adj.val),
                                         _lib.ptr(adj.t_rowptr), _lib.ptr(adj.t_col), _lib.ptr(adj.t_val),
-                                        adj.t_max_degree, N, B,
+                                        adj.t_max_degree, N, B, 1 if ctx.bf16 else 0,
                                         _lib.ptr(ctx.acts), _lib.ptr(ctx.masks), _lib.ptr(grad_update), _ptr_array(gw),
                                         _ptr_array(gb),
                                         _lib.ptr(gfeats), _lib.ptr(scratch), _stream()), "gcn_stack_bwd")
@@ -119,14 +120,16 @@ class GCNStackFn(torch.autograd.Function):
         grads = []
         for w, b in zip(gw, gb):
             grads += [w, b]
-        return (gfeats, None, None, None, None, *grads)
+        return (gfeats, None, None, None, None, None, *grads)
 
 
-def gcn_stack(feats, adj, in_features, hidden, cut_len, weights, biases):
+def gcn_stack(feats, adj, in_features, hidden, cut_len, weights, biases, bf16=False):
+    """``bf16``: round the operands of the per-vertex products to bf16 on their way into the matrix pipe (BASELINE
+    configs[3]/[4]); the default is the exact fp32 path."""
     params = []
     for w, b in zip(weights, biases):
         params += [w, b]
-    return GCNStackFn.apply(feats, adj, in_features, hidden, cut_len, *params)
+    return GCNStackFn.apply(feats, adj, in_features, hidden, cut_len, bf16, *params)
 
 
 class GCNLayerFn(torch.autograd.Function):
@@ -134,7 +137,7 @@ class GCNLayerFn(torch.autograd.Function):
     x (B,N,ld) -> y (B,N,out).  ``cut_len`` = out for a layer without the cut."""
 
     @staticmethod
-    def forward(ctx, x, adj, weight, bias, cut_len, relu):
+    def forward(ctx, x, adj, weight, bias, cut_len, relu, bf16=False):
         L = _lib.load()
         x = _req(x, "features")
         weight, bias = _req(weight, "weight"), _req(bias, "bias")
@@ -151,9 +154,9 @@ class GCNLayerFn(torch.autograd.Function):
                             x.device)
         _lib.check(L.a3vt_gcn_layer_fwd(_lib.ptr(x), ld, kin, _lib.ptr(weight), _lib.ptr(bias), nout, cut_len,
                                         1 if relu else 0, _lib.ptr(adj.rowptr), _lib.ptr(adj.col), _lib.ptr(adj.val),
-                                        adj.max_degree, N, B, _lib.ptr(y), ldy, _lib.ptr(scratch), _stream()),
-                   "gcn_layer_fwd")
-        ctx.adj, ctx.dims = adj, (kin, nout, cut_len, bool(relu), ldy)
+                                        adj.max_degree, N, B, 1 if bf16 else 0, _lib.ptr(y), ldy, _lib.ptr(scratch),
+                                        _stream()), "gcn_layer_fwd")
+        ctx.adj, ctx.dims, ctx.bf16 = adj, (kin, nout, cut_len, bool(relu), ldy), bool(bf16)
         ctx.save_for_backward(x, weight, y)
         return y[..., :nout] if ldy != nout else y
 
@@ -169,14 +172,14 @@ class GCNLayerFn(torch.autograd.Function):
         scratch = workspace("gcn", L.a3vt_gcn_layer_scratch_bytes(B, N, ld, nout, cut_len, 1), x.device)
         _lib.check(L.a3vt_gcn_layer_bwd(_lib.ptr(x), ld, kin, _lib.ptr(weight), nout, cut_len, 1 if relu else 0,
                                         _lib.ptr(adj.t_rowptr), _lib.ptr(adj.t_col), _lib.ptr(adj.t_val),
-                                        adj.t_max_degree, N, B,
+                                        adj.t_max_degree, N, B, 1 if ctx.bf16 else 0,
                                         _lib.ptr(y), ldy, _lib.ptr(gy), gy.shape[-1], _lib.ptr(gw), _lib.ptr(gb),
                                         _lib.ptr(gx), _lib.ptr(scratch), _stream()), "gcn_layer_bwd")
-        return gx, None, gw, gb, None, None
+        return gx, None, gw, gb, None, None, None
 
 
-def gcn_layer(x, adj, weight, bias, cut_len, relu):
-    return GCNLayerFn.apply(x, adj, weight, bias, cut_len, relu)
+def gcn_layer(x, adj, weight, bias, cut_len, relu, bf16=False):
+    return GCNLayerFn.apply(x, adj, weight, bias, cut_len, relu, bf16)
 
 
 class PosEncMaskFn(torch.autograd.Function):
@@ -403,8 +406,8 @@ def chamfer_nn(x, y):
     return dxy, ixy, dyx, iyx, cd
 
 
-def rowgemm(a, w):
-    """C = A @ W on the fp32 MFMA kernel (tests / bench): a (M,K) with K % 4 == 0, w (K,N) with N <= 304."""
+def rowgemm(a, w, bf16=False):
+    """C = A @ W on the MFMA kernel (tests / bench): a (M,K) with K % 4 == 0, w (K,N) with N <= 304."""
     L = _lib.load()
     a, w = _req(a, "a"), _req(w, "w")
     M, K = a.shape
@@ -412,7 +415,8 @@ def rowgemm(a, w):
     wt = torch.empty((L.a3vt_wt_rows(N), L.a3vt_wt_ld(K)), dtype=torch.float32, device=a.device)
     _lib.check(L.a3vt_transpose_weight(_lib.ptr(w), K, N, _lib.ptr(wt), _stream()), "transpose_weight")
     c = torch.empty((M, N), dtype=torch.float32, device=a.device)
-    _lib.check(L.a3vt_rowgemm(_lib.ptr(a), K, M, K, _lib.ptr(wt), N, _lib.ptr(c), N, _stream()), "rowgemm")
+    _lib.check(L.a3vt_rowgemm(_lib.ptr(a), K, M, K, _lib.ptr(wt), N, 1 if bf16 else 0, _lib.ptr(c), N, _stream()),
+               "rowgemm")
     return c
 
 

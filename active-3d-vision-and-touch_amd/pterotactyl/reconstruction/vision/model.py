@@ -159,7 +159,7 @@ class GCN_layer(nn.Module):
         pad = (-features.shape[-1]) % 4
         if pad:
             features = F.pad(features, (0, pad))
-        y = _ops.gcn_layer(features, csr, self.weight, self.bias, c, relu)
+        y = _ops.gcn_layer(features, csr, self.weight, self.bias, c, relu, getattr(self, "gemm_bf16", False))
         return y if relu else activation(y)
 
 
@@ -171,6 +171,9 @@ class GCN(nn.Module):
         self.input_features = input_features
         self.hidden = args.hidden_GCN_size
         self.cut = args.cut
+        # new knob (no reference counterpart): "bf16" rounds the operands of the per-vertex products to bf16 on their
+        # way into the matrix pipe (BASELINE configs[3]/[4]); everything stored stays fp32.  Default: exact fp32.
+        self.gemm_bf16 = getattr(args, "gemm_precision", "fp32") == "bf16"
         dims = [input_features] + [self.hidden] * (self.num_layers - 1) + [3]
         self.layers = nn.ModuleList(
             [GCN_layer(dims[i], dims[i + 1], args.cut, do_cut=i < self.num_layers - 1) for i in range(self.num_layers)])
@@ -184,7 +187,8 @@ class GCN(nn.Module):
             features = torch.nn.functional.pad(features, (0, pad))
         ws = [l.weight for l in self.layers]
         bs = [l.bias for l in self.layers]
-        return _ops.gcn_stack(features, adj, self.input_features, self.hidden, _cut_len(self.hidden, self.cut), ws, bs)
+        return _ops.gcn_stack(features, adj, self.input_features, self.hidden, _cut_len(self.hidden, self.cut), ws, bs,
+                              bf16=self.gemm_bf16)
 
 
 class Positional_Encoder(nn.Module):

@@ -45,6 +45,8 @@ def parse():
     p.add_argument("--cloud", default="ellipsoid", choices=["ellipsoid", "cube"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--profile-steps", type=int, default=2)
+    p.add_argument("--gemm-precision", default="fp32", choices=["fp32", "bf16"],
+                   help="bf16 = BASELINE configs[3]/[4] operand mode of the per-vertex products; NOT the headline metric")
     return p.parse_args()
 
 
@@ -99,7 +101,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     args = make_args(num_GCN_layers=a.layers, hidden_GCN_size=a.hidden, number_points=a.points, seed=0,
-                     exp_type="bench", exp_id=f"rank{rank}", eval=False, epochs=1, patience=70, batch_size=a.batch)
+                     exp_type="bench", exp_id=f"rank{rank}", eval=False, epochs=1, patience=70, batch_size=a.batch,
+                     gemm_precision=a.gemm_precision)
     os.chdir(os.environ.get("TMPDIR", "/tmp"))  # Engine writes config.json under ./experiments
     from a3vt_amd import mesh as amesh
     eng = train.Engine(args, loaders=((), ()))
@@ -169,19 +172,22 @@ def main():
         # dominant kernel = rowgemm (forward + dX launches share the kernel); dX launches are all hidden x hidden
         t_ms = tot[1] / max(n_dx, 1)
         achieved = flop / (t_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "rowgemm_kernel<19,EPI_DX_MASK> (fp32 MFMA 16x16x4, M x 300 x 300, dX = dZ W^T)",
-                "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3,
+        peak = 157.3 if a.gemm_precision == "fp32" else 1250.0   # 16x16x16 bf16 form: half the 16x16x32 rate
+        roof = {"bound": "mfma", "kernel": "rowgemm_kernel<19,EPI_DX_MASK> (fp32 MFMA 16x16x4, M x 300 x 300, dX = dZ W^T)"
+                if a.gemm_precision == "fp32" else "rowgemm_kernel<19,EPI_DX_MASK,bf16> (v_mfma_f32_16x16x16_bf16)",
+                "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "traffic": pmc_traffic(),
                 "avg_launch_ms": t_ms, "launches": n_dx, "flop_per_launch": flop,
                 "other_mfma_ms": per,
                 "mfma_ms_per_step": (tot[0] + tot[1] + tot[2]) / a.profile_steps}
 
-    default_cfg = (a.level, a.batch, a.points, a.layers, a.hidden) == (4, 64, 10000, 20, 300)
+    default_cfg = (a.level, a.batch, a.points, a.layers, a.hidden, a.gemm_precision) == (4, 64, 10000, 20, 300, "fp32")
     out = {
         "metric": "mesh-recon iters/sec (fwd+bwd, 2562-vert GCN + 10k-pt Chamfer) at bs=64",
         "value": world * a.steps / dt, "unit": "iters/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if a.gemm_precision == "fp32" else "f32 storage, bf16 GEMM operands (reduced precision, not the headline)",
+        "data": "synthetic",
         "config": {"workload": f"icosphere-{a.level} template ({vt.shape[0]} verts, {ft.shape[0]} faces), 3-stage GCN "
                                f"{a.layers}x{a.hidden} cut 0.33, bs={a.batch}/GPU, {a.points}-pt Chamfer x3 draws, "
                                f"Adam, {a.cloud} clouds" + (" (BASELINE.json configs[1])" if default_cfg else " (custom sizes)"),

@@ -47,6 +47,10 @@ int a3vt_csr_validate(const int32_t *rowptr_host, const int32_t *col_host, int n
  * `weights`, `biases`, `grad_weights`, `grad_biases` are HOST arrays of L DEVICE pointers.
  * `cut_len` = round(hidden * cut) (model.py:355; 99 for 300 * 0.33).
  * csr_* is A (row-normalised), csrT_* is its transpose (A is not symmetric after normalisation).
+ * gemm_bf16 (every GCN entry point and a3vt_rowgemm): 0 = the per-vertex products run as exact fp32 MFMA (the parity
+ * mode, BASELINE configs[1]/[2]); 1 = "bf16 + MFMA feature MLP" (configs[3]/[4]): the operands of X W, dZ W^T and
+ * X^T dZ are rounded to bf16 on their way into the matrix pipe (v_mfma_f32_16x16x16_bf16, fp32 accumulation); every
+ * stored tensor stays fp32.  Vertex positions then agree with the fp32 reference to ~2e-3 relative instead of 3e-7.
  * csr_max_degree / csrT_max_degree: the largest number of entries in a row of that matrix, or 0 if unknown.  The
  * fused vision + touch graphs have hub rows (chart centres linked to every seam vertex, ~1150 entries,
  * utility/utils.py:119-128); rows above 64 entries are aggregated by a whole workgroup in a second launch, which a
@@ -67,7 +71,7 @@ int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features,
                        const float *const *weights, const float *const *biases,
                        int num_layers, int hidden, int cut_len,
                        const int32_t *csr_rowptr, const int32_t *csr_col, const float *csr_val, int csr_max_degree,
-                       int n_vert, int batch,
+                       int n_vert, int batch, int gemm_bf16,
                        float *acts, uint8_t *masks, float *scratch, float *update, void *stream);
 
 /* Backward of the stack.  grad_update [M][3] -> grad_feats [M][ld_feats] (pad columns written as 0),
@@ -78,7 +82,7 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features,
                        int num_layers, int hidden, int cut_len,
                        const int32_t *csr_rowptr, const int32_t *csr_col, const float *csr_val,
                        const int32_t *csrT_rowptr, const int32_t *csrT_col, const float *csrT_val, int csrT_max_degree,
-                       int n_vert, int batch,
+                       int n_vert, int batch, int gemm_bf16,
                        const float *acts, const uint8_t *masks, const float *grad_update,
                        float *const *grad_weights, float *const *grad_biases, float *grad_feats,
                        float *scratch, void *stream);
@@ -99,11 +103,11 @@ size_t a3vt_gcn_layer_scratch_bytes(int batch, int n_vert, int ld_x, int out_fea
 int a3vt_gcn_layer_fwd(const float *x, int ld_x, int in_features, const float *weight, const float *bias,
                        int out_features, int cut_len, int relu,
                        const int32_t *csr_rowptr, const int32_t *csr_col, const float *csr_val, int csr_max_degree,
-                       int n_vert, int batch, float *y, int ld_y, float *scratch, void *stream);
+                       int n_vert, int batch, int gemm_bf16, float *y, int ld_y, float *scratch, void *stream);
 int a3vt_gcn_layer_bwd(const float *x, int ld_x, int in_features, const float *weight,
                        int out_features, int cut_len, int relu,
                        const int32_t *csrT_rowptr, const int32_t *csrT_col, const float *csrT_val, int csrT_max_degree,
-                       int n_vert, int batch, const float *y, int ld_y, const float *grad_y, int ld_gy,
+                       int n_vert, int batch, int gemm_bf16, const float *y, int ld_y, const float *grad_y, int ld_gy,
                        float *grad_weight, float *grad_bias, float *grad_x, float *scratch, void *stream);
 
 /* The dense per-vertex product alone (torch.matmul(features, self.weight), model.py:352) on the
@@ -113,7 +117,7 @@ int a3vt_gcn_layer_bwd(const float *x, int ld_x, int in_features, const float *w
 int a3vt_wt_rows(int n_out);
 int a3vt_wt_ld(int k);
 int a3vt_transpose_weight(const float *w, int k, int n_out, float *wt, void *stream);
-int a3vt_rowgemm(const float *a, int lda, int m, int k, const float *wt, int n_out,
+int a3vt_rowgemm(const float *a, int lda, int m, int k, const float *wt, int n_out, int gemm_bf16,
                  float *c, int ldc, void *stream);
 
 /* ---------------------------------------------------------------------------------------------

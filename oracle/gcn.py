@@ -34,9 +34,15 @@ def adj_matmul(adj, x):
     return torch.matmul(adj.to(x.dtype), x)
 
 
-def gcn_layer(x, weight, bias, adj, cut=0.33, do_cut=True, relu=True):
-    """model.py:351-363.  x (B,N,in), weight (1,in,out), bias (out,)."""
-    z = torch.matmul(x, weight)
+def bf16_round(t):
+    """Round to bf16 (nearest even) and back: what the bf16 operand mode of the MFMA kernels does to its inputs."""
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+def gcn_layer(x, weight, bias, adj, cut=0.33, do_cut=True, relu=True, bf16=False):
+    """model.py:351-363.  x (B,N,in), weight (1,in,out), bias (out,).  ``bf16``: emulate the product's bf16 operand
+    mode (operands of X W rounded to bf16, exact products, wide accumulation) — not a reference feature."""
+    z = torch.matmul(bf16_round(x), bf16_round(weight)) if bf16 else torch.matmul(x, weight)
     if do_cut:
         length = cut_length(z.shape[-1], cut)
         agg = adj_matmul(adj, z[:, :, :length]) + bias[:length]
@@ -46,12 +52,12 @@ def gcn_layer(x, weight, bias, adj, cut=0.33, do_cut=True, relu=True):
     return torch.relu(out) if relu else out
 
 
-def gcn(x, state, prefix, adj, num_layers, cut=0.33, collect=None):
+def gcn(x, state, prefix, adj, num_layers, cut=0.33, collect=None, bf16=False):
     """model.py:316-331 — ``num_layers`` layers, ReLU on all but the last, last layer aggregates all channels."""
     for i in range(num_layers):
         last = i == num_layers - 1
         x = gcn_layer(x, state[f"{prefix}.layers.{i}.weight"], state[f"{prefix}.layers.{i}.bias"],
-                      adj, cut, do_cut=not last, relu=not last)
+                      adj, cut, do_cut=not last, relu=not last, bf16=bf16 and not last)
         if collect is not None:
             collect.append(x)
     return x

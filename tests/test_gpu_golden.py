@@ -54,6 +54,22 @@ def test_g4_full_size_forward(cuda):
     assert torch.equal(charts["vision_charts"].cpu(), torch.from_numpy(z["verts_in"]))
 
 
+def test_g4_full_size_forward_bf16_mode(cuda):
+    """BASELINE configs[3]/[4] operand mode on the full 20 x 300 network vs the fp32 reference's vertex positions:
+    SURVEY App. B measured 1.4e-3 for bf16 rounding after every layer; the tolerance for this mode is 5e-3."""
+    model, utils = _facade()
+    z = load("g4_full_forward.npz")
+    args = make_args(gemm_precision="bf16")
+    info, verts = utils.load_mesh_vision(args, "vision_charts")
+    torch.manual_seed(0)
+    net = model.Deformation(info, verts, args).to(cuda)
+    charts = {"vision_charts": torch.from_numpy(z["verts_in"]).to(cuda), "vision_masks": 3 * torch.ones(2, 1824, 1, device=cuda)}
+    with torch.no_grad():
+        out, _ = net(torch.zeros(2, 1), charts)
+    err = rel_err(out, torch.from_numpy(z["verts_out"]))
+    assert 1e-5 < err < 5e-3, err
+
+
 def test_g6_chamfer(cuda):
     from a3vt_amd import ops
     _, utils = _facade()

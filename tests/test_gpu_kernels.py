@@ -153,6 +153,73 @@ def test_image_pool_fwd_bwd(cuda):
     assert torch.equal(f2, f.detach())
 
 
+@pytest.mark.parametrize("m,k,n", [(1000, 52, 300), (4099, 300, 300), (33000, 300, 300), (777, 300, 52)])
+def test_rowgemm_bf16_operand_mode(cuda, m, k, n):
+    """gemm_bf16 = 1: operands rounded to bf16 (RNE), exact products, fp32 accumulation — checked against exactly that
+    arithmetic in float64 (tolerance = fp32 accumulation only), and against the unrounded product at the bf16 level."""
+    from a3vt_amd import ops
+    from oracle import gcn as og
+    g = torch.Generator().manual_seed(m + k + n)
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(k, n, generator=g)
+    c = ops.rowgemm(a.to(cuda), w.to(cuda), bf16=True).cpu()
+    ref_bf = og.bf16_round(a).double() @ og.bf16_round(w).double()
+    assert rel_err(c, ref_bf) < 2e-6
+    assert 1e-4 < rel_err(c, a.double() @ w.double()) < 2e-2      # it really is the rounded product
+
+
+@pytest.mark.parametrize("tname,use_touch,L,B", [("ico2", False, 3, 3), ("atlas", True, 6, 2), ("ico4", False, 3, 13)])
+def test_gcn_stack_bf16_mode(cuda, tname, use_touch, L, B):
+    """BASELINE configs[3]/[4] ("bf16 + MFMA feature MLP"): the stack with bf16 GEMM operands.  Forward against the
+    oracle's emulation of the same rounding (float64 otherwise) and against the fp32 path; gradients against autograd of
+    that emulation at the bf16 level (the device's backward products round their operands too)."""
+    from a3vt_amd import mesh as amesh, ops
+    from oracle import gcn as og
+    from helpers import rel_l2
+    H = 300
+    args = make_args(use_touch=use_touch, num_GCN_layers=L, hidden_GCN_size=H, num_grasps=1)
+    verts, faces = template(tname)
+    adj_o, _ = oracle_adj(verts, faces, args)
+    n = adj_o[0].numel() - 1
+    st = og.init_state(50, H, L, seed=3)
+    g = torch.Generator().manual_seed(11)
+    feats = torch.randn(B, n, 50, generator=g) * 0.5
+    gup = torch.randn(B, n, 3, generator=g)
+    st64 = {k: v.double().requires_grad_(True) for k, v in st.items() if k.startswith("mesh_deform_1")}
+    f64 = feats.double().requires_grad_(True)
+    adj64 = (adj_o[0], adj_o[1], adj_o[2].double())
+    with torch.no_grad():
+        out_fp32 = og.gcn(feats.double(), {k: v.detach() for k, v in st64.items()}, "mesh_deform_1", adj64, L, 0.33)
+    # emulated forward with autograd straight through the roundings: same ReLU masks as the device forward (up to
+    # rounding ties), backward products with unrounded gradients
+    out_emul = og.gcn(f64, st64, "mesh_deform_1", adj64, L, 0.33, bf16=True)
+    (out_emul * gup.double()).sum().backward()
+    if use_touch:
+        sv, sf = amesh.load_asset("touch_chart")
+        r, c, nn_, _ = amesh.fused_pairs(verts, faces, sf, 1, False)
+    else:
+        r, c = amesh.vision_pairs(faces, verts.shape[0])
+        nn_ = verts.shape[0]
+    adj = ops.DeviceCSR(amesh.CSRAdjacency.from_pairs(r, c, nn_), cuda)
+    ws = [st[f"mesh_deform_1.layers.{i}.weight"].to(cuda).requires_grad_(True) for i in range(L)]
+    bs = [st[f"mesh_deform_1.layers.{i}.bias"].to(cuda).requires_grad_(True) for i in range(L)]
+    fd = torch.nn.functional.pad(feats, (0, 2)).to(cuda).requires_grad_(True)
+    out = ops.gcn_stack(fd, adj, 50, H, 99, ws, bs, bf16=True)
+    (out * gup.to(cuda)).sum().backward()
+    # same rounding -> close (a value within fp32 rounding of a bf16 tie may round the other way and move one element by
+    # 2^-8; hence 2e-3 rather than 1e-5); bf16 level against the exact path
+    assert rel_err(out, out_emul) < 2e-3 and rel_l2(out, out_emul) < 2e-4
+    assert rel_l2(out, out_fp32) < 1e-2
+    errs = [rel_l2(fd.grad[..., :50], f64.grad)]
+    for i in range(L):
+        errs.append(rel_l2(ws[i].grad, st64[f"mesh_deform_1.layers.{i}.weight"].grad))
+        errs.append(rel_l2(bs[i].grad, st64[f"mesh_deform_1.layers.{i}.bias"].grad))
+    assert max(errs) < 3e-2, errs
+    # the default path is untouched by the flag
+    out32 = ops.gcn_stack(fd.detach(), adj, 50, H, 99, [w.detach() for w in ws], [b.detach() for b in bs])
+    assert rel_err(out32, out_fp32) < 1e-4
+
+
 def test_posenc_mask_fwd_bwd(cuda):
     from a3vt_amd import ops
     from oracle import gcn as og
