@@ -21,8 +21,8 @@ __version__ = "0.1.0"
 def install_as_pterotactyl():
     """Register the mirror modules under the reference's import names
     (``pterotactyl.reconstruction.vision.model`` etc.) so existing callers pick up the HIP path.
-    Only names not already importable are installed for parent packages; the three hot-path modules are
-    always overridden."""
+    Only names not already importable are installed for parent packages; the listed modules are always
+    overridden."""
     import importlib
     import sys
     import types
@@ -31,8 +31,14 @@ def install_as_pterotactyl():
         "pterotactyl.reconstruction.vision.model": ".pterotactyl.reconstruction.vision.model",
         "pterotactyl.reconstruction.vision.train": ".pterotactyl.reconstruction.vision.train",
         "pterotactyl.utility.utils": ".pterotactyl.utility.utils",
+        # consumers of the same kernels
+        "pterotactyl.utility.data_loaders": ".pterotactyl.utility.data_loaders",
+        "pterotactyl.reconstruction.autoencoder.model": ".pterotactyl.reconstruction.autoencoder.model",
+        "pterotactyl.policies.DDQN.model": ".pterotactyl.policies.DDQN.model",
+        "pterotactyl.policies.scoring": ".pterotactyl.policies.scoring",
     }
     for parent in ("pterotactyl", "pterotactyl.reconstruction", "pterotactyl.reconstruction.vision",
+                   "pterotactyl.reconstruction.autoencoder", "pterotactyl.policies", "pterotactyl.policies.DDQN",
                    "pterotactyl.utility"):
         if parent not in sys.modules:
             try:
