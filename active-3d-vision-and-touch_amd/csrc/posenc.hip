@@ -14,6 +14,8 @@
 
 namespace a3vt {
 
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
 template <int I>
 struct PE {
   static constexpr int H1 = I / 4, H2 = I / 2, E = 63;
@@ -163,14 +165,17 @@ __global__ __launch_bounds__(kPEBwdThreads) void posenc_bwd_kernel(const float *
   constexpr int T = kPEBwdThreads;
   constexpr int H1 = P::H1, H2 = P::H2;
   extern __shared__ float smem[];
+  // per-vertex vectors, row = vertex.  E, H2 and H1 carry a trailing 1 so that the bias gradients fall out of the same
+  // outer-product tiles as the weight gradients; OH is the one-hot mask token (embedding gradient).
+  constexpr int LE = 64, LG = I, LH2 = H2 + 1, LD2 = H2, LH1 = H1 + 1, LD1 = H1, LOH = 4;
   float *sp = smem;                  // parameters (transposed image)
-  float *sE = sp + L::N;             // [T][63]
-  float *sG = sE + T * 63;           // [T][I]   gout
-  float *sH2 = sG + T * I;           // [T][H2]
-  float *sD2 = sH2 + T * H2;         // [T][H2]  dh2
-  float *sH1 = sD2 + T * H2;         // [T][H1]
-  float *sD1 = sH1 + T * H1;         // [T][H1]  dh1
-  int *stok = reinterpret_cast<int *>(sD1 + T * H1);
+  float *sE = sp + L::N;             // [T][64]  e | 1
+  float *sG = sE + T * LE;           // [T][I]   gout
+  float *sH2 = sG + T * LG;          // [T][H2+1] h2 | 1
+  float *sD2 = sH2 + T * LH2;        // [T][H2]  dh2
+  float *sH1 = sD2 + T * LD2;        // [T][H1+1] h1 | 1
+  float *sD1 = sH1 + T * LH1;        // [T][H1]  dh1
+  float *sOH = sD1 + T * LD1;        // [T][4]   one-hot token (all zero for padding rows); + 64 floats of slack
   pe_load_params<I>(params, sp);
   __syncthreads();
   const int t = threadIdx.x;
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(kPEBwdThreads) void posenc_bwd_kernel(const float *
     p[2] = verts[3 * (long long)v + 2];
   }
   // ---- forward recompute: e -> LDS, h1 / h2 in registers
-  float *myE = sE + t * 63;
+  float *myE = sE + t * LE;
 #pragma unroll 1
   for (int i = 0; i < 10; ++i) {
     const float f = pe_freq(i);
@@ -198,6 +203,7 @@ __global__ __launch_bounds__(kPEBwdThreads) void posenc_bwd_kernel(const float *
   myE[60] = p[0];
   myE[61] = p[1];
   myE[62] = p[2];
+  myE[63] = 1.f;
   float h1[H1], h2[H2];
 #pragma unroll
   for (int j = 0; j < H1; ++j) h1[j] = sp[L::ob1 + j];
@@ -210,8 +216,9 @@ __global__ __launch_bounds__(kPEBwdThreads) void posenc_bwd_kernel(const float *
 #pragma unroll
   for (int j = 0; j < H1; ++j) {
     h1[j] = h1[j] > 0.f ? h1[j] : 0.f;
-    sH1[t * H1 + j] = h1[j];
+    sH1[t * LH1 + j] = h1[j];
   }
+  sH1[t * LH1 + H1] = 1.f;
 #pragma unroll
   for (int j = 0; j < H2; ++j) h2[j] = sp[L::ob2 + j];
 #pragma unroll
@@ -221,11 +228,13 @@ __global__ __launch_bounds__(kPEBwdThreads) void posenc_bwd_kernel(const float *
 #pragma unroll
   for (int j = 0; j < H2; ++j) {
     h2[j] = h2[j] > 0.f ? h2[j] : 0.f;
-    sH2[t * H2 + j] = h2[j];
+    sH2[t * LH2 + j] = h2[j];
   }
+  sH2[t * LH2 + H2] = 1.f;
   int tok = live ? (int)mask[v] : 0;
   tok = tok < 0 ? 0 : (tok > 3 ? 3 : tok);
-  stok[t] = live ? tok : -1;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) sOH[t * LOH + k] = (live && tok == k) ? 1.f : 0.f;
 
   // ---- backward through the MLP
   float dh2[H2];
@@ -234,14 +243,14 @@ __global__ __launch_bounds__(kPEBwdThreads) void posenc_bwd_kernel(const float *
 #pragma unroll 1
   for (int o = 0; o < I; ++o) {
     const float g = live ? gfeats[(long long)v * ld + o] : 0.f;
-    sG[t * I + o] = g;
+    sG[t * LG + o] = g;
 #pragma unroll
     for (int k = 0; k < H2; ++k) dh2[k] += sp[L::oW3t + k * I + o] * g;
   }
 #pragma unroll
   for (int k = 0; k < H2; ++k) {
     dh2[k] = h2[k] > 0.f ? dh2[k] : 0.f;
-    sD2[t * H2 + k] = dh2[k];
+    sD2[t * LD2 + k] = dh2[k];
   }
   float dh1[H1];
 #pragma unroll
@@ -253,7 +262,7 @@ __global__ __launch_bounds__(kPEBwdThreads) void posenc_bwd_kernel(const float *
 #pragma unroll
   for (int k = 0; k < H1; ++k) {
     dh1[k] = h1[k] > 0.f ? dh1[k] : 0.f;
-    sD1[t * H1 + k] = dh1[k];
+    sD1[t * LD1 + k] = dh1[k];
   }
   // gradient w.r.t. the position: de_k = sum_j W1[j][k] dh1[j];
   // d sin(f p)/dp = f cos(f p) = f e[6i+3+c],  d cos(f p)/dp = -f sin(f p) = -f e[6i+c]
@@ -286,54 +295,44 @@ __global__ __launch_bounds__(kPEBwdThreads) void posenc_bwd_kernel(const float *
   }
   __syncthreads();
 
-  // ---- workgroup reductions of the outer products (fixed order over the 128 vertices)
-  for (int idx = t; idx < I * H2; idx += T) {  // dW3[o][k] = sum_v gout[v][o] h2[v][k]
-    const int o = idx / H2, k = idx % H2;
-    float s = 0.f;
+  // ---- workgroup reductions: every parameter gradient of the block is an outer-product sum over its T vertices,
+  // out[a][b] = sum_r A[r][a] B[r][b].  Each 16 x 16 tile of each product is one chain of T/4 exact-fp32 MFMAs
+  // (v_mfma_f32_16x16x4_f32, fixed order) fed straight from the LDS rows above; rows of padding vertices are zero in
+  // G / D2 / D1 / OH, columns past an array's width read the neighbouring row and only reach discarded outputs.
+  struct Job { const float *A; int lda, a0, na; const float *B; int ldb, b0; int kind; };
+  const int lane = t & 63, wave = t >> 6, l16 = lane & 15, kq = lane >> 4;
+  constexpr int NA3 = (I + 15) / 16, NB3 = (H2 + 1 + 15) / 16, NA2 = (H2 + 15) / 16, NB1 = 4;
+  constexpr int J3 = NA3 * NB3, JE = NA3, J2 = NA2, J1 = NB1, NJOBS = J3 + JE + J2 + J1;
+  for (int job = wave; job < NJOBS; job += T / 64) {
+    Job jb;
+    if (job < J3) jb = Job{sG, LG, (job / NB3) * 16, I, sH2, LH2, (job % NB3) * 16, 0};                 // dW3 | db3
+    else if (job < J3 + JE) jb = Job{sG, LG, (job - J3) * 16, I, sOH, LOH, 0, 1};                        // dE
+    else if (job < J3 + JE + J2) jb = Job{sD2, LD2, (job - J3 - JE) * 16, H2, sH1, LH1, 0, 2};           // dW2 | db2
+    else jb = Job{sD1, LD1, 0, H1, sE, LE, (job - J3 - JE - J2) * 16, 3};                                // dW1 | db1
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float *pa = jb.A + kq * jb.lda + jb.a0 + l16, *pb = jb.B + kq * jb.ldb + jb.b0 + l16;
 #pragma unroll 8
-    for (int r = 0; r < T; ++r) s += sG[r * I + o] * sH2[r * H2 + k];
-    out[P::oW3 + idx] = s;
-  }
-  for (int o = t; o < I; o += T) {  // db3, dE
-    float s = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    for (int r = 0; r < T; ++r) {
-      const float g = sG[r * I + o];
-      const int tk = stok[r];
-      s += g;
-      s0 += tk == 0 ? g : 0.f;
-      s1 += tk == 1 ? g : 0.f;
-      s2 += tk == 2 ? g : 0.f;
-      s3 += tk == 3 ? g : 0.f;
+    for (int st = 0; st < T / 4; ++st)
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[st * 4 * jb.lda], pb[st * 4 * jb.ldb], acc, 0, 0, 0);
+    const int col = jb.b0 + l16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = jb.a0 + kq * 4 + r;
+      if (row >= jb.na) continue;
+      const float val = acc[r];
+      if (jb.kind == 0) {          // row = o, col = k | bias column
+        if (col < H2) out[P::oW3 + row * H2 + col] = val;
+        else if (col == H2) out[P::ob3 + row] = val;
+      } else if (jb.kind == 1) {   // row = o, col = token
+        if (col < 4) out[P::oE + col * I + row] = val;
+      } else if (jb.kind == 2) {   // row = j, col = k | bias column
+        if (col < H1) out[P::oW2 + row * H1 + col] = val;
+        else if (col == H1) out[P::ob2 + row] = val;
+      } else {                     // row = j, col = k (63 = bias column)
+        if (col < 63) out[P::oW1 + row * 63 + col] = val;
+        else if (col == 63) out[P::ob1 + row] = val;
+      }
     }
-    out[P::ob3 + o] = s;
-    out[P::oE + 0 * I + o] = s0;
-    out[P::oE + 1 * I + o] = s1;
-    out[P::oE + 2 * I + o] = s2;
-    out[P::oE + 3 * I + o] = s3;
-  }
-  for (int idx = t; idx < H2 * H1; idx += T) {  // dW2[j][k] = sum_v dh2[v][j] h1[v][k]
-    const int j = idx / H1, k = idx % H1;
-    float s = 0.f;
-#pragma unroll 8
-    for (int r = 0; r < T; ++r) s += sD2[r * H2 + j] * sH1[r * H1 + k];
-    out[P::oW2 + idx] = s;
-  }
-  for (int j = t; j < H2; j += T) {
-    float s = 0.f;
-    for (int r = 0; r < T; ++r) s += sD2[r * H2 + j];
-    out[P::ob2 + j] = s;
-  }
-  for (int idx = t; idx < H1 * 63; idx += T) {  // dW1[j][k] = sum_v dh1[v][j] e[v][k]
-    const int j = idx / 63, k = idx % 63;
-    float s = 0.f;
-#pragma unroll 8
-    for (int r = 0; r < T; ++r) s += sD1[r * H1 + j] * sE[r * 63 + k];
-    out[P::oW1 + idx] = s;
-  }
-  for (int j = t; j < H1; j += T) {
-    float s = 0.f;
-    for (int r = 0; r < T; ++r) s += sD1[r * H1 + j];
-    out[P::ob1 + j] = s;
   }
 }
 
@@ -341,7 +340,7 @@ template <int I>
 static size_t posenc_bwd_smem() {
   using P = PE<I>;
   constexpr int T = kPEBwdThreads;
-  return (size_t)(PELds<I>::N + T * (63 + I + 2 * P::H2 + 2 * P::H1)) * sizeof(float) + T * sizeof(int);
+  return (size_t)(PELds<I>::N + T * (64 + I + (2 * P::H2 + 1) + (2 * P::H1 + 1) + 4) + 64) * sizeof(float);
 }
 
 int launch_posenc_bwd(const float *verts, const float *mask, int m, int input_size, const float *params,
