@@ -690,12 +690,6 @@ __global__ __launch_bounds__(1024, 1) void dw_kernel(DwArgs p) {
   const int l16 = lane & 15, q = lane >> 4;
   const int wi = wave & 3, wo = wave >> 2;  // waves of one SIMD share wo-spread, differ in nothing else
 
-  // 16-row images: floats, DMA wave-instructions (1 KiB each), LDS offsets
-  const int xfl = 16 * p.ldx, afl = 16 * p.ldz0, gfl = 16 * p.ldz1;
-  const int xin = (xfl + 255) >> 8, ain = (afl + 255) >> 8, gin = (gfl + 255) >> 8;
-  const int offA = xin * 256, offG = offA + ain * 256, offD = offG + gin * 256;
-  const int stage = offD + 256;  // + one dummy 1 KiB slot for idle DMA slots
-
   // tile ownership
   // balanced split: input tiles over wi; this column group's output tiles over wo
   const int tin = (p.k_in + 15) >> 4, tout = (p.n_out + 15) >> 4;
@@ -707,37 +701,52 @@ __global__ __launch_bounds__(1024, 1) void dw_kernel(DwArgs p) {
   const int no = gtn / 4 + (wo < gtn % 4 ? 1 : 0);
   const int o0 = gt0 + wo * (gtn / 4) + (wo < gtn % 4 ? wo : gtn % 4);
 
+  // Column windows.  A column group only consumes ITS output columns of dZ, so it stages just those: the part of them
+  // that lies in the aggregated block (z0 = dZa, columns < zsplit) and the part in the pass-through block (z1 = G).
+  // (Staging whole dZa / G rows in both groups made the kernel read dZ twice: 682 MB per launch against 460 MB.)
+  const int gcol0 = gt0 * 16, gcol1 = min(p.n_out, (gt0 + gtn) * 16);
+  const int a0 = min(gcol0, p.zsplit) & ~3, a1 = (min(gcol1, p.zsplit) + 3) & ~3;
+  const int g0 = max(gcol0, p.zsplit) & ~3, g1 = min((max(gcol1, p.zsplit) + 3) & ~3, p.ldz1);
+  const int wa = max(a1 - a0, 0), wg = max(g1 - g0, 0);
+
+  // 16-row images: floats, DMA wave-instructions (1 KiB each), LDS offsets
+  const int xfl = 16 * p.ldx, afl = 16 * wa, gfl = 16 * wg;
+  const int xin = (xfl + 255) >> 8, ain = (afl + 255) >> 8, gin = (gfl + 255) >> 8;
+  const int offA = xin * 256, offG = offA + ain * 256, offD = offG + gin * 256;
+  const int stage = offD + 256;  // + one dummy 1 KiB slot for idle DMA slots
+
   // row range of this workgroup in units of 16 rows
   const int units = (p.m + 15) >> 4;
   const int ubase = units / gridDim.x, urem = units % gridDim.x;
   const int u0 = blockIdx.x * ubase + (blockIdx.x < urem ? blockIdx.x : urem);
   const int nu = ubase + (blockIdx.x < urem ? 1 : 0);
 
-  // DMA slot s = wave*3 + j (wave-uniform): [0,xin) -> X, [xin,xin+ain) -> dZa, [..,+gin) -> G, else dummy.
-  // Every image is one contiguous run of 16*ld floats per unit, so each lane just bumps a pointer.
+  // DMA slot s = wave*3 + j (wave-uniform): [0,xin) -> X, [xin,xin+ain) -> dZa window, [..,+gin) -> G window, else
+  // dummy.  A lane's piece is float4 number f4 of the compact [16][w] image: row f4 / (w/4), column c0 + 4 (f4 % (w/4))
+  // of the source; the source advances by 16 rows per unit, so each lane just bumps a pointer.
   const float *sp[3];   // this lane's source for the next unit (zeros for idle lanes)
   int sstep[3];         // floats to advance per unit (0 for idle lanes)
   int sdst[3];          // LDS float offset of the slot inside a stage (wave-uniform)
-  int sf[3], sld[3];    // flat float index of this lane's piece inside the image, and the image's row stride
+  int srow[3];          // image row of this lane's piece (ragged-tail test); huge for idle lanes
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     const int s = wave * 3 + j;
     const float *img = nullptr;
-    int ld = 0, fl = 0, li = 0;
+    int ld = 0, w = 4, c0 = 0, li = 0;
     sdst[j] = offD;
     if (s < xin) {
-      img = p.x; ld = p.ldx; fl = xfl; li = s; sdst[j] = li * 256;
+      img = p.x; ld = p.ldx; w = p.ldx; c0 = 0; li = s; sdst[j] = li * 256;
     } else if (s < xin + ain) {
-      img = p.z0; ld = p.ldz0; fl = afl; li = s - xin; sdst[j] = offA + li * 256;
+      img = p.z0; ld = p.ldz0; w = wa; c0 = a0; li = s - xin; sdst[j] = offA + li * 256;
     } else if (s < xin + ain + gin) {
-      img = p.z1; ld = p.ldz1; fl = gfl; li = s - xin - ain; sdst[j] = offG + li * 256;
+      img = p.z1; ld = p.ldz1; w = wg; c0 = g0; li = s - xin - ain; sdst[j] = offG + li * 256;
     }
-    const int f = (li * 64 + lane) * 4;
-    const bool valid = img != nullptr && f < fl;
-    sp[j] = valid ? img + (size_t)u0 * 16 * ld + f : p.zeros;
+    const int wq = w >> 2, f4 = li * 64 + lane;
+    const int row = f4 / wq, c4 = f4 - row * wq;
+    const bool valid = img != nullptr && row < 16;
+    sp[j] = valid ? img + ((size_t)u0 * 16 + row) * ld + c0 + c4 * 4 : p.zeros;
     sstep[j] = valid ? 16 * ld : 0;
-    sf[j] = valid ? f : 0x7fffffff;
-    sld[j] = ld;
+    srow[j] = valid ? row : 0x7fffffff;
   }
 
   auto issue = [&](int unit, int buf) {
@@ -752,7 +761,7 @@ __global__ __launch_bounds__(1024, 1) void dw_kernel(DwArgs p) {
     } else {  // ragged global tail: rows >= m contribute zeros
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
-        glds16(sf[j] < rows_left * sld[j] ? sp[j] : p.zeros, base + sdst[j]);
+        glds16(srow[j] < rows_left ? sp[j] : p.zeros, base + sdst[j]);
         sp[j] += sstep[j];
       }
     }
@@ -769,28 +778,34 @@ __global__ __launch_bounds__(1024, 1) void dw_kernel(DwArgs p) {
 #pragma unroll
   for (int j = 0; j < DW_MAXO; ++j) {
     const int col = (o0 + j) * 16 + l16;
-    zoff[j] = col < p.zsplit ? offA + col : offG + col;
+    zoff[j] = col < p.zsplit ? offA + (col - a0) : offG + (col - g0);
   }
 
-  // 3-stage ring, one barrier per 16-row stage; unit t+2 is issued right after the barrier of iteration t.
+  // NST-stage ring, one barrier per 16-row stage; unit t+NST-1 is issued right after the barrier of iteration t (into
+  // the stage everyone finished reading before that barrier).  NST comes from the launcher: as many stages as the
+  // windowed images leave room for in LDS (4 at 300 x 300), at least 3.
   const int xoff = i0 * 16 + l16;
-  if (nu > 0) issue(u0, 0);
-  if (nu > 1) issue(u0 + 1, 1);
+  const int nst = p.nstage;
+  for (int d = 0; d < nst - 1; ++d)
+    if (d < nu) issue(u0 + d, d);
   int buf = 0;
   for (int t = 0; t < nu; ++t) {
-    if (t + 1 < nu) wait_vmcnt<3>();
+    const int younger = min(nu - 1 - t, nst - 2);  // stages issued after unit t that may still be in flight
+    if (younger >= 3) wait_vmcnt<9>();
+    else if (younger == 2) wait_vmcnt<6>();
+    else if (younger == 1) wait_vmcnt<3>();
     else wait_vmcnt<0>();
 #ifndef A3VT_DBG_NOBARRIER
     __builtin_amdgcn_s_barrier();
 #endif
 #ifndef A3VT_DBG_NODMA
-    if (t + 2 < nu) issue(u0 + t + 2, buf >= 1 ? buf - 1 : 2);
+    if (t + nst - 1 < nu) issue(u0 + t + nst - 1, buf >= 1 ? buf - 1 : nst - 1);
 #endif
     const float *sb = lds + buf * stage;
-    if (BF16) dw_stage_bf16(sb, p.ldx, p.ldz0, p.ldz1, offG, xoff, zoff, q, ni, no, acc);
-    else if (FAST) dw_stage_fast(sb, p.ldx, p.ldz0, p.ldz1, offG, xoff, zoff, q, ni == 5, no == 3, acc);
-    else dw_stage<-1, -1>(sb, p.ldx, p.ldz0, p.ldz1, offG, xoff, zoff, q, ni, no, acc);
-    buf = buf == 2 ? 0 : buf + 1;
+    if (BF16) dw_stage_bf16(sb, p.ldx, wa, wg, offG, xoff, zoff, q, ni, no, acc);
+    else if (FAST) dw_stage_fast(sb, p.ldx, wa, wg, offG, xoff, zoff, q, ni == 5, no == 3, acc);
+    else dw_stage<-1, -1>(sb, p.ldx, wa, wg, offG, xoff, zoff, q, ni, no, acc);
+    buf = buf == nst - 1 ? 0 : buf + 1;
   }
   wait_lgkm0();
 
@@ -830,11 +845,29 @@ int launch_dw(const DwArgs &a, hipStream_t s) {
     set_error("dw: rows too wide (%d + %d + %d floats)", a.ldx, a.ldz0, a.ldz1);
     return -1;
   }
-  const size_t shmem = 3 * (size_t)((xin + ain + gin) * 256 + 256) * sizeof(float);
-  if (shmem > 160 * 1024) {
-    set_error("dw: rows too wide for the 3-stage ring (%zu B)", shmem);
+  // Stage size of the largest column group (the kernel stages only each group's own dZ columns), ring as deep as fits.
+  const int tout_all = cdiv(a.n_out, 16), ngrp = dw_col_groups(a.n_out);
+  int worst = 0;
+  for (int gy = 0; gy < ngrp; ++gy) {
+    const int gbase = tout_all / ngrp, grem = tout_all % ngrp;
+    const int gt0 = gy * gbase + (gy < grem ? gy : grem), gtn = gbase + (gy < grem ? 1 : 0);
+    const int c0 = gt0 * 16, c1 = (gt0 + gtn) * 16 < a.n_out ? (gt0 + gtn) * 16 : a.n_out;
+    const int a0 = (c0 < a.zsplit ? c0 : a.zsplit) & ~3, a1 = ((c1 < a.zsplit ? c1 : a.zsplit) + 3) & ~3;
+    const int g0 = (c0 > a.zsplit ? c0 : a.zsplit) & ~3;
+    int g1 = ((c1 > a.zsplit ? c1 : a.zsplit) + 3) & ~3;
+    g1 = g1 < a.ldz1 ? g1 : a.ldz1;
+    const int wa = a1 > a0 ? a1 - a0 : 0, wg = g1 > g0 ? g1 - g0 : 0;
+    const int units = xin + (16 * wa + 255) / 256 + (16 * wg + 255) / 256 + 1;
+    worst = units > worst ? units : worst;
+  }
+  DwArgs args = a;
+  args.nstage = (int)((160 * 1024) / ((size_t)worst * 1024));
+  args.nstage = args.nstage > 5 ? 5 : args.nstage;
+  if (args.nstage < 3) {
+    set_error("dw: rows too wide for a 3-stage ring (%d KB per stage)", worst);
     return -1;
   }
+  const size_t shmem = (size_t)args.nstage * worst * 1024;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void *)dw_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -846,9 +879,9 @@ int launch_dw(const DwArgs &a, hipStream_t s) {
   const int tin = cdiv(a.k_in, 16), tout = cdiv(a.n_out, 16), groups = dw_col_groups(a.n_out);
   const bool fast = tin / 4 >= 4 && tin <= 20 && (tout / groups) / 4 >= 2 && cdiv(tout, groups) <= 12;
   const dim3 grid(dw_num_slabs(a.n_out), groups);
-  if (a.bf16) A3VT_LAUNCH((dw_kernel<false, true>), grid, dim3(1024), shmem, s, a);
-  else if (fast) A3VT_LAUNCH((dw_kernel<true, false>), grid, dim3(1024), shmem, s, a);
-  else A3VT_LAUNCH((dw_kernel<false, false>), grid, dim3(1024), shmem, s, a);
+  if (a.bf16) A3VT_LAUNCH((dw_kernel<false, true>), grid, dim3(1024), shmem, s, args);
+  else if (fast) A3VT_LAUNCH((dw_kernel<true, false>), grid, dim3(1024), shmem, s, args);
+  else A3VT_LAUNCH((dw_kernel<false, false>), grid, dim3(1024), shmem, s, args);
   A3VT_CHECK_LAUNCH();
   return 0;
 }

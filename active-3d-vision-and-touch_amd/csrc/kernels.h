@@ -54,6 +54,7 @@ struct DwArgs {
   int ldx, ldz0, ldz1, zsplit;
   int m, k_in, n_out;
   int bf16;  // as RowGemmArgs::bf16
+  int nstage;  // LDS ring depth (set by launch_dw)
 };
 int dw_num_slabs(int n_out);
 int launch_dw(const DwArgs &a, hipStream_t s);
