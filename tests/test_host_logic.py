@@ -203,3 +203,18 @@ def test_install_as_pterotactyl_registers_the_mirror():
             "assert hasattr(q, 'Graph_Model') and hasattr(s, 'score_actions'); print('ok')") % ROOT
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
+def test_public_header_is_plain_c(tmp_path):
+    """include/a3vt.h is the drop-in boundary: it must compile as C99 and as C++ with nothing but <stddef.h>/<stdint.h>."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "use.c"
+    src.write_text('#include "a3vt.h"\nint probe(void) { return a3vt_version() > 0 ? 0 : 1; }\n')
+    inc = os.path.join(ROOT, "include")
+    for cmd in (["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", inc, "-c", str(src), "-o", str(tmp_path / "c.o")],
+                ["g++", "-std=c++17", "-Wall", "-Werror", "-x", "c++", "-I", inc, "-c", str(src), "-o", str(tmp_path / "cc.o")]):
+        out = subprocess.run(cmd, capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
