@@ -171,12 +171,13 @@ def test_dataset_wire_format(tmp_path, finger):
     assert batch["img"].shape == (3, 3, 256, 256) and 0.0 <= batch["img"].min() and batch["img"].max() <= 1.0
     assert batch["touch_charts"].shape == ((3, 3, 25, 4) if finger else (3, 3, 4, 25, 4))
     name, grasps = batch["names"][0]
-    assert name.endswith("object_info/4") and len(grasps) <= 3
+    oid = os.path.basename(name)                              # glob order is file-system dependent: object 4 or 5
+    assert os.path.dirname(name).endswith("object_info") and oid in ("4", "5") and len(grasps) <= 3
     # validation instances are deterministic (seeded by position), unused grasp slots are all-zero charts
     again = valid[0]
     assert again["names"][1] == valid[0]["names"][1]
     assert torch.equal(batch["touch_charts"][0][len(grasps):], torch.zeros_like(batch["touch_charts"][0][len(grasps):]))
-    raw = np.load(os.path.join(str(tmp_path), "touch_charts", "4", "touch_charts.npy")).reshape(50, 4, 25, 4)
+    raw = np.load(os.path.join(str(tmp_path), "touch_charts", oid, "touch_charts.npy")).reshape(50, 4, 25, 4)
     if grasps:
         want = raw[grasps[0]][1] if finger else raw[grasps[0]]
         assert np.array_equal(batch["touch_charts"][0][0].numpy(), want)
