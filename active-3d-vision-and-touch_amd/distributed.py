@@ -30,22 +30,51 @@ def init_from_env(backend=None):
 
 
 class FlatGradBucket:
-    """Re-homes every parameter's ``.grad`` as a view into one contiguous buffer, so the whole gradient is
-    reduced with a single collective and the optimiser reads the averaged values in place."""
+    """One contiguous buffer for the whole gradient: a single collective reduces it and the optimiser reads the
+    averaged values in place (every ``.grad`` is a view into the buffer when ``optimizer.step()`` runs).
+
+    Step protocol: ``zero()`` -> ``loss.backward()`` -> ``all_reduce_mean()`` -> ``optimizer.step()``.
+    ``zero()`` clears the ``.grad`` fields rather than memsetting the buffer, so autograd *assigns* each gradient
+    instead of launching one ``grad += g`` kernel per parameter (131 launches per step on the 20 x 300 model);
+    ``all_reduce_mean()`` then gathers them into the buffer with one multi-tensor copy and re-homes ``.grad``."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(n, dtype=self.params[0].dtype, device=self.params[0].device)
+        self.views = []
         off = 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
+        self._rehome()
+
+    def _rehome(self):
+        for p, v in zip(self.params, self.views):
+            p.grad = v
 
     def zero(self):
-        self.flat.zero_()
+        for p in self.params:
+            p.grad = None
+
+    def gather(self):
+        """Collect the freshly assigned gradients into the flat buffer (no-op for gradients already living there)."""
+        pieces, fresh = [], False
+        for p, v in zip(self.params, self.views):
+            g = p.grad
+            if g is None:                               # parameter unused in this graph
+                g = torch.zeros_like(v)
+            if g.data_ptr() != v.data_ptr():
+                fresh = True
+            pieces.append(g)
+        if fresh:                                       # pieces that already live in the buffer must not alias the output
+            flat_pieces = [g.reshape(-1).clone() if g.data_ptr() == v.data_ptr() else g.reshape(-1)
+                           for g, v in zip(pieces, self.views)]
+            torch.cat(flat_pieces, out=self.flat)
+        self._rehome()
 
     def all_reduce_mean(self, async_op=False):
+        self.gather()
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return None
         self.flat.div_(dist.get_world_size())

@@ -149,7 +149,9 @@ def test_g8_image_modes(cuda, tag, use_touch):
     for key in [k for k in z.files if k.startswith("g:")]:
         gk = params[key[2:]].grad
         got = gk if gk.numel() < 40000 else gk[..., ::7, ::11]
-        assert_grad_close(got, torch.from_numpy(z[key]), key)
+        # MIOpen picks its convolution algorithms per process; with some of them a few more ReLU / max-pool decisions of
+        # the 14-layer encoders flip relative to the CPU reference (observed: relative L2 up to 1.1e-3) -> 3e-3 here
+        assert_grad_close(got, torch.from_numpy(z[key]), key, tol=3e-3, outlier_frac=3e-3, l2_tol=3e-3)
 
 
 @pytest.mark.parametrize("tag,kin,nout,do_cut,relu", [("cut", 50, 300, True, True), ("nocut", 300, 300, False, False)])
