@@ -401,10 +401,91 @@ static int launch_rowgemm_cols(const RowGemmArgs &a, hipStream_t s) {
   return launch_rowgemm_nt<19, EPI>(a, cdiv(nt, 19), s);
 }
 
+// ------------------------------------------------------------------------------------------------
+// rowtile: the same product for a handful of rows (the remainder of the load-balanced split below: 128 rows at
+// bs 64).  With so little work the ring kernel is pure latency (19 dependent DMA round trips, 12.7 us per launch,
+// 111 launches per step), so here every wave owns ONE 16 x 16 output tile and pulls its operands straight from
+// global memory into registers — all loads of up to 19 K-chunks in flight at once, no LDS, no barrier — then runs
+// the MFMA chain: one round trip instead of nineteen.  Same arithmetic order along K as rowgemm_kernel.
+// grid = (column tiles, row tiles / 4), 4 waves per workgroup.
+// ------------------------------------------------------------------------------------------------
+template <int EPI, bool BF16>
+__global__ __launch_bounds__(256) void rowtile_kernel(RowGemmArgs p) {
+  constexpr int KB = 19;  // K-chunks (of 16) per register block: all of K = 300 in one round trip
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l16 = lane & 15, q = lane >> 4;
+  const int mt = blockIdx.y * 4 + wave;
+  if (mt * 16 >= p.m) return;
+  const int n0 = p.col0 + blockIdx.x * 16;
+  const int ar = min(mt * 16 + l16, p.m - 1);                  // A row of this lane (ragged tail: duplicate, never stored)
+  const int br = min(n0 + l16, p.bt_rows - 1);                 // Bt row (= output column) of this lane
+  const float *a0r = p.a0 + (size_t)ar * p.lda0, *a1r = p.a1 + (size_t)ar * p.lda1;
+  const float *btr = p.bt + (size_t)br * p.ldb;
+  const int nch = (p.k + 15) >> 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int c0 = 0; c0 < nch; c0 += KB) {
+    f32x4 af[KB], bf[KB];
+#pragma unroll
+    for (int c = 0; c < KB; ++c) {
+      const int kk = (c0 + c) * 16 + q * 4;
+      const bool on = c0 + c < nch && kk < p.k;
+      af[c] = on ? *reinterpret_cast<const f32x4 *>((kk < p.ksplit ? a0r : a1r) + kk) : f32x4{0.f, 0.f, 0.f, 0.f};
+      bf[c] = on ? *reinterpret_cast<const f32x4 *>(btr + kk) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int c = 0; c < KB; ++c) {
+      if (BF16) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(cvt_bf16x4(af[c]), cvt_bf16x4(bf[c]), acc, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c][t], bf[c][t], acc, 0, 0, 0);
+      }
+    }
+  }
+  // C/D layout: this lane holds column n0 + l16 of rows 4q .. 4q+3 of the tile
+  const int col = n0 + l16;
+  const bool col_ok = col < p.n_store;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = mt * 16 + q * 4 + r;
+    const bool row_ok = row < p.m;
+    float v = acc[r];
+    if (EPI == EPI_PLAIN) {
+      if (row_ok && col_ok) p.c[(size_t)row * p.ldc + col] = v;
+    } else if (EPI == EPI_FWD_HIDDEN) {
+      // ReLU-sign byte of 4 consecutive pass-through columns: gathered from the 4 lanes that hold them
+      const unsigned mybit = (col_ok && col >= p.csplit && v > 0.f) ? 1u << (l16 & 3) : 0u;
+      unsigned bits = mybit;
+      bits |= __shfl_xor(bits, 1, 64);
+      bits |= __shfl_xor(bits, 2, 64);
+      if (row_ok && p.maskb && (l16 & 3) == 0 && (col | 3) >= p.csplit && col < ((p.n_store + 3) & ~3))
+        p.maskb[(size_t)row * p.mld + p.moff + (col >> 2)] = (uint8_t)bits;
+      if (row_ok && col_ok) {
+        if (col < p.csplit) p.c2[(size_t)row * p.ldc2 + col] = v;
+        else p.c[(size_t)row * p.ldc + col] = (v > 0.f || p.no_relu) ? v : 0.f;
+      }
+    } else {  // EPI_DX_MASK
+      if (row_ok && col_ok) {
+        const unsigned byte = p.maskb[(size_t)row * p.mld + (col < p.csplit ? 0 : p.moff) + (col >> 2)];
+        p.c[(size_t)row * p.ldc + col] = ((byte >> (col & 3)) & 1u) ? v : 0.f;
+      }
+    }
+  }
+}
+
+template <int EPI>
+static int launch_rowtile(const RowGemmArgs &a, hipStream_t s) {
+  const dim3 grid(cdiv(a.n_store, 16), cdiv(cdiv(a.m, 16), 4));
+  if (a.bf16) A3VT_LAUNCH((rowtile_kernel<EPI, true>), grid, dim3(256), 0, s, a);
+  else A3VT_LAUNCH((rowtile_kernel<EPI, false>), grid, dim3(256), 0, s, a);
+  A3VT_CHECK_LAUNCH();
+  return 0;
+}
+
 // Load balance.  The chip runs 2048 waves of this kernel at once (256 CUs x 4 SIMDs x 2), each owning 16-row
 // tiles in pairs; M = 163,968 rows = 10,248 tiles would leave almost every SIMD idle while a few run a sixth
 // tile pair (+20 % time).  When such a small remainder exists, the tiles that fill whole rounds go to the main
-// launch and the leftover rows are re-cut along N: one 16-column tile per workgroup.
+// launch and the leftover rows go to rowtile_kernel: one 16 x 16 tile per wave, operands from registers.
 template <int EPI>
 static int launch_rowgemm_epi(const RowGemmArgs &a0, hipStream_t s) {
   RowGemmArgs a = a0;
@@ -424,7 +505,7 @@ static int launch_rowgemm_epi(const RowGemmArgs &a0, hipStream_t s) {
   r.c = a.c + r0 * a.ldc;
   if (a.c2) r.c2 = a.c2 + r0 * a.ldc2;
   if (a.maskb) r.maskb = a.maskb + r0 * a.mld;
-  return launch_rowgemm_nt<1, EPI>(r, nt, s);
+  return launch_rowtile<EPI>(r, s);
 }
 
 // Rows of Bt the kernel stages for a given n (must exist, zero padded, in the Bt buffer).
