@@ -144,14 +144,48 @@ int launch_posenc_fwd(const float *verts, const float *mask, int m, int input_si
 }
 
 // ------------------------------------------------------------------------------------------------
-// Backward.  Workgroup = 128 vertices, one per thread.  Every per-vertex vector the weight-gradient outer
-// products need (e, gout, h2, dh2, h1, dh1) is parked in LDS rows; the thread keeps only the small hidden
-// vectors in registers and walks the long ones with rolled loops (no spills).  After one barrier the
-// workgroup reduces the outer products over its 128 vertices and writes one slab of partial gradients.
+// Backward.  Workgroup = 128 vertices (256 threads).  The per-vertex work is a chain of small dense products over the
+// block's vertices — the forward recompute (63 -> 12 -> 25), the back-propagation (50 -> 25 -> 12 -> 63) — and the
+// parameter gradients are outer-product sums over the same vertices, so everything runs as 16 x 16 tiles of
+// v_mfma_f32_16x16x4_f32 (exact fp32) on vertex rows parked in LDS; threads only compute sin / cos, the ReLU masks and
+// the 63-term position gradient.  (The first version did all of it with per-thread scalar FMAs fed by LDS reads at
+// two waves per CU: 445 us per call against ~70 us here.)
+// LDS: weight images as B operands [k][n] with the bias as an extra k row against a 1 in the vertex row, zero rows
+// where K is padded to a multiple of 4; vertex rows E|1, G, H1|1, H2|1, D2, D1, DE, one-hot token.
 // ------------------------------------------------------------------------------------------------
-constexpr int kPEBwdThreads = 128;
+constexpr int kPEBwdVerts = 128;
+constexpr int kPEBwdThreads = 256;
 
-int posenc_num_slabs(int m) { return cdiv(m, kPEBwdThreads); }
+int posenc_num_slabs(int m) { return cdiv(m, kPEBwdVerts); }
+
+template <int I>
+struct PEB {
+  using P = PE<I>;
+  static constexpr int T = kPEBwdVerts, H1 = P::H1, H2 = P::H2;
+  // B-operand weight images
+  static constexpr int oB1 = 0;                      // [64][H1]   rows 0..62 = W1^T, row 63 = b1          (E|1 -> h1)
+  static constexpr int oB2 = oB1 + 64 * H1;          // [16][H2]   rows 0..11 = W2^T, row 12 = b2, rest 0  (H1|1 -> h2)
+  static constexpr int oB3 = oB2 + 16 * H2;          // [52][H2]   = W3 (o, k), rows 50, 51 = 0            (G -> dh2)
+  static constexpr int oB4 = oB3 + 52 * H2;          // [28][H1]   = W2 (j, k), rows 25..27 = 0            (D2 -> dh1)
+  static constexpr int oB5 = oB4 + 28 * H1;          // [12][63]   = W1 (j, k)                             (D1 -> de)
+  static constexpr int NW = oB5 + H1 * 63 + 16;      // + slack for the 16-wide reads of the last row
+  // vertex rows
+  static constexpr int LE = 64, LG = 52, LH1 = 16, LH2 = 28, LD2 = 28, LD1 = 16, LDE = 64, LOH = 4;
+  static constexpr int oE = NW, oG = oE + T * LE, oH1 = oG + T * LG, oH2 = oH1 + T * LH1, oD2 = oH2 + T * LH2,
+                       oD1 = oD2 + T * LD2, oDE = oD1 + T * LD1, oOH = oDE + T * LDE, N = oOH + T * LOH + 64;
+  static_assert(I == 50, "layout written for I = 50 (H1 = 12, H2 = 25)");
+};
+
+// 16 x 16 tile of A[rows m0.., K] * B[K, cols n0..]: A rows in LDS (stride lda), B rows in LDS (stride ldb), K % 4 == 0.
+// The lane ends up with column n0 + l16 of rows m0 + 4 kq .. + 3.
+__device__ __forceinline__ f32x4 pe_tile(const float *A, int lda, int m0, const float *B, int ldb, int n0, int K, int l16,
+                                         int kq) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const float *pa = A + (m0 + l16) * lda + kq, *pb = B + kq * ldb + n0 + l16;
+#pragma unroll 4
+  for (int k = 0; k < K; k += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[k], pb[k * ldb], acc, 0, 0, 0);
+  return acc;
+}
 
 template <int I>
 __global__ __launch_bounds__(kPEBwdThreads) void posenc_bwd_kernel(const float *__restrict__ verts,
@@ -161,156 +195,179 @@ __global__ __launch_bounds__(kPEBwdThreads) void posenc_bwd_kernel(const float *
                                                                    float *__restrict__ gverts,
                                                                    float *__restrict__ slab) {
   using P = PE<I>;
-  using L = PELds<I>;
-  constexpr int T = kPEBwdThreads;
-  constexpr int H1 = P::H1, H2 = P::H2;
+  using B = PEB<I>;
+  constexpr int T = B::T, H1 = B::H1, H2 = B::H2;
   extern __shared__ float smem[];
-  // per-vertex vectors, row = vertex.  E, H2 and H1 carry a trailing 1 so that the bias gradients fall out of the same
-  // outer-product tiles as the weight gradients; OH is the one-hot mask token (embedding gradient).
-  constexpr int LE = 64, LG = I, LH2 = H2 + 1, LD2 = H2, LH1 = H1 + 1, LD1 = H1, LOH = 4;
-  float *sp = smem;                  // parameters (transposed image)
-  float *sE = sp + L::N;             // [T][64]  e | 1
-  float *sG = sE + T * LE;           // [T][I]   gout
-  float *sH2 = sG + T * LG;          // [T][H2+1] h2 | 1
-  float *sD2 = sH2 + T * LH2;        // [T][H2]  dh2
-  float *sH1 = sD2 + T * LD2;        // [T][H1+1] h1 | 1
-  float *sD1 = sH1 + T * LH1;        // [T][H1]  dh1
-  float *sOH = sD1 + T * LD1;        // [T][4]   one-hot token (all zero for padding rows); + 64 floats of slack
-  pe_load_params<I>(params, sp);
-  __syncthreads();
+  float *sE = smem + B::oE, *sG = smem + B::oG, *sH1 = smem + B::oH1, *sH2 = smem + B::oH2, *sD2 = smem + B::oD2,
+        *sD1 = smem + B::oD1, *sDE = smem + B::oDE, *sOH = smem + B::oOH;
   const int t = threadIdx.x;
-  const int v = blockIdx.x * T + t;
-  const bool live = v < m;
+  const int lane = t & 63, wave = t >> 6, l16 = lane & 15, kq = lane >> 4;
   float *out = slab + (size_t)blockIdx.x * P::N;
 
-  float p[3] = {0.f, 0.f, 0.f};
-  if (live) {
-    p[0] = verts[3 * (long long)v];
-    p[1] = verts[3 * (long long)v + 1];
-    p[2] = verts[3 * (long long)v + 2];
+  // ---- phase 0: weight images (all threads) and the vertex rows E|1, G, one-hot, constant columns (threads < T)
+  for (int i = t; i < B::NW; i += kPEBwdThreads) smem[i] = 0.f;
+  __syncthreads();
+  for (int i = t; i < H1 * 63; i += kPEBwdThreads) {  // W1 (j, k): transposed into B1, as is into B5
+    const int j = i / 63, k = i - j * 63;
+    const float w = params[P::oW1 + i];
+    smem[B::oB1 + k * H1 + j] = w;
+    smem[B::oB5 + i] = w;
   }
-  // ---- forward recompute: e -> LDS, h1 / h2 in registers
-  float *myE = sE + t * LE;
-#pragma unroll 1
-  for (int i = 0; i < 10; ++i) {
-    const float f = pe_freq(i);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      myE[6 * i + c] = sinf(f * p[c]);
-      myE[6 * i + 3 + c] = cosf(f * p[c]);
+  for (int i = t; i < H1; i += kPEBwdThreads) smem[B::oB1 + 63 * H1 + i] = params[P::ob1 + i];
+  for (int i = t; i < H2 * H1; i += kPEBwdThreads) {  // W2 (j, k)
+    const int j = i / H1, k = i - j * H1;
+    const float w = params[P::oW2 + i];
+    smem[B::oB2 + k * H2 + j] = w;
+    smem[B::oB4 + i] = w;
+  }
+  for (int i = t; i < H2; i += kPEBwdThreads) smem[B::oB2 + H1 * H2 + i] = params[P::ob2 + i];
+  for (int i = t; i < I * H2; i += kPEBwdThreads) smem[B::oB3 + i] = params[P::oW3 + i];  // W3 (o, k)
+  {  // embedding: two threads per vertex, five frequencies each
+    const int tv = t >> 1, half = t & 1;
+    const int v = blockIdx.x * T + tv;
+    float p[3] = {0.f, 0.f, 0.f};
+    if (v < m) {
+      p[0] = verts[3 * (long long)v];
+      p[1] = verts[3 * (long long)v + 1];
+      p[2] = verts[3 * (long long)v + 2];
     }
-  }
-  myE[60] = p[0];
-  myE[61] = p[1];
-  myE[62] = p[2];
-  myE[63] = 1.f;
-  float h1[H1], h2[H2];
-#pragma unroll
-  for (int j = 0; j < H1; ++j) h1[j] = sp[L::ob1 + j];
+    float *myE = sE + tv * B::LE;
 #pragma unroll 1
-  for (int k = 0; k < 63; ++k) {
-    const float ek = myE[k];
+    for (int i = half * 5; i < half * 5 + 5; ++i) {
+      const float f = pe_freq(i);
 #pragma unroll
-    for (int j = 0; j < H1; ++j) h1[j] += sp[L::oW1t + k * H1 + j] * ek;
-  }
-#pragma unroll
-  for (int j = 0; j < H1; ++j) {
-    h1[j] = h1[j] > 0.f ? h1[j] : 0.f;
-    sH1[t * LH1 + j] = h1[j];
-  }
-  sH1[t * LH1 + H1] = 1.f;
-#pragma unroll
-  for (int j = 0; j < H2; ++j) h2[j] = sp[L::ob2 + j];
-#pragma unroll
-  for (int k = 0; k < H1; ++k)
-#pragma unroll
-    for (int j = 0; j < H2; ++j) h2[j] += sp[L::oW2t + k * H2 + j] * h1[k];
-#pragma unroll
-  for (int j = 0; j < H2; ++j) {
-    h2[j] = h2[j] > 0.f ? h2[j] : 0.f;
-    sH2[t * LH2 + j] = h2[j];
-  }
-  sH2[t * LH2 + H2] = 1.f;
-  int tok = live ? (int)mask[v] : 0;
-  tok = tok < 0 ? 0 : (tok > 3 ? 3 : tok);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) sOH[t * LOH + k] = (live && tok == k) ? 1.f : 0.f;
-
-  // ---- backward through the MLP
-  float dh2[H2];
-#pragma unroll
-  for (int k = 0; k < H2; ++k) dh2[k] = 0.f;
-#pragma unroll 1
-  for (int o = 0; o < I; ++o) {
-    const float g = live ? gfeats[(long long)v * ld + o] : 0.f;
-    sG[t * LG + o] = g;
-#pragma unroll
-    for (int k = 0; k < H2; ++k) dh2[k] += sp[L::oW3t + k * I + o] * g;
-  }
-#pragma unroll
-  for (int k = 0; k < H2; ++k) {
-    dh2[k] = h2[k] > 0.f ? dh2[k] : 0.f;
-    sD2[t * LD2 + k] = dh2[k];
-  }
-  float dh1[H1];
-#pragma unroll
-  for (int k = 0; k < H1; ++k) dh1[k] = 0.f;
-#pragma unroll
-  for (int j = 0; j < H2; ++j)
-#pragma unroll
-    for (int k = 0; k < H1; ++k) dh1[k] += sp[L::oW2t + k * H2 + j] * dh2[j];
-#pragma unroll
-  for (int k = 0; k < H1; ++k) {
-    dh1[k] = h1[k] > 0.f ? dh1[k] : 0.f;
-    sD1[t * LD1 + k] = dh1[k];
-  }
-  // gradient w.r.t. the position: de_k = sum_j W1[j][k] dh1[j];
-  // d sin(f p)/dp = f cos(f p) = f e[6i+3+c],  d cos(f p)/dp = -f sin(f p) = -f e[6i+c]
-  float gp[3] = {0.f, 0.f, 0.f};
-#pragma unroll 1
-  for (int i = 0; i < 10; ++i) {
-    const float f = pe_freq(i);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      float ds = 0.f, dc = 0.f;
-#pragma unroll
-      for (int j = 0; j < H1; ++j) {
-        ds += sp[L::oW1t + (6 * i + c) * H1 + j] * dh1[j];
-        dc += sp[L::oW1t + (6 * i + 3 + c) * H1 + j] * dh1[j];
+      for (int c = 0; c < 3; ++c) {
+        myE[6 * i + c] = sinf(f * p[c]);
+        myE[6 * i + 3 + c] = cosf(f * p[c]);
       }
-      gp[c] += f * (myE[6 * i + 3 + c] * ds - myE[6 * i + c] * dc);
+    }
+    if (half == 0) {
+      myE[60] = p[0];
+      myE[61] = p[1];
+      myE[62] = p[2];
+      myE[63] = 1.f;
     }
   }
+  // upstream gradient rows: coalesced 16-byte pieces of the [T][ld] tile (columns >= I are zero by contract when ld >= 52)
+  for (int i = t; i < T * (B::LG / 4); i += kPEBwdThreads) {
+    const int r = i / (B::LG / 4), c4 = i - r * (B::LG / 4);
+    const int v = blockIdx.x * T + r;
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    if (v < m) {
+      if (c4 * 4 + 3 < ld) {
+        g = *reinterpret_cast<const f32x4 *>(gfeats + (long long)v * ld + c4 * 4);
+      } else {
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    float d = 0.f;
+        for (int k = 0; k < 4; ++k)
+          if (c4 * 4 + k < ld) g[k] = gfeats[(long long)v * ld + c4 * 4 + k];
+      }
 #pragma unroll
-    for (int j = 0; j < H1; ++j) d += sp[L::oW1t + (60 + c) * H1 + j] * dh1[j];
-    gp[c] += d;
+      for (int k = 0; k < 4; ++k)
+        if (c4 * 4 + k >= I) g[k] = 0.f;
+    }
+    *reinterpret_cast<f32x4 *>(sG + r * B::LG + c4 * 4) = g;
   }
-  if (live) {
-    gverts[3 * (long long)v + 0] = gp[0];
-    gverts[3 * (long long)v + 1] = gp[1];
-    gverts[3 * (long long)v + 2] = gp[2];
+  if (t < T) {
+    const int v = blockIdx.x * T + t;
+    const bool live = v < m;
+    int tok = live ? (int)mask[v] : 0;
+    tok = tok < 0 ? 0 : (tok > 3 ? 3 : tok);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sOH[t * B::LOH + k] = (live && tok == k) ? 1.f : 0.f;
+    sH1[t * B::LH1 + H1] = 1.f;   // bias column; the other pad columns stay finite zeros
+#pragma unroll
+    for (int k = H1 + 1; k < B::LH1; ++k) sH1[t * B::LH1 + k] = 0.f;
+    sH2[t * B::LH2 + H2] = 1.f;
+#pragma unroll
+    for (int k = H2 + 1; k < B::LH2; ++k) sH2[t * B::LH2 + k] = 0.f;
+#pragma unroll
+    for (int k = H2; k < B::LD2; ++k) sD2[t * B::LD2 + k] = 0.f;
+#pragma unroll
+    for (int k = H1; k < B::LD1; ++k) sD1[t * B::LD1 + k] = 0.f;
   }
   __syncthreads();
 
-  // ---- workgroup reductions: every parameter gradient of the block is an outer-product sum over its T vertices,
-  // out[a][b] = sum_r A[r][a] B[r][b].  Each 16 x 16 tile of each product is one chain of T/4 exact-fp32 MFMAs
-  // (v_mfma_f32_16x16x4_f32, fixed order) fed straight from the LDS rows above; rows of padding vertices are zero in
-  // G / D2 / D1 / OH, columns past an array's width read the neighbouring row and only reach discarded outputs.
-  struct Job { const float *A; int lda, a0, na; const float *B; int ldb, b0; int kind; };
-  const int lane = t & 63, wave = t >> 6, l16 = lane & 15, kq = lane >> 4;
+  constexpr int NW_ = kPEBwdThreads / 64, MT = T / 16;
+  // ---- phase 1: h1 = relu(E|1 . [W1^T; b1])
+  for (int tile = wave; tile < MT; tile += NW_) {
+    const f32x4 acc = pe_tile(sE, B::LE, tile * 16, smem + B::oB1, H1, 0, 64, l16, kq);
+    if (l16 < H1)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sH1[(tile * 16 + kq * 4 + r) * B::LH1 + l16] = acc[r] > 0.f ? acc[r] : 0.f;
+  }
+  __syncthreads();
+  // ---- phase 2: h2 = relu(H1|1 . [W2^T; b2])
+  for (int tile = wave; tile < MT * 2; tile += NW_) {
+    const int mt = tile >> 1, n0 = (tile & 1) * 16;
+    const f32x4 acc = pe_tile(sH1, B::LH1, mt * 16, smem + B::oB2, H2, n0, 16, l16, kq);
+    if (n0 + l16 < H2)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sH2[(mt * 16 + kq * 4 + r) * B::LH2 + n0 + l16] = acc[r] > 0.f ? acc[r] : 0.f;
+  }
+  __syncthreads();
+  // ---- phase 3: dh2 = (G . W3) * (h2 > 0)
+  for (int tile = wave; tile < MT * 2; tile += NW_) {
+    const int mt = tile >> 1, n0 = (tile & 1) * 16;
+    const f32x4 acc = pe_tile(sG, B::LG, mt * 16, smem + B::oB3, H2, n0, 52, l16, kq);
+    if (n0 + l16 < H2)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = mt * 16 + kq * 4 + r;
+        sD2[row * B::LD2 + n0 + l16] = sH2[row * B::LH2 + n0 + l16] > 0.f ? acc[r] : 0.f;
+      }
+  }
+  __syncthreads();
+  // ---- phase 4: dh1 = (D2 . W2) * (h1 > 0)
+  for (int tile = wave; tile < MT; tile += NW_) {
+    const f32x4 acc = pe_tile(sD2, B::LD2, tile * 16, smem + B::oB4, H1, 0, 28, l16, kq);
+    if (l16 < H1)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = tile * 16 + kq * 4 + r;
+        sD1[row * B::LD1 + l16] = sH1[row * B::LH1 + l16] > 0.f ? acc[r] : 0.f;
+      }
+  }
+  __syncthreads();
+  // ---- phase 5: de = D1 . W1
+  for (int tile = wave; tile < MT * 4; tile += NW_) {
+    const int mt = tile >> 2, n0 = (tile & 3) * 16;
+    const f32x4 acc = pe_tile(sD1, B::LD1, mt * 16, smem + B::oB5, 63, n0, H1, l16, kq);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sDE[(mt * 16 + kq * 4 + r) * B::LDE + n0 + l16] = acc[r];
+  }
+  __syncthreads();
+  // ---- phase 6: gradient w.r.t. the position.  d sin(f p)/dp = f cos(f p) = f e[6i+3+c], d cos(f p)/dp = -f e[6i+c]
+  if (t < T) {
+    const int v = blockIdx.x * T + t;
+    const float *e = sE + t * B::LE, *de = sDE + t * B::LDE;
+    float gp[3] = {de[60], de[61], de[62]};
+#pragma unroll 1
+    for (int i = 0; i < 10; ++i) {
+      const float f = pe_freq(i);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) gp[c] += f * (e[6 * i + 3 + c] * de[6 * i + c] - e[6 * i + c] * de[6 * i + 3 + c]);
+    }
+    if (v < m) {
+      gverts[3 * (long long)v + 0] = gp[0];
+      gverts[3 * (long long)v + 1] = gp[1];
+      gverts[3 * (long long)v + 2] = gp[2];
+    }
+  }
+
+  // ---- phase 7: parameter gradients of the block, out[a][b] = sum_r A[r][a] B[r][b] over its T vertex rows: each
+  // 16 x 16 tile of each product is one chain of T/4 MFMAs (fixed order).  Rows of padding vertices are zero in
+  // G / D2 / D1 / OH; columns past an array's width read the neighbouring row and only reach discarded outputs.
+  struct Job { const float *A; int lda, a0, na; const float *Bm; int ldb, b0; int kind; };
   constexpr int NA3 = (I + 15) / 16, NB3 = (H2 + 1 + 15) / 16, NA2 = (H2 + 15) / 16, NB1 = 4;
   constexpr int J3 = NA3 * NB3, JE = NA3, J2 = NA2, J1 = NB1, NJOBS = J3 + JE + J2 + J1;
-  for (int job = wave; job < NJOBS; job += T / 64) {
+  for (int job = wave; job < NJOBS; job += NW_) {
     Job jb;
-    if (job < J3) jb = Job{sG, LG, (job / NB3) * 16, I, sH2, LH2, (job % NB3) * 16, 0};                 // dW3 | db3
-    else if (job < J3 + JE) jb = Job{sG, LG, (job - J3) * 16, I, sOH, LOH, 0, 1};                        // dE
-    else if (job < J3 + JE + J2) jb = Job{sD2, LD2, (job - J3 - JE) * 16, H2, sH1, LH1, 0, 2};           // dW2 | db2
-    else jb = Job{sD1, LD1, 0, H1, sE, LE, (job - J3 - JE - J2) * 16, 3};                                // dW1 | db1
+    if (job < J3) jb = Job{sG, B::LG, (job / NB3) * 16, I, sH2, B::LH2, (job % NB3) * 16, 0};              // dW3 | db3
+    else if (job < J3 + JE) jb = Job{sG, B::LG, (job - J3) * 16, I, sOH, B::LOH, 0, 1};                    // dE
+    else if (job < J3 + JE + J2) jb = Job{sD2, B::LD2, (job - J3 - JE) * 16, H2, sH1, B::LH1, 0, 2};       // dW2 | db2
+    else jb = Job{sD1, B::LD1, 0, H1, sE, B::LE, (job - J3 - JE - J2) * 16, 3};                            // dW1 | db1
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const float *pa = jb.A + kq * jb.lda + jb.a0 + l16, *pb = jb.B + kq * jb.ldb + jb.b0 + l16;
+    const float *pa = jb.A + kq * jb.lda + jb.a0 + l16, *pb = jb.Bm + kq * jb.ldb + jb.b0 + l16;
 #pragma unroll 8
     for (int st = 0; st < T / 4; ++st)
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[st * 4 * jb.lda], pb[st * 4 * jb.ldb], acc, 0, 0, 0);
@@ -338,9 +395,7 @@ __global__ __launch_bounds__(kPEBwdThreads) void posenc_bwd_kernel(const float *
 
 template <int I>
 static size_t posenc_bwd_smem() {
-  using P = PE<I>;
-  constexpr int T = kPEBwdThreads;
-  return (size_t)(PELds<I>::N + T * (64 + I + (2 * P::H2 + 1) + (2 * P::H1 + 1) + 4) + 64) * sizeof(float);
+  return (size_t)PEB<I>::N * sizeof(float);
 }
 
 int launch_posenc_bwd(const float *verts, const float *mask, int m, int input_size, const float *params,
