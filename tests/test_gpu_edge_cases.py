@@ -125,3 +125,28 @@ def test_chamfer_ragged_sizes_and_ties(cuda, P, Q):
         assert int(ixy[0, 0, 0]) == 1 and float(dxy[0, 0, 0]) == 0.0
     cd_o = och.chamfer_pair(x[0].double(), y.double())
     assert rel_err(cd, cd_o) < 1e-5
+
+
+def test_error_conventions(cuda):
+    """C ABI: bad arguments return < 0 with a message in a3vt_last_error (surfaced as RuntimeError by the wrappers);
+    nothing is launched, nothing blocks.  The facade refuses CPU tensors instead of falling back."""
+    from a3vt_amd import lib, mesh as amesh, ops
+    from a3vt_amd.pterotactyl.utility import utils
+    L = lib.load()
+    verts, faces = template("ico1")
+    adj = ops.DeviceCSR(amesh.CSRAdjacency.from_pairs(*amesh.vision_pairs(faces, verts.shape[0]), verts.shape[0]), cuda)
+    n = verts.shape[0]
+    w = [torch.zeros(1, 50, 308, device=cuda), torch.zeros(1, 308, 3, device=cuda)]
+    b = [torch.zeros(308, device=cuda), torch.zeros(3, device=cuda)]
+    with pytest.raises(RuntimeError, match="hidden"):                       # hidden > 304 is not supported by the stack
+        ops.gcn_stack(torch.zeros(1, n, 52, device=cuda), adj, 50, 308, 100, w, b)
+    with pytest.raises(RuntimeError, match="vertices"):                     # adjacency / feature size mismatch
+        ops.gcn_stack(torch.zeros(1, n + 1, 52, device=cuda), adj, 50, 300, 99, w, b)
+    with pytest.raises(RuntimeError, match="GPU"):                          # no CPU fallback
+        utils.chamfer_distance(torch.zeros(1, n, 3), torch.from_numpy(faces), torch.zeros(1, 10, 3), num=10)
+    x = torch.zeros(1, 1, 4, 3, device=cuda)
+    rc = L.a3vt_chamfer_fwd(lib.ptr(x), lib.ptr(x), 1, 1, 0, 4, None, None, None, None, None, None)
+    assert rc < 0 and len(L.a3vt_last_error()) > 0
+    with pytest.raises(RuntimeError, match="multiple of 4"):                # feature rows must be 16-byte granular
+        ops.gcn_layer(torch.zeros(1, n, 50, device=cuda), adj, torch.zeros(1, 50, 16, device=cuda),
+                      torch.zeros(16, device=cuda), 5, True)
