@@ -204,3 +204,54 @@ def test_forward_capturable_in_hip_graph(cuda):
         graph.replay()
         ref, _ = net(img, {k: v.clone() for k, v in static.items()})
         assert torch.equal(out, ref)
+
+
+def test_multi_step_training_tracks_the_oracle(cuda):
+    """Six Adam steps of the touch model (L=3, H=64) on the HIP path vs the same six steps of the CPU oracle from the same
+    weights, injected surface samples per step: the loss trajectories stay together (drift < 1e-3 relative) and the
+    parameters end up at the same place — fwd, Chamfer, every backward kernel and the optimiser in one loop."""
+    from a3vt_amd import mesh as amesh
+    from a3vt_amd.pterotactyl.reconstruction.vision import model
+    from a3vt_amd.pterotactyl.utility import utils
+    from helpers import oracle_adj
+    from oracle import chamfer as och, gcn as og
+    args = make_args(use_touch=True, finger=False, num_grasps=1, num_GCN_layers=3, hidden_GCN_size=64)
+    info, verts = utils.load_mesh_vision(args, "vision_charts")
+    torch.manual_seed(5)
+    net = model.Deformation(info, verts, args).to(cuda)
+    opt = torch.optim.Adam(net.parameters(), lr=3e-4, weight_decay=0)
+    B, P, steps = 2, 600, 6
+    g = torch.Generator().manual_seed(3)
+    tc = torch.zeros(B, 1, 4, 25, 4)
+    tc[..., :3] = (torch.rand(B, 1, 4, 25, 3, generator=g) - 0.5) * 0.3
+    tc[..., 3] = 2
+    gt = random_cloud(B, 800, 7)
+    v, f = amesh.load_asset("vision_charts")
+    adj_o, faces_o = oracle_adj(v, f, args)
+    st = {k: t.detach().cpu().clone().requires_grad_(True) for k, t in net.state_dict().items()}
+    opt_o = torch.optim.Adam(list(st.values()), lr=3e-4, weight_decay=0)
+    ch_o = og.prepare_mesh(tc, torch.from_numpy(v), B, True)
+    F = faces_o.shape[0]
+    img = torch.zeros(B, 1)
+    charts = model.prepare_mesh({"img": img, "touch_charts": tc}, verts, args)
+    hip, ora = [], []
+    for it in range(steps):
+        fi = torch.randint(0, F, (3, B, P), generator=g)
+        u, w = torch.rand(3, B, P, generator=g), torch.rand(3, B, P, generator=g)
+        opt.zero_grad()
+        out = net(img, charts)[0]
+        loss = 9000.0 * utils.chamfer_distance(out, info["faces"], gt.to(cuda), num=P,
+                                               samples=(fi.to(torch.int32).to(cuda), u.to(cuda), w.to(cuda))).mean()
+        loss.backward()
+        opt.step()
+        hip.append(loss.item())
+        opt_o.zero_grad()
+        out_o, _ = og.deformation_forward(st, {"adj": adj_o}, ch_o, True, 3, 0.33)
+        loss_o = 9000.0 * och.chamfer_distance(out_o, faces_o, gt, num=P, samples=[(fi[r], u[r], w[r]) for r in range(3)]).mean()
+        loss_o.backward()
+        opt_o.step()
+        ora.append(loss_o.item())
+    assert hip[-1] < hip[0]                                                   # it trains
+    assert max(abs(a - b) / abs(b) for a, b in zip(hip, ora)) < 1e-3, (hip, ora)
+    for k, p in net.state_dict().items():
+        assert rel_err(p, st[k]) < 2e-3, k
