@@ -694,13 +694,23 @@ __device__ __forceinline__ void dw_stage_fast(const float *__restrict__ sb, int 
     const int r = q * 4 + ks;
     const float *xr = sb + r * ldx + xoff;
     const int ra = r * ldz0, rg = r * ldz1;
+#ifdef A3VT_DBG_NOLDSREAD
 #pragma unroll
-    for (int i = 0; i < DW_MAXI; ++i) av[i] = xr[(i < 4 || row5 ? i : 3) * 16];
+    for (int i = 0; i < DW_MAXI; ++i) av[i] = (float)(r + i);
 #pragma unroll
-    for (int j = 0; j < DW_MAXO; ++j) {
-      const int zo = zoff[j < 2 || col3 ? j : 1];
-      bv[j] = sb[zo + (zo < offG ? ra : rg)];
-    }
+    for (int j = 0; j < DW_MAXO; ++j) bv[j] = (float)(ra + j);
+    (void)xr; (void)rg;
+#else
+    // All five / three operand loads are unconditional: a wave without a 5th row tile or 3rd column tile reads a few
+    // floats past its window (still inside the stage) and never uses them.  Selecting the address instead
+    // ("i < 4 || row5 ? i : 3") made the compiler reuse the loaded a[3] through a v_mov, i.e. wait for the NEXT
+    // k-step's ds_reads (s_waitcnt lgkmcnt(0)) before the current k-step's MFMAs — 19 % of the launch.
+    (void)row5; (void)col3;
+#pragma unroll
+    for (int i = 0; i < DW_MAXI; ++i) av[i] = xr[i * 16];
+#pragma unroll
+    for (int j = 0; j < DW_MAXO; ++j) bv[j] = sb[zoff[j] + (zoff[j] < offG ? ra : rg)];
+#endif
   };
   load(0, a, b);
 #pragma unroll

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/../active-3d-vision-and-touch_amd/csrc"
 mkdir -p ../../gpurun_variants
 build() { # name flags...
   local name=$1; shift
-  hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared "$@" capi.hip gcn_gemm.hip gcn_csr.hip posenc.hip sample.hip chamfer.hip -o ../../gpurun_variants/liba3vt_$name.so
+  hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared "$@" capi.hip gcn_gemm.hip gcn_csr.hip posenc.hip sample.hip chamfer.hip pooling.hip -o ../../gpurun_variants/liba3vt_$name.so
 }
 build V1 -DA3VT_DBG_NODMA &
 build V2 -DA3VT_DBG_NOLDSREAD &
