@@ -661,11 +661,12 @@ __device__ __forceinline__ void dw_stage(const float *__restrict__ sb, int ldx, 
     for (int j = 0; j < DW_MAXO; ++j) b[j] = (float)(ra + j);
     (void)xr; (void)rg;
 #else
+    // unconditional loads (tiles a wave does not own read a few floats past its window, inside the stage, and are
+    // never multiplied): conditional ones become branches and early lgkmcnt waits, see dw_stage_fast
 #pragma unroll
-    for (int i = 0; i < DW_MAXI; ++i) a[i] = (NI >= 0 ? i < NI : i < ni) ? xr[i * 16] : 0.f;
+    for (int i = 0; i < DW_MAXI; ++i) a[i] = xr[i * 16];
 #pragma unroll
-    for (int j = 0; j < DW_MAXO; ++j)
-      b[j] = (NO >= 0 ? j < NO : j < no) ? sb[zoff[j] + (zoff[j] < offG ? ra : rg)] : 0.f;
+    for (int j = 0; j < DW_MAXO; ++j) b[j] = sb[zoff[j] + (zoff[j] < offG ? ra : rg)];
 #endif
 #pragma unroll
     for (int i = 0; i < DW_MAXI; ++i) {
