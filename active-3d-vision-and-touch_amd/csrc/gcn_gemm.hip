@@ -895,7 +895,10 @@ __global__ __launch_bounds__(1024, 1) void dw_kernel(DwArgs p) {
 #endif
     const float *sb = lds + buf * stage;
     if (BF16) dw_stage_bf16(sb, p.ldx, wa, wg, offG, xoff, zoff, q, ni, no, acc);
-    else if (FAST) dw_stage_fast(sb, p.ldx, wa, wg, offG, xoff, zoff, q, ni == 5, no == 3, acc);
+    // every wave runs five row tiles: the one SIMD whose waves own four (19 = 5+5+5+4) would otherwise idle for that
+    // fifth of the time anyway, its extra tile reads finite neighbouring data and is dropped at the slab write, and the
+    // k-step loop loses two of its three wave-uniform branches
+    else if (FAST) dw_stage_fast(sb, p.ldx, wa, wg, offG, xoff, zoff, q, true, no == 3, acc);
     else dw_stage<-1, -1>(sb, p.ldx, wa, wg, offG, xoff, zoff, q, ni, no, acc);
     buf = buf == nst - 1 ? 0 : buf + 1;
   }
