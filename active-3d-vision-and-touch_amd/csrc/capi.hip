@@ -322,7 +322,12 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
       if (int rc = launch_csr_bwd(g, hidden, cut_len, rowptrT, colT, valT, heavyT, n_vert, batch, dza, cpad,
                                   scratch + L.db_slab, s))
         return rc;
-      // the bias partials are reduced together with the weight-gradient slabs below (one launch for both)
+      // channels >= cut_len are dead bias parameters (model.py:358): written as exact zeros by the same launch.
+      // (Folding this reduce into the weight-gradient reduce below made that launch wait for the two long-running
+      // blocks that walk the 2048 bias slabs: 19.9 us per fused launch against 9.5 + 9.5 for two.)
+      if (int rc = launch_slab_reduce_z(scratch + L.db_slab, csr_bwd_num_slabs(batch, n_vert), cpad, cut_len, hidden,
+                                        grad_biases[i], s))
+        return rc;
     } else {
       if (int rc = launch_fill_zero(grad_biases[i], hidden, s)) return rc;
     }
@@ -360,15 +365,9 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
         ProfScope ps(PROF_DW, s);
         if (int rc = launch_dw(d, s)) return rc;
       }
-      // weight-gradient slabs of this panel; with the first panel also the layer's bias partials (channels >= cut_len
-      // are dead bias parameters, model.py:358: written as exact zeros)
-      const SlabJob jw{scratch + L.dw_slab, dw_num_slabs(hidden), (size_t)w * hidden, (size_t)w * hidden,
-                       (size_t)w * hidden, grad_weights[i] + (size_t)c0 * hidden};
-      SlabJob jbias{nullptr, 0, 0, 0, 0, nullptr};
-      if (c0 == 0 && cut_len > 0)
-        jbias = SlabJob{scratch + L.db_slab, csr_bwd_num_slabs(batch, n_vert), (size_t)cpad, (size_t)cut_len, (size_t)hidden,
-                        grad_biases[i]};
-      if (int rc = launch_slab_reduce2(jw, jbias, s)) return rc;
+      if (int rc = launch_slab_reduce(scratch + L.dw_slab, dw_num_slabs(hidden), (size_t)w * hidden, (size_t)w * hidden,
+                                      grad_weights[i] + (size_t)c0 * hidden, s))
+        return rc;
     }
 
     // dX_i = dZ W_i^T  (masked by the ReLU of layer i-1, whose output is X_i)
