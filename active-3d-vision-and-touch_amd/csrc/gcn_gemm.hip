@@ -985,42 +985,36 @@ int launch_dw(const DwArgs &a, hipStream_t s) {
 // Workgroup = 64 consecutive outputs x 16 slab groups (1024 threads): each thread sums its 1/16 of the slabs with
 // every load in flight at once (the reduce is latency-bound: 128 slabs x 360 KB per layer), then the sixteen
 // partials are combined through LDS in a fixed order.
-__global__ __launch_bounds__(1024) void slab_reduce_kernel(SlabJob ja, SlabJob jb, int blocks_a) {
+__global__ __launch_bounds__(1024) void slab_reduce_kernel(const float *__restrict__ slab, int nslab, size_t stride,
+                                                           size_t n, size_t n_out, float *__restrict__ out) {
   __shared__ float part[16][64];
-  const bool second = (int)blockIdx.x >= blocks_a;  // workgroup-uniform: which of the two reductions this block serves
-  const SlabJob j = second ? jb : ja;
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const size_t i = (size_t)(blockIdx.x - (second ? blocks_a : 0)) * 64 + lane;
-  const int per = (j.nslab + 15) / 16;
-  const int s0 = grp * per, s1 = min(s0 + per, j.nslab);
+  const size_t i = (size_t)blockIdx.x * 64 + lane;
+  const int per = (nslab + 15) / 16;
+  const int s0 = grp * per, s1 = min(s0 + per, nslab);
   float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (i < j.n) {
+  if (i < n) {
     int s = s0;
     for (; s + 7 < s1; s += 8) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) a[u] += j.slab[(size_t)(s + u) * j.stride + i];
+      for (int u = 0; u < 8; ++u) a[u] += slab[(size_t)(s + u) * stride + i];
     }
-    for (; s < s1; ++s) a[0] += j.slab[(size_t)s * j.stride + i];
+    for (; s < s1; ++s) a[0] += slab[(size_t)s * stride + i];
   }
   part[grp][lane] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   __syncthreads();
-  if (grp == 0 && i < j.n_out) {  // entries [n, n_out) are written as zeros (dead bias channels)
+  if (grp == 0 && i < n_out) {  // entries [n, n_out) are written as zeros (dead bias channels)
     float t = 0.f;
 #pragma unroll
     for (int g = 0; g < 16; ++g) t += part[g][lane];
-    j.out[i] = i < j.n ? t : 0.f;
+    out[i] = i < n ? t : 0.f;
   }
 }
 
-// Two independent reductions in one launch (a layer's weight-gradient and bias-gradient slabs).
-int launch_slab_reduce2(const SlabJob &ja, const SlabJob &jb, hipStream_t s) {
-  const int ba = cdiv((long long)ja.n_out, 64), bb = jb.out ? cdiv((long long)jb.n_out, 64) : 0;
-  A3VT_LAUNCH(slab_reduce_kernel, dim3(ba + bb), dim3(1024), 0, s, ja, jb, ba);
+int launch_slab_reduce_z(const float *slab, int nslab, size_t stride, size_t n, size_t n_out, float *out, hipStream_t s) {
+  A3VT_LAUNCH(slab_reduce_kernel, dim3(cdiv((long long)n_out, 64)), dim3(1024), 0, s, slab, nslab, stride, n, n_out, out);
   A3VT_CHECK_LAUNCH();
   return 0;
-}
-int launch_slab_reduce_z(const float *slab, int nslab, size_t stride, size_t n, size_t n_out, float *out, hipStream_t s) {
-  return launch_slab_reduce2(SlabJob{slab, nslab, stride, n, n_out, out}, SlabJob{nullptr, 0, 0, 0, 0, nullptr}, s);
 }
 int launch_slab_reduce(const float *slab, int nslab, size_t stride, size_t n, float *out, hipStream_t s) {
   return launch_slab_reduce_z(slab, nslab, stride, n, n, out, s);

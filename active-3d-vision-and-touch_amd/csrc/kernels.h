@@ -59,13 +59,6 @@ struct DwArgs {
 int dw_num_slabs(int n_out);
 int launch_dw(const DwArgs &a, hipStream_t s);
 int launch_copy_cols(const float *src, int ld_src, int c0, int w, float *dst, long long m, hipStream_t s);
-struct SlabJob {        // out[i] = sum_s slab[s * stride + i] for i < n;  out[n .. n_out) = 0
-  const float *slab;
-  int nslab;
-  size_t stride, n, n_out;
-  float *out;
-};
-int launch_slab_reduce2(const SlabJob &a, const SlabJob &b, hipStream_t s);   // b.out == nullptr: only a
 int launch_slab_reduce(const float *slab, int nslab, size_t stride, size_t n, float *out, hipStream_t s);
 // same, and out[n .. n_out) = 0
 int launch_slab_reduce_z(const float *slab, int nslab, size_t stride, size_t n, size_t n_out, float *out, hipStream_t s);
