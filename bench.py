@@ -15,7 +15,7 @@ Extra objects on the JSON line:
   2*M*300*300 flop per launch / mean launch duration measured with HIP events on the launch stream during
   extra (untimed) profiled steps, against the 157.3 TFLOP/s fp32 matrix peak (MI355X_MICROARCH.md).
 * ``cpu_baseline`` — the CPU oracle (a port of the reference path; kind "port") timed on this box's host cores
-  on a bounded sample: bs = 2 of the same workload, one iteration, scaled to iterations of bs 64.
+  on a bounded sample: bs = 4 of the same workload, one iteration (≈10 s), scaled to iterations of bs 64.
 """
 import argparse
 import ctypes
@@ -51,13 +51,13 @@ def parse():
 
 
 def cpu_baseline(level, layers, hidden, points, seed=0):
-    """Oracle (CPU port of the reference path) on a bounded sample: bs=2, one fwd+bwd iteration."""
+    """Oracle (CPU port of the reference path) on a bounded sample: bs=4, one fwd+bwd iteration (about 10 s)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import make_args, oracle_adj
     from a3vt_amd import mesh as amesh
     from a3vt_amd.synthetic import gt_cloud
     from oracle import chamfer as och, gcn as og
-    bs = 2
+    bs = 4
     args = make_args(num_GCN_layers=layers, hidden_GCN_size=hidden)
     verts, faces = amesh.icosphere(level)
     adj_o, faces_o = oracle_adj(verts, faces, args)
@@ -71,7 +71,7 @@ def cpu_baseline(level, layers, hidden, points, seed=0):
     (9000.0 * cd.mean()).backward()
     dt = time.perf_counter() - t0
     return {"value": (bs / 64.0) / dt, "unit": "iters/s at bs=64", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"bs=2 of the bs=64 workload, 1 fwd+bwd iteration (no optimizer), {dt:.1f} s of CPU work; "
+            "sample": f"bs={bs} of the bs=64 workload, 1 fwd+bwd iteration (no optimizer), {dt:.1f} s of CPU work; "
                       f"CSR aggregation + plain-C brute-force NN, torch CPU fp32"}
 
 
