@@ -4,12 +4,14 @@
 // utility/utils.py:207,212 (knn_points K=1, squared distances, point_reduction="mean") and the
 // mean over the 3 draws at utils.py:214-215.
 //
-// The search is brute force: 10k x 10k pairs per cloud pair cost 7 VALU lane-ops per pair here
-// (3 sub, 1 mul, 2 fma, 1/2 min3) in packed fp32 (v_pk_*_f32 processes two candidates per op), the
+// The search is brute force: 10k x 10k pairs per cloud pair cost 6.5 VALU lane-ops per pair here
+// (3 sub, 1 mul, 2 fma, 1/2 min3; scalar fp32 — packed v_pk_*_f32 issues at half the rate on gfx950), the
 // candidate cloud is broadcast from LDS, and each lane keeps R query points in registers.  The
 // arg-min is recovered without carrying an index through the hot loop: the loop only tracks the
 // best distance per 64-candidate chunk and remembers the winning chunk; that chunk is rescanned once
 // at the end.  Inputs are tiny (120 KB per cloud): the kernel is VALU-bound, not HBM-bound.
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -19,6 +21,7 @@ using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 constexpr int kNNTile = 2048;  // candidates staged in LDS per pass (SoA, 24 KiB)
 constexpr int kNNChunk = 64;   // arg-min granularity of the hot loop
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr float kFar = 1.0e18f;
 
 __device__ __forceinline__ f32x2 sqdist2(float qx, float qy, float qz, f32x2 cx, f32x2 cy, f32x2 cz) {
@@ -70,15 +73,23 @@ __global__ __launch_bounds__(256) void nn_kernel(const float *__restrict__ q, in
 #pragma unroll
       for (int r = 0; r < R; ++r) m[r] = 3.0e38f;
       const int j0 = ch * kNNChunk;
-#pragma unroll 8
-      for (int j = 0; j < kNNChunk; j += 2) {
-        const f32x2 cx = *reinterpret_cast<const f32x2 *>(sx + j0 + j);
-        const f32x2 cy = *reinterpret_cast<const f32x2 *>(sy + j0 + j);
-        const f32x2 cz = *reinterpret_cast<const f32x2 *>(sz + j0 + j);
+#pragma unroll 4
+      for (int j = 0; j < kNNChunk; j += 4) {
+        const f32x4 cx = *reinterpret_cast<const f32x4 *>(sx + j0 + j);
+        const f32x4 cy = *reinterpret_cast<const f32x4 *>(sy + j0 + j);
+        const f32x4 cz = *reinterpret_cast<const f32x4 *>(sz + j0 + j);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          const f32x2 d = sqdist2(qx[r], qy[r], qz[r], cx, cy, cz);
-          m[r] = fminf(m[r], fminf(d[0], d[1]));
+          // scalar fp32 ops: v_pk_*_f32 issues at half the rate on gfx950 (tools/ubench/valu_peak.hip) and drags s_nop
+          // hazards along; same fused arithmetic as sqdist2, two v_min3 per four candidates
+          float d[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float dx = qx[r] - cx[u], dy = qy[r] - cy[u], dz = qz[r] - cz[u];
+            d[u] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+          }
+          m[r] = __builtin_fminf(__builtin_fminf(m[r], d[0]), d[1]);
+          m[r] = __builtin_fminf(__builtin_fminf(m[r], d[2]), d[3]);
         }
       }
       const int gch = (t0 + j0) / kNNChunk;
@@ -114,18 +125,35 @@ __global__ __launch_bounds__(256) void nn_kernel(const float *__restrict__ q, in
   }
 }
 
+template <int R>
+static void launch_nn_r(const float *q, int nq, int q_mod, const float *c, int nc, int c_mod, int nclouds, float *dist,
+                        int32_t *idx, hipStream_t s) {
+  dim3 grid(cdiv(nq, 256 * R), nclouds);
+  A3VT_LAUNCH((nn_kernel<R>), grid, dim3(256), 0, s, q, nq, q_mod, c, nc, c_mod, dist, idx);
+}
+
 static int launch_nn(const float *q, int nq, int q_mod, const float *c, int nc, int c_mod, int nclouds, float *dist,
                      int32_t *idx, hipStream_t s) {
-  // 8 queries per lane when the cloud is large (fewer, fatter workgroups: all resident in one round, LDS reads
-  // amortised over more VALU work); 4 for small clouds so the grid still fills the chip.
-  if (nq >= 4096) {
-    constexpr int R = 8;
-    dim3 grid(cdiv(nq, 256 * R), nclouds);
-    A3VT_LAUNCH((nn_kernel<R>), grid, dim3(256), 0, s, q, nq, q_mod, c, nc, c_mod, dist, idx);
-  } else {
-    constexpr int R = 4;
-    dim3 grid(cdiv(nq, 256 * R), nclouds);
-    A3VT_LAUNCH((nn_kernel<R>), grid, dim3(256), 0, s, q, nq, q_mod, c, nc, c_mod, dist, idx);
+  // R queries per lane.  The kernel is VALU bound, so what sets its time is the busiest CU: workgroups per CU (rounded
+  // up) x R; among equals the smaller R wins (more waves per SIMD: R = 10 measured 5.5 ms where R = 5 takes 4.85).
+  // 10,000-point clouds x 192: R = 8 gives 960 workgroups = 3.75 per CU, so some CUs carry 4 x 8 = 32 units; R = 5
+  // gives 1,536 = exactly 6 per CU, 30 units, all resident at once (72 VGPRs) — measured 5.2 -> 4.85 ms per call.
+  static const int env_r = getenv("A3VT_NN_R") ? atoi(getenv("A3VT_NN_R")) : 0;  // developer override
+  int best_r = 4;
+  long long best_cost = -1;
+  for (int r : {5, 4, 6, 8, 3, 10}) {
+    const long long wgs = (long long)cdiv(nq, 256 * r) * nclouds;
+    const long long cost = ((wgs + 255) / 256) * r;
+    if (best_cost < 0 || cost < best_cost) best_cost = cost, best_r = r;
+  }
+  if (env_r) best_r = env_r;
+  switch (best_r) {
+    case 10: launch_nn_r<10>(q, nq, q_mod, c, nc, c_mod, nclouds, dist, idx, s); break;
+    case 8: launch_nn_r<8>(q, nq, q_mod, c, nc, c_mod, nclouds, dist, idx, s); break;
+    case 6: launch_nn_r<6>(q, nq, q_mod, c, nc, c_mod, nclouds, dist, idx, s); break;
+    case 5: launch_nn_r<5>(q, nq, q_mod, c, nc, c_mod, nclouds, dist, idx, s); break;
+    case 3: launch_nn_r<3>(q, nq, q_mod, c, nc, c_mod, nclouds, dist, idx, s); break;
+    default: launch_nn_r<4>(q, nq, q_mod, c, nc, c_mod, nclouds, dist, idx, s); break;
   }
   A3VT_CHECK_LAUNCH();
   return 0;

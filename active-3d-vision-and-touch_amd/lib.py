@@ -13,7 +13,9 @@ LIB_PATH = os.environ.get("A3VT_LIB", os.path.join(_HERE, "liba3vt.so"))  # A3VT
 SOURCES = ["capi.hip", "gcn_gemm.hip", "gcn_csr.hip", "posenc.hip", "sample.hip", "chamfer.hip", "pooling.hip"]
 # Per-file extra flags (none at present; sample.hip / gcn_csr.hip rely on IEEE NaN semantics — the reference's NaN
 # scrubs, a3vt_check_finite — so fast-math style flags must never be applied globally).
-EXTRA_FLAGS = {}
+# chamfer.hip: keep the nearest-neighbour loop on scalar fp32 ops (the SLP vectoriser would re-pack it into v_pk_*_f32,
+# which issues at half the rate on gfx950 and needs s_nop hazard padding)
+EXTRA_FLAGS = {"chamfer.hip": ["-fno-slp-vectorize"]}
 
 _vp, _i, _sz, _u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_uint64
 
