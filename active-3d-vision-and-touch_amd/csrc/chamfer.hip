@@ -135,21 +135,19 @@ static void launch_nn_r(const float *q, int nq, int q_mod, const float *c, int n
 static int launch_nn(const float *q, int nq, int q_mod, const float *c, int nc, int c_mod, int nclouds, float *dist,
                      int32_t *idx, hipStream_t s) {
   // R queries per lane.  The kernel is VALU bound, so what sets its time is the busiest CU: workgroups per CU (rounded
-  // up) x R; among equals the smaller R wins (more waves per SIMD: R = 10 measured 5.5 ms where R = 5 takes 4.85).
+  // up) x R; among equals the smaller R wins (more waves per SIMD: R = 10 measured 5.5 ms where R = 5 takes 4.85, R = 8 5.2).
   // 10,000-point clouds x 192: R = 8 gives 960 workgroups = 3.75 per CU, so some CUs carry 4 x 8 = 32 units; R = 5
   // gives 1,536 = exactly 6 per CU, 30 units, all resident at once (72 VGPRs) — measured 5.2 -> 4.85 ms per call.
   static const int env_r = getenv("A3VT_NN_R") ? atoi(getenv("A3VT_NN_R")) : 0;  // developer override
   int best_r = 4;
   long long best_cost = -1;
-  for (int r : {5, 4, 6, 8, 3, 10}) {
+  for (int r : {5, 4, 6, 3}) {  // 8 and 10 can never beat 4 and 5 under this cost (half the R, at most twice the workgroups)
     const long long wgs = (long long)cdiv(nq, 256 * r) * nclouds;
     const long long cost = ((wgs + 255) / 256) * r;
     if (best_cost < 0 || cost < best_cost) best_cost = cost, best_r = r;
   }
   if (env_r) best_r = env_r;
   switch (best_r) {
-    case 10: launch_nn_r<10>(q, nq, q_mod, c, nc, c_mod, nclouds, dist, idx, s); break;
-    case 8: launch_nn_r<8>(q, nq, q_mod, c, nc, c_mod, nclouds, dist, idx, s); break;
     case 6: launch_nn_r<6>(q, nq, q_mod, c, nc, c_mod, nclouds, dist, idx, s); break;
     case 5: launch_nn_r<5>(q, nq, q_mod, c, nc, c_mod, nclouds, dist, idx, s); break;
     case 3: launch_nn_r<3>(q, nq, q_mod, c, nc, c_mod, nclouds, dist, idx, s); break;

@@ -275,6 +275,34 @@ def test_chamfer_fwd_bwd(cuda, P, Q, B, draws):
     assert np.allclose(((x[0, 0] - yy) ** 2).sum(-1).numpy(), dxy[0, 0].cpu().numpy(), rtol=1e-5, atol=1e-12)
 
 
+@pytest.mark.parametrize("P,R", [(1280, 5), (1024, 4), (1536, 6), (200, 3)])
+def test_chamfer_nn_every_queries_per_lane_variant(cuda, P, R):
+    """launch_nn picks the queries-per-lane template from the workgroup count per CU (chamfer.hip); 256 clouds of these
+    sizes select R = 5 / 4 / 6 / 3.  Distances and first-arg-min indices against a brute-force fp64 search (the clouds
+    hold duplicated points, so ties exist and the lowest index must win)."""
+    from a3vt_amd import ops
+    B, Q = 256, 200
+    g = torch.Generator().manual_seed(P)
+    x = (torch.rand(1, B, P, 3, generator=g) * 0.3).float()
+    y = (torch.rand(B, Q, 3, generator=g) * 0.3).float()
+    y[:, Q // 2:] = y[:, :Q - Q // 2]          # every candidate twice: exact distance ties
+    x[0, :, :7] = y[:, :7]                     # and a few zero distances
+    dxy, ixy, dyx, iyx, _ = ops.chamfer_nn(x.to(cuda), y.to(cuda))
+    for b in (0, 1, B // 2, B - 1):
+        d = ((x[0, b].double()[:, None, :] - y[b].double()[None, :, :]) ** 2).sum(-1)
+        ref_d, ref_i = d.min(1)
+        # first arg-min of the fp32 distances the kernel computes: compare through the reported distance
+        got_i = ixy[0, b].cpu().long()
+        got_d = dxy[0, b].cpu().double()
+        assert torch.allclose(got_d, ref_d, rtol=1e-5, atol=1e-12)
+        assert (got_i < Q // 2 + (Q - 2 * (Q // 2))).all()      # of two identical candidates the first one
+        assert torch.allclose(d[torch.arange(P), got_i], ref_d, rtol=1e-5, atol=1e-12)
+        d2 = d.t()
+        ref_d2, _ = d2.min(1)
+        assert torch.allclose(dyx[0, b].cpu().double(), ref_d2, rtol=1e-5, atol=1e-12)
+        assert torch.allclose(d2[torch.arange(Q), iyx[0, b].cpu().long()], ref_d2, rtol=1e-5, atol=1e-12)
+
+
 def test_chamfer_known_answers(cuda):
     from a3vt_amd import ops
     x = random_cloud(2, 300, 4).to(cuda)
