@@ -10,6 +10,7 @@ from a3vt_amd import lib, ops  # noqa: E402
 M, K, N = 64 * 2562, 300, 300
 dev = torch.device("cuda", 0)
 zero = os.environ.get("ZERO", "0") == "1"
+BF16 = 1 if os.environ.get("BF16", "0") == "1" else 0   # operand mode (a3vt.h: gemm_bf16)
 a = torch.zeros(M, K, device=dev) if zero else torch.randn(M, K, device=dev)
 w = torch.zeros(K, N, device=dev) if zero else torch.randn(K, N, device=dev)
 L = lib.load()
@@ -17,13 +18,13 @@ wt = torch.empty((L.a3vt_wt_rows(N), L.a3vt_wt_ld(K)), device=dev)
 lib.check(L.a3vt_transpose_weight(lib.ptr(w), K, N, lib.ptr(wt), None), "t")
 c = torch.empty(M, N, device=dev)
 for _ in range(3):
-    lib.check(L.a3vt_rowgemm(lib.ptr(a), K, M, K, lib.ptr(wt), N, lib.ptr(c), N, None), "g")
+    lib.check(L.a3vt_rowgemm(lib.ptr(a), K, M, K, lib.ptr(wt), N, BF16, lib.ptr(c), N, None), "g")
 torch.cuda.synchronize()
 reps = int(os.environ.get('REPS', '20'))
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(reps):
-    L.a3vt_rowgemm(lib.ptr(a), K, M, K, lib.ptr(wt), N, lib.ptr(c), N, None)
+    L.a3vt_rowgemm(lib.ptr(a), K, M, K, lib.ptr(wt), N, BF16, lib.ptr(c), N, None)
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
