@@ -125,11 +125,7 @@ __global__ __launch_bounds__(256) void csr_heavy_kernel(const float *__restrict_
     const int v = heavy[64 + (int)(item % count)];
     const long long b = item / count, row = b * n_vert + v;
     const float *sb = src + b * n_vert * (long long)ld_src;
-#ifdef A3VT_DBG_CSR_NOROWPTR
-    const int e0 = v * 6, e1 = e0 + 7;  // ablation (timing only): no rowptr round trip
-#else
     const int e0 = rowptr[v], e1 = rowptr[v + 1];
-#endif
     const int per = ((e1 - e0 + 7) / 8 + 3) & ~3;  // edges per half-wave, a multiple of the gather's unroll
     const int s0 = min(e1, e0 + sub * per), s1 = min(e1, s0 + per);
     for (int ch0 = 0; ch0 < width; ch0 += 128) {
@@ -190,11 +186,7 @@ __global__ __launch_bounds__(256) void csr_fwd_kernel(const float *__restrict__ 
     if (!w.locate(g, threadIdx.x >> 5, n_vert, b, v)) continue;  // uniform per half-wave
     const long long row = b * n_vert + v;
     const float *zb = za + b * n_vert * (long long)ldza;
-#ifdef A3VT_DBG_CSR_NOROWPTR
-    const int e0 = v * 6, e1 = e0 + 7;  // ablation (timing only): no rowptr round trip
-#else
     const int e0 = rowptr[v], e1 = rowptr[v + 1];
-#endif
     if (e1 - e0 > heavy_thresh) continue;  // hub row: csr_heavy_kernel spreads it over a whole workgroup
     for (int ch0 = 0; ch0 < c; ch0 += 128) {
       const int ch = ch0 + hl * 4;
@@ -272,11 +264,7 @@ __global__ __launch_bounds__(256) void csr_bwd_kernel(const float *__restrict__ 
       f32x4 own = {0.f, 0.f, 0.f, 0.f};
       if (on) own = *reinterpret_cast<const f32x4 *>(gb + (long long)v * ldg + ch);
       bsum += own;
-  #ifdef A3VT_DBG_CSR_NOROWPTR
-    const int e0 = v * 6, e1 = e0 + 7;  // ablation (timing only): no rowptr round trip
-#else
-    const int e0 = rowptr[v], e1 = rowptr[v + 1];
-#endif
+      const int e0 = rowptr[v], e1 = rowptr[v + 1];
       if (e1 - e0 > heavy_thresh) continue;  // hub row: gathered and stored by csr_heavy_kernel (its bias share is counted above)
       const f32x4 acc = gather_row(gb, ldg, ch, on, e0, e1, hl, colidx, val);
       if (on) {
