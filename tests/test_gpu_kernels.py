@@ -26,6 +26,41 @@ def test_rowgemm_matches_fp64(cuda, m, k, n):
     assert rel_err(c, ref) < 2e-6
 
 
+def _fuzz_shapes(count, seed):
+    """Seeded random (m, k, n): k a multiple of 4 up to 452 (the image model's first layer), n up to 304, m from a few
+    rows to past the 2048-tile main/remainder split (32,768 rows)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(count):
+        k = 4 * int(rng.integers(1, 114))
+        n = int(rng.integers(1, 305))
+        m = int(rng.choice([rng.integers(1, 64), rng.integers(64, 3000), rng.integers(3000, 20000),
+                            rng.integers(32700, 36000)]))
+        out.append((m, k, n))
+    return out
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_rowgemm_shape_fuzz(cuda, bf16):
+    """Every launch path of a3vt_rowgemm (column blocks for few rows, 1/4/8/13/19-tile kernels, main + rowtile remainder
+    split, ragged last tile, K tail chunk) on 48 seeded random shapes against fp64 (operands rounded to bf16 first in
+    the bf16 operand mode)."""
+    from a3vt_amd import ops
+    from oracle.gcn import bf16_round
+    for m, k, n in _fuzz_shapes(48, 20261002):
+        g = torch.Generator().manual_seed(m * 7 + k * 3 + n)
+        a = torch.randn(m, k, generator=g)
+        w = torch.randn(k, n, generator=g)
+        c = ops.rowgemm(a.to(cuda), w.to(cuda), bf16=bf16).cpu()
+        if bf16:
+            ref = bf16_round(a).double() @ bf16_round(w).double()
+        else:
+            ref = a.double() @ w.double()
+        assert c.shape == (m, n)
+        assert torch.isfinite(c).all(), (m, k, n)
+        assert rel_err(c, ref) < 3e-6, (m, k, n, rel_err(c, ref))
+
+
 def _state_to(dev, st):
     return {k: v.to(dev) for k, v in st.items()}
 
@@ -69,6 +104,43 @@ def test_gcn_stack_fwd_bwd(cuda, tname, use_touch, L, H, B):
     for i in range(L):
         assert_grad_close(ws[i].grad, st64[f"mesh_deform_1.layers.{i}.weight"].grad, f"dW layer {i}")
         assert_grad_close(bs[i].grad, st64[f"mesh_deform_1.layers.{i}.bias"].grad, f"db layer {i}")
+
+
+def test_gcn_stack_config_fuzz(cuda):
+    """Twelve seeded random (template, layers, hidden, cut, batch) stacks against the fp64 oracle: hidden any multiple
+    of 4 up to 304, cut ratios that put 0 .. hidden channels through the aggregation, 1-5 layers."""
+    from a3vt_amd import mesh as amesh, ops
+    from oracle import gcn as og
+    rng = np.random.default_rng(77)
+    for it in range(12):
+        tname = ["ico1", "ico2", "ico3", "atlas"][int(rng.integers(0, 4))]
+        L, H, B = int(rng.integers(1, 6)), 4 * int(rng.integers(2, 77)), int(rng.integers(1, 5))
+        cut = float(rng.choice([0.0, 0.1, 0.33, 0.5, 0.77, 1.0]))
+        args = make_args(num_GCN_layers=L, hidden_GCN_size=H, cut=cut)
+        verts, faces = template(tname)
+        adj_o, _ = oracle_adj(verts, faces, args)
+        n = adj_o[0].numel() - 1
+        st = og.init_state(50, H, L, seed=100 + it)
+        g = torch.Generator().manual_seed(500 + it)
+        feats = torch.randn(B, n, 50, generator=g) * 0.5
+        gup = torch.randn(B, n, 3, generator=g)
+        st64 = {k: v.double().requires_grad_(True) for k, v in st.items() if k.startswith("mesh_deform_1")}
+        f64 = feats.double().requires_grad_(True)
+        out_o = og.gcn(f64, st64, "mesh_deform_1", (adj_o[0], adj_o[1], adj_o[2].double()), L, cut)
+        (out_o * gup.double()).sum().backward()
+        r, c = amesh.vision_pairs(faces, verts.shape[0])
+        adj = ops.DeviceCSR(amesh.CSRAdjacency.from_pairs(r, c, verts.shape[0]), cuda)
+        ws = [st[f"mesh_deform_1.layers.{i}.weight"].to(cuda).requires_grad_(True) for i in range(L)]
+        bs = [st[f"mesh_deform_1.layers.{i}.bias"].to(cuda).requires_grad_(True) for i in range(L)]
+        fd = torch.nn.functional.pad(feats, (0, 2)).to(cuda).requires_grad_(True)
+        out = ops.gcn_stack(fd, adj, 50, H, round(H * cut), ws, bs)
+        (out * gup.to(cuda)).sum().backward()
+        tag = f"[{it}: {tname} L={L} H={H} cut={cut} B={B}]"
+        assert rel_err(out, out_o) < 1e-4, tag
+        assert_grad_close(fd.grad[..., :50], f64.grad, "grad_feats " + tag)
+        for i in range(L):
+            assert_grad_close(ws[i].grad, st64[f"mesh_deform_1.layers.{i}.weight"].grad, f"dW layer {i} " + tag)
+            assert_grad_close(bs[i].grad, st64[f"mesh_deform_1.layers.{i}.bias"].grad, f"db layer {i} " + tag)
 
 
 @pytest.mark.parametrize("tname,use_touch,B,kin,nout,cut,do_cut,relu", [
