@@ -667,10 +667,15 @@ int a3vt_sample_points_bwd(const int32_t *faces, int batch, int n_vert, int n_fa
                            static_cast<hipStream_t>(stream));
 }
 
+size_t a3vt_chamfer_scratch_bytes(int draws, int batch, int p, int q) {
+  (void)p;
+  return draws > 0 && batch > 0 && q > 0 ? chamfer_scratch_bytes(draws, batch, q) : 0;
+}
+
 int a3vt_chamfer_fwd(const float *x, const float *y, int draws, int batch, int p, int q, float *dist_xy,
-                     int32_t *idx_xy, float *dist_yx, int32_t *idx_yx, float *cd, void *stream) {
+                     int32_t *idx_xy, float *dist_yx, int32_t *idx_yx, float *cd, void *scratch, void *stream) {
   A3VT_CHECK_ARG(x && y && dist_xy && idx_xy && dist_yx && idx_yx && cd);
-  return launch_chamfer_fwd(x, y, draws, batch, p, q, dist_xy, idx_xy, dist_yx, idx_yx, cd,
+  return launch_chamfer_fwd(x, y, draws, batch, p, q, dist_xy, idx_xy, dist_yx, idx_yx, cd, scratch,
                             static_cast<hipStream_t>(stream));
 }
 

@@ -157,6 +157,229 @@ static int launch_nn(const float *q, int nq, int q_mod, const float *c, int nc, 
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Single pass, both directions.  The two nn_kernel launches evaluate the same P x Q distance matrix twice (row minima,
+// then column minima with the roles swapped).  nn2_kernel evaluates every pair ONCE: the row minima stay in registers
+// exactly as above, and the column minimum of each candidate is folded on the way —
+//   in the lane: min over its R queries;
+//   in the wave, 4 candidates at a time: a transposing butterfly over the quad (DPP quad_perm; afterwards lane l holds
+//   candidate l & 3), row_ror 4 / 8 across the quads of a 16-lane row, two xor shuffles across the rows; then the first
+//   lane whose own minimum equals the wave's is found with a ballot;
+//   in the workgroup: a 64-bit LDS atomic min of (distance bits << 32 | wave << 6 | lane) per candidate — non-negative
+//   floats order like their bit patterns, and among equal distances the smallest (wave, lane) is the smallest query index
+//   because every lane owns R CONSECUTIVE queries; per tile one 64-bit global atomic min per candidate and workgroup.
+// nn2_cols_kernel then turns each candidate's (distance, wave, lane) into the index: it re-evaluates that lane's R
+// queries (same arithmetic) and takes the first that reproduces the distance.  ~42 instead of 65 wave-instructions per
+// candidate and 64 R queries.  Needs 8 bytes per candidate of scratch (a3vt_chamfer_scratch_bytes).
+// ------------------------------------------------------------------------------------------------
+constexpr int kNN2Tile = 1024;
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+  return __builtin_bit_cast(float,
+                            __builtin_amdgcn_update_dpp(0x7f800000, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void nn2_kernel(const float *__restrict__ xs, int np, const float *__restrict__ ys,
+                                                  int nq, int batch, float *__restrict__ dxy,
+                                                  int32_t *__restrict__ ixy, unsigned long long *__restrict__ colmin) {
+  __shared__ __attribute__((aligned(16))) float sx[kNN2Tile], sy[kNN2Tile], sz[kNN2Tile];
+  __shared__ unsigned long long scol[kNN2Tile];
+  const int z = blockIdx.y;
+  const float *qb = xs + (long long)z * np * 3;
+  const float *cb = ys + (long long)(z % batch) * nq * 3;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q0 = blockIdx.x * (256 * R) + wave * (64 * R) + lane * R;  // R consecutive queries per lane
+  const unsigned gwl = ((unsigned)(blockIdx.x * 4 + wave) << 6);       // (wave of the cloud) << 6; the lane goes below
+
+  float qx[R], qy[R], qz[R], best[R];
+  int bchunk[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int qi = min(q0 + r, np - 1);
+    qx[r] = qb[qi * 3 + 0];
+    qy[r] = qb[qi * 3 + 1];
+    qz[r] = qb[qi * 3 + 2];
+    best[r] = 3.0e38f;
+    bchunk[r] = 0;
+  }
+  const bool b0 = lane & 1, b1 = lane & 2;
+
+  for (int t0 = 0; t0 < nq; t0 += kNN2Tile) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < kNN2Tile; i += 256) {
+      const int ci = t0 + i;
+      const bool ok = ci < nq;
+      sx[i] = ok ? cb[ci * 3 + 0] : kFar;
+      sy[i] = ok ? cb[ci * 3 + 1] : kFar;
+      sz[i] = ok ? cb[ci * 3 + 2] : kFar;
+      scol[i] = ~0ull;
+    }
+    __syncthreads();
+    const int ntile = min(kNN2Tile, nq - t0);
+    const int nchunk = (ntile + kNNChunk - 1) / kNNChunk;
+    for (int ch = 0; ch < nchunk; ++ch) {
+      float m[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) m[r] = 3.0e38f;
+      const int j0 = ch * kNNChunk;
+#pragma unroll 1
+      for (int j = 0; j < kNNChunk; j += 4) {
+        const f32x4 cx = *reinterpret_cast<const f32x4 *>(sx + j0 + j);
+        const f32x4 cy = *reinterpret_cast<const f32x4 *>(sy + j0 + j);
+        const f32x4 cz = *reinterpret_cast<const f32x4 *>(sz + j0 + j);
+        float cm[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};  // this lane's minimum per candidate
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          float d[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float dx = qx[r] - cx[u], dy = qy[r] - cy[u], dz = qz[r] - cz[u];
+            d[u] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+            cm[u] = __builtin_fminf(cm[u], d[u]);
+          }
+          m[r] = __builtin_fminf(__builtin_fminf(m[r], d[0]), d[1]);
+          m[r] = __builtin_fminf(__builtin_fminf(m[r], d[2]), d[3]);
+        }
+        // quad butterfly: afterwards this lane holds the quad's minimum of candidate (lane & 3)
+        float k0 = b0 ? cm[1] : cm[0], k1 = b0 ? cm[3] : cm[2];
+        const float s0 = b0 ? cm[0] : cm[1], s1 = b0 ? cm[2] : cm[3];
+        k0 = __builtin_fminf(k0, dpp_f<0xB1>(s0));  // quad_perm [1,0,3,2]
+        k1 = __builtin_fminf(k1, dpp_f<0xB1>(s1));
+        float k = b1 ? k1 : k0;
+        const float sn = b1 ? k0 : k1;
+        k = __builtin_fminf(k, dpp_f<0x4E>(sn));  // quad_perm [2,3,0,1]
+        k = __builtin_fminf(k, dpp_f<0x124>(k));  // row_ror:4 (same quad position, next quad of the 16-lane row)
+        k = __builtin_fminf(k, dpp_f<0x128>(k));  // row_ror:8
+        // across the four 16-lane rows: xor shuffles (v_permlane16/32_swap would avoid the LDS crossbar, but gave wrong
+        // minima right behind the DPP steps — 75 % of the column results — and saved only 0.06 ms)
+        k = __builtin_fminf(k, __shfl_xor(k, 16, 64));
+        k = __builtin_fminf(k, __shfl_xor(k, 32, 64));
+        // every lane learns the wave minimum of all four candidates; the first lane that holds it signs the entry
+        const float w0 = dpp_f<0x00>(k), w1 = dpp_f<0x55>(k), w2 = dpp_f<0xAA>(k), w3 = dpp_f<0xFF>(k);
+        const int l0 = __builtin_ctzll(__builtin_amdgcn_ballot_w64(cm[0] == w0));
+        const int l1 = __builtin_ctzll(__builtin_amdgcn_ballot_w64(cm[1] == w1));
+        const int l2 = __builtin_ctzll(__builtin_amdgcn_ballot_w64(cm[2] == w2));
+        const int l3 = __builtin_ctzll(__builtin_amdgcn_ballot_w64(cm[3] == w3));
+        if (lane < 4) {
+          const int ll = lane == 0 ? l0 : lane == 1 ? l1 : lane == 2 ? l2 : l3;
+          const unsigned long long packed =
+              ((unsigned long long)__builtin_bit_cast(unsigned, k) << 32) | (unsigned long long)(gwl | (unsigned)ll);
+          atomicMin(&scol[j0 + j + lane], packed);
+        }
+      }
+      const int gch = (t0 + j0) / kNNChunk;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (m[r] < best[r]) {  // strict: the earliest chunk holding the minimum wins
+          best[r] = m[r];
+          bchunk[r] = gch;
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ntile; i += 256) atomicMin(colmin + (long long)z * nq + t0 + i, scol[i]);
+  }
+
+  // Row direction: rescan the winning chunk (same arithmetic) for the first arg-min.
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int qi = q0 + r;
+    if (qi >= np) continue;
+    const int j0 = bchunk[r] * kNNChunk;
+    float bd = 3.0e38f;
+    int bj = j0;
+    for (int j = 0; j < kNNChunk; ++j) {
+      const int ja = j0 + j;
+      const float cxv = ja < nq ? cb[ja * 3 + 0] : kFar, cyv = ja < nq ? cb[ja * 3 + 1] : kFar,
+                  czv = ja < nq ? cb[ja * 3 + 2] : kFar;
+      const float dx = qx[r] - cxv, dy = qy[r] - cyv, dz = qz[r] - czv;
+      const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+      if (d < bd) {
+        bd = d;
+        bj = ja;
+      }
+    }
+    dxy[(long long)z * np + qi] = bd;
+    ixy[(long long)z * np + qi] = bj;
+  }
+}
+
+// Column direction: (distance, wave, lane) -> index.  One thread per candidate.
+template <int R>
+__global__ __launch_bounds__(256) void nn2_cols_kernel(const float *__restrict__ xs, int np,
+                                                       const float *__restrict__ ys, int nq, int batch, int nclouds,
+                                                       const unsigned long long *__restrict__ colmin,
+                                                       float *__restrict__ dyx, int32_t *__restrict__ iyx) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)nclouds * nq) return;
+  const int z = (int)(t / nq), j = (int)(t - (long long)z * nq);
+  const unsigned long long packed = colmin[t];
+  const float dmin = __builtin_bit_cast(float, (unsigned)(packed >> 32));
+  const unsigned id = (unsigned)packed;
+  const int gw = id >> 6, ln = id & 63;
+  const int base = (gw >> 2) * (256 * R) + (gw & 3) * (64 * R) + ln * R;
+  const float *qb = xs + (long long)z * np * 3;
+  const float *c = ys + ((long long)(z % batch) * nq + j) * 3;
+  const float cxv = c[0], cyv = c[1], czv = c[2];
+  int found = min(base, np - 1);
+#pragma unroll
+  for (int r = R - 1; r >= 0; --r) {
+    const int qi = min(base + r, np - 1);
+    const float dx = qb[qi * 3 + 0] - cxv, dy = qb[qi * 3 + 1] - cyv, dz = qb[qi * 3 + 2] - czv;
+    const float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+    if (d == dmin) found = qi;  // descending r: the first query of the lane that reproduces the distance stays
+  }
+  dyx[t] = dmin;
+  iyx[t] = found;
+}
+
+size_t chamfer_scratch_bytes(int draws, int batch, int q) {
+  return (size_t)draws * batch * q * sizeof(unsigned long long);
+}
+
+template <int R>
+static void launch_nn2_r(const float *x, int p, const float *y, int q, int batch, int nclouds, float *dxy, int32_t *ixy,
+                         float *dyx, int32_t *iyx, unsigned long long *colmin, hipStream_t s) {
+  dim3 grid(cdiv(p, 256 * R), nclouds);
+  A3VT_LAUNCH((nn2_kernel<R>), grid, dim3(256), 0, s, x, p, y, q, batch, dxy, ixy, colmin);
+  const long long total = (long long)nclouds * q;
+  A3VT_LAUNCH((nn2_cols_kernel<R>), dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, x, p, y, q, batch, nclouds,
+              colmin, dyx, iyx);
+}
+
+static int launch_nn2(const float *x, int p, const float *y, int q, int batch, int nclouds, float *dxy, int32_t *ixy,
+                      float *dyx, int32_t *iyx, void *scratch, hipStream_t s) {
+  auto *colmin = static_cast<unsigned long long *>(scratch);
+  (void)hipGetLastError();
+  if (hipMemsetAsync(colmin, 0xFF, (size_t)nclouds * q * sizeof(unsigned long long), s) != hipSuccess) {
+    set_error("chamfer_fwd: clearing the column scratch failed");
+    return -2;
+  }
+  static const int env_r = getenv("A3VT_NN_R") ? atoi(getenv("A3VT_NN_R")) : 0;  // developer override
+  int best_r = 4;
+  long long best_cost = -1;
+  // balance rule of launch_nn, plus the column fold: ~28 wave-instructions per 4 candidates whatever R is, i.e. about
+  // 1.1 queries' worth — larger R amortises it (10,000 x 192: R = 10 -> 768 workgroups = 3 per CU, 3.9 ms; R = 5 4.1 ms)
+  for (int r : {10, 8, 6, 5, 4, 3}) {
+    const long long wgs = (long long)cdiv(p, 256 * r) * nclouds;
+    const long long cost = ((wgs + 255) / 256) * (10 * r + 11);
+    if (best_cost < 0 || cost < best_cost) best_cost = cost, best_r = r;
+  }
+  if (env_r) best_r = env_r;
+  switch (best_r) {
+    case 10: launch_nn2_r<10>(x, p, y, q, batch, nclouds, dxy, ixy, dyx, iyx, colmin, s); break;
+    case 8: launch_nn2_r<8>(x, p, y, q, batch, nclouds, dxy, ixy, dyx, iyx, colmin, s); break;
+    case 6: launch_nn2_r<6>(x, p, y, q, batch, nclouds, dxy, ixy, dyx, iyx, colmin, s); break;
+    case 5: launch_nn2_r<5>(x, p, y, q, batch, nclouds, dxy, ixy, dyx, iyx, colmin, s); break;
+    case 3: launch_nn2_r<3>(x, p, y, q, batch, nclouds, dxy, ixy, dyx, iyx, colmin, s); break;
+    default: launch_nn2_r<4>(x, p, y, q, batch, nclouds, dxy, ixy, dyx, iyx, colmin, s); break;
+  }
+  A3VT_CHECK_LAUNCH();
+  return 0;
+}
+
 // cd[b] = (1/draws) * sum_r ( mean_i dxy[r][b][i] + mean_j dyx[r][b][j] ) ; one workgroup per b, fixed order.
 __global__ __launch_bounds__(256) void chamfer_reduce_kernel(const float *__restrict__ dxy,
                                                              const float *__restrict__ dyx, int draws, int batch,
@@ -181,15 +404,20 @@ __global__ __launch_bounds__(256) void chamfer_reduce_kernel(const float *__rest
 }
 
 int launch_chamfer_fwd(const float *x, const float *y, int draws, int batch, int p, int q, float *dxy, int32_t *ixy,
-                       float *dyx, int32_t *iyx, float *cd, hipStream_t s) {
+                       float *dyx, int32_t *iyx, float *cd, void *scratch, hipStream_t s) {
   if (p <= 0 || q <= 0 || draws <= 0 || batch <= 0) {
     set_error("chamfer_fwd: empty input (draws=%d batch=%d p=%d q=%d)", draws, batch, p, q);
     return -1;
   }
-  // x -> y: queries = x clouds (draws*batch distinct), candidates = y[b]
-  if (int rc = launch_nn(x, p, draws * batch, y, q, batch, draws * batch, dxy, ixy, s)) return rc;
-  // y -> x: queries = y[b], candidates = x[r][b]
-  if (int rc = launch_nn(y, q, batch, x, p, draws * batch, draws * batch, dyx, iyx, s)) return rc;
+  if (scratch && (long long)cdiv(p, 256 * 3) * 4 < (1 << 26)) {
+    // one pass over the distance matrix for both directions (rows = predicted clouds, columns = ground truth)
+    if (int rc = launch_nn2(x, p, y, q, batch, draws * batch, dxy, ixy, dyx, iyx, scratch, s)) return rc;
+  } else {
+    // x -> y: queries = x clouds (draws*batch distinct), candidates = y[b]
+    if (int rc = launch_nn(x, p, draws * batch, y, q, batch, draws * batch, dxy, ixy, s)) return rc;
+    // y -> x: queries = y[b], candidates = x[r][b]
+    if (int rc = launch_nn(y, q, batch, x, p, draws * batch, draws * batch, dyx, iyx, s)) return rc;
+  }
   A3VT_LAUNCH(chamfer_reduce_kernel, dim3(batch), dim3(256), 0, s, dxy, dyx, draws, batch, p, q, cd);
   A3VT_CHECK_LAUNCH();
   return 0;

@@ -133,8 +133,9 @@ int launch_pool_fwd(PoolArgs a, hipStream_t s);
 int launch_pool_bwd(PoolArgs a, hipStream_t s);
 
 // chamfer.hip
+size_t chamfer_scratch_bytes(int draws, int batch, int q);
 int launch_chamfer_fwd(const float *x, const float *y, int draws, int batch, int p, int q, float *dxy, int32_t *ixy,
-                       float *dyx, int32_t *iyx, float *cd, hipStream_t s);
+                       float *dyx, int32_t *iyx, float *cd, void *scratch, hipStream_t s);
 int launch_chamfer_bwd(const float *x, const float *y, int draws, int batch, int p, int q, const int32_t *ixy,
                        const int32_t *iyx, const float *gcd, float *gx, float *gy, hipStream_t s);
 

@@ -48,7 +48,8 @@ SIGNATURES = {
     "a3vt_sample_points_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _u64, _u64,
                                     _vp, _vp, _vp, _vp, _vp]),
     "a3vt_sample_points_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "a3vt_chamfer_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "a3vt_chamfer_scratch_bytes": (_sz, [_i, _i, _i, _i]),
+    "a3vt_chamfer_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "a3vt_chamfer_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "a3vt_check_finite": (_i, [_vp, _sz, _vp, _vp]),
     "a3vt_profile_enable": (_i, [_i]),

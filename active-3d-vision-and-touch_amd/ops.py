@@ -369,8 +369,10 @@ class ChamferFn(torch.autograd.Function):
         dyx = torch.empty((draws, B, Q), dtype=torch.float32, device=dev)
         iyx = torch.empty((draws, B, Q), dtype=torch.int32, device=dev)
         cd = torch.empty((B,), dtype=torch.float32, device=dev)
+        scratch = torch.empty((L.a3vt_chamfer_scratch_bytes(draws, B, P, Q),), dtype=torch.uint8, device=dev)
         _lib.check(L.a3vt_chamfer_fwd(_lib.ptr(x), _lib.ptr(y), draws, B, P, Q, _lib.ptr(dxy), _lib.ptr(ixy),
-                                      _lib.ptr(dyx), _lib.ptr(iyx), _lib.ptr(cd), _stream()), "chamfer_fwd")
+                                      _lib.ptr(dyx), _lib.ptr(iyx), _lib.ptr(cd), _lib.ptr(scratch), _stream()),
+                   "chamfer_fwd")
         ctx.save_for_backward(x, y, ixy, iyx)
         ctx.aux = (dxy, dyx)
         return cd
@@ -389,8 +391,9 @@ class ChamferFn(torch.autograd.Function):
         return gx, gy
 
 
-def chamfer_nn(x, y):
-    """Raw nearest-neighbour outputs (dist_xy, idx_xy, dist_yx, idx_yx, cd) — used by tests and scoring."""
+def chamfer_nn(x, y, single_pass=True):
+    """Raw nearest-neighbour outputs (dist_xy, idx_xy, dist_yx, idx_yx, cd) — used by tests and scoring.
+    ``single_pass=False`` runs the two-pass search (no scratch); the results are identical."""
     L = _lib.load()
     x, y = _req(x, "x"), _req(y, "y")
     draws, B, P, _ = x.shape
@@ -401,8 +404,11 @@ def chamfer_nn(x, y):
     dyx = torch.empty((draws, B, Q), dtype=torch.float32, device=dev)
     iyx = torch.empty((draws, B, Q), dtype=torch.int32, device=dev)
     cd = torch.empty((B,), dtype=torch.float32, device=dev)
+    scratch = torch.empty((L.a3vt_chamfer_scratch_bytes(draws, B, P, Q),), dtype=torch.uint8, device=dev) \
+        if single_pass else None
     _lib.check(L.a3vt_chamfer_fwd(_lib.ptr(x), _lib.ptr(y), draws, B, P, Q, _lib.ptr(dxy), _lib.ptr(ixy),
-                                  _lib.ptr(dyx), _lib.ptr(iyx), _lib.ptr(cd), _stream()), "chamfer_fwd")
+                                  _lib.ptr(dyx), _lib.ptr(iyx), _lib.ptr(cd), _lib.ptr(scratch), _stream()),
+               "chamfer_fwd")
     return dxy, ixy, dyx, iyx, cd
 
 

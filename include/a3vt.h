@@ -186,10 +186,14 @@ int a3vt_sample_points_bwd(const int32_t *faces, int batch, int n_vert, int n_fa
  * and the mean over draws at utils.py:214-215.
  * x [draws][batch][p][3] (predicted clouds), y [batch][q][3] (ground truth, shared by the draws).
  * Outputs: dist_xy/idx_xy [draws][batch][p], dist_yx/idx_yx [draws][batch][q],
- *          cd [batch] = (1/draws) sum_r ( mean_i dist_xy + mean_j dist_yx ). */
+ *          cd [batch] = (1/draws) sum_r ( mean_i dist_xy + mean_j dist_yx ).
+ * scratch: a3vt_chamfer_scratch_bytes() bytes (8 per ground-truth point and cloud), contents irrelevant: with it both
+ *          directions come out of ONE pass over the distance matrix; NULL selects the two-pass search (same results,
+ *          bit for bit — every distance is the same fma chain and ties go to the lowest index either way). */
+size_t a3vt_chamfer_scratch_bytes(int draws, int batch, int p, int q);
 int a3vt_chamfer_fwd(const float *x, const float *y, int draws, int batch, int p, int q,
                      float *dist_xy, int32_t *idx_xy, float *dist_yx, int32_t *idx_yx, float *cd,
-                     void *stream);
+                     void *scratch, void *stream);
 /* grad_cd [batch].  grad_x [draws][batch][p][3] overwritten; grad_y [batch][q][3] overwritten, may be
  * NULL (the trainer's ground truth needs no gradient, vision/train.py:141-143). */
 int a3vt_chamfer_bwd(const float *x, const float *y, int draws, int batch, int p, int q,

@@ -145,7 +145,7 @@ def test_error_conventions(cuda):
     with pytest.raises(RuntimeError, match="GPU"):                          # no CPU fallback
         utils.chamfer_distance(torch.zeros(1, n, 3), torch.from_numpy(faces), torch.zeros(1, 10, 3), num=10)
     x = torch.zeros(1, 1, 4, 3, device=cuda)
-    rc = L.a3vt_chamfer_fwd(lib.ptr(x), lib.ptr(x), 1, 1, 0, 4, None, None, None, None, None, None)
+    rc = L.a3vt_chamfer_fwd(lib.ptr(x), lib.ptr(x), 1, 1, 0, 4, None, None, None, None, None, None, None)
     assert rc < 0 and len(L.a3vt_last_error()) > 0
     with pytest.raises(RuntimeError, match="multiple of 4"):                # feature rows must be 16-byte granular
         ops.gcn_layer(torch.zeros(1, n, 50, device=cuda), adj, torch.zeros(1, 50, 16, device=cuda),

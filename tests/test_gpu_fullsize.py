@@ -24,6 +24,9 @@ def test_chamfer_fullsize_properties(cuda):
     nn = torch.gather(y, 1, ixy[0].long()[..., None].expand(-1, -1, 3))
     assert torch.allclose(((x - nn) ** 2).sum(-1), dxy[0], rtol=1e-5, atol=1e-12)
     assert (dxy[0] <= ((x - y) ** 2).sum(-1) * (1 + 1e-5)).all()         # never worse than the same-index pairing
+    two = ops.chamfer_nn(x[None], y, single_pass=False)                  # single-pass search == two-pass search, bit for bit
+    for u, v in zip((dxy, ixy, dyx, iyx), two):
+        assert torch.equal(u, v)
 
 
 def test_rowgemm_fullsize_linearity(cuda):

@@ -347,11 +347,13 @@ def test_chamfer_fwd_bwd(cuda, P, Q, B, draws):
     assert np.allclose(((x[0, 0] - yy) ** 2).sum(-1).numpy(), dxy[0, 0].cpu().numpy(), rtol=1e-5, atol=1e-12)
 
 
-@pytest.mark.parametrize("P,R", [(1280, 5), (1024, 4), (1536, 6), (200, 3)])
-def test_chamfer_nn_every_queries_per_lane_variant(cuda, P, R):
-    """launch_nn picks the queries-per-lane template from the workgroup count per CU (chamfer.hip); 256 clouds of these
-    sizes select R = 5 / 4 / 6 / 3.  Distances and first-arg-min indices against a brute-force fp64 search (the clouds
-    hold duplicated points, so ties exist and the lowest index must win)."""
+@pytest.mark.parametrize("single_pass", [True, False])
+@pytest.mark.parametrize("P,R", [(1280, 5), (1024, 4), (1536, 6), (200, 3), (2048, 8), (2560, 10)])
+def test_chamfer_nn_every_queries_per_lane_variant(cuda, P, R, single_pass):
+    """launch_nn / launch_nn2 pick the queries-per-lane template from the workgroup count per CU (chamfer.hip); 256 clouds
+    of these sizes select R = 5 / 4 / 6 / 3 (and 8 / 10 in the single-pass search; the two-pass one falls back to 4 and
+    5 there).  Distances and first-arg-min indices against a brute-force fp64 search (the clouds hold duplicated points,
+    so ties exist and the lowest index must win)."""
     from a3vt_amd import ops
     B, Q = 256, 200
     g = torch.Generator().manual_seed(P)
@@ -359,7 +361,7 @@ def test_chamfer_nn_every_queries_per_lane_variant(cuda, P, R):
     y = (torch.rand(B, Q, 3, generator=g) * 0.3).float()
     y[:, Q // 2:] = y[:, :Q - Q // 2]          # every candidate twice: exact distance ties
     x[0, :, :7] = y[:, :7]                     # and a few zero distances
-    dxy, ixy, dyx, iyx, _ = ops.chamfer_nn(x.to(cuda), y.to(cuda))
+    dxy, ixy, dyx, iyx, _ = ops.chamfer_nn(x.to(cuda), y.to(cuda), single_pass=single_pass)
     for b in (0, 1, B // 2, B - 1):
         d = ((x[0, b].double()[:, None, :] - y[b].double()[None, :, :]) ** 2).sum(-1)
         ref_d, ref_i = d.min(1)
@@ -373,6 +375,27 @@ def test_chamfer_nn_every_queries_per_lane_variant(cuda, P, R):
         ref_d2, _ = d2.min(1)
         assert torch.allclose(dyx[0, b].cpu().double(), ref_d2, rtol=1e-5, atol=1e-12)
         assert torch.allclose(d2[torch.arange(Q), iyx[0, b].cpu().long()], ref_d2, rtol=1e-5, atol=1e-12)
+
+
+@pytest.mark.parametrize("draws,B,P,Q,dup", [(1, 1, 1, 1, False), (1, 2, 100, 37, False), (3, 2, 1000, 2176, True),
+                                             (2, 1, 4099, 5000, False), (2, 3, 777, 1025, True), (1, 1, 5, 3000, False),
+                                             (1, 64, 2600, 700, True)])
+def test_chamfer_single_pass_equals_two_pass(cuda, draws, B, P, Q, dup):
+    """The single-pass search (both directions from one sweep over the distance matrix, column minima folded through DPP
+    butterflies and 64-bit atomic minima of (distance, wave, lane)) against the two-pass search: every output bit for bit,
+    including the tie rule (duplicated queries AND candidates: lowest index wins in both directions)."""
+    from a3vt_amd import ops
+    g = torch.Generator().manual_seed(P * 7 + Q)
+    x = (torch.rand(draws, B, P, 3, generator=g) * 0.3).float()
+    y = (torch.rand(B, Q, 3, generator=g) * 0.3).float()
+    if dup:
+        y[:, Q // 2:] = y[:, :Q - Q // 2]
+        x[:, :, P // 2:] = x[:, :, :P - P // 2]
+        x[0, :, :3] = y[:, :3]
+    a = ops.chamfer_nn(x.to(cuda), y.to(cuda), single_pass=False)
+    b = ops.chamfer_nn(x.to(cuda), y.to(cuda), single_pass=True)
+    for name, u, v in zip(("dist_xy", "idx_xy", "dist_yx", "idx_yx", "cd"), a, b):
+        assert torch.equal(u, v), f"{name}: {(u != v).sum().item()} of {u.numel()} differ"
 
 
 def test_chamfer_known_answers(cuda):

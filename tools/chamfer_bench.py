@@ -13,13 +13,14 @@ dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 x = torch.randn(3, 64, 10000, 3, device=dev) * 0.1
 y = torch.randn(64, 10000, 3, device=dev) * 0.1
-out = ops.chamfer_nn(x, y)
+single = os.environ.get("SINGLE", "1") == "1"   # 0: the two-pass search
+out = ops.chamfer_nn(x, y, single_pass=single)
 torch.cuda.synchronize()
 reps = int(os.environ.get("REPS", "10"))
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(reps):
-    ops.chamfer_nn(x, y)
+    ops.chamfer_nn(x, y, single_pass=single)
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
