@@ -175,9 +175,8 @@ static int launch_nn(const float *q, int nq, int q_mod, const float *c, int nc, 
 constexpr int kNN2Tile = 1024;
 
 template <int CTRL>
-__device__ __forceinline__ float dpp_f(float x) {
-  return __builtin_bit_cast(float,
-                            __builtin_amdgcn_update_dpp(0x7f800000, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, false));
+__device__ __forceinline__ unsigned dpp_u(unsigned x) {  // `old` = the identity of min: lets the DPP move fold into v_min_u32
+  return (unsigned)__builtin_amdgcn_update_dpp(-1, (int)x, CTRL, 0xF, 0xF, false);
 }
 
 template <int R>
@@ -242,32 +241,33 @@ __global__ __launch_bounds__(256) void nn2_kernel(const float *__restrict__ xs, 
           m[r] = __builtin_fminf(__builtin_fminf(m[r], d[0]), d[1]);
           m[r] = __builtin_fminf(__builtin_fminf(m[r], d[2]), d[3]);
         }
+        // The fold runs on the bit patterns (non-negative floats order like unsigned integers): v_min_u32 takes a DPP
+        // operand directly and needs no NaN canonicalisation, so every step below is one instruction.
+        const unsigned c0 = __builtin_bit_cast(unsigned, cm[0]), c1 = __builtin_bit_cast(unsigned, cm[1]),
+                       c2 = __builtin_bit_cast(unsigned, cm[2]), c3 = __builtin_bit_cast(unsigned, cm[3]);
         // quad butterfly: afterwards this lane holds the quad's minimum of candidate (lane & 3)
-        float k0 = b0 ? cm[1] : cm[0], k1 = b0 ? cm[3] : cm[2];
-        const float s0 = b0 ? cm[0] : cm[1], s1 = b0 ? cm[2] : cm[3];
-        k0 = __builtin_fminf(k0, dpp_f<0xB1>(s0));  // quad_perm [1,0,3,2]
-        k1 = __builtin_fminf(k1, dpp_f<0xB1>(s1));
-        float k = b1 ? k1 : k0;
-        const float sn = b1 ? k0 : k1;
-        k = __builtin_fminf(k, dpp_f<0x4E>(sn));  // quad_perm [2,3,0,1]
-        k = __builtin_fminf(k, dpp_f<0x124>(k));  // row_ror:4 (same quad position, next quad of the 16-lane row)
-        k = __builtin_fminf(k, dpp_f<0x128>(k));  // row_ror:8
+        unsigned k0 = b0 ? c1 : c0, k1 = b0 ? c3 : c2;
+        const unsigned s0 = b0 ? c0 : c1, s1 = b0 ? c2 : c3;
+        k0 = min(k0, dpp_u<0xB1>(s0));  // quad_perm [1,0,3,2]
+        k1 = min(k1, dpp_u<0xB1>(s1));
+        unsigned k = b1 ? k1 : k0;
+        const unsigned sn = b1 ? k0 : k1;
+        k = min(k, dpp_u<0x4E>(sn));   // quad_perm [2,3,0,1]
+        k = min(k, dpp_u<0x124>(k));   // row_ror:4 (same quad position, next quad of the 16-lane row)
+        k = min(k, dpp_u<0x128>(k));   // row_ror:8
         // across the four 16-lane rows: xor shuffles (v_permlane16/32_swap would avoid the LDS crossbar, but gave wrong
         // minima right behind the DPP steps — 75 % of the column results — and saved only 0.06 ms)
-        k = __builtin_fminf(k, __shfl_xor(k, 16, 64));
-        k = __builtin_fminf(k, __shfl_xor(k, 32, 64));
+        k = min(k, (unsigned)__shfl_xor((int)k, 16, 64));
+        k = min(k, (unsigned)__shfl_xor((int)k, 32, 64));
         // every lane learns the wave minimum of all four candidates; the first lane that holds it signs the entry
-        const float w0 = dpp_f<0x00>(k), w1 = dpp_f<0x55>(k), w2 = dpp_f<0xAA>(k), w3 = dpp_f<0xFF>(k);
-        const int l0 = __builtin_ctzll(__builtin_amdgcn_ballot_w64(cm[0] == w0));
-        const int l1 = __builtin_ctzll(__builtin_amdgcn_ballot_w64(cm[1] == w1));
-        const int l2 = __builtin_ctzll(__builtin_amdgcn_ballot_w64(cm[2] == w2));
-        const int l3 = __builtin_ctzll(__builtin_amdgcn_ballot_w64(cm[3] == w3));
-        if (lane < 4) {
-          const int ll = lane == 0 ? l0 : lane == 1 ? l1 : lane == 2 ? l2 : l3;
-          const unsigned long long packed =
-              ((unsigned long long)__builtin_bit_cast(unsigned, k) << 32) | (unsigned long long)(gwl | (unsigned)ll);
-          atomicMin(&scol[j0 + j + lane], packed);
-        }
+        const unsigned w0 = dpp_u<0x00>(k), w1 = dpp_u<0x55>(k), w2 = dpp_u<0xAA>(k), w3 = dpp_u<0xFF>(k);
+        const unsigned l0 = __builtin_ctzll(__builtin_amdgcn_ballot_w64(c0 == w0));
+        const unsigned l1 = __builtin_ctzll(__builtin_amdgcn_ballot_w64(c1 == w1));
+        const unsigned l2 = __builtin_ctzll(__builtin_amdgcn_ballot_w64(c2 == w2));
+        const unsigned l3 = __builtin_ctzll(__builtin_amdgcn_ballot_w64(c3 == w3));
+        const unsigned ll = b1 ? (b0 ? l3 : l2) : (b0 ? l1 : l0);  // the winner of this lane's candidate (lane & 3)
+        const unsigned long long packed = ((unsigned long long)k << 32) | (unsigned long long)(gwl | ll);
+        if (lane < 4) atomicMin(&scol[j0 + j + lane], packed);
       }
       const int gch = (t0 + j0) / kNNChunk;
 #pragma unroll
