@@ -183,7 +183,7 @@ template <int R>
 __global__ __launch_bounds__(256) void nn2_kernel(const float *__restrict__ xs, int np, const float *__restrict__ ys,
                                                   int nq, int batch, float *__restrict__ dxy,
                                                   int32_t *__restrict__ ixy, unsigned long long *__restrict__ colmin) {
-  __shared__ __attribute__((aligned(16))) float sx[kNN2Tile], sy[kNN2Tile], sz[kNN2Tile];
+  __shared__ __attribute__((aligned(16))) float sx[kNN2Tile + 4], sy[kNN2Tile + 4], sz[kNN2Tile + 4];
   __shared__ unsigned long long scol[kNN2Tile];
   const int z = blockIdx.y;
   const float *qb = xs + (long long)z * np * 3;
@@ -223,11 +223,16 @@ __global__ __launch_bounds__(256) void nn2_kernel(const float *__restrict__ xs, 
 #pragma unroll
       for (int r = 0; r < R; ++r) m[r] = 3.0e38f;
       const int j0 = ch * kNNChunk;
+      // the next four candidates are fetched while the current four are worked on (the tile arrays are padded by one
+      // group, so the read past the last chunk is harmless)
+      f32x4 nx = *reinterpret_cast<const f32x4 *>(sx + j0), ny = *reinterpret_cast<const f32x4 *>(sy + j0),
+            nz = *reinterpret_cast<const f32x4 *>(sz + j0);
 #pragma unroll 1
       for (int j = 0; j < kNNChunk; j += 4) {
-        const f32x4 cx = *reinterpret_cast<const f32x4 *>(sx + j0 + j);
-        const f32x4 cy = *reinterpret_cast<const f32x4 *>(sy + j0 + j);
-        const f32x4 cz = *reinterpret_cast<const f32x4 *>(sz + j0 + j);
+        const f32x4 cx = nx, cy = ny, cz = nz;
+        nx = *reinterpret_cast<const f32x4 *>(sx + j0 + j + 4);
+        ny = *reinterpret_cast<const f32x4 *>(sy + j0 + j + 4);
+        nz = *reinterpret_cast<const f32x4 *>(sz + j0 + j + 4);
         float cm[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};  // this lane's minimum per candidate
 #pragma unroll
         for (int r = 0; r < R; ++r) {

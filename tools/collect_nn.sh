@@ -15,7 +15,7 @@ f = glob.glob("$OUT/pass/*/*counter_collection.csv")[0]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"].split("(")[0]
-    if "nn_kernel" in k:
+    if "nn_kernel" in k or "nn2_kernel" in k:
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for k, d in agg.items():
