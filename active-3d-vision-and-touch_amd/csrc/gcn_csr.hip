@@ -318,7 +318,11 @@ int launch_csr_bwd(const float *g, int ldg, int c, const int32_t *rowptrT, const
 // its k-pieces in registers.  k <= 320.
 // ------------------------------------------------------------------------------------------------
 constexpr int kThinPieces = 5;  // 16 lanes * 5 pieces * 4 floats = 320 channels max
-constexpr int kThinBlocks = 1024;
+// Both kernels are grid-stride loops with a per-block preamble (60 weight registers per lane): the grids are what is
+// resident at once — 3 workgroups per CU for thin_bwd (155 VGPRs), 5 for thin_fwd (88) — so no block waits for a slot
+// and then runs alone (thin_bwd: 1024 blocks at 768 resident took two rounds, 128 us per call; 768 take 99.  thin_fwd: 73 -> 52 us).
+constexpr int kThinBlocks = 768;
+constexpr int kThinFwdBlocks = 1280;
 int thin_num_slabs() { return kThinBlocks; }
 
 __global__ __launch_bounds__(256) void thin_fwd_kernel(const float *__restrict__ x, int ldx, int k,
@@ -445,7 +449,7 @@ int launch_thin_fwd(const float *x, int ldx, int k, const float *w, const float 
     return -1;
   }
   const long long m = (long long)batch * n_vert;
-  const int grid = (int)(cdiv(m, 16) < 4096 ? cdiv(m, 16) : 4096);
+  const int grid = (int)(cdiv(m, 16) < kThinFwdBlocks ? cdiv(m, 16) : kThinFwdBlocks);
   A3VT_LAUNCH(thin_fwd_kernel, dim3(grid), dim3(256), 0, s, x, ldx, k, w, m, z3);
   A3VT_CHECK_LAUNCH();
   return launch_csr3(z3, bias, rowptr, col, val, heavy, n_vert, batch, update, 3, s);
