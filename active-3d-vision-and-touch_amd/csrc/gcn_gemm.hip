@@ -9,6 +9,7 @@
 // Both use v_mfma_f32_16x16x4_f32 (exact fp32 fma chain, 64 FLOP/clk/SIMD — MI355X_MICROARCH.md
 // "Matrix cores"), operands staged HBM/L2 -> LDS with LDS-DMA (global_load_lds_dwordx4), counted
 // vmcnt waits and raw s_barrier so the next chunk's DMA stays in flight under the MFMAs.
+#include <stdlib.h>
 #include <type_traits>
 
 #include "common.h"
@@ -44,6 +45,70 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// One 16 x 16 output tile — rows row_base + 16 mt .., columns n0 .. — with its operands pulled straight from global
+// memory into registers: all loads of up to 19 K-chunks in flight at once, no LDS, no barrier, then the MFMA chain (one
+// round trip instead of nineteen).  Same arithmetic order along K as rowgemm_kernel.  Used for the handful of rows the
+// load-balanced split leaves over (launch_rowgemm_epi): by rowtile_kernel, and by the tail of rowgemm_kernel itself.
+template <int EPI, bool BF16>
+__device__ __forceinline__ void rowtile_unit(const RowGemmArgs &p, int row_base, int row_end, int mt, int n0, int lane) {
+  constexpr int KB = 19;  // K-chunks (of 16) per register block: all of K = 300 in one round trip
+  const int l16 = lane & 15, q = lane >> 4;
+  const int ar = min(row_base + mt * 16 + l16, row_end - 1);  // A row of this lane (ragged tail: duplicate, never stored)
+  const int br = min(n0 + l16, p.bt_rows - 1);                 // Bt row (= output column) of this lane
+  const float *a0r = p.a0 + (size_t)ar * p.lda0, *a1r = p.a1 + (size_t)ar * p.lda1;
+  const float *btr = p.bt + (size_t)br * p.ldb;
+  const int nch = (p.k + 15) >> 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int c0 = 0; c0 < nch; c0 += KB) {
+    f32x4 af[KB], bf[KB];
+#pragma unroll
+    for (int c = 0; c < KB; ++c) {
+      const int kk = (c0 + c) * 16 + q * 4;
+      const bool on = c0 + c < nch && kk < p.k;
+      af[c] = on ? *reinterpret_cast<const f32x4 *>((kk < p.ksplit ? a0r : a1r) + kk) : f32x4{0.f, 0.f, 0.f, 0.f};
+      bf[c] = on ? *reinterpret_cast<const f32x4 *>(btr + kk) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int c = 0; c < KB; ++c) {
+      if (BF16) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(cvt_bf16x4(af[c]), cvt_bf16x4(bf[c]), acc, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c][t], bf[c][t], acc, 0, 0, 0);
+      }
+    }
+  }
+  // C/D layout: this lane holds column n0 + l16 of rows 4q .. 4q+3 of the tile
+  const int col = n0 + l16;
+  const bool col_ok = col < p.n_store;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = row_base + mt * 16 + q * 4 + r;
+    const bool row_ok = row < row_end;
+    float v = acc[r];
+    if (EPI == EPI_PLAIN) {
+      if (row_ok && col_ok) p.c[(size_t)row * p.ldc + col] = v;
+    } else if (EPI == EPI_FWD_HIDDEN) {
+      // ReLU-sign byte of 4 consecutive pass-through columns: gathered from the 4 lanes that hold them
+      const unsigned mybit = (col_ok && col >= p.csplit && v > 0.f) ? 1u << (l16 & 3) : 0u;
+      unsigned bits = mybit;
+      bits |= __shfl_xor(bits, 1, 64);
+      bits |= __shfl_xor(bits, 2, 64);
+      if (row_ok && p.maskb && (l16 & 3) == 0 && (col | 3) >= p.csplit && col < ((p.n_store + 3) & ~3))
+        p.maskb[(size_t)row * p.mld + p.moff + (col >> 2)] = (uint8_t)bits;
+      if (row_ok && col_ok) {
+        if (col < p.csplit) p.c2[(size_t)row * p.ldc2 + col] = v;
+        else p.c[(size_t)row * p.ldc + col] = (v > 0.f || p.no_relu) ? v : 0.f;
+      }
+    } else {  // EPI_DX_MASK
+      if (row_ok && col_ok) {
+        const unsigned byte = p.maskb[(size_t)row * p.mld + (col < p.csplit ? 0 : p.moff) + (col >> 2)];
+        p.c[(size_t)row * p.ldc + col] = ((byte >> (col & 3)) & 1u) ? v : 0.f;
+      }
+    }
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // rowgemm: persistent workgroups; the M rows are cut into 16-row tiles that are dealt evenly to the
@@ -345,6 +410,15 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
     wait_lgkm0();
     __builtin_amdgcn_s_barrier();  // epilogue slices are free again before the next round's DMA
   }
+  // Leftover rows of the load-balanced split (a few 16-row tiles): one 16 x 16 output tile per wave, dealt across the
+  // workgroups, operands straight from global memory (rowtile_unit) — a couple of microseconds at the end of this launch
+  // instead of a launch of their own.
+  if (p.rem_rows > 0) {
+    const int ntl = min(NT, (p.n_store - col0 + 15) >> 4);  // n-tiles of this column block that exist
+    const int units = ((p.rem_rows + 15) >> 4) * ntl;
+    for (int u = wave * gridDim.x + blockIdx.x; u < units; u += WAVES * gridDim.x)
+      rowtile_unit<EPI, BF16>(p, p.rem_row0, p.rem_row0 + p.rem_rows, u / ntl, col0 + (u % ntl) * 16, lane);
+  }
 }
 
 template <int NT>
@@ -411,66 +485,10 @@ static int launch_rowgemm_cols(const RowGemmArgs &a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 template <int EPI, bool BF16>
 __global__ __launch_bounds__(256) void rowtile_kernel(RowGemmArgs p) {
-  constexpr int KB = 19;  // K-chunks (of 16) per register block: all of K = 300 in one round trip
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int l16 = lane & 15, q = lane >> 4;
   const int mt = blockIdx.y * 4 + wave;
   if (mt * 16 >= p.m) return;
-  const int n0 = p.col0 + blockIdx.x * 16;
-  const int ar = min(mt * 16 + l16, p.m - 1);                  // A row of this lane (ragged tail: duplicate, never stored)
-  const int br = min(n0 + l16, p.bt_rows - 1);                 // Bt row (= output column) of this lane
-  const float *a0r = p.a0 + (size_t)ar * p.lda0, *a1r = p.a1 + (size_t)ar * p.lda1;
-  const float *btr = p.bt + (size_t)br * p.ldb;
-  const int nch = (p.k + 15) >> 4;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int c0 = 0; c0 < nch; c0 += KB) {
-    f32x4 af[KB], bf[KB];
-#pragma unroll
-    for (int c = 0; c < KB; ++c) {
-      const int kk = (c0 + c) * 16 + q * 4;
-      const bool on = c0 + c < nch && kk < p.k;
-      af[c] = on ? *reinterpret_cast<const f32x4 *>((kk < p.ksplit ? a0r : a1r) + kk) : f32x4{0.f, 0.f, 0.f, 0.f};
-      bf[c] = on ? *reinterpret_cast<const f32x4 *>(btr + kk) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int c = 0; c < KB; ++c) {
-      if (BF16) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(cvt_bf16x4(af[c]), cvt_bf16x4(bf[c]), acc, 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[c][t], bf[c][t], acc, 0, 0, 0);
-      }
-    }
-  }
-  // C/D layout: this lane holds column n0 + l16 of rows 4q .. 4q+3 of the tile
-  const int col = n0 + l16;
-  const bool col_ok = col < p.n_store;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = mt * 16 + q * 4 + r;
-    const bool row_ok = row < p.m;
-    float v = acc[r];
-    if (EPI == EPI_PLAIN) {
-      if (row_ok && col_ok) p.c[(size_t)row * p.ldc + col] = v;
-    } else if (EPI == EPI_FWD_HIDDEN) {
-      // ReLU-sign byte of 4 consecutive pass-through columns: gathered from the 4 lanes that hold them
-      const unsigned mybit = (col_ok && col >= p.csplit && v > 0.f) ? 1u << (l16 & 3) : 0u;
-      unsigned bits = mybit;
-      bits |= __shfl_xor(bits, 1, 64);
-      bits |= __shfl_xor(bits, 2, 64);
-      if (row_ok && p.maskb && (l16 & 3) == 0 && (col | 3) >= p.csplit && col < ((p.n_store + 3) & ~3))
-        p.maskb[(size_t)row * p.mld + p.moff + (col >> 2)] = (uint8_t)bits;
-      if (row_ok && col_ok) {
-        if (col < p.csplit) p.c2[(size_t)row * p.ldc2 + col] = v;
-        else p.c[(size_t)row * p.ldc + col] = (v > 0.f || p.no_relu) ? v : 0.f;
-      }
-    } else {  // EPI_DX_MASK
-      if (row_ok && col_ok) {
-        const unsigned byte = p.maskb[(size_t)row * p.mld + (col < p.csplit ? 0 : p.moff) + (col >> 2)];
-        p.c[(size_t)row * p.ldc + col] = ((byte >> (col & 3)) & 1u) ? v : 0.f;
-      }
-    }
-  }
+  rowtile_unit<EPI, BF16>(p, 0, p.m, mt, p.col0 + blockIdx.x * 16, lane);
 }
 
 template <int EPI>
@@ -496,6 +514,12 @@ static int launch_rowgemm_epi(const RowGemmArgs &a0, hipStream_t s) {
   if (full == 0 || rem == 0 || rem * nt > 1024 || nt < 2) return launch_rowgemm_cols<EPI>(a, s);
   RowGemmArgs m = a;
   m.m = full * 16;
+  static const bool separate = getenv("A3VT_ROWTILE_SEPARATE") != nullptr;  // developer switch: remainder as its own launch
+  if (!separate) {
+    m.rem_row0 = full * 16;
+    m.rem_rows = a.m - full * 16;
+    return launch_rowgemm_cols<EPI>(m, s);
+  }
   if (int rc = launch_rowgemm_cols<EPI>(m, s)) return rc;
   RowGemmArgs r = a;
   const size_t r0 = (size_t)full * 16;

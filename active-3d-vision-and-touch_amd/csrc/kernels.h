@@ -27,6 +27,9 @@ struct RowGemmArgs {
   int ldc, ldc2, csplit, mld, moff;
   int no_relu;  // EPI_FWD_HIDDEN: store the pass-through channels without the ReLU (identity activation)
   int bf16;     // operands rounded to bf16, v_mfma_f32_16x16x16_bf16, fp32 accumulate (default: exact fp32 MFMA)
+  // rows [rem_row0, rem_row0 + rem_rows) beyond the m rows of the main loop: the few leftover tiles of the load-balanced
+  // split, done by the tail of the same launch (set by launch_rowgemm; 0 = none)
+  int rem_row0, rem_rows;
 };
 int rowgemm_bt_rows(int n_store);
 int launch_rowgemm(const RowGemmArgs &a, int epi, hipStream_t s);
