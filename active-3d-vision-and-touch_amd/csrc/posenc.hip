@@ -108,9 +108,39 @@ __global__ __launch_bounds__(256) void posenc_fwd_kernel(const float *__restrict
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= m) return;
   const float p[3] = {verts[3 * (long long)v], verts[3 * (long long)v + 1], verts[3 * (long long)v + 2]};
-  float e[63], h1[P::H1], h2[P::H2];
-  pe_embed<I>(p, e);
-  pe_mlp<I>(sp, e, h1, h2);
+  // The 63-wide embedding is never held whole (63 + 12 + 25 live floats put the kernel at 256 VGPRs, one wave per SIMD):
+  // each frequency's six values go straight into the first layer's accumulators, in the same k order as pe_mlp.
+  float h1[P::H1], h2[P::H2];
+#pragma unroll
+  for (int j = 0; j < P::H1; ++j) h1[j] = sp[L::ob1 + j];
+#pragma unroll 1
+  for (int i = 0; i < 10; ++i) {
+    const float f = pe_freq(i);
+    float e6[6];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      e6[c] = sinf(f * p[c]);
+      e6[3 + c] = cosf(f * p[c]);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 6; ++kk)
+#pragma unroll
+      for (int j = 0; j < P::H1; ++j) h1[j] += sp[L::oW1t + (6 * i + kk) * P::H1 + j] * e6[kk];
+  }
+#pragma unroll
+  for (int kk = 0; kk < 3; ++kk)
+#pragma unroll
+    for (int j = 0; j < P::H1; ++j) h1[j] += sp[L::oW1t + (60 + kk) * P::H1 + j] * p[kk];
+#pragma unroll
+  for (int j = 0; j < P::H1; ++j) h1[j] = h1[j] > 0.f ? h1[j] : 0.f;
+#pragma unroll
+  for (int j = 0; j < P::H2; ++j) h2[j] = sp[L::ob2 + j];
+#pragma unroll
+  for (int k = 0; k < P::H1; ++k)
+#pragma unroll
+    for (int j = 0; j < P::H2; ++j) h2[j] += sp[L::oW2t + k * P::H2 + j] * h1[k];
+#pragma unroll
+  for (int j = 0; j < P::H2; ++j) h2[j] = h2[j] > 0.f ? h2[j] : 0.f;
   int tok = (int)mask[v];  // mask.long() (model.py:413)
   tok = tok < 0 ? 0 : (tok > 3 ? 3 : tok);
   float *out = feats + (long long)v * ld;
