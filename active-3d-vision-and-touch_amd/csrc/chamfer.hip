@@ -386,24 +386,28 @@ static int launch_nn2(const float *x, int p, const float *y, int q, int batch, i
 }
 
 // cd[b] = (1/draws) * sum_r ( mean_i dxy[r][b][i] + mean_j dyx[r][b][j] ) ; one workgroup per b, fixed order.
-__global__ __launch_bounds__(256) void chamfer_reduce_kernel(const float *__restrict__ dxy,
-                                                             const float *__restrict__ dyx, int draws, int batch,
-                                                             int p, int q, float *__restrict__ cd) {
-  __shared__ float red[4];
+__global__ __launch_bounds__(1024) void chamfer_reduce_kernel(const float *__restrict__ dxy,
+                                                              const float *__restrict__ dyx, int draws, int batch,
+                                                              int p, int q, float *__restrict__ cd) {
+  // 1024 threads per sample (only `batch` workgroups exist: the reduce is latency-bound, so each gets many loads in flight)
+  __shared__ float red[16];
   const int b = blockIdx.x;
   float total = 0.f;
   for (int r = 0; r < draws; ++r) {
     float s1 = 0.f, s2 = 0.f;
     const float *a = dxy + ((long long)r * batch + b) * p;
     const float *bb = dyx + ((long long)r * batch + b) * q;
-    for (int i = threadIdx.x; i < p; i += 256) s1 += a[i];
-    for (int i = threadIdx.x; i < q; i += 256) s2 += bb[i];
+    for (int i = threadIdx.x; i < p; i += 1024) s1 += a[i];
+    for (int i = threadIdx.x; i < q; i += 1024) s2 += bb[i];
     float v = s1 / (float)p + s2 / (float)q;
     v = wave_sum(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    total += (red[0] + red[1]) + (red[2] + red[3]);
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w];  // fixed order
+    total += t;
   }
   if (threadIdx.x == 0) cd[b] = total / (float)draws;
 }
@@ -423,7 +427,7 @@ int launch_chamfer_fwd(const float *x, const float *y, int draws, int batch, int
     // y -> x: queries = y[b], candidates = x[r][b]
     if (int rc = launch_nn(y, q, batch, x, p, draws * batch, draws * batch, dyx, iyx, s)) return rc;
   }
-  A3VT_LAUNCH(chamfer_reduce_kernel, dim3(batch), dim3(256), 0, s, dxy, dyx, draws, batch, p, q, cd);
+  A3VT_LAUNCH(chamfer_reduce_kernel, dim3(batch), dim3(1024), 0, s, dxy, dyx, draws, batch, p, q, cd);
   A3VT_CHECK_LAUNCH();
   return 0;
 }
