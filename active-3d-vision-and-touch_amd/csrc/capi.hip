@@ -70,6 +70,7 @@ struct StackLayout {
   size_t za;             // [M][cpad]
   size_t z3;             // [2][M][4]
   size_t ping[2];        // [M][hidden] each (fwd without acts: layer outputs; bwd: gradients)
+  size_t panel;          // bwd, inputs wider than 304 columns only: [M][300] contiguous column block of X_0 for dW_0
   size_t dw_slab, db_slab, thin_dw_slab, thin_db_slab;
   size_t heavy;          // int32 list of hub rows (csr_heavy_scratch_ints)
   size_t total;
@@ -96,6 +97,8 @@ static StackLayout stack_layout(int batch, int n_vert, int in_features, int hidd
   L.heavy = take(csr_heavy_scratch_ints(n_vert));
   if (need_backward) {
     const size_t kin = kmax;
+    // its own region: with hidden < 300 a ping buffer ([M][hidden]) is smaller than a 300-column block of X_0
+    L.panel = take(pad4(in_features) > 304 ? m * 300 : 0);
     L.dw_slab = take((size_t)dw_num_slabs(hidden) * kin * hidden);
     L.db_slab = take((size_t)csr_bwd_num_slabs(batch, n_vert) * cpad);
     L.thin_dw_slab = take((size_t)thin_num_slabs() * kin * 3);
@@ -107,8 +110,10 @@ static StackLayout stack_layout(int batch, int n_vert, int in_features, int hidd
 
 static int check_stack_dims(int ld_feats, int in_features, int num_layers, int hidden, int cut_len) {
   if (num_layers < 1) { set_error("gcn_stack: num_layers=%d", num_layers); return -1; }
-  if (ld_feats % 4 != 0 || ld_feats < in_features) {
-    set_error("gcn_stack: ld_feats=%d must be a multiple of 4 and >= in_features=%d", ld_feats, in_features);
+  // the scratch layout (weight-image stride, dW slabs) is sized from in_features alone: the row stride must be the
+  // 4-float granule right above it, nothing wider
+  if (ld_feats != pad4(in_features)) {
+    set_error("gcn_stack: ld_feats=%d must be in_features=%d rounded up to a multiple of 4", ld_feats, in_features);
     return -1;
   }
   if (num_layers > 1 && (hidden % 4 != 0 || hidden > 304 || cut_len < 0 || cut_len > hidden)) {
@@ -333,14 +338,13 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
     }
 
     // dW_i = X_i^T dZ.  The kernel covers up to 304 input channels per pass; wider inputs (the 448-wide image
-    // model's first layer) go in column blocks of <= 300, each first copied into a contiguous panel (the free
-    // gradient ping buffer).
+    // model's first layer) go in column blocks of <= 300, each first copied into a contiguous panel (StackLayout::panel).
     for (int c0 = 0; c0 < kin; c0 += 300) {
       const int w = kin - c0 < 300 ? kin - c0 : 300;
       const float *xs = x;
       int ldxs = ldx;
       if (kin > 304) {
-        float *panel = scratch + L.ping[cur ^ 1];
+        float *panel = scratch + L.panel;
         const int wp = pad4(w);
         if (wp != w) { set_error("gcn_stack: in_features=%d needs a multiple of 4 past 300", kin); return -1; }
         if (int rc = launch_copy_cols(x, ldx, c0, w, panel, (long long)m, s)) return rc;

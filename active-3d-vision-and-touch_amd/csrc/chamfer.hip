@@ -433,104 +433,104 @@ int launch_chamfer_fwd(const float *x, const float *y, int draws, int batch, int
 }
 
 // Gradient.  With g = grad_cd[b] / draws:
-//   gx[r][b][i]  = g * (2/P) (x_i - y_nn(i))                       (direct store, kernel A)
-//   gx[r][b][nn(j)] += g * (2/Q) (x_nn(j) - y_j)                   (atomic, kernel B)
-//   gy[b][nn(i)] -= first term ;  gy[b][j] -= second term          (atomic, optional)
-__global__ __launch_bounds__(256) void chamfer_bwd_x_kernel(const float *__restrict__ x, const float *__restrict__ y,
-                                                            int draws, int batch, int p, int q,
-                                                            const int32_t *__restrict__ ixy,
-                                                            const float *__restrict__ gcd, float *__restrict__ gx,
-                                                            float *__restrict__ gy) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // (r, b, i)
-  const long long total = (long long)draws * batch * p;
-  if (i >= total) return;
-  const int b = (int)((i / p) % batch);
-  const float coef = gcd[b] / (float)draws * (2.0f / (float)p);
-  const long long yj = (long long)b * q + ixy[i];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    const float t = coef * (x[i * 3 + d] - y[yj * 3 + d]);
-    gx[i * 3 + d] = t;
-    if (gy) atomicAdd(gy + yj * 3 + d, -t);
-  }
-}
+//   gx[r][b][i] = g (2/P) (x_i - y_nn(i))  +  g (2/Q) sum_{j : nn(j) = i} (x_i - y_j)
+//   gy[b][j]    = - sum_r [ g (2/Q) (x_nn_r(j) - y_j)  +  g (2/P) sum_{i : nn_r(i) = j} (x_i - y_j) ]
+// Both are "a direct term per target point plus a scatter of the other cloud's nearest-neighbour pairs into it".  One
+// kernel serves both: a workgroup owns a tile of ONE target cloud, accumulates the scattered differences of every source
+// cloud in 64-bit fixed point in LDS (common.h: integer sums do not depend on the arrival order, so the gradient is
+// reproducible bit for bit, unlike the float atomics this replaces), and writes each gradient element exactly once —
+// direct term included, so nothing has to be zeroed or added to afterwards.  Any cloud size: the target is cut into
+// tiles of <= kBwdTile points (24 bytes of LDS each); every tile's workgroup scans all source points and keeps those
+// whose neighbour falls into its tile.
+constexpr int kBwdTile = 6144;  // 144 KiB of accumulators
 
-__global__ __launch_bounds__(256) void chamfer_bwd_y_kernel(const float *__restrict__ x, const float *__restrict__ y,
-                                                            int draws, int batch, int p, int q,
-                                                            const int32_t *__restrict__ iyx,
-                                                            const float *__restrict__ gcd, float *__restrict__ gx,
-                                                            float *__restrict__ gy) {
-  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // (r, b, j)
-  const long long total = (long long)draws * batch * q;
-  if (j >= total) return;
-  const long long rb = j / q;
-  const int b = (int)(rb % batch);
-  const int jj = (int)(j - rb * q);
-  const float coef = gcd[b] / (float)draws * (2.0f / (float)q);
-  const long long xi = rb * p + iyx[j];
-  const long long yj = (long long)b * q + jj;
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    const float t = coef * (x[xi * 3 + d] - y[yj * 3 + d]);
-    atomicAdd(gx + xi * 3 + d, t);
-    if (gy) atomicAdd(gy + yj * 3 + d, -t);
-  }
-}
+// grid = (target clouds, tiles).  Target cloud t: points tgt + t*nt*3; its sources: src + (s * src_stride_s +
+// (t % src_mod)) * ns * 3 for s < nsrc.  idx_t2s[(s*idx_stride + t) * nt + i] = neighbour of target point i in source s,
+// idx_s2t[(s*idx_stride + t) * ns + j] = neighbour of source point j (of source s) in the target cloud.
+// out[t][i] = sign * sum_s ( ct * (T_i - S_nn(i)) + cs * sum_{j: nn(j)=i} (T_i - S_j) ),  ct = g*2/nt, cs = g*2/ns.
+__global__ __launch_bounds__(1024) void chamfer_bwd_kernel(const float *__restrict__ tgt, int nt,
+                                                           const float *__restrict__ src, int ns, int nsrc,
+                                                           long long src_stride_s, int src_mod, long long idx_stride,
+                                                           const int32_t *__restrict__ idx_t2s,
+                                                           const int32_t *__restrict__ idx_s2t,
+                                                           const float *__restrict__ gcd, int batch, float inv_draws,
+                                                           float *__restrict__ out) {
+  extern __shared__ long long facc[];  // [tile][3]
+  __shared__ float red[2][16];
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const int tile = (nt + gridDim.y - 1) / gridDim.y;
+  const int i0 = blockIdx.y * tile, i1 = min(nt, i0 + tile);
+  const float *T = tgt + (long long)t * nt * 3;
+  const float g = gcd[t % batch] * inv_draws;
+  const float ct = g * (2.0f / (float)nt), cs = g * (2.0f / (float)ns);
 
-// The same term with the scatter in LDS: one workgroup owns one predicted cloud (draw r, sample b), accumulates
-//   acc[nn(j)] += g (2/Q) (x_nn(j) - y_j)   over its Q ground-truth points with ds_add_f32 (120 KB for 10 k points),
-// then adds the cloud's slice to grad_x with one coalesced pass — plain read-modify-write, no other workgroup touches
-// this cloud and the direct term (chamfer_bwd_x_kernel) was launched before.  Used when grad_y is not wanted (the
-// trainer) and the cloud fits in LDS; 0.30 -> 0.05 ms per step at the benchmark sizes.
-__global__ __launch_bounds__(1024) void chamfer_bwd_y_lds_kernel(const float *__restrict__ x,
-                                                                 const float *__restrict__ y, int draws, int batch,
-                                                                 int p, int q, const int32_t *__restrict__ iyx,
-                                                                 const float *__restrict__ gcd, float *__restrict__ gx) {
-  extern __shared__ float acc[];
-  const int rb = blockIdx.x, b = rb % batch;
-  for (int i = threadIdx.x; i < p * 3; i += blockDim.x) acc[i] = 0.f;
+  // bound on |T_i - S_j| per coordinate: max|T| + max|S| over the clouds involved (the same value in every tile)
+  float mx = 0.f;
+  for (int i = tid; i < nt * 3; i += 1024) mx = fmaxf(mx, fabsf(T[i]));
+  float ms = 0.f;
+  for (int s = 0; s < nsrc; ++s) {
+    const float *S = src + (s * src_stride_s + (t % src_mod)) * ns * 3;
+    for (int j = tid; j < ns * 3; j += 1024) ms = fmaxf(ms, fabsf(S[j]));
+  }
+  mx = wave_max(mx);
+  ms = wave_max(ms);
+  if ((tid & 63) == 0) red[0][tid >> 6] = mx, red[1][tid >> 6] = ms;
+  for (int i = tid; i < (i1 - i0) * 3; i += 1024) facc[i] = 0;
   __syncthreads();
-  const float coef = gcd[b] / (float)draws * (2.0f / (float)q);
-  const float *xb = x + (long long)rb * p * 3;
-  const float *yb = y + (long long)b * q * 3;
-  const int32_t *ib = iyx + (long long)rb * q;
-  for (int j = threadIdx.x; j < q; j += blockDim.x) {
-    const int xi = ib[j];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) atomicAdd(acc + xi * 3 + d, coef * (xb[xi * 3 + d] - yb[j * 3 + d]));
+  for (int w = 0; w < 16; ++w) mx = fmaxf(mx, red[0][w]), ms = fmaxf(ms, red[1][w]);
+  const float bound = mx + ms;
+  const bool finite = bound < 3.0e38f;  // false for Inf / NaN coordinates: the gradient is then NaN, loudly
+  const FixScale fs = fix_scale(finite ? bound : 0.f, (long long)nsrc * ns);
+
+  for (int s = 0; s < nsrc; ++s) {
+    const float *S = src + (s * src_stride_s + (t % src_mod)) * ns * 3;
+    const int32_t *nn = idx_s2t + (s * idx_stride + t) * ns;
+    for (int j = tid; j < ns; j += 1024) {
+      const int i = nn[j];
+      if (i < i0 || i >= i1) continue;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) fix_add(facc + (i - i0) * 3 + d, fix_from(T[i * 3 + d] - S[j * 3 + d], fs));
+    }
   }
   __syncthreads();
-  float *gb = gx + (long long)rb * p * 3;
-  for (int i = threadIdx.x; i < p * 3; i += blockDim.x) {
-    const float a = acc[i];
-    if (a != 0.f) gb[i] += a;
+  float *o = out + (long long)t * nt * 3;
+  for (int k = tid; k < (i1 - i0) * 3; k += 1024) {
+    const int i = i0 + k / 3, d = k - (k / 3) * 3;
+    float direct = 0.f;
+    for (int s = 0; s < nsrc; ++s) {  // fixed order over the draws
+      const float *S = src + (s * src_stride_s + (t % src_mod)) * ns * 3;
+      const int j = idx_t2s[(s * idx_stride + t) * nt + i];
+      direct += T[i * 3 + d] - S[j * 3 + d];
+    }
+    const float v = ct * direct + cs * fix_to(facc[k], fs);
+    o[i0 * 3 + k] = finite ? v : __builtin_nanf("");
   }
 }
 
 int launch_chamfer_bwd(const float *x, const float *y, int draws, int batch, int p, int q, const int32_t *ixy,
                        const int32_t *iyx, const float *gcd, float *gx, float *gy, hipStream_t s) {
-  if (gy)
-    if (int rc = launch_fill_zero(gy, (size_t)batch * q * 3, s)) return rc;
-  const long long tx = (long long)draws * batch * p, ty = (long long)draws * batch * q;
-  A3VT_LAUNCH(chamfer_bwd_x_kernel, dim3(cdiv(tx, 256)), dim3(256), 0, s, x, y, draws, batch, p, q, ixy, gcd, gx,
-                     gy);
-  A3VT_CHECK_LAUNCH();
-  const size_t shmem = (size_t)p * 3 * sizeof(float);
-  if (!gy && shmem <= 144 * 1024) {
-    static size_t attr = 64 * 1024;
-    if (shmem > attr) {
-      (void)hipFuncSetAttribute((const void *)chamfer_bwd_y_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                144 * 1024);
-      attr = 144 * 1024;
-    }
-    A3VT_LAUNCH(chamfer_bwd_y_lds_kernel, dim3(draws * batch), dim3(1024), shmem, s, x, y, draws, batch, p, q, iyx, gcd,
-                gx);
-    A3VT_CHECK_LAUNCH();
-    return 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)chamfer_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kBwdTile * 3 * sizeof(long long));
+    attr_set = true;
   }
-  A3VT_LAUNCH(chamfer_bwd_y_kernel, dim3(cdiv(ty, 256)), dim3(256), 0, s, x, y, draws, batch, p, q, iyx, gcd, gx,
-                     gy);
-  A3VT_CHECK_LAUNCH();
+  const float inv_draws = 1.0f / (float)draws;
+  {  // grad_x: targets = the draws*batch predicted clouds, one source each (y[b])
+    const int tiles = cdiv(p, kBwdTile), tile = cdiv(p, tiles);
+    A3VT_LAUNCH(chamfer_bwd_kernel, dim3(draws * batch, tiles), dim3(1024), (size_t)tile * 3 * sizeof(long long), s, x, p, y,
+                q, 1, 0ll, batch, 0ll, ixy, iyx, gcd, batch, inv_draws, gx);
+    A3VT_CHECK_LAUNCH();
+  }
+  if (gy) {  // grad_y: targets = the batch ground-truth clouds, sources = their `draws` predicted clouds
+    const int tiles = cdiv(q, kBwdTile), tile = cdiv(q, tiles);
+    // d cd / d y_j has the opposite sign of the pair differences (y_j - x_i) handled as (T - S) with T = y: the kernel
+    // computes sum (y - x) terms, which IS the gradient w.r.t. y — no sign flip needed.
+    A3VT_LAUNCH(chamfer_bwd_kernel, dim3(batch, tiles), dim3(1024), (size_t)tile * 3 * sizeof(long long), s, y, q, x, p,
+                draws, (long long)batch, batch, (long long)batch, iyx, ixy, gcd, batch, inv_draws, gy);
+    A3VT_CHECK_LAUNCH();
+  }
   return 0;
 }
 

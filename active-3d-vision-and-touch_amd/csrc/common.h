@@ -47,4 +47,34 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// 64-lane butterfly max; every lane gets the result.
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// ---- order-independent float accumulation (deterministic scatter-adds) ---------------------------------------------
+// A float atomicAdd makes a sum depend on the order in which the threads arrive.  The backward scatters of this library
+// (Chamfer y -> x term, surface-sample -> vertex, pooled-feature -> map) instead accumulate in 64-bit fixed point:
+// integer addition is associative, so every order gives the same bits.  With |term| < 2^e for every term and at most
+// 2^c terms per accumulator, terms are scaled by 2^(62 - e - c): the sum cannot overflow and its resolution is
+// 2^-(62-c) of the largest term — about 2^-44 at 2^18 terms, far below the fp32 rounding of the terms themselves.
+struct FixScale {
+  int shift;  // term * 2^shift -> integer
+};
+// bound: any finite upper bound on |term| (> 0 or 0); count: upper bound on the number of terms per accumulator
+__device__ __forceinline__ FixScale fix_scale(float bound, long long count) {
+  int e = 0;
+  (void)frexpf(bound, &e);  // bound = m * 2^e, 0.5 <= m < 1  ->  |term| <= bound < 2^e  (e = 0 for bound == 0)
+  int c = 1;
+  while ((1ll << c) <= count) ++c;
+  return FixScale{62 - e - c};
+}
+__device__ __forceinline__ long long fix_from(float t, FixScale s) { return __float2ll_rn(ldexpf(t, s.shift)); }
+__device__ __forceinline__ float fix_to(long long a, FixScale s) { return ldexpf((float)a, -s.shift); }
+__device__ __forceinline__ void fix_add(long long *acc, long long v) {
+  atomicAdd(reinterpret_cast<unsigned long long *>(acc), (unsigned long long)v);
+}
+
 }  // namespace a3vt

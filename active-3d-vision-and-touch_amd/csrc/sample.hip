@@ -163,86 +163,74 @@ int launch_sample_fwd(const float *verts, const int32_t *faces, const float *cdf
   return 0;
 }
 
-__global__ __launch_bounds__(256) void sample_bwd_kernel(const int32_t *__restrict__ faces, int batch, int n_vert,
-                                                         long long total, int num, const int32_t *__restrict__ fi,
-                                                         const float *__restrict__ u, const float *__restrict__ v,
-                                                         const float *__restrict__ gp, float *__restrict__ gverts) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int b = (int)((i / num) % batch);
-  const float su = sqrtf(u[i]);
-  const float w[3] = {1.0f - su, su * (1.0f - v[i]), su * v[i]};
-  const int32_t *fc = faces + 3 * (long long)fi[i];
-  const float g0 = gp[i * 3], g1 = gp[i * 3 + 1], g2 = gp[i * 3 + 2];
-  float *gb = gverts + (long long)b * n_vert * 3;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    float *dst = gb + 3 * (long long)fc[k];
-    atomicAdd(dst + 0, w[k] * g0);
-    atomicAdd(dst + 1, w[k] * g1);
-    atomicAdd(dst + 2, w[k] * g2);
+// Backward of the barycentric blend: grad_verts[b][f_k] += w_k * grad_points[s] for the 3 corners of every sample's face
+// (the reference's autograd does this with index_put atomics, utils.py:174-187).  One workgroup owns a tile of <= 6144
+// vertices of ONE mesh, scans the mesh's draws * num samples and accumulates the contributions that land in its tile in
+// 64-bit fixed point in LDS (common.h): integer sums do not depend on the arrival order, so the vertex gradient is
+// reproducible bit for bit — the float atomics this replaces were the reason a training step was not.  Every gradient
+// element is written exactly once (nothing to zero beforehand).  grid = (batch, tiles).
+constexpr int kSampleBwdTile = 6144;  // 144 KiB of accumulators
+__global__ __launch_bounds__(1024) void sample_bwd_kernel(const int32_t *__restrict__ faces, int batch, int n_vert,
+                                                          int draws, int num, const int32_t *__restrict__ fi,
+                                                          const float *__restrict__ u, const float *__restrict__ v,
+                                                          const float *__restrict__ gp, float *__restrict__ gverts) {
+  extern __shared__ long long facc[];  // [tile][3]
+  __shared__ float red[16];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int tile = (n_vert + gridDim.y - 1) / gridDim.y;
+  const int v0 = blockIdx.y * tile, v1 = min(n_vert, v0 + tile);
+  // bound on |w_k * g| (0 <= w_k <= 1): the largest |grad_points| component of this mesh's samples
+  float mx = 0.f;
+  for (int d = 0; d < draws; ++d) {
+    const float *g = gp + ((long long)d * batch + b) * num * 3;
+    for (int i = tid; i < num * 3; i += 1024) mx = fmaxf(mx, fabsf(g[i]));
   }
-}
-
-// Same scatter with the vertex gradient of ONE mesh accumulated in LDS (n_vert * 12 bytes; 30 KB for 2562 vertices):
-// the ~9 float atomics per sample hit LDS (ds_add_f32) instead of L2, and each workgroup then adds its slice of the
-// mesh's samples to global memory with one coalesced pass.  grid = (batch, kSampleSplits).
-constexpr int kSampleSplits = 4;
-__global__ __launch_bounds__(1024) void sample_bwd_lds_kernel(const int32_t *__restrict__ faces, int batch, int n_vert,
-                                                              int draws, int num, const int32_t *__restrict__ fi,
-                                                              const float *__restrict__ u, const float *__restrict__ v,
-                                                              const float *__restrict__ gp, float *__restrict__ gverts) {
-  extern __shared__ float acc[];
-  const int b = blockIdx.x;
-  const int nf = n_vert * 3;
-  for (int i = threadIdx.x; i < nf; i += blockDim.x) acc[i] = 0.f;
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  for (int i = tid; i < (v1 - v0) * 3; i += 1024) facc[i] = 0;
   __syncthreads();
-  const int per = (num + gridDim.y - 1) / gridDim.y;
-  const int j0 = blockIdx.y * per, j1 = min(num, j0 + per);
+#pragma unroll
+  for (int w = 0; w < 16; ++w) mx = fmaxf(mx, red[w]);
+  const bool finite = mx < 3.0e38f;
+  const FixScale fs = fix_scale(finite ? mx : 0.f, (long long)draws * num);
   for (int d = 0; d < draws; ++d) {
     const long long base = ((long long)d * batch + b) * num;
-    for (int j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
+    for (int j = tid; j < num; j += 1024) {
       const long long i = base + j;
+      const int32_t *fc = faces + 3 * (long long)fi[i];
+      const int c0 = fc[0], c1 = fc[1], c2 = fc[2];
+      const bool in0 = c0 >= v0 && c0 < v1, in1 = c1 >= v0 && c1 < v1, in2 = c2 >= v0 && c2 < v1;
+      if (!(in0 || in1 || in2)) continue;
       const float su = sqrtf(u[i]);
       const float w[3] = {1.0f - su, su * (1.0f - v[i]), su * v[i]};
-      const int32_t *fc = faces + 3 * (long long)fi[i];
-      const float g0 = gp[i * 3], g1 = gp[i * 3 + 1], g2 = gp[i * 3 + 2];
+      const float g[3] = {gp[i * 3], gp[i * 3 + 1], gp[i * 3 + 2]};
+      const int c[3] = {c0, c1, c2};
+      const bool in[3] = {in0, in1, in2};
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        float *dst = acc + 3 * fc[k];
-        atomicAdd(dst + 0, w[k] * g0);
-        atomicAdd(dst + 1, w[k] * g1);
-        atomicAdd(dst + 2, w[k] * g2);
+        if (!in[k]) continue;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) fix_add(facc + (c[k] - v0) * 3 + e, fix_from(w[k] * g[e], fs));
       }
     }
   }
   __syncthreads();
-  float *gb = gverts + (long long)b * nf;
-  for (int i = threadIdx.x; i < nf; i += blockDim.x) {
-    const float a = acc[i];
-    if (a != 0.f) atomicAdd(gb + i, a);
-  }
+  float *gb = gverts + ((long long)b * n_vert + v0) * 3;
+  for (int i = tid; i < (v1 - v0) * 3; i += 1024) gb[i] = finite ? fix_to(facc[i], fs) : __builtin_nanf("");
 }
 
 int launch_sample_bwd(const int32_t *faces, int batch, int n_vert, int n_faces, int draws, int num, const int32_t *fi,
                       const float *u, const float *v, const float *gpoints, float *gverts, hipStream_t s) {
   (void)n_faces;
-  if (int rc = launch_fill_zero(gverts, (size_t)batch * n_vert * 3, s)) return rc;
-  const size_t shmem = (size_t)n_vert * 3 * sizeof(float);
-  if (shmem <= 144 * 1024) {  // up to 12 288 vertices per mesh (icosphere-5: 10 242)
-    static size_t attr = 64 * 1024;
-    if (shmem > attr) {
-      (void)hipFuncSetAttribute((const void *)sample_bwd_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-      attr = 144 * 1024;
-    }
-    A3VT_LAUNCH(sample_bwd_lds_kernel, dim3(batch, kSampleSplits), dim3(1024), shmem, s, faces, batch, n_vert, draws, num,
-                fi, u, v, gpoints, gverts);
-    A3VT_CHECK_LAUNCH();
-    return 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)sample_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kSampleBwdTile * 3 * sizeof(long long));
+    attr_set = true;
   }
-  const long long total = (long long)draws * batch * num;
-  A3VT_LAUNCH(sample_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, faces, batch, n_vert, total, num, fi, u,
-                     v, gpoints, gverts);
+  const int tiles = cdiv(n_vert, kSampleBwdTile), tile = cdiv(n_vert, tiles);
+  A3VT_LAUNCH(sample_bwd_kernel, dim3(batch, tiles), dim3(1024), (size_t)tile * 3 * sizeof(long long), s, faces, batch,
+              n_vert, draws, num, fi, u, v, gpoints, gverts);
   A3VT_CHECK_LAUNCH();
   return 0;
 }

@@ -11,6 +11,7 @@ import os
 
 import torch
 import torch.distributed as dist
+import torch.utils.data
 
 
 def init_from_env(backend=None):
@@ -92,6 +93,82 @@ def broadcast_parameters(module, src=0):
     for p in ps:
         p.copy_(flat[off:off + p.numel()].view_as(p))
         off += p.numel()
+
+
+class RankPlan:
+    """What one rank does in one epoch: ``indices`` (its shard of the dataset, int64) and ``seed`` (for the python /
+    numpy / torch generators of this rank: grasp choices, point shuffles, the Philox surface-sample stream)."""
+
+    def __init__(self, indices, seed):
+        self.indices, self.seed = indices, seed
+
+    def __len__(self):
+        return len(self.indices)
+
+
+def rank_plan(rank, world, seed, n_items, epoch=0, shuffle=True, pad=True):
+    """Per-rank data plan of the data-parallel trainer (SURVEY §8d "per-rank seed = seed + rank", §8e).
+
+    All ranks derive the SAME permutation of ``range(n_items)`` from ``(seed, epoch)`` (no communication) and take every
+    ``world``-th entry starting at ``rank`` — shards are disjoint and together cover the dataset.  ``pad=True`` (training)
+    first extends the permutation by wrapping around to a multiple of ``world`` so that every rank runs the same number of
+    steps (a rank with one batch fewer would leave the others waiting in the gradient all-reduce); ``pad=False``
+    (validation) leaves the shards uneven and exactly disjoint — the scores are summed across ranks afterwards.
+    The rank's RNG seed is ``seed + rank`` in both cases (same for every epoch: the generators just keep running)."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world {world}")
+    if shuffle:
+        import numpy as np
+        order = np.random.default_rng([int(seed), int(epoch)]).permutation(n_items).astype("int64")
+    else:
+        order = torch.arange(n_items, dtype=torch.int64).numpy()
+    if pad and n_items % world and n_items > 0:
+        import numpy as np
+        extra = world - n_items % world
+        order = np.concatenate([order, order[:extra] if extra <= n_items else np.resize(order, extra)])
+    return RankPlan(order[rank::world].copy(), int(seed) + int(rank))
+
+
+class ShardSampler(torch.utils.data.Sampler):
+    """``DataLoader`` sampler over this rank's :func:`rank_plan` shard; call ``set_epoch`` before each epoch."""
+
+    def __init__(self, n_items, rank, world, seed, shuffle=True, pad=True):
+        self.n_items, self.rank, self.world, self.seed, self.shuffle, self.pad = n_items, rank, world, seed, shuffle, pad
+        self.epoch = 0
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def plan(self):
+        return rank_plan(self.rank, self.world, self.seed, self.n_items, self.epoch, self.shuffle, self.pad)
+
+    def __iter__(self):
+        return iter(self.plan().indices.tolist())
+
+    def __len__(self):
+        return len(self.plan())
+
+
+def seed_rank(seed, rank):
+    """Seed python / numpy / torch of this process with ``seed + rank`` (after the weights were broadcast): ranks then
+    draw different grasp subsets, point shuffles and surface samples instead of N copies of the same batch."""
+    import random
+
+    import numpy as np
+    s = int(seed) + int(rank)
+    random.seed(s)
+    np.random.seed(s % (2 ** 32))
+    torch.manual_seed(s)
+    return s
+
+
+def all_reduce_sum_(*tensors):
+    """In-place sum over ranks of a few small tensors (validation loss / example counts); no-op for one process."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return tensors
+    for t in tensors:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return tensors
 
 
 def shard_range(global_batch, rank, world):

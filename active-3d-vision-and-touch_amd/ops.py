@@ -25,6 +25,8 @@ def _req(t, name, dtype=torch.float32):
 
 
 _WORKSPACES = {}
+# call counters (tests assert that forward-only callers never allocate the activation stash)
+STATS = {"stack_calls": 0, "stack_stash_calls": 0}
 
 
 def workspace(tag, nbytes, device):
@@ -56,6 +58,14 @@ class DeviceCSR:
         return self.val.device
 
 
+def _wants_grad(*tensors):
+    """Whether a backward pass can follow this call.  Decided OUTSIDE ``Function.forward``: inside it
+    ``ctx.needs_input_grad`` is still True for parameters under ``torch.no_grad()`` (it mirrors ``requires_grad``, not the
+    grad mode), which would make the forward-only callers (``Engine.validate``, ``policies/scoring.py``) allocate and write
+    the whole activation stash."""
+    return torch.is_grad_enabled() and any(t.requires_grad for t in tensors)
+
+
 def _ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
@@ -64,7 +74,7 @@ class GCNStackFn(torch.autograd.Function):
     """One GCN (reference ``GCN.forward``, vision/model.py:316-331): feats (B,N,ld) -> update (B,N,3)."""
 
     @staticmethod
-    def forward(ctx, feats, adj, in_features, hidden, cut_len, bf16, *params):
+    def forward(ctx, feats, adj, in_features, hidden, cut_len, bf16, need_bwd, *params):
         L = _lib.load()
         feats = _req(feats, "feats")
         B, N, ld = feats.shape
@@ -73,10 +83,11 @@ class GCNStackFn(torch.autograd.Function):
         weights = [_req(p, "weight") for p in params[0::2]]
         biases = [_req(p, "bias") for p in params[1::2]]
         nl = len(weights)
-        need_bwd = any(ctx.needs_input_grad)
         M = B * N
         acts = masks = None
+        STATS["stack_calls"] += 1
         if need_bwd and nl > 1:
+            STATS["stack_stash_calls"] += 1
             acts = torch.empty((nl - 1, M, hidden), dtype=torch.float32, device=feats.device)
             masks = torch.empty(L.a3vt_gcn_stack_mask_bytes(B, N, hidden, nl, cut_len), dtype=torch.uint8,
                                 device=feats.device)
@@ -120,7 +131,7 @@ class GCNStackFn(torch.autograd.Function):
         grads = []
         for w, b in zip(gw, gb):
             grads += [w, b]
-        return (gfeats, None, None, None, None, None, *grads)
+        return (gfeats, None, None, None, None, None, None, *grads)
 
 
 def gcn_stack(feats, adj, in_features, hidden, cut_len, weights, biases, bf16=False):
@@ -129,7 +140,7 @@ def gcn_stack(feats, adj, in_features, hidden, cut_len, weights, biases, bf16=Fa
     params = []
     for w, b in zip(weights, biases):
         params += [w, b]
-    return GCNStackFn.apply(feats, adj, in_features, hidden, cut_len, bf16, *params)
+    return GCNStackFn.apply(feats, adj, in_features, hidden, cut_len, bf16, _wants_grad(feats, *params), *params)
 
 
 class GCNLayerFn(torch.autograd.Function):
@@ -137,7 +148,7 @@ class GCNLayerFn(torch.autograd.Function):
     x (B,N,ld) -> y (B,N,out).  ``cut_len`` = out for a layer without the cut."""
 
     @staticmethod
-    def forward(ctx, x, adj, weight, bias, cut_len, relu, bf16=False):
+    def forward(ctx, x, adj, weight, bias, cut_len, relu, bf16=False, need_bwd=True):
         L = _lib.load()
         x = _req(x, "features")
         weight, bias = _req(weight, "weight"), _req(bias, "bias")
@@ -147,7 +158,6 @@ class GCNLayerFn(torch.autograd.Function):
         kin, nout = weight.shape[-2], weight.shape[-1]
         if ld % 4 != 0 or ld < kin:
             raise RuntimeError(f"a3vt: feature row length {ld} must be a multiple of 4 and >= in_features={kin}")
-        need_bwd = any(ctx.needs_input_grad)
         ldy = (nout + 3) // 4 * 4
         y = torch.empty((B, N, ldy), dtype=torch.float32, device=x.device)
         scratch = workspace("gcn", L.a3vt_gcn_layer_scratch_bytes(B, N, ld, nout, cut_len, 1 if need_bwd else 0),
@@ -175,11 +185,11 @@ class GCNLayerFn(torch.autograd.Function):
                                         adj.t_max_degree, N, B, 1 if ctx.bf16 else 0,
                                         _lib.ptr(y), ldy, _lib.ptr(gy), gy.shape[-1], _lib.ptr(gw), _lib.ptr(gb),
                                         _lib.ptr(gx), _lib.ptr(scratch), _stream()), "gcn_layer_bwd")
-        return gx, None, gw, gb, None, None, None
+        return gx, None, gw, gb, None, None, None, None
 
 
 def gcn_layer(x, adj, weight, bias, cut_len, relu, bf16=False):
-    return GCNLayerFn.apply(x, adj, weight, bias, cut_len, relu, bf16)
+    return GCNLayerFn.apply(x, adj, weight, bias, cut_len, relu, bf16, _wants_grad(x, weight, bias))
 
 
 class PosEncMaskFn(torch.autograd.Function):

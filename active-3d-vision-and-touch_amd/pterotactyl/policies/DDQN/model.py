@@ -73,8 +73,8 @@ class Graph_Model(nn.Module):
                            self.mask_embedding(mask)), dim=-1)
         adj = _csr_of(self._adj_info, "adj")
         x = feats
-        for i, layer in enumerate(self.layers):
-            x = layer(x, adj, F.relu if i != self.num_layers - 1 else _identity)
+        for i, layer in enumerate(self.layers):   # layer 0 always takes the ReLU, also when it is the only layer (:118)
+            x = layer(x, adj, F.relu if i == 0 or i != self.num_layers - 1 else _identity)
         return torch.max(x, dim=1)[0]
 
 

@@ -12,10 +12,10 @@ per-vertex products + CSR neighbour aggregation, activations saved for backward)
 encoder + mask embedding is one fused kernel, and nothing synchronises the host (the reference's NaN
 trap at :326-329 becomes an optional deferred flag, ``Deformation.finite_flag``).
 
-``use_img=True``: ``Image_Encoder`` (:27-164) is a plain torch module here — its convolutions run on
-MIOpen, the per-vertex bilinear pooling on ``grid_sample`` (not hand-written) — and the
-448-wide vertex features go through the same HIP GCN stack; only the tiny positional/mask encoders fall back
-from the fused kernel (built for I = 50) to torch ops on the GPU.
+``use_img=True``: ``Image_Encoder`` (:27-164) keeps its convolutions as torch modules on MIOpen (SURVEY §2b
+K13: not hand-written); the per-vertex projection + bilinear pooling is the fused HIP kernel of
+``csrc/pooling.hip`` (``a3vt_image_pool_fwd/bwd``), and the 448-wide vertex features go through the same HIP
+GCN stack.
 """
 import math
 import weakref

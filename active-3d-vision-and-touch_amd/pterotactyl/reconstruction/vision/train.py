@@ -9,8 +9,11 @@ current_loss, checkpoint_dir, results_dir``), same checkpoint files (``<ckpt>/mo
 
 Differences: the hot loop never blocks on the device except every ``log_interval`` iterations (the reference
 calls ``loss.item()`` every step, :151-153); tensorboard / submitit are optional; early stop raises
-``StopIteration`` instead of ``exit()`` (:284); with ``WORLD_SIZE`` > 1 gradients are averaged with one
-flat-bucket RCCL all-reduce (``a3vt_amd.distributed``).  Datasets: ``get_loaders`` reads the reference's on-disk
+``StopIteration`` instead of ``exit()`` (:284); with ``WORLD_SIZE`` > 1 each rank trains on its own shard of every
+epoch (``distributed.rank_plan``: same permutation on all ranks, every ``world``-th item; python / numpy / torch re-seeded
+with ``seed + rank`` after the weight broadcast so grasp choices and surface samples differ per rank), gradients are
+averaged with one flat-bucket RCCL all-reduce, and validation is sharded with the loss and example counts summed over
+ranks (``a3vt_amd.distributed``).  Datasets: ``get_loaders`` reads the reference's on-disk
 layout through ``utility/data_loaders.py`` (``args.data_root`` / ``PTEROTACTYL_DATA``; worker count ``args.num_workers``,
 default 16 as the reference); or pass ``loaders=(train_loader, valid_loader)`` (e.g. ``a3vt_amd.synthetic.SyntheticLoader``).
 Batches are uploaded one step ahead on a copy stream (``data_loaders.DevicePrefetcher``).
@@ -61,6 +64,8 @@ class Engine:
         self.n_vision_charts = self.initial_mesh.shape[0]
         self.encoder = model.Deformation(self.mesh_info, self.initial_mesh, self.args).to(self.initial_mesh.device)
         adist.broadcast_parameters(self.encoder)
+        if self.world > 1:   # identical weights everywhere; from here on every rank draws its own random numbers
+            adist.seed_rank(self.args.seed, self.rank)
         self.bucket = None
         if not self.args.eval:
             params = list(self.encoder.parameters())
@@ -82,6 +87,8 @@ class Engine:
         self.load()
         for epoch in range(self.epoch, self.args.epochs):
             self.epoch = epoch
+            if hasattr(getattr(train_loader, "sampler", None), "set_epoch"):
+                train_loader.sampler.set_epoch(epoch)
             self.train(train_loader, writer)
             with torch.no_grad():
                 self.validate(valid_loaders, writer)
@@ -92,21 +99,27 @@ class Engine:
         if self._loaders is not None:
             return self._loaders
         from torch.utils.data import DataLoader   # dataset classes: utility/data_loaders.py on args.data_root
+        workers = getattr(self.args, "num_workers", 16)
         train_loader = ""
         if not self.args.eval:
             train_data = data_loaders.mesh_loader_vision(self.args, set_type="recon_train")
-            train_loader = DataLoader(train_data, batch_size=self.args.batch_size, shuffle=True, num_workers=getattr(self.args, "num_workers", 16),
+            # one shard per rank and epoch (world 1: the whole set, shuffled — the reference's shuffle=True, :96-103)
+            sampler = adist.ShardSampler(len(train_data), self.rank, self.world, self.args.seed, shuffle=True, pad=True)
+            train_loader = DataLoader(train_data, batch_size=self.args.batch_size, sampler=sampler, num_workers=workers,
                                       collate_fn=train_data.collate, pin_memory=True)
         valid_data = data_loaders.mesh_loader_vision(self.args, set_type="test" if self.args.eval else "valid")
-        valid_loader = DataLoader(valid_data, batch_size=self.args.batch_size, shuffle=False, num_workers=getattr(self.args, "num_workers", 16),
+        vsampler = adist.ShardSampler(len(valid_data), self.rank, self.world, self.args.seed, shuffle=False, pad=False)
+        valid_loader = DataLoader(valid_data, batch_size=self.args.batch_size, sampler=vsampler, num_workers=workers,
                                   collate_fn=valid_data.collate, pin_memory=True)
         return train_loader, valid_loader
 
-    def train_step(self, img, charts, gt_points):
-        """One optimisation step on device tensors; returns the (device) scalar loss.  No host sync."""
+    def train_step(self, img, charts, gt_points, samples=None):
+        """One optimisation step on device tensors; returns the (device) scalar loss.  No host sync.
+        ``samples``: optional injected (face_idx, u, v) surface draws (parity tests); default = the Philox stream."""
         self.bucket.zero()
         verts = self.encoder(img, charts)[0]
-        loss = utils.chamfer_distance(verts, self.mesh_info["faces_i32"], gt_points, num=self.args.number_points)
+        loss = utils.chamfer_distance(verts, self.mesh_info["faces_i32"], gt_points, num=self.args.number_points,
+                                      samples=samples)
         loss = self.args.loss_coeff * loss.mean()
         loss.backward()
         self.bucket.all_reduce_mean()
@@ -144,6 +157,10 @@ class Engine:
             loss = utils.chamfer_distance(verts, self.mesh_info["faces_i32"], gt_points, num=self.args.number_points)
             total_loss += self.args.loss_coeff * loss.sum()
             num_examples += float(img.shape[0])
+        if self.world > 1 and hasattr(getattr(valid_loader, "sampler", None), "plan"):   # sharded validation: sum over ranks
+            count = torch.tensor(float(num_examples), device=dev)
+            adist.all_reduce_sum_(total_loss, count)
+            num_examples = count.item()
         total = (total_loss / max(num_examples, 1.0)).item()
         if self.rank == 0:
             print("*******************************************************")

@@ -4,8 +4,20 @@ The reference's dataset (``download_data.sh``) is not available offline; these b
 of ``mesh_loader_vision.collate`` (``utility/data_loaders.py:249-258``): ``gt_points (B,P,3)``,
 ``img`` (dummy ``(B,1)`` when ``use_img`` is off), ``touch_charts`` and ``names``.
 """
+from types import SimpleNamespace
+
 import numpy as np
 import torch
+
+
+def make_args(**kw):
+    """Argument namespace with the reference trainer's defaults for this path (``vision/train.py:375-386``: 20 GCN
+    layers x 300 hidden, cut 0.33, loss_coeff 9000, Adam lr 3e-4) — what ``Engine`` / ``Deformation`` read from
+    ``args``.  Keyword arguments override; ``num_stages`` and ``gemm_precision`` are this package's own knobs."""
+    d = dict(use_img=False, use_touch=False, finger=False, num_grasps=1, num_GCN_layers=20, hidden_GCN_size=300,
+             cut=0.33, number_points=1000, loss_coeff=9000.0, lr=3e-4, seed=0, num_stages=3)
+    d.update(kw)
+    return SimpleNamespace(**d)
 
 
 def gt_cloud(batch, points, seed=0, kind="ellipsoid"):

@@ -8,20 +8,32 @@ Workload at every N (weak scaling): BASELINE.json configs[1] per GPU — 2562-ve
 GCN (20 layers x 300 hidden, cut 0.33 — the reference defaults, vision/train.py:375-386), bs = 64 per GPU,
 10 000-point Chamfer x 3 draws, fp32, Adam(lr 3e-4).  Synthetic seeded inputs: ellipsoid-surface
 ground-truth clouds, reference weight init.  ``value`` = (N * K iterations of bs 64) / wall time, inputs resident
-in HBM, barrier + synchronize on both sides, max over ranks.
+in HBM, barrier + synchronize on both sides, max over ranks.  Nothing on the timed (product) leg comes from ``tests/``
+or ``oracle/``.
 
-Extra objects on the JSON line:
+Extra objects on the JSON line — everything in them is measured IN THIS RUN (nothing is read from ``profiles/``):
+* ``step_ms``   — p10 / median / p90 of the per-iteration device time (one HIP event per iteration boundary on the
+  compute stream, SURVEY §8d protocol) over the timed steps.
 * ``roofline``  — the dominant kernel (fp32-MFMA per-vertex product, hidden x hidden): algorithmic
   2*M*300*300 flop per launch / mean launch duration measured with HIP events on the launch stream during
   extra (untimed) profiled steps, against the 157.3 TFLOP/s fp32 matrix peak (MI355X_MICROARCH.md).
-* ``cpu_baseline`` — the CPU oracle (a port of the reference path; kind "port") timed on this box's host cores
-  on a bounded sample: bs = 4 of the same workload, one iteration (≈10 s), scaled to iterations of bs 64.
+  ``traffic`` = HBM bytes per launch of that kernel from the PMC counters FETCH_SIZE (doubled, as the guide prescribes
+  for gfx950) + WRITE_SIZE, collected by two child ``rocprofv3 --pmc`` passes over a short run of the same kernel at
+  the same shape (``tools/stack_bench.py``); null when rocprofv3 is unavailable, fails, or the mode is not fp32.
+* ``cpu_baseline`` — the CPU oracle (a restatement of the reference path; kind "port") timed on this box's host
+  cores, rank 0 at N = 1 only, inside a ~75 s budget: the reference-faithful variant (dense (N,N) adjacency products as
+  vision/model.py:356,360 + compiled brute-force nearest neighbour) and the CSR variant, bs 2 and bs 8, median of up to
+  3 iterations after a warm-up, all cores and 1 core.  ``value`` = the reference-faithful variant on all cores.
 """
 import argparse
 import ctypes
 import json
 import os
+import shutil
+import signal
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -35,8 +47,8 @@ import torch.distributed as dist  # noqa: E402
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=10)
-    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--batch", type=int, default=64, help="meshes per GPU")
     p.add_argument("--points", type=int, default=10000)
     p.add_argument("--level", type=int, default=4, help="icosphere level (4 -> 2562 vertices)")
@@ -44,77 +56,158 @@ def parse():
     p.add_argument("--hidden", type=int, default=300)
     p.add_argument("--cloud", default="ellipsoid", choices=["ellipsoid", "cube"])
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-budget", type=float, default=75.0, help="seconds of wall time for the cpu_baseline leg")
+    p.add_argument("--no-traffic", action="store_true", help="skip the child rocprofv3 --pmc passes")
     p.add_argument("--profile-steps", type=int, default=2)
-    p.add_argument("--gemm-precision", default="fp32", choices=["fp32", "bf16"],
-                   help="bf16 = BASELINE configs[3]/[4] operand mode of the per-vertex products; NOT the headline metric")
+    p.add_argument("--gemm-precision", default="fp32", choices=["fp32", "bf16", "bf16s"],
+                   help="bf16 = operand mode, bf16s = bf16 activation storage (BASELINE configs[3]/[4]); NOT the headline")
     return p.parse_args()
 
 
-def cpu_baseline(level, layers, hidden, points, seed=0):
-    """Oracle (CPU port of the reference path) on a bounded sample: bs=4, one fwd+bwd iteration (about 10 s)."""
+# ---- cpu_baseline leg (the only place bench.py touches oracle/ and tests/helpers) ------------------------------------
+def cpu_baseline(level, layers, hidden, points, budget_s, seed=0):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from helpers import make_args, oracle_adj
+    import statistics
+    from helpers import oracle_adj
     from a3vt_amd import mesh as amesh
-    from a3vt_amd.synthetic import gt_cloud
+    from a3vt_amd.synthetic import gt_cloud, make_args
     from oracle import chamfer as och, gcn as og
-    bs = 4
+    t_start = time.perf_counter()
     args = make_args(num_GCN_layers=layers, hidden_GCN_size=hidden)
     verts, faces = amesh.icosphere(level)
-    adj_o, faces_o = oracle_adj(verts, faces, args)
+    adj_csr, faces_o = oracle_adj(verts, faces, args)
+    n = verts.shape[0]
+    dense = torch.zeros(n, n)
+    rp, col, val = adj_csr
+    rows = torch.repeat_interleave(torch.arange(n), rp[1:] - rp[:-1])
+    dense[rows, col] = val                                    # the (N,N) float matrix the reference multiplies with
     st = {k: v.requires_grad_(True) for k, v in og.init_state(50, hidden, layers, seed=seed).items()}
-    ch = og.prepare_mesh(None, torch.from_numpy(verts), bs, False)
-    gt = gt_cloud(bs, points, seed)
-    torch.manual_seed(seed)
-    t0 = time.perf_counter()
-    out, _ = og.deformation_forward(st, {"adj": adj_o}, ch, False, layers, 0.33)
-    cd = och.chamfer_distance(out, faces_o, gt, num=points, use_c=True)
-    (9000.0 * cd.mean()).backward()
-    dt = time.perf_counter() - t0
-    return {"value": (bs / 64.0) / dt, "unit": "iters/s at bs=64", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"bs={bs} of the bs=64 workload, 1 fwd+bwd iteration (no optimizer), {dt:.1f} s of CPU work; "
-                      f"CSR aggregation + plain-C brute-force NN, torch CPU fp32"}
+    all_cores = torch.get_num_threads()
+
+    def one_iteration(bs, adj):
+        for p in st.values():
+            p.grad = None
+        ch = og.prepare_mesh(None, torch.from_numpy(verts), bs, False)
+        gt = gt_cloud(bs, points, seed)
+        torch.manual_seed(seed)
+        t0 = time.perf_counter()
+        out, _ = og.deformation_forward(st, {"adj": adj}, ch, False, layers, 0.33)
+        cd = och.chamfer_distance(out, faces_o, gt, num=points, use_c=True)
+        (9000.0 * cd.mean()).backward()
+        return time.perf_counter() - t0
+
+    def leg(name, bs, adj, threads, cap_s, warm=True):
+        """median of up to 3 iterations after one warm-up, stopping early when `cap_s` or the global budget is spent"""
+        left = budget_s - (time.perf_counter() - t_start)
+        if left <= 2.0:
+            return {"skipped": "cpu budget spent"}
+        cap = min(cap_s, left)
+        torch.set_num_threads(threads)
+        och.set_threads(threads)
+        try:
+            t_leg = time.perf_counter()
+            times = []
+            w = one_iteration(bs, adj) if warm else None
+            while len(times) < 3 and (not times or time.perf_counter() - t_leg + times[-1] < cap):
+                times.append(one_iteration(bs, adj))
+            med = statistics.median(times)
+            return {"bs": bs, "threads": threads, "s_per_iter": med, "iters_timed": len(times),
+                    "warmup_s": w, "mesh_per_s": bs / med, "iters_per_s_at_bs64": (bs / 64.0) / med}
+        finally:
+            torch.set_num_threads(all_cores)
+            och.set_threads(all_cores)
+
+    variants = {}
+    variants["faithful_bs2_allcores"] = leg("faithful", 2, dense, all_cores, 25.0)
+    variants["csr_bs2_allcores"] = leg("csr", 2, adj_csr, all_cores, 8.0)
+    variants["csr_bs8_allcores"] = leg("csr", 8, adj_csr, all_cores, 12.0)
+    variants["faithful_bs8_allcores"] = leg("faithful", 8, dense, all_cores, 15.0, warm=False)
+    variants["csr_bs2_1core"] = leg("csr", 2, adj_csr, 1, 10.0, warm=False)
+    variants["faithful_bs2_1core"] = leg("faithful", 2, dense, 1, 10.0, warm=False)
+    head = variants["faithful_bs2_allcores"]
+    spent = time.perf_counter() - t_start
+    return {"value": head.get("iters_per_s_at_bs64"), "unit": "iters/s at bs=64", "cores": all_cores, "kind": "port",
+            "sample": f"oracle (CPU restatement of the reference path), reference-faithful variant: dense (N,N) adjacency "
+                      f"products + compiled brute-force NN, bs=2 of the bs=64 workload, median of {head.get('iters_timed')} "
+                      f"fwd+bwd iterations after 1 warm-up (no optimizer), all {all_cores} threads; scaled by 2/64. "
+                      f"{spent:.0f} s of CPU wall time for all variants",
+            "variants": variants}
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed PMC collection (tools/collect_traffic.sh:
-    separate --pmc passes; FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM": it reports half of a wide coalesced
-    stream on gfx950; WRITE_SIZE exact).  None when the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_summary.json")
+# ---- roofline.traffic: child rocprofv3 --pmc passes over the dominant kernel at the bench shape ------------------------
+def _run_child(cmd, timeout_s, cwd):
+    """Run `cmd` in its own process group; on timeout kill exactly that group."""
+    pr = subprocess.Popen(cmd, cwd=cwd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
     try:
-        with open(path) as f:
-            d = json.load(f)
-        k = next(v for name, v in d.items() if "rowgemm_kernel<19, 2" in name)
-        return (2.0 * k["FETCH_SIZE_KiB_max"] + k["WRITE_SIZE_KiB_max"]) * 1024.0
-    except Exception:
-        return None
+        return pr.wait(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(pr.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        pr.wait()
+        return -9
+
+
+def measure_traffic(batch, level, hidden, kernel_tag="rowgemm_kernel<19, 2"):
+    """HBM bytes per launch of the dominant kernel: FETCH_SIZE x 2 (MI355X_MICROARCH.md "HBM": gfx950 tallies the 128-B
+    requests of wide coalesced reads at 64 B) + WRITE_SIZE, each from its own --pmc pass (they do not fit one pass);
+    kernel-trace only, no other trace domain.  Returns (bytes or None, note)."""
+    import csv
+    import glob
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    vals = {}
+    with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as tmp:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, c)
+            cmd = [rocprof, "--kernel-trace", "--pmc", c, "--output-format", "csv", "-d", out, "--", sys.executable,
+                   os.path.join(ROOT, "tools", "stack_bench.py"), "--layers", "4", "--reps", "2", "--batch", str(batch),
+                   "--level", str(level), "--hidden", str(hidden)]
+            rc = _run_child(cmd, 150, tmp)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if rc != 0 or not files:
+                return None, f"rocprofv3 --pmc {c} pass failed (rc={rc})"
+            best = []
+            with open(files[0]) as f:
+                for r in csv.DictReader(f):
+                    if r.get("Counter_Name") == c and kernel_tag in r.get("Kernel_Name", ""):
+                        best.append(float(r["Counter_Value"]))
+            if not best:
+                return None, f"kernel {kernel_tag} not in the {c} pass"
+            vals[c] = max(best)                      # the hidden x hidden launches are the largest of that instantiation
+    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, \
+        "FETCH_SIZE x2 + WRITE_SIZE (KiB), max over the launches of 2 stack fwd+bwd calls, measured in this run"
 
 
 def main():
     a = parse()
-    from a3vt_amd import distributed as adist, lib
+    from a3vt_amd import distributed as adist, lib, mesh as amesh
     from a3vt_amd.pterotactyl.reconstruction.vision import model, train
-    from a3vt_amd.synthetic import gt_cloud
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from helpers import make_args
+    from a3vt_amd.pterotactyl.utility import utils
+    from a3vt_amd.synthetic import gt_cloud, make_args
 
     rank, world, local = adist.init_from_env("nccl")
+    if a.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch N > 1 with torch.distributed.run "
+                         f"(--nproc-per-node {a.gpus})")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     args = make_args(num_GCN_layers=a.layers, hidden_GCN_size=a.hidden, number_points=a.points, seed=0,
                      exp_type="bench", exp_id=f"rank{rank}", eval=False, epochs=1, patience=70, batch_size=a.batch,
                      gemm_precision=a.gemm_precision)
     os.chdir(os.environ.get("TMPDIR", "/tmp"))  # Engine writes config.json under ./experiments
-    from a3vt_amd import mesh as amesh
     eng = train.Engine(args, loaders=((), ()))
     verts, faces = amesh.icosphere(a.level)
     # icosphere template instead of the packaged atlas (BASELINE.json configs[1])
-    from a3vt_amd.pterotactyl.utility import utils
     vt, ft = torch.from_numpy(verts).to(dev), torch.from_numpy(faces).to(dev)
     eng.mesh_info, eng.initial_mesh = utils.adj_init(vt, ft, args), vt
     eng.n_vision_charts = vt.shape[0]
     torch.manual_seed(0)
     eng.encoder = model.Deformation(eng.mesh_info, vt, args).to(dev)
     adist.broadcast_parameters(eng.encoder)
+    adist.seed_rank(1234, rank)                  # per-rank RNG stream (surface samples), SURVEY §8d
     params = list(eng.encoder.parameters())
     eng.bucket = adist.FlatGradBucket(params)
     try:
@@ -128,7 +221,6 @@ def main():
     batch = {"img": torch.zeros(a.batch, 1)}
     img = batch["img"].to(dev)
     charts = model.prepare_mesh(batch, vt, args)
-    torch.manual_seed(1234 + rank)
 
     def step(i):
         return eng.train_step(img, charts, clouds[i % len(clouds)])
@@ -141,9 +233,12 @@ def main():
     for i in range(a.warmup):
         loss = step(i)
     fence()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(a.steps):
         loss = step(a.warmup + i)
+        marks[i + 1].record()
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -151,6 +246,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     final_loss = loss.item()
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
+    pick = lambda q: per_step[min(len(per_step) - 1, int(round(q * (len(per_step) - 1))))]  # noqa: E731
+    step_ms = {"p10": pick(0.1), "median": pick(0.5), "p90": pick(0.9), "n": len(per_step),
+               "how": "one HIP event per iteration boundary on the compute stream (rank 0)"}
 
     # roofline leg: per-launch device time of the MFMA kernels, HIP events on the launch stream
     L = lib.load()
@@ -172,31 +271,40 @@ def main():
         # dominant kernel = rowgemm (forward + dX launches share the kernel); dX launches are all hidden x hidden
         t_ms = tot[1] / max(n_dx, 1)
         achieved = flop / (t_ms * 1e-3) / 1e12
-        peak = 157.3 if a.gemm_precision == "fp32" else 1250.0   # 16x16x16 bf16 form: half the 16x16x32 rate
+        fp32 = a.gemm_precision == "fp32"
+        peak = 157.3 if fp32 else 2500.0
         roof = {"bound": "mfma", "kernel": "rowgemm_kernel<19,EPI_DX_MASK> (fp32 MFMA 16x16x4, M x 300 x 300, dX = dZ W^T)"
-                if a.gemm_precision == "fp32" else "rowgemm_kernel<19,EPI_DX_MASK,bf16> (v_mfma_f32_16x16x16_bf16)",
+                if fp32 else f"dX product of the {a.gemm_precision} mode (bf16 MFMA, fp32 accumulate)",
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                "traffic": pmc_traffic(),
-                "avg_launch_ms": t_ms, "launches": n_dx, "flop_per_launch": flop,
-                "other_mfma_ms": per,
-                "mfma_ms_per_step": (tot[0] + tot[1] + tot[2]) / a.profile_steps}
+                "traffic": None, "avg_launch_ms": t_ms, "launches": n_dx, "flop_per_launch": flop,
+                "other_mfma_ms": per, "mfma_ms_per_step": (tot[0] + tot[1] + tot[2]) / a.profile_steps}
+        if rank == 0 and world == 1 and fp32 and not a.no_traffic:
+            fence()
+            try:
+                roof["traffic"], roof["traffic_how"] = measure_traffic(a.batch, a.level, a.hidden)
+            except Exception as e:  # the traffic figure is auxiliary: never fail the bench line over it
+                roof["traffic_how"] = f"not measured: {type(e).__name__}: {e}"
 
+    dtype = {"fp32": "f32", "bf16": "f32 storage, bf16 GEMM operands (reduced precision, not the headline)",
+             "bf16s": "bf16 activation storage + bf16 GEMM operands, fp32 accumulate / weights / optimizer (reduced "
+                      "precision, not the headline)"}[a.gemm_precision]
     default_cfg = (a.level, a.batch, a.points, a.layers, a.hidden, a.gemm_precision) == (4, 64, 10000, 20, 300, "fp32")
+    pts = f"{a.points // 1000}k" if a.points % 1000 == 0 else str(a.points)
     out = {
-        "metric": "mesh-recon iters/sec (fwd+bwd, 2562-vert GCN + 10k-pt Chamfer) at bs=64",
+        "metric": f"mesh-recon iters/sec (fwd+bwd, {vt.shape[0]}-vert GCN + {pts}-pt Chamfer) at bs={a.batch}",
         "value": world * a.steps / dt, "unit": "iters/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if a.gemm_precision == "fp32" else "f32 storage, bf16 GEMM operands (reduced precision, not the headline)",
-        "data": "synthetic",
+        "dtype": dtype, "data": "synthetic",
         "config": {"workload": f"icosphere-{a.level} template ({vt.shape[0]} verts, {ft.shape[0]} faces), 3-stage GCN "
                                f"{a.layers}x{a.hidden} cut 0.33, bs={a.batch}/GPU, {a.points}-pt Chamfer x3 draws, "
                                f"Adam, {a.cloud} clouds" + (" (BASELINE.json configs[1])" if default_cfg else " (custom sizes)"),
                    "global_batch": a.batch * world, "parallelism": f"dp{world}", "final_loss": final_loss},
+        "step_ms": step_ms,
     }
     if roof is not None:
         out["roofline"] = roof
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a.level, a.layers, a.hidden, a.points)
+        out["cpu_baseline"] = cpu_baseline(a.level, a.layers, a.hidden, a.points, a.cpu_budget)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

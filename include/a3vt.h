@@ -56,7 +56,7 @@ int a3vt_csr_validate(const int32_t *rowptr_host, const int32_t *col_host, int n
  * utility/utils.py:119-128); rows above 64 entries are aggregated by a whole workgroup in a second launch, which a
  * known small maximum lets the library skip.  Results do not depend on the value.
  *
- * feats  : [M][ld_feats] with ld_feats >= in_features, ld_feats % 4 == 0; pad columns must be zero.
+ * feats  : [M][ld_feats] with ld_feats == in_features rounded up to a multiple of 4; pad columns must be zero.
  * acts   : saved inputs of layers 1..L-1, [L-1][M][hidden]   (needed by the backward pass)
  * masks  : ReLU sign bytes of those activations (1 byte per 4 channels), a3vt_gcn_stack_mask_bytes() bytes;
  *          the backward pass reads these 16 MB per layer instead of re-reading the 197 MB activation

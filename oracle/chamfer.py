@@ -28,7 +28,8 @@ def build_c(force=False):
     src = os.path.join(_HERE, "chamfer_nn.c")
     out = os.path.join(_HERE, "libchamfer_nn.so")
     if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
-        subprocess.check_call(["gcc", "-O3", "-ffp-contract=off", "-fopenmp", "-shared", "-fPIC", src, "-o", out])
+        subprocess.check_call(["gcc", "-O3", "-ffp-contract=off", "-mfma", "-fopenmp", "-shared", "-fPIC", src, "-o", out,
+                               "-lm"])
     return out
 
 
@@ -39,18 +40,39 @@ def _lib():
         _LIB.oracle_nn_sqdist.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                           ctypes.c_void_p, ctypes.c_void_p]
         _LIB.oracle_nn_sqdist.restype = None
+        _LIB.oracle_nn_sqdist_fma.argtypes = _LIB.oracle_nn_sqdist.argtypes
+        _LIB.oracle_nn_sqdist_fma.restype = None
     return _LIB
 
 
-def nn_sqdist_c(x, y):
+def set_threads(n):
+    """OpenMP thread count of the C searches (bench.py's 1-core leg)."""
+    _lib().oracle_set_threads(int(n))
+
+
+def nn_sqdist_c(x, y, fma=False):
     """Brute-force squared-L2 nearest neighbour of every row of x (P,3) in y (Q,3), float32, in C.
-    Returns (dist float32 (P,), idx int32 (P,)); first minimum wins ties."""
+    Returns (dist float32 (P,), idx int32 (P,)); first minimum wins ties.  ``fma``: contract the products the way the
+    device compiler does (chamfer_nn.c), which makes the result comparable bit for bit with the HIP kernels."""
     x = np.ascontiguousarray(x, dtype=np.float32)
     y = np.ascontiguousarray(y, dtype=np.float32)
     dist = np.empty(x.shape[0], dtype=np.float32)
     idx = np.empty(x.shape[0], dtype=np.int32)
-    _lib().oracle_nn_sqdist(x.ctypes.data, x.shape[0], y.ctypes.data, y.shape[0], dist.ctypes.data, idx.ctypes.data)
+    fn = _lib().oracle_nn_sqdist_fma if fma else _lib().oracle_nn_sqdist
+    fn(x.ctypes.data, x.shape[0], y.ctypes.data, y.shape[0], dist.ctypes.data, idx.ctypes.data)
     return dist, idx
+
+
+def chamfer_grad_from_indices(x, y, ixy, iyx, g):
+    """Closed-form gradients of sum_b g_b * cd_b for ONE cloud pair given the nearest-neighbour indices,
+    in float64: returns (grad_x (P,3), grad_y (Q,3)).  For sizes where :func:`chamfer_grad_x`'s torch search is slow."""
+    x, y = x.double(), y.double()
+    ixy, iyx = ixy.long(), iyx.long()
+    a = g * (2.0 / x.shape[0]) * (x - y[ixy])            # d/dx of mean_i |x_i - y_nn(i)|^2
+    b = g * (2.0 / y.shape[0]) * (x[iyx] - y)            # d/dx_nn(j) of mean_j |y_j - x_nn(j)|^2
+    gx = a.clone().index_add_(0, iyx, b)
+    gy = (-b).index_add_(0, ixy, -a)
+    return gx, gy
 
 
 def nn_sqdist(x, y, chunk=2048):

@@ -145,7 +145,7 @@ def image_pooling(maps, verts):
 
 
 def deformation_forward_img(state, adj_info, charts, img, use_touch, num_layers=20, cut=0.33, cnn=(5, 6, 3),
-                            training=False):
+                            training=False, bf16=False):
     """model.py:203-286 for ``use_img=True``: stage 1 on the vision charts with the vision-only adjacency
     ('origional', :198-200,317-318) and the global encoder's maps; touch charts join in stage 2 (:254-259); stages 2-3
     use the local encoder's maps (pooled with the global encoder's projection, :265,277) and the fused adjacency."""
@@ -156,7 +156,7 @@ def deformation_forward_img(state, adj_info, charts, img, use_touch, num_layers=
     mask = charts["vision_masks"].clone()
     mask_features = mask_encoder(mask, state)
     feats = positional_encoder(vertices, state) + mask_features + image_pooling(gmaps, vertices)
-    update = gcn(feats, state, "mesh_deform_1", adj_info["origional"], num_layers, cut)
+    update = gcn(feats, state, "mesh_deform_1", adj_info["origional"], num_layers, cut, bf16=bf16)
     vertices = vertices + update[:, :vc]
     if use_touch:
         vertices = torch.cat((vertices, charts["touch_charts"].clone()), dim=1)
@@ -164,7 +164,7 @@ def deformation_forward_img(state, adj_info, charts, img, use_touch, num_layers=
         mask_features = mask_encoder(mask, state)
     for _ in range(2):
         feats = positional_encoder(vertices, state) + mask_features + image_pooling(lmaps, vertices)
-        update = gcn(feats, state, "mesh_deform_2", adj_info["adj"], num_layers, cut)
+        update = gcn(feats, state, "mesh_deform_2", adj_info["adj"], num_layers, cut, bf16=bf16)
         vertices = torch.cat((vertices[:, :vc] + update[:, :vc], vertices[:, vc:]), dim=1)
     return vertices, mask
 

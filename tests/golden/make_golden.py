@@ -19,6 +19,9 @@ Fixtures (names follow SURVEY §8c):
   g9_autoencoder.npz   reconstruction/autoencoder AutoEncoder (L=3, H=300): latent, folded points, Chamfer loss with
                        the gradient on the SECOND cloud (autoencoder/train.py:145-150), selected grads
   g10_graph_model.npz  policies/DDQN Graph_Model (3 layers, 300 -> 200 -> 200 -> 50): Q values + selected grads
+  g11_loader_batch.npz the reference's ``mesh_loader_vision`` (utility/data_loaders.py:132-258) on the miniature dataset
+                       ``golden_util.write_mini_dataset`` writes: instance list, seeded validation grasp choices, seeded
+                       training draws, one collated batch (touch_charts, gt_points, image samples), finger variant
 """
 import hashlib
 import os
@@ -31,6 +34,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(HERE))
 
 from oracle import mesh as omesh  # noqa: E402
 from oracle import ref_shim  # noqa: E402
@@ -397,7 +401,71 @@ def g10():
     save("g10_graph_model.npz", **out)
 
 
+def g11():
+    """The reference's vision-trainer dataset class reading the miniature dataset: its module-level location constants
+    (data_loaders.py:18-29) are pointed at a temporary directory, ``glob`` is made order-stable (sorted) so that the
+    position-derived validation seeds (:160-170) do not depend on the file system."""
+    import importlib
+    import random
+    import tempfile
+    from glob import glob as _glob
+    from golden_util import write_mini_dataset
+    dl = importlib.import_module("pterotactyl.utility.data_loaders")
+    out = {}
+    with tempfile.TemporaryDirectory() as root:
+        write_mini_dataset(root, n=6, seed=0)
+        dl.POINT_CLOUD_LOCATION = os.path.join(root, "point_cloud_info") + "/"
+        dl.TOUCH_LOCATION = os.path.join(root, "touch_charts") + "/"
+        dl.IMAGE_LOCATION = os.path.join(root, "images_colourful") + "/"
+        dl.OBJ_LOCATION = os.path.join(root, "object_info") + "/"
+        dl.DATA_SPLIT = np.load(os.path.join(root, "data_split.npy"), allow_pickle=True).item()
+        dl.glob = lambda pat: sorted(_glob(pat))
+        dl.tqdm = lambda it: it
+        for tag, finger in (("full", False), ("finger", True)):
+            a = NS(use_touch=True, use_img=True, finger=finger, num_grasps=3, number_points=500, eval=False,
+                   limit_data=False, val_grasps=-1)
+            valid = dl.mesh_loader_vision(a, set_type="valid")
+            train = dl.mesh_loader_vision(a, set_type="recon_train")
+            if not finger:
+                out["valid_names"] = np.array([int(n) for n, _ in valid.object_names], dtype=np.int64)
+                out["valid_seeds"] = np.array([s_ for _, s_ in valid.object_names], dtype=np.int64)
+                out["train_names"] = np.array([int(n) for n, _ in train.object_names], dtype=np.int64)
+                grasps = np.full((len(valid), 3), -1, dtype=np.int64)
+                for i in range(len(valid)):
+                    g_ = valid.get_validation_instance(i)[1]
+                    grasps[i, :len(g_)] = g_
+                out["valid_grasps"] = grasps
+                random.seed(7)                                   # training instances draw from the global python RNG
+                draws = [train.get_training_instance(0) for _ in range(6)]
+                out["train_draw_names"] = np.array([int(o) for o, _ in draws], dtype=np.int64)
+                tg = np.full((6, 3), -1, dtype=np.int64)
+                for i, (_, g_) in enumerate(draws):
+                    tg[i, :len(g_)] = g_
+                out["train_draw_grasps"] = tg
+                a.eval, a.val_grasps = True, 2                    # evaluation mode: fixed grasp count (:183-184)
+                test = dl.mesh_loader_vision(a, set_type="test")
+                out["test_grasps_val2"] = np.array([test.get_validation_instance(i)[1] for i in range(len(test))], dtype=np.int64)
+                a.eval, a.val_grasps = False, -1
+            np.random.seed(11)                                    # get_points shuffles with the global numpy RNG (:196)
+            batch = valid.collate([valid[i] for i in (0, 3, 7)])
+            out[f"{tag}_touch_charts"] = batch["touch_charts"].numpy()
+            if not finger:
+                out["gt_points"] = batch["gt_points"].numpy()
+                out["img_sub"] = batch["img"][:, :, ::16, ::16].numpy()
+                out["img_sum"] = batch["img"].double().sum(dim=(1, 2, 3)).numpy()
+                out["batch_names"] = np.array([int(os.path.basename(n)) for n, _ in batch["names"]], dtype=np.int64)
+                out["batch_name_dir"] = np.array([ord(c) for c in os.path.basename(os.path.dirname(batch["names"][0][0]))], dtype=np.int64)
+        a = NS(use_touch=False, use_img=False, finger=False, num_grasps=3, number_points=500, eval=False,
+               limit_data=False, val_grasps=-1)
+        plain = dl.mesh_loader_vision(a, set_type="valid")
+        b = plain.collate([plain[0], plain[1]])
+        out["plain_img_shape"] = np.array(b["img"].shape, dtype=np.int64)
+        out["plain_touch_shape"] = np.array(b["touch_charts"].shape, dtype=np.int64)
+        out["plain_touch_value"] = b["touch_charts"].numpy()
+    save("g11_loader_batch.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for w in which:
         globals()[w]()

@@ -1,17 +1,9 @@
 """Shared builders for the parity tests (seeded inputs, oracle <-> HIP plumbing)."""
-from types import SimpleNamespace
-
 import numpy as np
 import torch
 
 from a3vt_amd import mesh as amesh
-
-
-def make_args(**kw):
-    d = dict(use_img=False, use_touch=False, finger=False, num_grasps=1, num_GCN_layers=20, hidden_GCN_size=300,
-             cut=0.33, number_points=1000, loss_coeff=9000.0, lr=3e-4, seed=0, num_stages=3)
-    d.update(kw)
-    return SimpleNamespace(**d)
+from a3vt_amd.synthetic import make_args  # noqa: F401  (re-exported: the tests build their args through helpers)
 
 
 def template(name):

@@ -66,12 +66,14 @@ def test_training_step_fullsize_is_finite_and_repeatable(cuda):
         out = net(torch.zeros(B, 1), charts)[0]
         loss = 9000.0 * utils.chamfer_distance(out, info["faces"], gt, num=P, samples=samples).mean()
         loss.backward()
-        outs.append((out.detach().clone(), loss.item(), net.mesh_deform_2.layers[5].weight.grad.clone()))
+        outs.append((out.detach().clone(), loss.item(),
+                     torch.cat([p.grad.reshape(-1) for p in net.parameters()]).clone()))
     assert flag.item() == 0 and all(torch.isfinite(p.grad).all() for p in net.parameters())
     assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]          # forward + loss bitwise repeatable
-    # weight gradients: the GCN backward is deterministic (slab reductions); only the sampling / Chamfer scatter
-    # use float atomics, which perturbs the incoming gradient in the last bits
-    rel = ((outs[0][2] - outs[1][2]).abs().max() / outs[0][2].abs().max()).item()
-    assert rel < 1e-4
+    # weight gradients: every backward kernel is deterministic (slab reductions in the GCN, 64-bit fixed-point
+    # accumulation in the sampling / Chamfer scatters) -> the whole training step reproduces bit for bit
+    assert torch.equal(outs[0][2], outs[1][2])
+    for p in net.parameters():
+        assert p.grad is not None
     # only the first N_vision vertices move and the mask is the vision token
     assert torch.equal(net(torch.zeros(B, 1), charts)[1], 3 * torch.ones(B, v.shape[0], 1, device=cuda))

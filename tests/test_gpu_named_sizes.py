@@ -1,0 +1,309 @@
+"""-m gpu: parity at the sizes BASELINE.json names beyond configs[1] — 25 000 / 50 000-point Chamfer (configs[3] /
+configs[4]), the 10 242-vertex icosphere-5 template (configs[4]), the configs[3] composite (image + 4 touch charts +
+bf16 GEMM operands + 25 k points), the touch-chart trainer's shape (touch/train.py:109-116), and the 448-wide input with
+a narrow hidden size (scratch-layout regression).
+
+Tolerances: nearest-neighbour distances / indices EXACT against the plain-C oracle built with the device's product
+contraction (oracle/chamfer_nn.c, ``fma=True``) and 1e-5 against the uncontracted form; Chamfer gradient 1e-4; vertex
+positions 1e-4 relative in fp32 (north_star) and 5e-3 in the bf16 operand mode; gradients through
+ReLU stacks via helpers.assert_grad_close."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_grad_close, make_args, oracle_adj, random_cloud, rel_err, rel_l2, template
+
+pytestmark = pytest.mark.gpu
+
+
+# ---- (a) Chamfer at 25 000 and 50 000 points: utility/utils.py:204-217 at configs[3] / configs[4] sizes ---------------
+@pytest.mark.parametrize("P,Q,B", [(25000, 25000, 2), (50000, 50000, 1), (25000, 30000, 1)])
+def test_chamfer_named_sizes_exact_nn_and_gradient(cuda, P, Q, B):
+    """One draw of P predicted points against Q ground-truth points.  Forward: distances and first-arg-min indices of both
+    directions bit for bit against the C oracle, with the single-pass search (scratch) and the two-pass search (no
+    scratch).  Backward: clouds this large exceed the LDS image of the y -> x scatter, so this crosses into the
+    large-cloud path of a3vt_chamfer_bwd; gradient w.r.t. both clouds against the closed form in float64."""
+    from a3vt_amd import ops
+    from oracle import chamfer as och
+    x = random_cloud(B, P, 31).reshape(1, B, P, 3) * 1.15
+    y = random_cloud(B, Q, 32)
+    xd, yd = x.to(cuda), y.to(cuda)
+    outs = {sp: ops.chamfer_nn(xd, yd, single_pass=sp) for sp in (True, False)}
+    for name, u, v in zip(("dist_xy", "idx_xy", "dist_yx", "idx_yx", "cd"), outs[True], outs[False]):
+        assert torch.equal(u, v), name
+    dxy, ixy, dyx, iyx, cd = (t.cpu() for t in outs[True])
+    gcd = torch.rand(B, dtype=torch.float64) + 0.5
+    xg, yg = xd.clone().requires_grad_(True), yd.clone().requires_grad_(True)
+    (ops.ChamferFn.apply(xg, yg) * gcd.to(cuda).float()).sum().backward()
+    xg2 = xd.clone().requires_grad_(True)                      # the trainer's form: no gradient on the second cloud
+    (ops.ChamferFn.apply(xg2, yd) * gcd.to(cuda).float()).sum().backward()
+    for b in range(B):
+        xb, yb = x[0, b].numpy(), y[b].numpy()
+        d1, i1 = och.nn_sqdist_c(xb, yb, fma=True)
+        d2, i2 = och.nn_sqdist_c(yb, xb, fma=True)
+        assert np.array_equal(dxy[0, b].numpy(), d1) and np.array_equal(ixy[0, b].numpy(), i1)
+        assert np.array_equal(dyx[0, b].numpy(), d2) and np.array_equal(iyx[0, b].numpy(), i2)
+        d1p, _ = och.nn_sqdist_c(xb, yb)                       # uncontracted products: equal to rounding
+        assert np.allclose(dxy[0, b].numpy(), d1p, rtol=1e-5, atol=1e-12)
+        cd_o = d1.astype(np.float64).mean() + d2.astype(np.float64).mean()
+        assert abs(cd[b].item() - cd_o) < 1e-5 * cd_o
+        gx_o, gy_o = och.chamfer_grad_from_indices(x[0, b], y[b], torch.from_numpy(i1), torch.from_numpy(i2), gcd[b])
+        assert rel_err(xg.grad[0, b], gx_o) < 1e-4 and rel_err(yg.grad[b], gy_o) < 1e-4
+        assert rel_err(xg2.grad[0, b], gx_o) < 1e-4
+    # the backward scatter is deterministic: a second evaluation reproduces every bit
+    xg3 = xd.clone().requires_grad_(True)
+    (ops.ChamferFn.apply(xg3, yd) * gcd.to(cuda).float()).sum().backward()
+    assert torch.equal(xg3.grad, xg2.grad)
+
+
+def test_chamfer_touch_trainer_shape(cuda):
+    """reconstruction/touch/train.py:109-116: ``chamfer_distance(verts (128,25,3), faces (32,3), gt, num=4000)`` — the
+    touch-chart trainer's call (25-vertex / 32-face chart meshes, batch 128, 4 000 samples, 3 draws) against the oracle
+    on injected samples: loss 1e-4, vertex gradient 1e-4."""
+    from a3vt_amd import mesh as amesh
+    from a3vt_amd.pterotactyl.utility import utils
+    from oracle import chamfer as och
+    sv, sf = amesh.load_asset("touch_chart")
+    B, P, Q = 128, 4000, 4000
+    g = torch.Generator().manual_seed(5)
+    verts = torch.from_numpy(sv)[None] * 0.2 + 0.01 * torch.randn(B, 25, 3, generator=g)
+    gt = verts.mean(1, keepdim=True) + 0.02 * torch.randn(B, Q, 3, generator=g)
+    fi = torch.randint(0, sf.shape[0], (3, B, P), generator=g)
+    u, v = torch.rand(3, B, P, generator=g), torch.rand(3, B, P, generator=g)
+    vd = verts.to(cuda).requires_grad_(True)
+    faces = torch.from_numpy(sf).to(cuda)
+    cd = utils.chamfer_distance(vd, faces, gt.to(cuda), P, samples=(fi.to(torch.int32).to(cuda), u.to(cuda), v.to(cuda)))
+    assert cd.shape == (B,)
+    (9000.0 * cd.mean()).backward()
+    sub = slice(0, 16)                                         # the oracle on 16 of the 128 meshes (seconds)
+    v64 = verts[sub].double().requires_grad_(True)
+    cd_o = och.chamfer_distance(v64, torch.from_numpy(sf), gt[sub].double(), num=P,
+                                samples=[(fi[r][sub], u[r][sub].double(), v[r][sub].double()) for r in range(3)], use_c=True)
+    (9000.0 * cd_o.sum() / B).backward()
+    assert rel_err(cd[sub], cd_o) < 1e-4
+    assert rel_err(vd.grad[sub], v64.grad) < 1e-4
+    # production sampling (Philox) at this shape: finite, same scale as the injected-sample result
+    cd2 = utils.chamfer_distance(vd.detach(), faces, gt.to(cuda), P)
+    assert torch.isfinite(cd2).all() and abs(cd2.mean().item() / cd.mean().item() - 1) < 0.2
+
+
+# ---- (b) icosphere-5 (10 242 vertices, configs[4]) ------------------------------------------------------------------
+@pytest.mark.parametrize("bf16", [False, True])
+def test_gcn_stack_icosphere5(cuda, bf16):
+    """L=3, H=300, B=8 on the 10 242-vertex template (81 936 rows: three main/remainder splits of the MFMA launch, CSR of
+    71 682 entries) against the fp64 oracle; in the bf16 operand mode against the oracle's emulation of the rounding."""
+    from a3vt_amd import mesh as amesh, ops
+    from oracle import gcn as og
+    L, H, B = 3, 300, 8
+    args = make_args(num_GCN_layers=L, hidden_GCN_size=H)
+    verts, faces = template("ico5")
+    assert verts.shape[0] == 10242 and faces.shape[0] == 20480
+    adj_o, _ = oracle_adj(verts, faces, args)
+    assert adj_o[1].numel() == 71682                          # nnz of the level-5 icosphere
+    st = og.init_state(50, H, L, seed=9)
+    g = torch.Generator().manual_seed(13)
+    feats = torch.randn(B, 10242, 50, generator=g) * 0.5
+    gup = torch.randn(B, 10242, 3, generator=g)
+    st64 = {k: v.double().requires_grad_(True) for k, v in st.items() if k.startswith("mesh_deform_1")}
+    f64 = feats.double().requires_grad_(True)
+    out_o = og.gcn(f64, st64, "mesh_deform_1", (adj_o[0], adj_o[1], adj_o[2].double()), L, 0.33, bf16=bf16)
+    (out_o * gup.double()).sum().backward()
+    r, c = amesh.vision_pairs(faces, verts.shape[0])
+    adj = ops.DeviceCSR(amesh.CSRAdjacency.from_pairs(r, c, verts.shape[0]), cuda)
+    ws = [st[f"mesh_deform_1.layers.{i}.weight"].to(cuda).requires_grad_(True) for i in range(L)]
+    bs = [st[f"mesh_deform_1.layers.{i}.bias"].to(cuda).requires_grad_(True) for i in range(L)]
+    fd = torch.nn.functional.pad(feats, (0, 2)).to(cuda).requires_grad_(True)
+    out = ops.gcn_stack(fd, adj, 50, H, 99, ws, bs, bf16=bf16)
+    (out * gup.to(cuda)).sum().backward()
+    if not bf16:
+        assert rel_err(out, out_o) < 1e-4
+        assert_grad_close(fd.grad[..., :50], f64.grad, "grad_feats")
+        for i in range(L):
+            assert_grad_close(ws[i].grad, st64[f"mesh_deform_1.layers.{i}.weight"].grad, f"dW layer {i}")
+            assert_grad_close(bs[i].grad, st64[f"mesh_deform_1.layers.{i}.bias"].grad, f"db layer {i}")
+    else:   # same tolerances as test_gcn_stack_bf16_mode (a bf16 rounding tie may go the other way on the device)
+        assert rel_err(out, out_o) < 2e-3 and rel_l2(out, out_o) < 2e-4
+        errs = [rel_l2(fd.grad[..., :50], f64.grad)]
+        for i in range(L):
+            errs.append(rel_l2(ws[i].grad, st64[f"mesh_deform_1.layers.{i}.weight"].grad))
+            errs.append(rel_l2(bs[i].grad, st64[f"mesh_deform_1.layers.{i}.bias"].grad))
+        assert max(errs) < 3e-2, errs
+
+
+@pytest.mark.parametrize("hidden", [32, 64, 128])
+def test_gcn_stack_wide_input_narrow_hidden(cuda, hidden):
+    """The image model's 448-wide features into a stack whose hidden size is below 300: the backward's 300-column panel
+    of X_0 is larger than a gradient ping buffer ([M][hidden]) and must live in its own scratch region (regression:
+    it used to overrun the live gradient)."""
+    from a3vt_amd import mesh as amesh, ops
+    from oracle import gcn as og
+    L, B, I = 3, 4, 448
+    args = make_args(num_GCN_layers=L, hidden_GCN_size=hidden)
+    verts, faces = template("ico3")
+    adj_o, _ = oracle_adj(verts, faces, args)
+    n = verts.shape[0]
+    st = og.init_state(I, hidden, L, seed=21)
+    g = torch.Generator().manual_seed(hidden)
+    feats = torch.randn(B, n, I, generator=g) * 0.3
+    gup = torch.randn(B, n, 3, generator=g)
+    st64 = {k: v.double().requires_grad_(True) for k, v in st.items() if k.startswith("mesh_deform_1")}
+    f64 = feats.double().requires_grad_(True)
+    out_o = og.gcn(f64, st64, "mesh_deform_1", (adj_o[0], adj_o[1], adj_o[2].double()), L, 0.33)
+    (out_o * gup.double()).sum().backward()
+    r, c = amesh.vision_pairs(faces, n)
+    adj = ops.DeviceCSR(amesh.CSRAdjacency.from_pairs(r, c, n), cuda)
+    ws = [st[f"mesh_deform_1.layers.{i}.weight"].to(cuda).requires_grad_(True) for i in range(L)]
+    bs = [st[f"mesh_deform_1.layers.{i}.bias"].to(cuda).requires_grad_(True) for i in range(L)]
+    fd = feats.to(cuda).requires_grad_(True)
+    out = ops.gcn_stack(fd, adj, I, hidden, round(hidden * 0.33), ws, bs)
+    (out * gup.to(cuda)).sum().backward()
+    assert rel_err(out, out_o) < 1e-4
+    assert_grad_close(fd.grad, f64.grad, "grad_feats")
+    for i in range(L):
+        assert_grad_close(ws[i].grad, st64[f"mesh_deform_1.layers.{i}.weight"].grad, f"dW layer {i}")
+        assert_grad_close(bs[i].grad, st64[f"mesh_deform_1.layers.{i}.bias"].grad, f"db layer {i}")
+
+
+def test_forward_only_callers_do_not_stash_activations(cuda):
+    """Under torch.no_grad() (Engine.validate, policies/scoring.py, environment.py:221-257) the stack must take the
+    forward-only path: no activation / mask stash is allocated although the parameters require grad."""
+    from a3vt_amd import ops
+    from a3vt_amd.pterotactyl.reconstruction.vision import model
+    from a3vt_amd.pterotactyl.utility import utils
+    args = make_args(num_GCN_layers=4, hidden_GCN_size=64)
+    v, f = template("ico2")
+    vt, ft = torch.from_numpy(v).to(cuda), torch.from_numpy(f).to(cuda)
+    net = model.Deformation(utils.adj_init(vt, ft, args), vt, args).to(cuda)
+    charts = model.prepare_mesh({"img": torch.zeros(2, 1)}, vt, args)
+    before = dict(ops.STATS)
+    with torch.no_grad():
+        out_eval = net(torch.zeros(2, 1), charts)[0]
+    assert ops.STATS["stack_calls"] == before["stack_calls"] + 3
+    assert ops.STATS["stack_stash_calls"] == before["stack_stash_calls"]
+    out_train = net(torch.zeros(2, 1), charts)[0]
+    assert ops.STATS["stack_stash_calls"] == before["stack_stash_calls"] + 3
+    assert torch.equal(out_eval, out_train.detach())
+    layer = model.GCN_layer(52, 32).to(cuda)                  # the stand-alone layer decides the same way
+    x = torch.randn(2, v.shape[0], 52, device=cuda)
+    with torch.no_grad():
+        y0 = layer(x, net.adj_info["csr"], torch.relu)
+    assert torch.equal(y0, layer(x, net.adj_info["csr"], torch.relu).detach())
+
+
+# ---- (c) configs[3] composite: image + 4 touch charts + bf16 operands + 25 000-point Chamfer --------------------------
+def test_config3_composite_bs2(cuda):
+    """BASELINE.json configs[3] at bs 2: ``use_img`` (default CNNs, 448-wide features), ``use_touch`` with
+    ``num_grasps=1, finger=False`` (4 chart slots fused into the atlas: N = 1924), the full 20 x 300 GCNs with bf16 GEMM
+    operands, 25 000-point Chamfer x 3 draws.  Vertex positions against ``oracle.gcn.deformation_forward_img`` with the
+    bf16 emulation (tolerance 5e-3 relative: bf16 rounding after every layer); the Chamfer loss of THESE
+    positions against the oracle's Chamfer on the same injected samples (1e-4)."""
+    from a3vt_amd import mesh as amesh
+    from a3vt_amd.pterotactyl.reconstruction.vision import model
+    from a3vt_amd.pterotactyl.utility import utils
+    from oracle import chamfer as och, gcn as og, mesh as omesh
+    args = make_args(use_img=True, use_touch=True, num_grasps=1, finger=False, gemm_precision="bf16",
+                     CNN_ker_size=5, num_CNN_blocks=6, layers_per_block=3, number_points=25000)
+    info, verts = utils.load_mesh_vision(args, "vision_charts")
+    torch.manual_seed(0)
+    net = model.Deformation(info, verts, args).to(cuda).eval()
+    B, P = 2, 25000
+    g = torch.Generator().manual_seed(23)
+    img = torch.rand(B, 3, 256, 256, generator=g)
+    tc = torch.zeros(B, 1, 4, 25, 4)
+    tc[..., :3] = (torch.rand(B, 1, 4, 1, 3, generator=g) - 0.5) * 0.3 + 0.004 * torch.randn(B, 1, 4, 25, 3, generator=g)
+    tc[..., 3] = 2
+    tc[1, 0, 3] = 0                                           # one empty slot (all-zero chart, mask 0)
+    batch = {"img": img, "touch_charts": tc}
+    charts = model.prepare_mesh(batch, verts, args)
+    with torch.no_grad():
+        out, mask = net(img.to(cuda), charts)
+    assert out.shape == (B, 1924, 3) and mask.shape == (B, 1924, 1)
+    v, f = amesh.load_asset("vision_charts")
+    sv, sf = amesh.load_asset("touch_chart")
+    oinfo = omesh.adj_init(v, f, True, 1, False, sv, sf)
+    adj = {k: tuple(torch.from_numpy(a) if i == 2 else torch.from_numpy(a).long() for i, a in enumerate(omesh.dense_to_csr(oinfo[k])))
+           for k in ("origional", "adj")}
+    st = {k: t.detach().cpu() for k, t in net.state_dict().items()}
+    ch = og.prepare_mesh(tc, torch.from_numpy(v), B, True)
+    with torch.no_grad():
+        out_o, mask_o = og.deformation_forward_img(st, adj, ch, img, True, 20, 0.33, training=False, bf16=True)
+        out_f, _ = og.deformation_forward_img(st, adj, ch, img, True, 20, 0.33, training=False, bf16=False)
+    assert torch.equal(mask.cpu(), mask_o)
+    e_bf, e_fp = rel_err(out, out_o), rel_err(out, out_f)
+    assert e_bf < 5e-3 and e_fp < 5e-3, (e_bf, e_fp)           # vs the emulation and vs the exact fp32 network
+    assert torch.equal(out[:, 1824:].cpu(), ch["touch_charts"])  # touch vertices never move
+    F_ = info["faces"].shape[0]
+    fi = torch.randint(0, F_, (3, B, P), generator=g)
+    u, w = torch.rand(3, B, P, generator=g), torch.rand(3, B, P, generator=g)
+    gt = random_cloud(B, P, 41)
+    cd = utils.chamfer_distance(out, info["faces"], gt.to(cuda), num=P,
+                                samples=(fi.to(torch.int32).to(cuda), u.to(cuda), w.to(cuda)))
+    cd_o = och.chamfer_distance(out.cpu(), torch.from_numpy(oinfo["faces"]), gt, num=P,
+                                samples=[(fi[r], u[r], w[r]) for r in range(3)], use_c=True)
+    assert rel_err(cd, cd_o) < 1e-4
+
+
+# ---- (d) full-size property tests for configs[3] and the configs[4] shard ---------------------------------------------
+def _repeatable_training_step(cuda, net, img, charts, faces, gt, P, n_faces):
+    from a3vt_amd.pterotactyl.utility import utils
+    flag = torch.zeros((), dtype=torch.int32, device=cuda)
+    net.finite_flag = flag
+    g = torch.Generator().manual_seed(1)
+    B = gt.shape[0]
+    samples = (torch.randint(0, n_faces, (3, B, P), generator=g).to(torch.int32).to(cuda),
+               torch.rand(3, B, P, generator=g).to(cuda), torch.rand(3, B, P, generator=g).to(cuda))
+    outs = []
+    for _ in range(2):
+        net.zero_grad()
+        out = net(img, charts)[0]
+        loss = 9000.0 * utils.chamfer_distance(out, faces, gt, num=P, samples=samples).mean()
+        loss.backward()
+        outs.append((out.detach().clone(), loss.item(),
+                     [p.grad.clone() for n, p in net.named_parameters() if n.startswith(("mesh_deform", "positional"))]))
+    assert flag.item() == 0 and all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+    return outs
+
+
+def test_config4_shard_fullsize_is_finite_and_repeatable(cuda):
+    """configs[4] per-GPU shard: 10 242-vertex template, bs 8, 50 000-point Chamfer, 20 x 300 GCNs, bf16 operands: finite,
+    forward + loss bitwise repeatable, GCN weight gradients bitwise repeatable (deterministic backward scatter)."""
+    from a3vt_amd.pterotactyl.reconstruction.vision import model
+    from a3vt_amd.pterotactyl.utility import utils
+    args = make_args(gemm_precision="bf16", number_points=50000)
+    v, f = template("ico5")
+    vt, ft = torch.from_numpy(v).to(cuda), torch.from_numpy(f).to(cuda)
+    info = utils.adj_init(vt, ft, args)
+    torch.manual_seed(0)
+    net = model.Deformation(info, vt, args).to(cuda)
+    B, P = 8, 50000
+    charts = model.prepare_mesh({"img": torch.zeros(B, 1)}, vt, args)
+    outs = _repeatable_training_step(cuda, net, torch.zeros(B, 1), charts, info["faces"], random_cloud(B, P, 3).to(cuda), P,
+                                     f.shape[0])
+    for a, b in zip(outs[0][2], outs[1][2]):
+        assert torch.equal(a, b)
+    assert outs[0][0].shape == (B, 10242, 3)
+
+
+def test_config3_fullsize_is_finite_and_repeatable(cuda):
+    """configs[3] at its full batch: image model + 4 touch charts, bs 64, 25 000-point Chamfer, bf16 operands."""
+    from a3vt_amd.pterotactyl.reconstruction.vision import model
+    from a3vt_amd.pterotactyl.utility import utils
+    from a3vt_amd.synthetic import touch_charts
+    args = make_args(use_img=True, use_touch=True, num_grasps=1, finger=False, gemm_precision="bf16",
+                     CNN_ker_size=5, num_CNN_blocks=6, layers_per_block=3, number_points=25000)
+    info, verts = utils.load_mesh_vision(args, "vision_charts")
+    torch.manual_seed(0)
+    net = model.Deformation(info, verts, args).to(cuda)
+    net.eval()                                                # BN on running statistics: the image branch is then deterministic too
+    B, P = 64, 25000
+    g = torch.Generator().manual_seed(2)
+    img = torch.rand(B, 3, 256, 256, generator=g).to(cuda)
+    batch = {"img": img, "touch_charts": touch_charts(B, args, seed=3)}
+    charts = model.prepare_mesh(batch, verts, args)
+    outs = _repeatable_training_step(cuda, net, img, charts, info["faces"], random_cloud(B, P, 4).to(cuda), P,
+                                     info["faces"].shape[0])
+    assert outs[0][0].shape == (B, 1924, 3)
+    # the GCN / encoder gradients only depend on deterministic kernels downstream of the (MIOpen) image maps
+    for a, b in zip(outs[0][2], outs[1][2]):
+        assert torch.equal(a, b)

@@ -74,7 +74,9 @@ def test_forward_only_scoring_path_matches_training_forward(cuda):
 @pytest.mark.parametrize("use_img", [False, True])
 def test_batched_scoring(cuda, use_img):
     """K candidate touches x E environment elements in one batch give the scores of the reference's
-    sequential loop (environment.py:174-180 -> compute_obs -> get_score) — bit for bit on the same surface samples."""
+    sequential loop (environment.py:174-180 -> compute_obs -> get_score): against the ORACLE evaluating that loop one
+    candidate at a time on the same injected surface samples (1e-4 on positions and scores; image-free model — the
+    image model's oracle comparison is test_g8 / test_config3), and bit for bit against the sequential HIP loop."""
     from a3vt_amd.pterotactyl.policies import scoring
     from a3vt_amd.pterotactyl.reconstruction.vision import model
     from a3vt_amd.pterotactyl.utility import utils
@@ -103,6 +105,21 @@ def test_batched_scoring(cuda, use_img):
                torch.rand(3, E, P, generator=g).to(cuda), torch.rand(3, E, P, generator=g).to(cuda))
     score, v_all, m_all = scoring.score_actions(net, img, charts_list, gt, info["faces"], P, args.loss_coeff, samples=samples)
     assert score.shape == (K, E) and v_all.shape == (K, E, 1949, 3) and m_all.shape == (K, E, 1949, 1)
+    if not use_img:   # the reference's loop on the CPU oracle: compute_obs (environment.py:221-249) + get_score (:252-257)
+        from a3vt_amd import mesh as amesh
+        from helpers import oracle_adj
+        from oracle import chamfer as och, gcn as og
+        v_np, f_np = amesh.load_asset("vision_charts")
+        adj_o, faces_o = oracle_adj(v_np, f_np, args)
+        st = {k_: t.detach().cpu() for k_, t in net.state_dict().items()}
+        smp = [(samples[0][r].cpu().long(), samples[1][r].cpu(), samples[2][r].cpu()) for r in range(3)]
+        for k in range(K):
+            ch = {k_: t.cpu() for k_, t in charts_list[k].items()}
+            with torch.no_grad():
+                v_o, m_o = og.deformation_forward(st, {"adj": adj_o}, ch, True, 3, 0.33)
+                s_o = args.loss_coeff * och.chamfer_distance(v_o, faces_o, gt.cpu(), num=P, samples=smp, use_c=True)
+            assert rel_err(v_all[k], v_o) < 1e-4 and torch.equal(m_all[k].cpu(), m_o)
+            assert rel_err(score[k], s_o) < 1e-4, (k, score[k], s_o)
     for k in range(K):                                   # the reference's loop: one candidate per call
         with torch.no_grad():
             v, m = net(img.to(cuda) if use_img else img, charts_list[k])
@@ -255,3 +272,66 @@ def test_multi_step_training_tracks_the_oracle(cuda):
     assert max(abs(a - b) / abs(b) for a, b in zip(hip, ora)) < 1e-3, (hip, ora)
     for k, p in net.state_dict().items():
         assert rel_err(p, st[k]) < 2e-3, k
+
+
+def test_engine_train_step_reproduces_reference_step(cuda, tmp_path):
+    """``Engine.train_step`` itself — flat gradient bucket + fused Adam, the path ``bench.py`` and ``Engine.train`` run —
+    against fixture g7 (the REAL reference's loss before / after one Adam step and a weight sample, BASELINE configs[0]
+    sizes: atlas, bs 2, 10 000-point Chamfer, 3 stages), on the reference's own surface draws."""
+    from golden_util import g7_cloud, load
+    from a3vt_amd.pterotactyl.reconstruction.vision import model, train
+    from oracle import chamfer as och
+    z = load("g7_train_step.npz")
+    args = make_args(exp_type="t", exp_id="g7", eval=False, epochs=1, patience=70, batch_size=2, log_interval=0,
+                     number_points=10000)
+    os.chdir(tmp_path)
+    eng = train.Engine(args, loaders=((), ()))
+    torch.manual_seed(0)                                        # Engine.__init__ seeds with args.seed = 0 as well
+    eng.setup()
+    assert eng.bucket is not None and type(eng.optimizer).__name__ == "Adam"
+    gt = g7_cloud().to(cuda)
+    faces_cpu = eng.mesh_info["faces"].cpu()
+    charts = model.prepare_mesh({"img": torch.zeros(2, 1)}, eng.initial_mesh, args)
+    losses = []
+    for it in range(2):
+        with torch.no_grad():
+            out = eng.encoder(torch.zeros(2, 1), charts)[0]
+        torch.manual_seed(1000 + it)                            # the reference's draws for this evaluation (make_golden.g7)
+        draws = [och.draw_samples(och.face_probabilities(out.cpu(), faces_cpu), 10000) for _ in range(3)]
+        samples = (torch.stack([d[0] for d in draws]).to(torch.int32).to(cuda), torch.stack([d[1] for d in draws]).to(cuda),
+                   torch.stack([d[2] for d in draws]).to(cuda))
+        if it == 0:
+            losses.append(eng.train_step(torch.zeros(2, 1), charts, gt, samples=samples).item())
+            assert all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(eng.bucket.params, eng.bucket.views))
+        else:
+            from a3vt_amd.pterotactyl.utility import utils
+            with torch.no_grad():
+                cd = utils.chamfer_distance(out, eng.mesh_info["faces"], gt, num=10000, samples=samples)
+            losses.append(9000.0 * cd.mean().item())
+    assert abs(losses[0] - float(z["loss_before_s3"])) < 1e-4 * abs(losses[0])
+    assert abs(losses[1] - float(z["loss_after_s3"])) < 1e-3 * abs(losses[1])
+    w = eng.encoder.mesh_deform_1.layers[19].weight.detach().cpu().numpy()[0, :16]
+    np.testing.assert_allclose(w, z["w_after_sample_s3"], rtol=0, atol=5e-6)
+
+
+def test_bench_under_torchrun_single_rank(cuda):
+    """The driver's multi-GPU launch line at N = 1: ``python -m torch.distributed.run ... bench.py --gpus 1`` must come up
+    (env rendezvous on 127.0.0.1, RCCL-capable init path, Engine + flat bucket) and print one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--batch", "8", "--layers", "3", "--points", "1000", "--no-cpu-baseline", "--no-traffic", "--profile-steps", "1"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["config"]["parallelism"] == "dp1"
+    assert d["roofline"]["traffic"] is None and "step_ms" in d and "cpu_baseline" not in d
+    assert d["metric"].startswith("mesh-recon iters/sec (fwd+bwd, 2562-vert GCN + 1k-pt Chamfer) at bs=8")
+    # a wrong --gpus is refused instead of silently measuring something else
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True,
+                         text=True, timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)

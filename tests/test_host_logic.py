@@ -190,6 +190,60 @@ def test_dataset_wire_format(tmp_path, finger):
     assert b["img"].shape == (2, 1) and b["touch_charts"].shape == (2, 1)
 
 
+def test_dataset_loader_matches_reference_fixture(tmp_path, monkeypatch):
+    """the mirror's ``mesh_loader_vision`` against fixture g11 — what the REFERENCE's class
+    (utility/data_loaders.py:132-258) yields on the same miniature dataset (tests/golden/make_golden.py::g11): instance
+    list and position-derived seeds, seeded validation grasp subsets, training draws from the global python RNG, the
+    ``val_grasps`` evaluation mode, and one collated batch bit for bit (touch charts, shuffled ground-truth points, image
+    scaling and layout)."""
+    import random
+    from glob import glob as _glob
+    from golden_util import load, write_mini_dataset
+    from helpers import make_args
+    from a3vt_amd.pterotactyl.utility import data_loaders
+    z = load("g11_loader_batch.npz")
+    root = str(tmp_path)
+    write_mini_dataset(root, n=6, seed=0)
+    monkeypatch.setattr(data_loaders, "glob", lambda pat: sorted(_glob(pat)))   # as the fixture: file-system independent order
+    for tag, finger in (("full", False), ("finger", True)):
+        args = make_args(use_touch=True, use_img=True, finger=finger, num_grasps=3, number_points=500, eval=False,
+                         data_root=root, limit_data=False, val_grasps=-1)
+        valid = data_loaders.mesh_loader_vision(args, set_type="valid")
+        train = data_loaders.mesh_loader_vision(args, set_type="recon_train")
+        if not finger:
+            assert [int(n) for n, _ in valid.object_names] == z["valid_names"].tolist()
+            assert [s for _, s in valid.object_names] == z["valid_seeds"].tolist()
+            assert [int(n) for n, _ in train.object_names] == z["train_names"].tolist()
+            for i in range(len(valid)):
+                want = [g for g in z["valid_grasps"][i].tolist() if g >= 0]
+                assert valid.get_validation_instance(i)[1] == want, i
+            random.seed(7)
+            for i in range(6):
+                obj, grasps = train.get_training_instance(0)
+                assert int(obj) == int(z["train_draw_names"][i])
+                assert grasps == [g for g in z["train_draw_grasps"][i].tolist() if g >= 0]
+            args.eval, args.val_grasps = True, 2
+            test = data_loaders.mesh_loader_vision(args, set_type="test")
+            assert [test.get_validation_instance(i)[1] for i in range(len(test))] == z["test_grasps_val2"].tolist()
+            args.eval, args.val_grasps = False, -1
+        np.random.seed(11)
+        batch = valid.collate([valid[i] for i in (0, 3, 7)])
+        assert np.array_equal(batch["touch_charts"].numpy(), z[f"{tag}_touch_charts"])
+        if not finger:
+            assert np.array_equal(batch["gt_points"].numpy(), z["gt_points"])
+            assert np.array_equal(batch["img"][:, :, ::16, ::16].numpy(), z["img_sub"])
+            assert np.allclose(batch["img"].double().sum(dim=(1, 2, 3)).numpy(), z["img_sum"], rtol=1e-12)
+            assert [int(os.path.basename(n)) for n, _ in batch["names"]] == z["batch_names"].tolist()
+            assert os.path.basename(os.path.dirname(batch["names"][0][0])) == "".join(chr(c) for c in z["batch_name_dir"])
+    args = make_args(use_touch=False, use_img=False, finger=False, num_grasps=3, number_points=500, eval=False,
+                     data_root=root, limit_data=False, val_grasps=-1)
+    plain = data_loaders.mesh_loader_vision(args, set_type="valid")
+    b = plain.collate([plain[0], plain[1]])
+    assert list(b["img"].shape) == z["plain_img_shape"].tolist()
+    assert list(b["touch_charts"].shape) == z["plain_touch_shape"].tolist()
+    assert np.array_equal(b["touch_charts"].numpy(), z["plain_touch_value"])
+
+
 def test_install_as_pterotactyl_registers_the_mirror():
     """existing callers keep their imports; the mirror modules answer under the reference's names."""
     import subprocess
