@@ -118,9 +118,13 @@ def test_gcn_stack_icosphere5(cuda, bf16):
     if not bf16:
         assert rel_err(out, out_o) < 1e-4
         assert_grad_close(fd.grad[..., :50], f64.grad, "grad_feats")
+        # Weight gradients are sums over 81 936 rows.  Of the 49 M hidden pre-activations a few dozen lie within fp32
+        # rounding of zero and take the other ReLU branch than in float64; each such flip changes ONE row's dZ by O(1),
+        # i.e. every element of dW by about one term of a sum whose maximum is ~sqrt(M) terms = 3e-3 of it.  The element
+        # tolerance is therefore 5e-3 here (1e-3 at the smaller sizes); the relative L2 bound stays 1e-3.
         for i in range(L):
-            assert_grad_close(ws[i].grad, st64[f"mesh_deform_1.layers.{i}.weight"].grad, f"dW layer {i}")
-            assert_grad_close(bs[i].grad, st64[f"mesh_deform_1.layers.{i}.bias"].grad, f"db layer {i}")
+            assert_grad_close(ws[i].grad, st64[f"mesh_deform_1.layers.{i}.weight"].grad, f"dW layer {i}", tol=5e-3)
+            assert_grad_close(bs[i].grad, st64[f"mesh_deform_1.layers.{i}.bias"].grad, f"db layer {i}", tol=5e-3)
     else:   # same tolerances as test_gcn_stack_bf16_mode (a bf16 rounding tie may go the other way on the device)
         assert rel_err(out, out_o) < 2e-3 and rel_l2(out, out_o) < 2e-4
         errs = [rel_l2(fd.grad[..., :50], f64.grad)]
