@@ -125,6 +125,285 @@ static int check_stack_dims(int ld_feats, int in_features, int num_layers, int h
   return 0;
 }
 
+
+// ---- bf16 STORAGE mode (gemm_bf16 == 2): scratch layout and the stack loops on the bf16 kernels (gcn_bf16s.hip) ----------
+static inline int pad8(int n) { return (n + 7) & ~7; }
+// ReLU-sign bytes per row in this mode: the aggregated-channel bytes cover pad8(cut_len) columns, and the row length is
+// even so that the 2-byte groups of an 8-column epilogue store never straddle rows
+static inline int mask_ld16(int hidden, int cut_len) { return (pad8(cut_len) / 4 + (hidden + 3) / 4 + 1) & ~1; }
+
+struct Stack16Layout {
+  size_t wt, wt_stride;   // bf16 weight images (offsets / stride in floats)
+  size_t feats16;         // [M][ld0] bf16: the stack's fp32 input features, converted
+  size_t za;              // [M][cpad] bf16
+  size_t z3;              // [2][M][4] fp32
+  size_t ping[2];         // [M][ldh] bf16 each
+  size_t dw_slab, db_slab, thin_dw_slab, thin_db_slab, heavy, total;
+  int ld0, ldh, cpad;
+};
+
+static Stack16Layout stack16_layout(int batch, int n_vert, int in_features, int hidden, int num_layers, int cut_len,
+                                    int need_backward) {
+  Stack16Layout L{};
+  const size_t m = (size_t)batch * n_vert;
+  L.ld0 = pad8(in_features);
+  L.ldh = pad8(hidden);
+  L.cpad = pad8(cut_len);
+  size_t off = 0;
+  auto take = [&](size_t nfloats) {
+    const size_t o = off;
+    off = align_up(off + nfloats, 64);
+    return o;
+  };
+  auto take16 = [&](size_t nelems) { return take((nelems + 1) / 2 + 64); };  // bf16 region (+ slack for 16-byte tails)
+  // images: forward W_i^T [bt_rows(hidden)][2 pad16(k_i / 2)], backward W_i [bt_rows(n_store_i)][2 pad16(ldh / 2)]
+  const int kmax = L.ld0 > L.ldh ? L.ld0 : L.ldh;
+  const int rows_f = rowgemm_bt_rows(hidden), rows_b = rowgemm_bt_rows(kmax);
+  const size_t img_f = (size_t)rows_f * pad16(kmax / 2), img_b = (size_t)rows_b * pad16(L.ldh / 2);
+  L.wt_stride = align_up(img_f > img_b ? img_f : img_b, 64);
+  L.wt = take(L.wt_stride * (num_layers > 1 ? num_layers - 1 : 1));
+  L.feats16 = take16(m * L.ld0);
+  L.za = take16(m * (L.cpad > 8 ? L.cpad : 8));
+  L.z3 = take(2 * m * 4);
+  L.ping[0] = take16(m * L.ldh);
+  L.ping[1] = take16(m * L.ldh);
+  L.heavy = take(csr_heavy_scratch_ints(n_vert));
+  if (need_backward) {
+    const size_t kin = in_features > hidden ? in_features : hidden;
+    L.dw_slab = take((size_t)dw16_num_slabs(hidden) * (kin > 304 ? 304 : kin) * hidden);
+    L.db_slab = take((size_t)csr_bwd_num_slabs(batch, n_vert) * (L.cpad > 8 ? L.cpad : 8));
+    L.thin_dw_slab = take((size_t)thin_num_slabs() * hidden * 3);
+    L.thin_db_slab = take((size_t)thin_num_slabs() * 3);
+  }
+  L.total = off;
+  return L;
+}
+
+static int check_stack16_dims(int num_layers, int hidden, int in_features) {
+  if (num_layers < 2) { set_error("gcn_stack: the bf16 storage mode needs at least one hidden layer"); return -1; }
+  if (hidden > 304 || hidden % 4 != 0 || hidden < 16) { set_error("gcn_stack: bf16 storage mode: hidden=%d unsupported", hidden); return -1; }
+  if (in_features > 600) { set_error("gcn_stack: in_features=%d > 600 unsupported", in_features); return -1; }
+  if (in_features > 304 && in_features % 8 != 0) {
+    set_error("gcn_stack: bf16 storage mode: in_features=%d > 304 must be a multiple of 8", in_features);
+    return -1;
+  }
+  return 0;
+}
+
+static int stack_fwd16(const float *feats, int ld_feats, int in_features, const float *const *weights,
+                       const float *const *biases, int num_layers, int hidden, int cut_len, const int32_t *rowptr,
+                       const int32_t *col, const float *val, int max_degree, int n_vert, int batch, void *acts,
+                       uint8_t *masks, float *scratch, float *update, hipStream_t s) {
+  if (int rc = check_stack16_dims(num_layers, hidden, in_features)) return rc;
+  const float *zeros = zero_page();
+  A3VT_CHECK_ARG(zeros != nullptr);
+  const Stack16Layout L = stack16_layout(batch, n_vert, in_features, hidden, num_layers, cut_len, 0);
+  const size_t m = (size_t)batch * n_vert;
+  const int mld = mask_ld16(hidden, cut_len);
+  const size_t mpad = (m + 31) / 32 * 32;
+  using u16 = unsigned short;
+  int32_t *heavy = nullptr;
+  if (max_degree <= 0 || max_degree > csr_heavy_degree()) {
+    heavy = reinterpret_cast<int32_t *>(scratch + L.heavy);
+    if (int rc = launch_csr_heavy_list(rowptr, n_vert, heavy, s)) return rc;
+  }
+  if (num_layers - 1 > kMaxImages) { set_error("gcn_stack: bf16 storage mode supports up to %d hidden layers", kMaxImages); return -1; }
+  {
+    WeightImages wi{};
+    int max_ld = 0;
+    for (int i = 0; i + 1 < num_layers; ++i) {
+      wi.w[i] = weights[i];
+      wi.k[i] = i == 0 ? in_features : hidden;
+      wi.rows[i] = rowgemm_bt_rows(hidden);
+      wi.ld[i] = 2 * pad16((i == 0 ? L.ld0 : L.ldh) / 2);
+      max_ld = wi.ld[i] > max_ld ? wi.ld[i] : max_ld;
+    }
+    wi.dst = scratch + L.wt;
+    wi.dst_stride = L.wt_stride;
+    wi.n = hidden;
+    wi.count = num_layers - 1;
+    wi.transpose = 1;
+    if (int rc = launch_weight_images16(wi, rowgemm_bt_rows(hidden), max_ld, s)) return rc;
+  }
+  u16 *f16 = reinterpret_cast<u16 *>(scratch + L.feats16);
+  if (int rc = launch_cvt_rows(feats, ld_feats, in_features, f16, L.ld0, (long long)m, s)) return rc;
+
+  const u16 *x = f16;
+  int ldx = L.ld0;
+  u16 *za = reinterpret_cast<u16 *>(scratch + L.za);
+  for (int i = 0; i + 1 < num_layers; ++i) {
+    u16 *y = acts ? static_cast<u16 *>(acts) + (size_t)i * m * L.ldh : reinterpret_cast<u16 *>(scratch + L.ping[i & 1]);
+    RowGemmArgs g{};
+    g.a0 = g.a1 = reinterpret_cast<const float *>(x);
+    g.lda0 = g.lda1 = ldx / 2;
+    g.ksplit = g.k = ldx / 2;
+    g.bt = scratch + L.wt + L.wt_stride * i;
+    g.ldb = pad16(ldx / 2);
+    g.zeros = zeros;
+    g.m = (int)m;
+    g.n_store = hidden;
+    g.c = reinterpret_cast<float *>(y);
+    g.ldc = L.ldh;
+    g.c2 = reinterpret_cast<float *>(za);
+    g.ldc2 = L.cpad > 8 ? L.cpad : 8;
+    g.csplit = cut_len;
+    uint8_t *mk = masks ? masks + (size_t)i * mpad * mld : nullptr;
+    g.maskb = mk;
+    g.mld = mld;
+    g.moff = L.cpad / 4;
+    g.bf16 = 2;
+    {
+      ProfScope ps(PROF_GEMM_FWD, s);
+      if (int rc = launch_rowgemm(g, EPI_FWD_HIDDEN, s)) return rc;
+    }
+    if (cut_len > 0)
+      if (int rc = launch_csr16_fwd(za, g.ldc2, biases[i], cut_len, rowptr, col, val, heavy, n_vert, batch, y, L.ldh, mk, mld, 1, s))
+        return rc;
+    x = y;
+    ldx = L.ldh;
+  }
+  const int last = num_layers - 1;
+  if (int rc = launch_thin16_fwd_product(x, ldx, hidden, weights[last], (long long)m, scratch + L.z3, s)) return rc;
+  return launch_csr3(scratch + L.z3, biases[last], rowptr, col, val, heavy, n_vert, batch, update, 3, s);
+}
+
+static int stack_bwd16(const float *feats, int ld_feats, int in_features, const float *const *weights, int num_layers,
+                       int hidden, int cut_len, const int32_t *rowptrT, const int32_t *colT, const float *valT,
+                       int max_degreeT, int n_vert, int batch, const void *acts, const uint8_t *masks,
+                       const float *grad_update, float *const *grad_weights, float *const *grad_biases,
+                       float *grad_feats, float *scratch, hipStream_t s) {
+  if (int rc = check_stack16_dims(num_layers, hidden, in_features)) return rc;
+  const float *zeros = zero_page();
+  A3VT_CHECK_ARG(zeros != nullptr);
+  const Stack16Layout L = stack16_layout(batch, n_vert, in_features, hidden, num_layers, cut_len, 1);
+  const size_t m = (size_t)batch * n_vert;
+  const int mld = mask_ld16(hidden, cut_len);
+  const size_t mpad = (m + 31) / 32 * 32;
+  const int last = num_layers - 1;
+  using u16 = unsigned short;
+  const u16 *acts16 = static_cast<const u16 *>(acts);
+  int32_t *heavyT = nullptr;
+  if (max_degreeT <= 0 || max_degreeT > csr_heavy_degree()) {
+    heavyT = reinterpret_cast<int32_t *>(scratch + L.heavy);
+    if (int rc = launch_csr_heavy_list(rowptrT, n_vert, heavyT, s)) return rc;
+  }
+  // the stack's input in bf16 again (the scratch is shared between calls: the forward's copy may be gone)
+  u16 *f16 = reinterpret_cast<u16 *>(scratch + L.feats16);
+  if (int rc = launch_cvt_rows(feats, ld_feats, in_features, f16, L.ld0, (long long)m, s)) return rc;
+
+  // ---- output layer: dz3 = A^T dU, then one pass over X_{L-1}: G (bf16, ReLU-masked), dW, db partials
+  u16 *ping[2] = {reinterpret_cast<u16 *>(scratch + L.ping[0]), reinterpret_cast<u16 *>(scratch + L.ping[1])};
+  {
+    float *du4 = scratch + L.z3, *res = scratch + L.z3 + m * 4;
+    if (int rc = launch_pad3to4(grad_update, (long long)m, du4, s)) return rc;
+    if (int rc = launch_csr3(du4, nullptr, rowptrT, colT, valT, heavyT, n_vert, batch, res, 4, s)) return rc;
+    const u16 *x = acts16 + (size_t)(last - 1) * m * L.ldh;
+    if (int rc = launch_thin16_bwd_main(x, L.ldh, hidden, weights[last], res, grad_update, (long long)m, 1, ping[0], L.ldh,
+                                        scratch + L.thin_dw_slab, scratch + L.thin_db_slab, s))
+      return rc;
+    if (int rc = launch_slab_reduce(scratch + L.thin_dw_slab, thin_num_slabs(), (size_t)hidden * 3, (size_t)hidden * 3,
+                                    grad_weights[last], s))
+      return rc;
+    if (int rc = launch_slab_reduce(scratch + L.thin_db_slab, thin_num_slabs(), 3, 3, grad_biases[last], s)) return rc;
+  }
+  // bf16 images Bt = W_i (zero padded) for dX_i = dZ W_i^T
+  {
+    WeightImages wi{};
+    int max_rows = 0;
+    for (int i = 0; i < last; ++i) {
+      wi.w[i] = weights[i];
+      wi.k[i] = i == 0 ? in_features : hidden;
+      wi.rows[i] = rowgemm_bt_rows(i == 0 ? ld_feats : L.ldh);
+      wi.ld[i] = 2 * pad16(L.ldh / 2);
+      max_rows = wi.rows[i] > max_rows ? wi.rows[i] : max_rows;
+    }
+    wi.dst = scratch + L.wt;
+    wi.dst_stride = L.wt_stride;
+    wi.n = hidden;
+    wi.count = last;
+    wi.transpose = 0;
+    if (int rc = launch_weight_images16(wi, max_rows, 2 * pad16(L.ldh / 2), s)) return rc;
+  }
+  u16 *dza = reinterpret_cast<u16 *>(scratch + L.za);
+  const int cpad = L.cpad, ldza = cpad > 8 ? cpad : 8;
+  int cur = 0;
+  for (int i = last - 1; i >= 0; --i) {
+    u16 *g = ping[cur];
+    const u16 *x = i == 0 ? f16 : acts16 + (size_t)(i - 1) * m * L.ldh;
+    const int ldx = i == 0 ? L.ld0 : L.ldh;
+    const int kin = i == 0 ? in_features : hidden;
+    if (cut_len > 0) {
+      if (int rc = launch_csr16_bwd(g, L.ldh, cut_len, cpad, rowptrT, colT, valT, heavyT, n_vert, batch, dza, ldza,
+                                    scratch + L.db_slab, s))
+        return rc;
+      if (int rc = launch_slab_reduce_z(scratch + L.db_slab, csr_bwd_num_slabs(batch, n_vert), cpad, cut_len, hidden,
+                                        grad_biases[i], s))
+        return rc;
+    } else {
+      if (int rc = launch_fill_zero(grad_biases[i], hidden, s)) return rc;
+    }
+    // dW_i = X_i^T dZ in panels of <= 304 input channels (windows of the rows: no copies)
+    for (int c0 = 0; c0 < kin; c0 += 304) {
+      const int w = kin - c0 < 304 ? kin - c0 : 304;
+      Dw16Args d{};
+      d.x = x;
+      d.ldx = ldx;
+      d.xc0 = c0;
+      d.xw = pad8(w);
+      d.z0 = dza;
+      d.ldz0 = ldza;
+      d.z1 = g;
+      d.ldz1 = L.ldh;
+      d.zsplit = cut_len > 0 ? cpad : 0;
+      d.zeros = zeros;
+      d.slab = scratch + L.dw_slab;
+      d.m = (int)m;
+      d.k_in = w;
+      d.n_out = hidden;
+      {
+        ProfScope ps(PROF_DW, s);
+        if (int rc = launch_dw16(d, s)) return rc;
+      }
+      if (int rc = launch_slab_reduce(scratch + L.dw_slab, dw16_num_slabs(hidden), (size_t)w * hidden, (size_t)w * hidden,
+                                      grad_weights[i] + (size_t)c0 * hidden, s))
+        return rc;
+    }
+    // dX_i = dZ W_i^T
+    RowGemmArgs r{};
+    r.a0 = reinterpret_cast<const float *>(dza);
+    r.lda0 = ldza / 2;
+    r.a1 = reinterpret_cast<const float *>(g);
+    r.lda1 = L.ldh / 2;
+    r.ksplit = cut_len > 0 ? cpad / 2 : 0;
+    r.k = L.ldh / 2;
+    r.bt = scratch + L.wt + L.wt_stride * i;
+    r.ldb = pad16(L.ldh / 2);
+    r.zeros = zeros;
+    r.m = (int)m;
+    r.bf16 = 2;
+    if (i == 0) {
+      r.n_store = ld_feats;
+      r.c = grad_feats;
+      r.ldc = ld_feats;
+      if (int rc = launch_rowgemm(r, EPI_PLAIN, s)) return rc;
+    } else {
+      r.n_store = hidden;
+      r.c = reinterpret_cast<float *>(ping[cur ^ 1]);
+      r.ldc = L.ldh;
+      r.maskb = const_cast<uint8_t *>(masks) + (size_t)(i - 1) * mpad * mld;
+      r.mld = mld;
+      r.moff = cpad / 4;
+      r.csplit = cut_len;
+      {
+        ProfScope ps(PROF_GEMM_DX, s);
+        if (int rc = launch_rowgemm(r, EPI_DX_MASK, s)) return rc;
+      }
+      cur ^= 1;
+    }
+  }
+  return 0;
+}
+
 }  // namespace a3vt
 
 using namespace a3vt;
@@ -161,16 +440,43 @@ size_t a3vt_gcn_stack_scratch_bytes(int batch, int n_vert, int in_features, int 
   return stack_layout(batch, n_vert, in_features, hidden, num_layers, cut_len, need_backward).total * sizeof(float);
 }
 
+size_t a3vt_gcn_stack_scratch_bytes_mode(int batch, int n_vert, int in_features, int hidden, int num_layers,
+                                         int cut_len, int need_backward, int gemm_bf16) {
+  if (gemm_bf16 == 2)
+    return stack16_layout(batch, n_vert, in_features, hidden, num_layers, cut_len, need_backward).total * sizeof(float);
+  return a3vt_gcn_stack_scratch_bytes(batch, n_vert, in_features, hidden, num_layers, cut_len, need_backward);
+}
+
+int a3vt_gcn_stack_stash_bytes(int batch, int n_vert, int hidden, int num_layers, int cut_len, int gemm_bf16,
+                               size_t *acts_bytes, size_t *mask_bytes) {
+  A3VT_CHECK_ARG(acts_bytes && mask_bytes && batch > 0 && n_vert > 0);
+  *acts_bytes = *mask_bytes = 0;
+  if (num_layers < 2) return 0;
+  const size_t m = (size_t)batch * n_vert, mpad = (m + 31) / 32 * 32;
+  if (gemm_bf16 == 2) {
+    *acts_bytes = (size_t)(num_layers - 1) * m * pad8(hidden) * 2 + 256;   // + slack: 16-byte reads of the last row's tail
+    *mask_bytes = (size_t)(num_layers - 1) * mpad * mask_ld16(hidden, cut_len);
+  } else {
+    *acts_bytes = (size_t)(num_layers - 1) * m * hidden * sizeof(float);
+    *mask_bytes = a3vt_gcn_stack_mask_bytes(batch, n_vert, hidden, num_layers, cut_len);
+  }
+  return 0;
+}
+
 int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const float *const *weights,
                        const float *const *biases, int num_layers, int hidden, int cut_len,
                        const int32_t *rowptr, const int32_t *col, const float *val, int max_degree, int n_vert,
-                       int batch, int gemm_bf16, float *acts, uint8_t *masks, float *scratch, float *update,
+                       int batch, int gemm_bf16, void *acts_v, uint8_t *masks, float *scratch, float *update,
                        void *stream) {
+  float *acts = static_cast<float *>(acts_v);
   A3VT_CHECK_ARG(feats && weights && biases && rowptr && col && val && scratch && update);
   A3VT_CHECK_ARG((acts == nullptr) == (masks == nullptr) || num_layers < 2);
   A3VT_CHECK_ARG(n_vert > 0 && batch > 0);
   if (int rc = check_stack_dims(ld_feats, in_features, num_layers, hidden, cut_len)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (gemm_bf16 == 2)  // bf16 storage: `acts` holds bf16 rows (a3vt_gcn_stack_stash_bytes)
+    return stack_fwd16(feats, ld_feats, in_features, weights, biases, num_layers, hidden, cut_len, rowptr, col, val,
+                       max_degree, n_vert, batch, acts, masks, scratch, update, s);
   const float *zeros = zero_page();
   A3VT_CHECK_ARG(zeros != nullptr);
   const StackLayout L = stack_layout(batch, n_vert, in_features, hidden, num_layers, cut_len, 0);
@@ -251,9 +557,10 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
                        const float *const *biases, int num_layers, int hidden, int cut_len,
                        const int32_t *rowptr, const int32_t *col, const float *val, const int32_t *rowptrT,
                        const int32_t *colT, const float *valT, int max_degreeT, int n_vert, int batch, int gemm_bf16,
-                       const float *acts,
+                       const void *acts_v,
                        const uint8_t *masks, const float *grad_update, float *const *grad_weights, float *const *grad_biases,
                        float *grad_feats, float *scratch, void *stream) {
+  const float *acts = static_cast<const float *>(acts_v);
   (void)biases; (void)rowptr; (void)col; (void)val;
   A3VT_CHECK_ARG(feats && weights && rowptrT && colT && valT && grad_update && grad_weights && grad_biases);
   A3VT_CHECK_ARG(grad_feats && scratch && n_vert > 0 && batch > 0);
@@ -261,6 +568,10 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
   A3VT_CHECK_ARG(num_layers <= 2 || masks != nullptr);
   if (int rc = check_stack_dims(ld_feats, in_features, num_layers, hidden, cut_len)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (gemm_bf16 == 2)
+    return stack_bwd16(feats, ld_feats, in_features, weights, num_layers, hidden, cut_len, rowptrT, colT, valT,
+                       max_degreeT, n_vert, batch, acts, masks, grad_update, grad_weights, grad_biases, grad_feats,
+                       scratch, s);
   const float *zeros = zero_page();
   A3VT_CHECK_ARG(zeros != nullptr);
   const StackLayout L = stack_layout(batch, n_vert, in_features, hidden, num_layers, cut_len, 1);

@@ -1,0 +1,744 @@
+// gcn_bf16s.hip — the GCN stack's kernels for bf16 STORAGE (gemm mode 2, BASELINE configs[3]/[4]: "bf16 + MFMA feature
+// MLP"): activations, their gradients, the raw aggregated channels and the weight images are bf16 in HBM; every sum
+// (MFMA accumulators, neighbour aggregation, bias / weight gradients) is fp32; master weights, optimizer state, the
+// stack's input features and its 3-channel output stay fp32.  In fp32 the hidden-layer products are MFMA-bound
+// (AI = 75 flop/B); with bf16 operands the matrix pipe is 16x faster and the same products become HBM-bound
+//  — so what matters here is bytes: a launch moves 100 + 100 MB instead of 197 + 197 MB.
+//
+//   rowgemm (Z = X W, dX = dZ W^T)  : gcn_gemm.hip, MODE 2 of rowgemm_kernel (v_mfma_f32_16x16x32_bf16 on raw LDS rows)
+//   dw16_kernel (dW = X^T dZ)        : here — reduction over rows; the [row][channel] LDS images are consumed COLUMN-wise
+//                                     through ds_read_b64_tr_b16 (hardware transpose read), no register shuffles
+//   csr16_* / thin16_*              : here — the CSR gathers and the 3-channel output layer on bf16 rows (8 channels per
+//                                     16-byte lane access, 16-lane groups per vertex)
+#include <stdlib.h>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace a3vt {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using s16x4 = __attribute__((ext_vector_type(4))) short;
+using s16x8 = __attribute__((ext_vector_type(8))) short;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u16 = unsigned short;
+
+__device__ __forceinline__ unsigned pack2_bf16(float a, float b) {  // RNE, a in the low half
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2));
+}
+__device__ __forceinline__ u16 bf16_of(float v) { return (u16)(pack2_bf16(v, 0.f) & 0xffffu); }
+__device__ __forceinline__ float f32_of(u16 h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+// 8 bf16 (one 16-byte access) <-> 8 floats
+struct F8 {
+  f32x4 lo, hi;
+};
+__device__ __forceinline__ F8 unpack8(u32x4 r) {
+  F8 o;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    o.lo[2 * t] = __builtin_bit_cast(float, r[t] << 16);
+    o.lo[2 * t + 1] = __builtin_bit_cast(float, r[t] & 0xffff0000u);
+    o.hi[2 * t] = __builtin_bit_cast(float, r[2 + t] << 16);
+    o.hi[2 * t + 1] = __builtin_bit_cast(float, r[2 + t] & 0xffff0000u);
+  }
+  return o;
+}
+__device__ __forceinline__ u32x4 pack8(const F8 &v) {
+  return u32x4{pack2_bf16(v.lo[0], v.lo[1]), pack2_bf16(v.lo[2], v.lo[3]), pack2_bf16(v.hi[0], v.hi[1]),
+               pack2_bf16(v.hi[2], v.hi[3])};
+}
+__device__ __forceinline__ float f8_get(const F8 &v, int t) { return t < 4 ? v.lo[t] : v.hi[t - 4]; }
+
+__device__ __forceinline__ void glds16b(const void *gsrc, void *lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                   (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 rows -> bf16 rows, zero padded to ld_out (stack input features; ld_out % 8 == 0)
+// ------------------------------------------------------------------------------------------------
+__global__ void cvt_rows_kernel(const float *__restrict__ in, int ld_in, int n, u16 *__restrict__ out, int ld_out,
+                                long long m) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // one 8-column group per thread
+  const int g8 = ld_out >> 3;
+  if (i >= m * g8) return;
+  const long long r = i / g8;
+  const int c = (int)(i - r * g8) * 8;
+  F8 v;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const float x = c + t < n ? in[r * ld_in + c + t] : 0.f;
+    if (t < 4) v.lo[t] = x;
+    else v.hi[t - 4] = x;
+  }
+  *reinterpret_cast<u32x4 *>(out + r * ld_out + c) = pack8(v);
+}
+int launch_cvt_rows(const float *in, int ld_in, int n, void *out, int ld_out, long long m, hipStream_t s) {
+  const long long total = m * (ld_out >> 3);
+  A3VT_LAUNCH(cvt_rows_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, in, ld_in, n, static_cast<u16 *>(out),
+              ld_out, m);
+  A3VT_CHECK_LAUNCH();
+  return 0;
+}
+
+// bf16 weight images of up to kMaxImages layers in one launch (blockIdx.z = layer): dst_l [rows_l][ld_l] bf16 =
+// W_l^T (transpose = 1, W_l is [k_l][n]) or W_l (transpose = 0), zero padded.  dst_l = dst + l * dst_stride (floats).
+__global__ void weight_images16_kernel(WeightImages w) {
+  const int l = blockIdx.z;
+  const float *src = w.w[l];
+  u16 *dst = reinterpret_cast<u16 *>(w.dst + (size_t)l * w.dst_stride);
+  const int k = w.k[l], n = w.n, rows = w.rows[l], ld = w.ld[l];
+  const int tid = threadIdx.y * 32 + threadIdx.x;
+  const int nblk = gridDim.x * gridDim.y, blk = blockIdx.y * gridDim.x + blockIdx.x;
+  for (int idx = blk * 256 + tid; idx < rows * ld; idx += nblk * 256) {
+    const int r = idx / ld, c = idx % ld;
+    float v = 0.f;
+    if (w.transpose) {
+      if (c < k && r < n) v = src[(size_t)c * n + r];
+    } else {
+      if (r < k && c < n) v = src[(size_t)r * n + c];
+    }
+    dst[idx] = bf16_of(v);
+  }
+}
+int launch_weight_images16(const WeightImages &w, int max_rows, int max_ld, hipStream_t s) {
+  A3VT_LAUNCH(weight_images16_kernel, dim3(cdiv(max_ld, 32), cdiv(max_rows, 32), w.count), dim3(32, 8), 0, s, w);
+  A3VT_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dW = X^T dZ on bf16 rows.  Same decomposition as dw_kernel (gcn_gemm.hip): persistent 1024-thread workgroups, grid =
+// (row slabs, column groups); wave (wi, wo) owns input tiles i0.. (ni <= 5) x output tiles o0.. (no <= 3) of its column
+// group; a workgroup's partial [k_in][n_out] goes to its slab, slab_reduce sums the slabs in a fixed order.
+// A stage is 32 rows: the X window and this column group's dZa / G windows are DMA'd into compact [32][w] images.  The
+// MFMA sums over ROWS, so both operands are needed column-wise: lane 16 g + i of v_mfma_f32_16x16x32_bf16 holds
+// A[m = i][k = 8 g + j] = X[row 8 g + j][channel i] — eight rows of one channel.  ds_read_b64_tr_b16 delivers exactly
+// that from the row-major image: per 16-lane group a 4-row x 16-column block comes back column-major, so two reads (rows
+// 8 g .. 8 g + 3 and 8 g + 4 .. 8 g + 7) fill an operand.
+// ------------------------------------------------------------------------------------------------
+constexpr int DW16_MAXI = 5, DW16_MAXO = 3;
+
+__device__ __forceinline__ bf16x8 tr_operand(const u16 *lds_row0_col, int row_stride_elems) {
+  // address of (row 0 of the lane's block, the lane's 4-column quad); the second block sits 4 rows further
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(lds_row0_col));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4 *)(lds_row0_col + 4 * row_stride_elems));
+  return __builtin_bit_cast(bf16x8, (s16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]});
+}
+
+__global__ __launch_bounds__(1024, 1) void dw16_kernel(Dw16Args p) {
+  extern __shared__ __attribute__((aligned(16))) u16 lds16[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l16 = lane & 15, g = lane >> 4;      // MFMA k-group g: rows 8 g .. 8 g + 7 of the stage
+  const int bq = l16 >> 2, bp = l16 & 3;         // transposed-read address role: block row bq, column quad bp
+  const int wi = wave & 3, wo = wave >> 2;
+
+  const int tin = (p.k_in + 15) >> 4, tout = (p.n_out + 15) >> 4;
+  const int ni = tin / 4 + (wi < tin % 4 ? 1 : 0);
+  const int i0 = wi * (tin / 4) + (wi < tin % 4 ? wi : tin % 4);
+  const int gbase = tout / gridDim.y, grem = tout % gridDim.y;
+  const int gt0 = blockIdx.y * gbase + ((int)blockIdx.y < grem ? blockIdx.y : grem);
+  const int gtn = gbase + ((int)blockIdx.y < grem ? 1 : 0);
+  const int no = gtn / 4 + (wo < gtn % 4 ? 1 : 0);
+  const int o0 = gt0 + wo * (gtn / 4) + (wo < gtn % 4 ? wo : gtn % 4);
+
+  // column windows of this group in dZa (columns < zsplit) and G (columns >= zsplit), multiples of 8 elements
+  const int gcol0 = gt0 * 16, gcol1 = min((gt0 + gtn) * 16, p.ldz1);
+  const int a0 = min(gcol0, p.zsplit) & ~7, a1 = (min(gcol1, p.zsplit) + 7) & ~7;
+  const int g0 = max(gcol0, p.zsplit) & ~7, g1 = min((max(gcol1, p.zsplit) + 7) & ~7, p.ldz1);
+  const int wa = max(a1 - a0, 0), wg = max(g1 - g0, 0), wx = p.xw;
+
+  // 32-row images: elements, DMA wave-instructions (1 KiB = 512 elements each), LDS element offsets
+  const int xin = (32 * wx + 511) >> 9, ain = (32 * wa + 511) >> 9, gin = (32 * wg + 511) >> 9;
+  const int offA = xin * 512, offG = offA + ain * 512, offD = offG + gin * 512;
+  const int stage = offD + 512;  // + one dummy 1 KiB slot for idle DMA slots
+
+  const int units = (p.m + 31) >> 5;
+  const int ubase = units / gridDim.x, urem = units % gridDim.x;
+  const int u0 = blockIdx.x * ubase + ((int)blockIdx.x < urem ? blockIdx.x : urem);
+  const int nu = ubase + ((int)blockIdx.x < urem ? 1 : 0);
+
+  // DMA slots: s = wave * 2 + j
+  const u16 *sp[2];
+  long long sstep[2];
+  int sdst[2], srow[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int s = wave * 2 + j;
+    const u16 *img = nullptr;
+    int ld = 0, w = 8, c0 = 0, li = 0;
+    sdst[j] = offD;
+    if (s < xin) {
+      img = p.x; ld = p.ldx; w = wx; c0 = p.xc0; li = s; sdst[j] = li * 512;
+    } else if (s < xin + ain) {
+      img = p.z0; ld = p.ldz0; w = wa; c0 = a0; li = s - xin; sdst[j] = offA + li * 512;
+    } else if (s < xin + ain + gin) {
+      img = p.z1; ld = p.ldz1; w = wg; c0 = g0; li = s - xin - ain; sdst[j] = offG + li * 512;
+    }
+    const int w8 = w >> 3, f8 = li * 64 + lane;
+    const int row = f8 / w8, c8 = f8 - row * w8;
+    const bool valid = img != nullptr && row < 32;
+    sp[j] = valid ? img + ((size_t)u0 * 32 + row) * ld + c0 + c8 * 8 : reinterpret_cast<const u16 *>(p.zeros);
+    sstep[j] = valid ? 32ll * ld : 0;
+    srow[j] = valid ? row : 0x7fffffff;
+  }
+  auto issue = [&](int unit, int buf) {
+    u16 *base = lds16 + buf * stage;
+    const int rows_left = p.m - unit * 32;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      glds16b(srow[j] < rows_left || rows_left >= 32 ? (const void *)sp[j] : (const void *)p.zeros, base + sdst[j]);
+      sp[j] += sstep[j];
+    }
+  };
+
+  f32x4 acc[DW16_MAXI][DW16_MAXO];
+#pragma unroll
+  for (int i = 0; i < DW16_MAXI; ++i)
+#pragma unroll
+    for (int j = 0; j < DW16_MAXO; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // per-lane element offsets (inside a stage) of the transposed reads: block row (8 g + bq), column quad 4 bp of the tile
+  int xoff[DW16_MAXI], zoff[DW16_MAXO], zld[DW16_MAXO];
+#pragma unroll
+  for (int i = 0; i < DW16_MAXI; ++i) {
+    const int ch = min((i0 + i) * 16 + 4 * bp, wx - 4);  // tiles past ni are clamped (read, never used)
+    xoff[i] = (8 * g + bq) * wx + ch;
+  }
+#pragma unroll
+  for (int j = 0; j < DW16_MAXO; ++j) {
+    const int col = (o0 + j) * 16 + 4 * bp;
+    const bool in_a = col < p.zsplit;
+    const int w = in_a ? wa : wg;
+    const int c = in_a ? min(col - a0, max(wa - 4, 0)) : min(max(col - g0, 0), max(wg - 4, 0));
+    zld[j] = w;
+    zoff[j] = (in_a ? offA : offG) + (8 * g + bq) * w + c;
+  }
+
+  const int nst = p.nstage;
+  for (int d = 0; d < nst - 1; ++d)
+    if (d < nu) issue(u0 + d, d);
+  int buf = 0;
+  for (int t = 0; t < nu; ++t) {
+    const int younger = min(nu - 1 - t, nst - 2);
+    if (younger >= 3) wait_vm<6>();
+    else if (younger == 2) wait_vm<4>();
+    else if (younger == 1) wait_vm<2>();
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    if (t + nst - 1 < nu) issue(u0 + t + nst - 1, buf >= 1 ? buf - 1 : nst - 1);
+    const u16 *sb = lds16 + buf * stage;
+    bf16x8 a[DW16_MAXI], b[DW16_MAXO];
+    // every lane issues every read (the transposed read needs EXEC all ones); unused tiles are clamped in-bounds
+#pragma unroll
+    for (int i = 0; i < DW16_MAXI; ++i) a[i] = tr_operand(sb + xoff[i], wx);
+#pragma unroll
+    for (int j = 0; j < DW16_MAXO; ++j) b[j] = tr_operand(sb + zoff[j], zld[j]);
+#pragma unroll
+    for (int i = 0; i < DW16_MAXI; ++i) {
+      if (i >= ni) continue;  // wave-uniform
+#pragma unroll
+      for (int j = 0; j < DW16_MAXO; ++j)
+        if (j < no) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    buf = buf == nst - 1 ? 0 : buf + 1;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  // C/D layout: lane holds column (lane & 15) of rows 4 g .. 4 g + 3 of the tile (row = input channel)
+  float *slab = p.slab + (size_t)blockIdx.x * p.k_in * p.n_out;
+#pragma unroll
+  for (int i = 0; i < DW16_MAXI; ++i) {
+    if (i >= ni) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int kin = (i0 + i) * 16 + g * 4 + r;
+      if (kin >= p.k_in) continue;
+#pragma unroll
+      for (int j = 0; j < DW16_MAXO; ++j) {
+        if (j >= no) continue;
+        const int col = (o0 + j) * 16 + l16;
+        if (col < p.n_out) slab[(size_t)kin * p.n_out + col] = acc[i][j][r];
+      }
+    }
+  }
+}
+
+static int dw16_col_groups(int n_out) { return cdiv(cdiv(n_out, 16), 4 * DW16_MAXO); }
+int dw16_num_slabs(int n_out) {
+  const int g = dw16_col_groups(n_out);
+  return 256 / g > 0 ? 256 / g : 1;
+}
+
+int launch_dw16(const Dw16Args &a, hipStream_t s) {
+  if (a.ldx % 8 || a.ldz0 % 8 || a.ldz1 % 8 || a.xw % 8 || a.xc0 % 8 || a.zsplit % 8 || a.xw > DW16_MAXI * 64 ||
+      a.k_in > a.xw || a.xc0 + a.xw > a.ldx || a.n_out > a.ldz1 || a.zsplit > a.ldz0) {
+    set_error("dw16: unsupported dims k_in=%d xw=%d n_out=%d ldx=%d ldz0=%d ldz1=%d zsplit=%d", a.k_in, a.xw, a.n_out,
+              a.ldx, a.ldz0, a.ldz1, a.zsplit);
+    return -1;
+  }
+  const int tout_all = cdiv(a.n_out, 16), ngrp = dw16_col_groups(a.n_out);
+  const int xin = cdiv(32 * a.xw, 512);
+  int worst = 0;
+  for (int gy = 0; gy < ngrp; ++gy) {
+    const int gbase = tout_all / ngrp, grem = tout_all % ngrp;
+    const int gt0 = gy * gbase + (gy < grem ? gy : grem), gtn = gbase + (gy < grem ? 1 : 0);
+    const int c0 = gt0 * 16, c1 = (gt0 + gtn) * 16 < a.ldz1 ? (gt0 + gtn) * 16 : a.ldz1;
+    const int a0 = (c0 < a.zsplit ? c0 : a.zsplit) & ~7, a1 = ((c1 < a.zsplit ? c1 : a.zsplit) + 7) & ~7;
+    const int g0 = (c0 > a.zsplit ? c0 : a.zsplit) & ~7;
+    int g1 = ((c1 > a.zsplit ? c1 : a.zsplit) + 7) & ~7;
+    g1 = g1 < a.ldz1 ? g1 : a.ldz1;
+    const int wa = a1 > a0 ? a1 - a0 : 0, wg = g1 > g0 ? g1 - g0 : 0;
+    const int slots = xin + cdiv(32 * wa, 512) + cdiv(32 * wg, 512);
+    if (slots > 32) {
+      set_error("dw16: rows too wide (%d DMA slots per stage, 32 available)", slots);
+      return -1;
+    }
+    worst = slots + 1 > worst ? slots + 1 : worst;
+  }
+  Dw16Args args = a;
+  args.nstage = (int)((160 * 1024) / ((size_t)worst * 1024));
+  args.nstage = args.nstage > 5 ? 5 : args.nstage;
+  if (args.nstage < 3) {
+    set_error("dw16: rows too wide for a 3-stage ring (%d KB per stage)", worst);
+    return -1;
+  }
+  const size_t shmem = (size_t)args.nstage * worst * 1024;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)dw16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  A3VT_LAUNCH(dw16_kernel, dim3(dw16_num_slabs(a.n_out), ngrp), dim3(1024), shmem, s, args);
+  A3VT_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// CSR neighbour aggregation on bf16 rows.  A 16-lane group owns one vertex; lane l handles channels 8 l .. 8 l + 7 (one
+// 16-byte load of the neighbour row), so up to 128 aggregated channels per pass; sums in fp32.  Work mapping as the
+// fp32 kernels (gcn_csr.hip): mesh b is processed by the workgroups of XCD group b % 8.
+// ------------------------------------------------------------------------------------------------
+struct XcdWalk16 {
+  int xcd, nloc, stride, gps, nmesh;
+  long long ngroups;
+  __device__ XcdWalk16(int batch, int n_vert) {
+    xcd = blockIdx.x & 7;
+    nloc = blockIdx.x >> 3;
+    stride = (gridDim.x + 7 - xcd) >> 3;
+    gps = (n_vert + 15) >> 4;  // 16 vertices per workgroup pass
+    nmesh = batch > xcd ? (batch - xcd + 7) >> 3 : 0;
+    ngroups = (long long)nmesh * gps;
+  }
+  __device__ bool locate(long long g, int sub, int n_vert, long long &b, int &v) const {
+    b = xcd + 8 * (g / gps);
+    v = (int)(g % gps) * 16 + sub;
+    return v < n_vert;
+  }
+};
+
+// weighted sum of neighbour rows for one vertex by a 16-lane group; (col, val) fetched 16 at a time and handed around
+__device__ __forceinline__ F8 gather_row16(const u16 *__restrict__ base, long long ld, int ch, bool lane_on, int e0,
+                                           int e1, int hl, const int32_t *__restrict__ colidx,
+                                           const float *__restrict__ val) {
+  F8 acc;
+  acc.lo = acc.hi = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int eb = e0; eb < e1; eb += 16) {
+    const int n = min(16, e1 - eb);
+    const int myc = hl < n ? colidx[eb + hl] : 0;
+    const float myw = hl < n ? val[eb + hl] : 0.f;
+    int j = 0;
+    for (; j + 3 < n; j += 4) {
+      int c[4];
+      float w[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        c[t] = __shfl(myc, j + t, 16);
+        w[t] = __shfl(myw, j + t, 16);
+      }
+      if (lane_on) {
+        u32x4 r[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) r[t] = *reinterpret_cast<const u32x4 *>(base + c[t] * ld + ch);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const F8 v = unpack8(r[t]);
+          acc.lo += w[t] * v.lo;
+          acc.hi += w[t] * v.hi;
+        }
+      }
+    }
+    for (; j < n; ++j) {
+      const int c0 = __shfl(myc, j, 16);
+      const float w0 = __shfl(myw, j, 16);
+      if (lane_on) {
+        const F8 v = unpack8(*reinterpret_cast<const u32x4 *>(base + c0 * ld + ch));
+        acc.lo += w0 * v.lo;
+        acc.hi += w0 * v.hi;
+      }
+    }
+  }
+  return acc;
+}
+
+// forward epilogue of one vertex's 8-channel group: bias, ReLU, sign bytes, bf16 store of the channels < c
+__device__ __forceinline__ void csr16_fwd_store(const F8 &acc, int ch, int c, const float *__restrict__ bias, int relu,
+                                                u16 *__restrict__ yo, uint8_t *__restrict__ mrow) {
+  F8 o;
+  unsigned bits = 0;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const float pre = ch + t < c ? f8_get(acc, t) + bias[ch + t] : 0.f;
+    const float out = (pre > 0.f || !relu) ? pre : 0.f;
+    bits |= (pre > 0.f ? 1u : 0u) << t;
+    if (t < 4) o.lo[t] = out;
+    else o.hi[t - 4] = out;
+  }
+  if (ch + 7 < c) {
+    *reinterpret_cast<u32x4 *>(yo) = pack8(o);
+  } else {
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+      if (ch + t < c) yo[t] = bf16_of(f8_get(o, t));
+  }
+  if (mrow) {
+    mrow[ch >> 2] = (uint8_t)(bits & 15u);
+    mrow[(ch >> 2) + 1] = (uint8_t)(bits >> 4);
+  }
+}
+
+__global__ __launch_bounds__(256) void csr16_fwd_kernel(const u16 *__restrict__ za, int ldza,
+                                                        const float *__restrict__ bias, int c,
+                                                        const int32_t *__restrict__ rowptr,
+                                                        const int32_t *__restrict__ colidx,
+                                                        const float *__restrict__ val, int n_vert, int batch,
+                                                        u16 *__restrict__ y, int ldy, uint8_t *__restrict__ maskb,
+                                                        int mld, int relu, int heavy_thresh) {
+  const int hl = threadIdx.x & 15, sub = threadIdx.x >> 4;
+  const XcdWalk16 w(batch, n_vert);
+  for (long long g = w.nloc; g < w.ngroups; g += w.stride) {
+    long long b;
+    int v;
+    if (!w.locate(g, sub, n_vert, b, v)) continue;  // uniform per 16-lane group
+    const long long row = b * n_vert + v;
+    const u16 *zb = za + b * n_vert * (long long)ldza;
+    const int e0 = rowptr[v], e1 = rowptr[v + 1];
+    if (e1 - e0 > heavy_thresh) continue;
+    for (int ch0 = 0; ch0 < c; ch0 += 128) {
+      const int ch = ch0 + hl * 8;
+      const bool on = ch < c;
+      const F8 acc = gather_row16(zb, ldza, ch, on, e0, e1, hl, colidx, val);
+      if (on) csr16_fwd_store(acc, ch, c, bias, relu, y + row * ldy + ch, maskb ? maskb + row * mld : nullptr);
+    }
+  }
+}
+
+// Hub rows (see gcn_csr.hip): one workgroup per (mesh, row); its 16 lane groups take a sixteenth of the edge list each.
+template <int MODE>  // 0 forward epilogue, 1 backward (A^T gather, channels [c, cpad) pass the own gradient through)
+__global__ __launch_bounds__(256) void csr16_heavy_kernel(const u16 *__restrict__ src, int ld_src,
+                                                          const float *__restrict__ bias, int c, int cpad,
+                                                          const int32_t *__restrict__ rowptr,
+                                                          const int32_t *__restrict__ colidx,
+                                                          const float *__restrict__ val, int n_vert, int batch,
+                                                          const int32_t *__restrict__ heavy, u16 *__restrict__ dst,
+                                                          int ld_dst, uint8_t *__restrict__ maskb, int mld, int relu) {
+  __shared__ F8 red[16][16];
+  const int hl = threadIdx.x & 15, sub = threadIdx.x >> 4;
+  const int count = heavy[0];
+  const int width = MODE == 0 ? c : cpad;
+  for (long long item = blockIdx.x; item < (long long)count * batch; item += gridDim.x) {
+    const int v = heavy[64 + (int)(item % count)];
+    const long long b = item / count, row = b * n_vert + v;
+    const u16 *sb = src + b * n_vert * (long long)ld_src;
+    const int e0 = rowptr[v], e1 = rowptr[v + 1];
+    const int per = ((e1 - e0 + 15) / 16 + 3) & ~3;
+    const int s0 = min(e1, e0 + sub * per), s1 = min(e1, s0 + per);
+    for (int ch0 = 0; ch0 < width; ch0 += 128) {
+      const int ch = ch0 + hl * 8;
+      const bool on = ch < width;
+      red[sub][hl] = gather_row16(sb, ld_src, ch, on, s0, s1, hl, colidx, val);
+      __syncthreads();
+      if (sub == 0 && on) {
+        F8 acc = red[0][hl];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) {
+          acc.lo += red[r][hl].lo;
+          acc.hi += red[r][hl].hi;
+        }
+        u16 *o = dst + row * ld_dst + ch;
+        if (MODE == 0) {
+          csr16_fwd_store(acc, ch, c, bias, relu, o, maskb ? maskb + row * mld : nullptr);
+        } else {
+          const F8 own = unpack8(*reinterpret_cast<const u32x4 *>(sb + (long long)v * ld_src + ch));
+          F8 out;
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            const float x = ch + t < c ? f8_get(acc, t) : f8_get(own, t);
+            if (t < 4) out.lo[t] = x;
+            else out.hi[t - 4] = x;
+          }
+          *reinterpret_cast<u32x4 *>(o) = pack8(out);
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+int launch_csr16_fwd(const void *za, int ldza, const float *bias, int c, const int32_t *rowptr, const int32_t *col,
+                     const float *val, const int32_t *heavy, int n_vert, int batch, void *y, int ldy, uint8_t *maskb,
+                     int mld, int relu, hipStream_t s) {
+  if (ldza % 8 != 0 || ldza < ((c + 7) & ~7)) {
+    set_error("csr16_fwd: ldza=%d must be a multiple of 8 and >= pad8(c=%d)", ldza, c);
+    return -1;
+  }
+  const long long m = (long long)batch * n_vert;
+  const int grid = (int)(cdiv(m, 16) < 4096 ? (cdiv(m, 16) + 7) / 8 * 8 : 4096);
+  A3VT_LAUNCH(csr16_fwd_kernel, dim3(grid), dim3(256), 0, s, static_cast<const u16 *>(za), ldza, bias, c, rowptr, col, val,
+              n_vert, batch, static_cast<u16 *>(y), ldy, maskb, mld, relu, heavy ? csr_heavy_degree() : 0x7fffffff);
+  A3VT_CHECK_LAUNCH();
+  if (heavy) {
+    A3VT_LAUNCH(csr16_heavy_kernel<0>, dim3(2048), dim3(256), 0, s, static_cast<const u16 *>(za), ldza, bias, c,
+                (c + 7) & ~7, rowptr, col, val, n_vert, batch, heavy, static_cast<u16 *>(y), ldy, maskb, mld, relu);
+    A3VT_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+// Backward: dZa[m][ch] = sum_e valT[e] G[b][colT[e]][ch] (ch < c), = G[m][ch] (c <= ch < cpad); bias-gradient partials.
+__global__ __launch_bounds__(256) void csr16_bwd_kernel(const u16 *__restrict__ g, int ldg, int c, int cpad,
+                                                        const int32_t *__restrict__ rowptr,
+                                                        const int32_t *__restrict__ colidx,
+                                                        const float *__restrict__ val, int n_vert, int batch,
+                                                        u16 *__restrict__ dza, int lddza,
+                                                        float *__restrict__ db_slab, int heavy_thresh) {
+  __shared__ float red[16][128];
+  const int hl = threadIdx.x & 15, sub = threadIdx.x >> 4;
+  for (int ch0 = 0; ch0 < cpad; ch0 += 128) {
+    const int ch = ch0 + hl * 8;
+    const bool on = ch < cpad;
+    F8 bsum;
+    bsum.lo = bsum.hi = f32x4{0.f, 0.f, 0.f, 0.f};
+    const XcdWalk16 w(batch, n_vert);
+    for (long long gi = w.nloc; gi < w.ngroups; gi += w.stride) {
+      long long b;
+      int v;
+      if (!w.locate(gi, sub, n_vert, b, v)) continue;
+      const long long row = b * n_vert + v;
+      const u16 *gb = g + b * n_vert * (long long)ldg;
+      F8 own;
+      own.lo = own.hi = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (on) own = unpack8(*reinterpret_cast<const u32x4 *>(gb + (long long)v * ldg + ch));
+      bsum.lo += own.lo;
+      bsum.hi += own.hi;
+      const int e0 = rowptr[v], e1 = rowptr[v + 1];
+      if (e1 - e0 > heavy_thresh) continue;
+      const F8 acc = gather_row16(gb, ldg, ch, on, e0, e1, hl, colidx, val);
+      if (on) {
+        F8 out;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const float x = ch + t < c ? f8_get(acc, t) : f8_get(own, t);
+          if (t < 4) out.lo[t] = x;
+          else out.hi[t - 4] = x;
+        }
+        *reinterpret_cast<u32x4 *>(dza + row * lddza + ch) = pack8(out);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) red[sub][hl * 8 + t] = f8_get(bsum, t);
+    __syncthreads();
+    if (threadIdx.x < 128 && ch0 + threadIdx.x < cpad) {
+      float sm = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sm += red[r][threadIdx.x];
+      db_slab[(size_t)blockIdx.x * cpad + ch0 + threadIdx.x] = sm;
+    }
+    __syncthreads();
+  }
+}
+
+int launch_csr16_bwd(const void *g, int ldg, int c, int cpad, const int32_t *rowptrT, const int32_t *colT,
+                     const float *valT, const int32_t *heavyT, int n_vert, int batch, void *dza, int lddza,
+                     float *db_slab, hipStream_t s) {
+  if (ldg % 8 != 0 || lddza % 8 != 0 || cpad % 8 != 0 || lddza < cpad || ldg < cpad) {
+    set_error("csr16_bwd: ldg=%d lddza=%d cpad=%d violate alignment rules", ldg, lddza, cpad);
+    return -1;
+  }
+  A3VT_LAUNCH(csr16_bwd_kernel, dim3(csr_bwd_num_slabs(batch, n_vert)), dim3(256), 0, s, static_cast<const u16 *>(g), ldg,
+              c, cpad, rowptrT, colT, valT, n_vert, batch, static_cast<u16 *>(dza), lddza, db_slab,
+              heavyT ? csr_heavy_degree() : 0x7fffffff);
+  A3VT_CHECK_LAUNCH();
+  if (heavyT) {
+    A3VT_LAUNCH(csr16_heavy_kernel<1>, dim3(2048), dim3(256), 0, s, static_cast<const u16 *>(g), ldg, nullptr, c, cpad,
+                rowptrT, colT, valT, n_vert, batch, heavyT, static_cast<u16 *>(dza), lddza, nullptr, 0, 0);
+    A3VT_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Output layer (3 channels) on bf16 rows: z3 = X W (16 lanes per row, 3 x 8-channel pieces per lane: k <= 384), then
+// the fp32 3-channel aggregation of gcn_csr.hip; backward fuses G_prev (bf16, ReLU-masked by X > 0), dW and db partials.
+// ------------------------------------------------------------------------------------------------
+constexpr int kThin16Pieces = 3;
+
+__global__ __launch_bounds__(256) void thin16_fwd_kernel(const u16 *__restrict__ x, int ldx, int k,
+                                                         const float *__restrict__ w, long long m,
+                                                         float *__restrict__ z3) {
+  const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  float wr[kThin16Pieces][8][3];
+#pragma unroll
+  for (int p = 0; p < kThin16Pieces; ++p)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int kk = (p * 16 + l16) * 8 + t;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) wr[p][t][j] = kk < k ? w[kk * 3 + j] : 0.f;
+    }
+  for (long long row = (long long)blockIdx.x * 16 + grp; row < m; row += (long long)gridDim.x * 16) {
+    const u16 *xr = x + row * ldx;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int p = 0; p < kThin16Pieces; ++p) {
+      const int kk = (p * 16 + l16) * 8;
+      if (kk < k) {
+        const F8 xv = unpack8(*reinterpret_cast<const u32x4 *>(xr + kk));
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const float xe = f8_get(xv, t);
+          s0 += xe * wr[p][t][0];
+          s1 += xe * wr[p][t][1];
+          s2 += xe * wr[p][t][2];
+        }
+      }
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+      s0 += __shfl_xor(s0, off, 16);
+      s1 += __shfl_xor(s1, off, 16);
+      s2 += __shfl_xor(s2, off, 16);
+    }
+    if (l16 == 0) *reinterpret_cast<f32x4 *>(z3 + row * 4) = f32x4{s0, s1, s2, 0.f};
+  }
+}
+
+int launch_thin16_fwd_product(const void *x, int ldx, int k, const float *w, long long m, float *z3, hipStream_t s) {
+  if (k > kThin16Pieces * 128 || ldx % 8 != 0) {
+    set_error("thin16_fwd: k=%d (max %d) ldx=%d unsupported", k, kThin16Pieces * 128, ldx);
+    return -1;
+  }
+  const int grid = (int)(cdiv(m, 16) < 1280 ? cdiv(m, 16) : 1280);
+  A3VT_LAUNCH(thin16_fwd_kernel, dim3(grid), dim3(256), 0, s, static_cast<const u16 *>(x), ldx, k, w, m, z3);
+  A3VT_CHECK_LAUNCH();
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void thin16_bwd_kernel(const u16 *__restrict__ x, int ldx, int k,
+                                                         const float *__restrict__ w,
+                                                         const float *__restrict__ dz3,
+                                                         const float *__restrict__ du, long long m, int apply_mask,
+                                                         u16 *__restrict__ gprev, int ldg,
+                                                         float *__restrict__ dw_slab, float *__restrict__ db_slab) {
+  __shared__ float red[16][kThin16Pieces * 24 + 1];
+  const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  float wr[kThin16Pieces][8][3], dwp[kThin16Pieces][8][3];
+#pragma unroll
+  for (int p = 0; p < kThin16Pieces; ++p)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int kk = (p * 16 + l16) * 8 + t;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        wr[p][t][j] = kk < k ? w[kk * 3 + j] : 0.f;
+        dwp[p][t][j] = 0.f;
+      }
+    }
+  float db0 = 0.f, db1 = 0.f, db2 = 0.f;
+  for (long long row = (long long)blockIdx.x * 16 + grp; row < m; row += (long long)gridDim.x * 16) {
+    const f32x4 d = *reinterpret_cast<const f32x4 *>(dz3 + row * 4);
+    if (l16 == 0) {
+      db0 += du[row * 3 + 0];
+      db1 += du[row * 3 + 1];
+      db2 += du[row * 3 + 2];
+    }
+    const u16 *xr = x + row * ldx;
+    u16 *gr = gprev + row * ldg;
+#pragma unroll
+    for (int p = 0; p < kThin16Pieces; ++p) {
+      const int kk = (p * 16 + l16) * 8;
+      if (kk < ldg) {  // pad columns [k, ldg) are written as zeros (wr = 0 there)
+        const F8 xv = unpack8(*reinterpret_cast<const u32x4 *>(xr + kk));
+        F8 o;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const float xe = f8_get(xv, t);
+          const float gk = d[0] * wr[p][t][0] + d[1] * wr[p][t][1] + d[2] * wr[p][t][2];
+          const float ov = (!apply_mask || xe > 0.f) ? gk : 0.f;
+          if (t < 4) o.lo[t] = ov;
+          else o.hi[t - 4] = ov;
+          dwp[p][t][0] += xe * d[0];
+          dwp[p][t][1] += xe * d[1];
+          dwp[p][t][2] += xe * d[2];
+        }
+        *reinterpret_cast<u32x4 *>(gr + kk) = pack8(o);
+      }
+    }
+  }
+  float *slab = dw_slab + (size_t)blockIdx.x * k * 3;
+  for (int col = 0; col < 16; ++col) {
+    if (l16 == col) {
+#pragma unroll
+      for (int p = 0; p < kThin16Pieces; ++p)
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) red[grp][(p * 8 + t) * 3 + j] = dwp[p][t][j];
+    }
+    __syncthreads();
+    if (threadIdx.x < kThin16Pieces * 24) {
+      float sm = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sm += red[r][threadIdx.x];
+      const int p = threadIdx.x / 24, t = (threadIdx.x % 24) / 3, j = threadIdx.x % 3;
+      const int kk = (p * 16 + col) * 8 + t;
+      if (kk < k) slab[kk * 3 + j] = sm;
+    }
+    __syncthreads();
+  }
+  if (l16 == 0) {
+    red[grp][0] = db0;
+    red[grp][1] = db1;
+    red[grp][2] = db2;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float sm = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sm += red[r][threadIdx.x];
+    db_slab[(size_t)blockIdx.x * 3 + threadIdx.x] = sm;
+  }
+}
+
+int launch_thin16_bwd_main(const void *x, int ldx, int k, const float *w, const float *dz3, const float *du, long long m,
+                           int apply_mask, void *gprev, int ldg, float *dw_slab, float *db_slab, hipStream_t s) {
+  if (k > kThin16Pieces * 128 || ldx % 8 != 0 || ldg % 8 != 0 || ldg > kThin16Pieces * 128 || ldg > ldx) {
+    set_error("thin16_bwd: k=%d ldx=%d ldg=%d unsupported", k, ldx, ldg);
+    return -1;
+  }
+  A3VT_LAUNCH(thin16_bwd_kernel, dim3(thin_num_slabs()), dim3(256), 0, s, static_cast<const u16 *>(x), ldx, k, w, dz3, du,
+              m, apply_mask, static_cast<u16 *>(gprev), ldg, dw_slab, db_slab);
+  A3VT_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace a3vt

@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void csr3_heavy_kernel(const float *__restrict
   }
 }
 
-static int launch_csr3(const float *z, const float *bias, const int32_t *rowptr, const int32_t *col, const float *val,
+int launch_csr3(const float *z, const float *bias, const int32_t *rowptr, const int32_t *col, const float *val,
                        const int32_t *heavy, int n_vert, int batch, float *out, int ldo, hipStream_t s) {
   const long long m = (long long)batch * n_vert;
   A3VT_LAUNCH(csr3_kernel, dim3(cdiv(m, 256)), dim3(256), 0, s, z, bias, rowptr, col, val, n_vert, m, out, ldo,
@@ -556,7 +556,7 @@ __global__ void pad3to4_kernel(const float *__restrict__ in, long long m, float 
   if (i >= m) return;
   *reinterpret_cast<f32x4 *>(out + i * 4) = f32x4{in[i * 3], in[i * 3 + 1], in[i * 3 + 2], 0.f};
 }
-static int launch_pad3to4(const float *in, long long m, float *out, hipStream_t s) {
+int launch_pad3to4(const float *in, long long m, float *out, hipStream_t s) {
   A3VT_LAUNCH(pad3to4_kernel, dim3(cdiv(m, 256)), dim3(256), 0, s, in, m, out);
   A3VT_CHECK_LAUNCH();
   return 0;

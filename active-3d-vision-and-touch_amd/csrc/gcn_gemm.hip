@@ -40,6 +40,27 @@ __device__ __forceinline__ s16x4 cvt_bf16x4(f32x4 v) {
   return __builtin_bit_cast(s16x4, r);
 }
 
+// bf16 STORAGE mode (gemm mode 2, "bf16s"): activations, gradients and the weight images are stored as bf16; a staged
+// 64-byte chunk row then holds 32 k values instead of 16 and a lane's ds_read_b128 (8 consecutive bf16 of its row) IS
+// the A / B operand of v_mfma_f32_16x16x32_bf16 — no conversion, one MFMA per (m-tile, n-tile) and chunk, half the chunks.
+// All pointers / strides of RowGemmArgs stay in 4-byte units on the operand side (a row of 304 bf16 = 152 "floats"); the
+// outputs of the hidden-layer epilogues are bf16 with their leading dimension in elements.  fp32 accumulation throughout.
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u16 = unsigned short;
+__device__ __forceinline__ f32x4 mfma_bf16s(f32x4 a, f32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ u16 to_bf16(float v) {  // round to nearest even (v_cvt_pk_bf16_f32)
+  const bf16x2 r = __builtin_convertvector((f32x2){v, 0.f}, bf16x2);
+  return (u16)(__builtin_bit_cast(unsigned, r) & 0xffffu);
+}
+__device__ __forceinline__ f32x4 pack_bf16x8(f32x4 lo, f32x4 hi) {  // 8 floats -> 8 bf16 in one 16-byte register group
+  const s16x4 a = cvt_bf16x4(lo), b = cvt_bf16x4(hi);
+  const u32x2 ua = __builtin_bit_cast(u32x2, a), ub = __builtin_bit_cast(u32x2, b);
+  using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+  return __builtin_bit_cast(f32x4, (u32x4){ua[0], ua[1], ub[0], ub[1]});
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -50,7 +71,7 @@ __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0
 // memory into registers: all loads of up to 19 K-chunks in flight at once, no LDS, no barrier, then the MFMA chain (one
 // round trip instead of nineteen).  Same arithmetic order along K as rowgemm_kernel.  Used for the handful of rows the
 // load-balanced split leaves over (launch_rowgemm_epi): by rowtile_kernel, and by the tail of rowgemm_kernel itself.
-template <int EPI, bool BF16>
+template <int EPI, int MODE>
 __device__ __forceinline__ void rowtile_unit(const RowGemmArgs &p, int row_base, int row_end, int mt, int n0, int lane) {
   constexpr int KB = 19;  // K-chunks (of 16) per register block: all of K = 300 in one round trip
   const int l16 = lane & 15, q = lane >> 4;
@@ -71,7 +92,9 @@ __device__ __forceinline__ void rowtile_unit(const RowGemmArgs &p, int row_base,
     }
 #pragma unroll
     for (int c = 0; c < KB; ++c) {
-      if (BF16) {
+      if (MODE == 2) {
+        acc = mfma_bf16s(af[c], bf[c], acc);
+      } else if (MODE == 1) {
         acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(cvt_bf16x4(af[c]), cvt_bf16x4(bf[c]), acc, 0, 0, 0);
       } else {
 #pragma unroll
@@ -97,12 +120,22 @@ __device__ __forceinline__ void rowtile_unit(const RowGemmArgs &p, int row_base,
       bits |= __shfl_xor(bits, 2, 64);
       if (row_ok && p.maskb && (l16 & 3) == 0 && (col | 3) >= p.csplit && col < ((p.n_store + 3) & ~3))
         p.maskb[(size_t)row * p.mld + p.moff + (col >> 2)] = (uint8_t)bits;
-      if (row_ok && col_ok) {
+      if (MODE == 2) {  // bf16 rows; the pad columns [n_store, ldc) are written too (exact zeros: Bt rows there are zero)
+        if (row_ok && col < p.ldc) {
+          if (col < p.csplit) reinterpret_cast<u16 *>(p.c2)[(size_t)row * p.ldc2 + col] = to_bf16(v);
+          else reinterpret_cast<u16 *>(p.c)[(size_t)row * p.ldc + col] = to_bf16((v > 0.f || p.no_relu) ? v : 0.f);
+        }
+      } else if (row_ok && col_ok) {
         if (col < p.csplit) p.c2[(size_t)row * p.ldc2 + col] = v;
         else p.c[(size_t)row * p.ldc + col] = (v > 0.f || p.no_relu) ? v : 0.f;
       }
     } else {  // EPI_DX_MASK
-      if (row_ok && col_ok) {
+      if (MODE == 2) {
+        if (row_ok && col < p.ldc) {
+          const unsigned byte = col_ok ? p.maskb[(size_t)row * p.mld + (col < p.csplit ? 0 : p.moff) + (col >> 2)] : 0u;
+          reinterpret_cast<u16 *>(p.c)[(size_t)row * p.ldc + col] = to_bf16(((byte >> (col & 3)) & 1u) ? v : 0.f);
+        }
+      } else if (row_ok && col_ok) {
         const unsigned byte = p.maskb[(size_t)row * p.mld + (col < p.csplit ? 0 : p.moff) + (col >> 2)];
         p.c[(size_t)row * p.ldc + col] = ((byte >> (col & 3)) & 1u) ? v : 0.f;
       }
@@ -127,8 +160,10 @@ __device__ __forceinline__ void rowtile_unit(const RowGemmArgs &p, int row_base,
 // deeper ring because a handful of MFMAs per chunk cannot cover a DMA round trip.  Known cost: the epilogue is
 // bound by the CU's store path (~7-10 B/clk: 770 KB per CU per launch = 30-45 us) and is not overlapped.
 // ------------------------------------------------------------------------------------------------
-template <int NT, int EPI, int NSTAGE, int WAVES, bool BF16>
+template <int NT, int EPI, int NSTAGE, int WAVES, int MODE>
 __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
+  constexpr bool BF16 = MODE == 1;   // bf16 operand mode (fp32 storage, operands rounded on the way into the matrix pipe)
+  constexpr bool ST16 = MODE == 2;   // bf16 storage mode
   constexpr int MT = 2;
   constexpr int BROWS = ((NT * 16 + 16 * WAVES - 1) / (16 * WAVES)) * (16 * WAVES);  // Bt rows staged per chunk
   constexpr int A_INSTR = MT;                   // DMA wave-instructions per wave per chunk (16 rows each)
@@ -265,7 +300,20 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
 #pragma unroll
         for (int jp = 0; jp < NP; ++jp) {
           f32x4 bn0 = bc0, bn1 = bc1;
-          if (BF16) {
+          if (ST16) {
+            acc[0][2 * jp] = mfma_bf16s(af[0], bc0, acc[0][2 * jp]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (jp + 1 < NP) {
+              bn0 = *reinterpret_cast<const f32x4 *>(sBl + (2 * jp + 2) * 256);
+              if (2 * jp + 3 < NT) bn1 = *reinterpret_cast<const f32x4 *>(sBl + (2 * jp + 3) * 256);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (2 * jp + 1 < NT) acc[0][2 * jp + 1] = mfma_bf16s(af[0], bc1, acc[0][2 * jp + 1]);
+            if (nm > 1) {
+              acc[1][2 * jp] = mfma_bf16s(af[1], bc0, acc[1][2 * jp]);
+              if (2 * jp + 1 < NT) acc[1][2 * jp + 1] = mfma_bf16s(af[1], bc1, acc[1][2 * jp + 1]);
+            }
+          } else if (BF16) {
             const s16x4 b0 = cvt_bf16x4(bc0), b1 = cvt_bf16x4(bc1);
             acc[0][2 * jp] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(abf[0], b0, acc[0][2 * jp], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -349,6 +397,68 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
             }
           }
           __builtin_amdgcn_wave_barrier();
+          if (ST16 && EPI != EPI_PLAIN) {
+            // bf16 rows out: a lane packs 8 consecutive columns into one 16-byte store.  Columns up to the padded row
+            // length ldc are written (the pad columns hold exact zeros: their Bt rows are zero).
+            const int f8row = ncols / 8, nf8 = 16 * f8row;
+            for (int f = lane; f < nf8; f += 64) {
+              const int rl = f / f8row, c8 = f - rl * f8row;
+              const int row = row0 + i * 16 + rl;
+              const int col = col0 + j0 * 16 + c8 * 8;
+              if (row >= p.m || col >= p.ldc) continue;
+              f32x4 v[2] = {*reinterpret_cast<const f32x4 *>(ep + rl * stride + c8 * 8),
+                            *reinterpret_cast<const f32x4 *>(ep + rl * stride + c8 * 8 + 4)};
+              u16 *yo = reinterpret_cast<u16 *>(p.c) + (size_t)row * p.ldc + col;
+              if (EPI == EPI_FWD_HIDDEN) {
+                if (p.maskb) {
+#pragma unroll
+                  for (int h = 0; h < 2; ++h) {
+                    const int g4 = col + 4 * h;
+                    if (g4 + 3 < p.csplit || g4 >= ((p.n_store + 3) & ~3)) continue;
+                    unsigned bits = 0;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                      bits |= ((g4 + t >= p.csplit && g4 + t < p.n_store && v[h][t] > 0.f) ? 1u : 0u) << t;
+                    p.maskb[(size_t)row * p.mld + p.moff + (g4 >> 2)] = (uint8_t)bits;
+                  }
+                }
+                u16 *zo = reinterpret_cast<u16 *>(p.c2) + (size_t)row * p.ldc2 + col;
+                if (col + 7 < p.csplit) {  // aggregated channels: raw Z for the neighbour gather
+                  *reinterpret_cast<f32x4 *>(zo) = pack_bf16x8(v[0], v[1]);
+                } else if (col >= p.csplit) {  // pass-through channels: ReLU(Z), no bias
+#pragma unroll
+                  for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[h][t] = (v[h][t] > 0.f || p.no_relu) ? v[h][t] : 0.f;
+                  *reinterpret_cast<f32x4 *>(yo) = pack_bf16x8(v[0], v[1]);
+                } else {  // the group that straddles the cut
+#pragma unroll
+                  for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                      const int cc = col + 4 * h + t;
+                      if (cc < p.csplit) zo[4 * h + t] = to_bf16(v[h][t]);
+                      else yo[4 * h + t] = to_bf16((v[h][t] > 0.f || p.no_relu) ? v[h][t] : 0.f);
+                    }
+                }
+              } else {  // EPI_DX_MASK
+                const int ur = i * 16 + rl;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                  const int g4 = col + 4 * h;
+                  const unsigned ba = mslot[ur * p.mld + (g4 >> 2)];
+                  const unsigned bb = mslot[ur * p.mld + p.moff + (g4 >> 2)];
+#pragma unroll
+                  for (int t = 0; t < 4; ++t) {
+                    const unsigned bit = ((g4 + t < p.csplit ? ba : bb) >> t) & 1u;
+                    v[h][t] = bit ? v[h][t] : 0.f;
+                  }
+                }
+                *reinterpret_cast<f32x4 *>(yo) = pack_bf16x8(v[0], v[1]);
+              }
+            }
+            continue;
+          }
           const int nf4 = 16 * f4row;
           for (int f = lane; f < nf4; f += 64) {
             const int rl = f / f4row, c4 = f - rl * f4row;
@@ -417,7 +527,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
     const int ntl = min(NT, (p.n_store - col0 + 15) >> 4);  // n-tiles of this column block that exist
     const int units = ((p.rem_rows + 15) >> 4) * ntl;
     for (int u = wave * gridDim.x + blockIdx.x; u < units; u += WAVES * gridDim.x)
-      rowtile_unit<EPI, BF16>(p, p.rem_row0, p.rem_row0 + p.rem_rows, u / ntl, col0 + (u % ntl) * 16, lane);
+      rowtile_unit<EPI, MODE>(p, p.rem_row0, p.rem_row0 + p.rem_rows, u / ntl, col0 + (u % ntl) * 16, lane);
   }
 }
 
@@ -439,9 +549,11 @@ static int launch_rowgemm_nt(const RowGemmArgs &a, int grid_y, hipStream_t s) {
   static_assert(shmem * C::WG_PER_CU <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)rowgemm_kernel<NT, EPI, C::NSTAGE, C::WAVES, false>,
+    (void)hipFuncSetAttribute((const void *)rowgemm_kernel<NT, EPI, C::NSTAGE, C::WAVES, 0>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    (void)hipFuncSetAttribute((const void *)rowgemm_kernel<NT, EPI, C::NSTAGE, C::WAVES, true>,
+    (void)hipFuncSetAttribute((const void *)rowgemm_kernel<NT, EPI, C::NSTAGE, C::WAVES, 1>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    (void)hipFuncSetAttribute((const void *)rowgemm_kernel<NT, EPI, C::NSTAGE, C::WAVES, 2>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     attr_set = true;
   }
@@ -449,10 +561,12 @@ static int launch_rowgemm_nt(const RowGemmArgs &a, int grid_y, hipStream_t s) {
   const int max_wg = 256 * C::WG_PER_CU;
   // one tile per wave until every CU has a workgroup; beyond that the kernel deals tiles evenly (two per wave per round)
   const int grid = cdiv(tiles, C::WAVES) < max_wg ? cdiv(tiles, C::WAVES) : max_wg;
-  if (a.bf16)
-    A3VT_LAUNCH((rowgemm_kernel<NT, EPI, C::NSTAGE, C::WAVES, true>), dim3(grid, grid_y), dim3(64 * C::WAVES), shmem, s, a);
+  if (a.bf16 == 2)
+    A3VT_LAUNCH((rowgemm_kernel<NT, EPI, C::NSTAGE, C::WAVES, 2>), dim3(grid, grid_y), dim3(64 * C::WAVES), shmem, s, a);
+  else if (a.bf16)
+    A3VT_LAUNCH((rowgemm_kernel<NT, EPI, C::NSTAGE, C::WAVES, 1>), dim3(grid, grid_y), dim3(64 * C::WAVES), shmem, s, a);
   else
-    A3VT_LAUNCH((rowgemm_kernel<NT, EPI, C::NSTAGE, C::WAVES, false>), dim3(grid, grid_y), dim3(64 * C::WAVES), shmem, s, a);
+    A3VT_LAUNCH((rowgemm_kernel<NT, EPI, C::NSTAGE, C::WAVES, 0>), dim3(grid, grid_y), dim3(64 * C::WAVES), shmem, s, a);
   A3VT_CHECK_LAUNCH();
   return 0;
 }
@@ -483,19 +597,20 @@ static int launch_rowgemm_cols(const RowGemmArgs &a, hipStream_t s) {
 // the MFMA chain: one round trip instead of nineteen.  Same arithmetic order along K as rowgemm_kernel.
 // grid = (column tiles, row tiles / 4), 4 waves per workgroup.
 // ------------------------------------------------------------------------------------------------
-template <int EPI, bool BF16>
+template <int EPI, int MODE>
 __global__ __launch_bounds__(256) void rowtile_kernel(RowGemmArgs p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int mt = blockIdx.y * 4 + wave;
   if (mt * 16 >= p.m) return;
-  rowtile_unit<EPI, BF16>(p, 0, p.m, mt, p.col0 + blockIdx.x * 16, lane);
+  rowtile_unit<EPI, MODE>(p, 0, p.m, mt, p.col0 + blockIdx.x * 16, lane);
 }
 
 template <int EPI>
 static int launch_rowtile(const RowGemmArgs &a, hipStream_t s) {
   const dim3 grid(cdiv(a.n_store, 16), cdiv(cdiv(a.m, 16), 4));
-  if (a.bf16) A3VT_LAUNCH((rowtile_kernel<EPI, true>), grid, dim3(256), 0, s, a);
-  else A3VT_LAUNCH((rowtile_kernel<EPI, false>), grid, dim3(256), 0, s, a);
+  if (a.bf16 == 2) A3VT_LAUNCH((rowtile_kernel<EPI, 2>), grid, dim3(256), 0, s, a);
+  else if (a.bf16) A3VT_LAUNCH((rowtile_kernel<EPI, 1>), grid, dim3(256), 0, s, a);
+  else A3VT_LAUNCH((rowtile_kernel<EPI, 0>), grid, dim3(256), 0, s, a);
   A3VT_CHECK_LAUNCH();
   return 0;
 }

@@ -26,7 +26,11 @@ struct RowGemmArgs {
   int m, k, n_store;
   int ldc, ldc2, csplit, mld, moff;
   int no_relu;  // EPI_FWD_HIDDEN: store the pass-through channels without the ReLU (identity activation)
-  int bf16;     // operands rounded to bf16, v_mfma_f32_16x16x16_bf16, fp32 accumulate (default: exact fp32 MFMA)
+  // 0: exact fp32 MFMA.  1: fp32 storage, operands rounded to bf16 on the way into v_mfma_f32_16x16x16_bf16.
+  // 2: bf16 STORAGE — a0 / a1 / bt point at bf16 rows (lda*, ldb, k, ksplit still in 4-byte units = pairs of bf16),
+  //    v_mfma_f32_16x16x32_bf16; EPI_FWD_HIDDEN / EPI_DX_MASK write bf16 (c, c2 as bf16 with ldc, ldc2 in ELEMENTS, all
+  //    columns < ldc written), EPI_PLAIN writes fp32.  fp32 accumulation in every mode.
+  int bf16;
   // rows [rem_row0, rem_row0 + rem_rows) beyond the m rows of the main loop: the few leftover tiles of the load-balanced
   // split, done by the tail of the same launch (set by launch_rowgemm; 0 = none)
   int rem_row0, rem_rows;
@@ -99,6 +103,35 @@ int launch_vertex_update(const float *vin, const float *upd, int batch, int n_ve
                          hipStream_t s);
 int launch_check_finite(const float *d, size_t n, int32_t *flag, hipStream_t s);
 int launch_fill_zero(float *d, size_t n, hipStream_t s);
+
+// gcn_bf16s.hip — bf16-storage variants (gemm mode 2); `void *` rows are bf16, leading dimensions in elements
+int launch_cvt_rows(const float *in, int ld_in, int n, void *out, int ld_out, long long m, hipStream_t s);
+int launch_weight_images16(const WeightImages &w, int max_rows, int max_ld, hipStream_t s);  // ld / rows in bf16 elements
+struct Dw16Args {
+  const unsigned short *x;   // [M][ldx] bf16; input channels [xc0, xc0 + xw) are used (xw = k_in rounded up to 8)
+  const unsigned short *z0;  // dZa [M][ldz0]: columns [0, zsplit)
+  const unsigned short *z1;  // G   [M][ldz1]: columns [zsplit, n_out)
+  const float *zeros;
+  float *slab;               // [dw16_num_slabs(n_out)][k_in][n_out] fp32
+  int ldx, xc0, xw, ldz0, ldz1, zsplit;
+  int m, k_in, n_out;
+  int nstage;                // set by launch_dw16
+};
+int dw16_num_slabs(int n_out);
+int launch_dw16(const Dw16Args &a, hipStream_t s);
+int launch_csr16_fwd(const void *za, int ldza, const float *bias, int c, const int32_t *rowptr, const int32_t *col,
+                     const float *val, const int32_t *heavy, int n_vert, int batch, void *y, int ldy, uint8_t *maskb,
+                     int mld, int relu, hipStream_t s);
+int launch_csr16_bwd(const void *g, int ldg, int c, int cpad, const int32_t *rowptrT, const int32_t *colT,
+                     const float *valT, const int32_t *heavyT, int n_vert, int batch, void *dza, int lddza,
+                     float *db_slab, hipStream_t s);
+int launch_thin16_fwd_product(const void *x, int ldx, int k, const float *w, long long m, float *z3, hipStream_t s);
+int launch_thin16_bwd_main(const void *x, int ldx, int k, const float *w, const float *dz3, const float *du, long long m,
+                           int apply_mask, void *gprev, int ldg, float *dw_slab, float *db_slab, hipStream_t s);
+// 3-channel aggregation / padding helpers of the output layer (gcn_csr.hip), shared with the bf16-storage path
+int launch_csr3(const float *z, const float *bias, const int32_t *rowptr, const int32_t *col, const float *val,
+                const int32_t *heavy, int n_vert, int batch, float *out, int ldo, hipStream_t s);
+int launch_pad3to4(const float *in, long long m, float *out, hipStream_t s);
 
 // posenc.hip
 size_t posenc_param_count(int input_size);

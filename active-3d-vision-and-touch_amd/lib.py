@@ -10,7 +10,8 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("A3VT_LIB", os.path.join(_HERE, "liba3vt.so"))  # A3VT_LIB: developer override (variant builds)
-SOURCES = ["capi.hip", "gcn_gemm.hip", "gcn_csr.hip", "posenc.hip", "sample.hip", "chamfer.hip", "pooling.hip"]
+SOURCES = ["capi.hip", "gcn_gemm.hip", "gcn_csr.hip", "gcn_bf16s.hip", "posenc.hip", "sample.hip", "chamfer.hip",
+           "pooling.hip"]
 # Per-file extra flags (none at present; sample.hip / gcn_csr.hip rely on IEEE NaN semantics — the reference's NaN
 # scrubs, a3vt_check_finite — so fast-math style flags must never be applied globally).
 # chamfer.hip: keep the nearest-neighbour loop on scalar fp32 ops (the SLP vectoriser would re-pack it into v_pk_*_f32,
@@ -26,6 +27,8 @@ SIGNATURES = {
     "a3vt_csr_validate": (_i, [_vp, _vp, _i, _i]),
     "a3vt_gcn_stack_scratch_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "a3vt_gcn_stack_mask_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "a3vt_gcn_stack_scratch_bytes_mode": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i]),
+    "a3vt_gcn_stack_stash_bytes": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp]),
     "a3vt_gcn_stack_fwd": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "a3vt_gcn_stack_bwd": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -70,6 +70,17 @@ def _ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
+GEMM_MODES = {"fp32": 0, "bf16": 1, "bf16s": 2}
+
+
+def gemm_mode(bf16):
+    """0 exact fp32 MFMA; 1 bf16 operands, fp32 storage; 2 bf16 storage (activations / gradients / weight images bf16 in
+    HBM, fp32 accumulation).  Accepts the mode number, a bool (True = 1) or the ``args.gemm_precision`` string."""
+    if isinstance(bf16, str):
+        return GEMM_MODES[bf16]
+    return int(bf16)
+
+
 class GCNStackFn(torch.autograd.Function):
     """One GCN (reference ``GCN.forward``, vision/model.py:316-331): feats (B,N,ld) -> update (B,N,3)."""
 
@@ -83,24 +94,26 @@ class GCNStackFn(torch.autograd.Function):
         weights = [_req(p, "weight") for p in params[0::2]]
         biases = [_req(p, "bias") for p in params[1::2]]
         nl = len(weights)
-        M = B * N
+        mode = gemm_mode(bf16)
         acts = masks = None
         STATS["stack_calls"] += 1
         if need_bwd and nl > 1:
             STATS["stack_stash_calls"] += 1
-            acts = torch.empty((nl - 1, M, hidden), dtype=torch.float32, device=feats.device)
-            masks = torch.empty(L.a3vt_gcn_stack_mask_bytes(B, N, hidden, nl, cut_len), dtype=torch.uint8,
-                                device=feats.device)
-        nbytes = L.a3vt_gcn_stack_scratch_bytes(B, N, in_features, hidden, nl, cut_len, 1 if need_bwd else 0)
+            ab, mb = ctypes.c_size_t(0), ctypes.c_size_t(0)
+            _lib.check(L.a3vt_gcn_stack_stash_bytes(B, N, hidden, nl, cut_len, mode, ctypes.byref(ab), ctypes.byref(mb)),
+                       "gcn_stack_stash_bytes")
+            acts = torch.empty(ab.value, dtype=torch.uint8, device=feats.device)    # fp32 or bf16 rows, by mode
+            masks = torch.empty(mb.value, dtype=torch.uint8, device=feats.device)
+        nbytes = L.a3vt_gcn_stack_scratch_bytes_mode(B, N, in_features, hidden, nl, cut_len, 1 if need_bwd else 0, mode)
         scratch = workspace("gcn", nbytes, feats.device)
         update = torch.empty((B, N, 3), dtype=torch.float32, device=feats.device)
         wp, bp = _ptr_array(weights), _ptr_array(biases)
         _lib.check(L.a3vt_gcn_stack_fwd(_lib.ptr(feats), ld, in_features, wp, bp, nl, hidden, cut_len,
                                         _lib.ptr(adj.rowptr), _lib.ptr(adj.col), _lib.ptr(adj.val), adj.max_degree, N, B,
-                                        1 if bf16 else 0,
+                                        mode,
                                         _lib.ptr(acts), _lib.ptr(masks), _lib.ptr(scratch), _lib.ptr(update), _stream()),
                    "gcn_stack_fwd")
-        ctx.adj, ctx.dims, ctx.bf16 = adj, (in_features, hidden, cut_len, nl), bool(bf16)
+        ctx.adj, ctx.dims, ctx.mode = adj, (in_features, hidden, cut_len, nl), mode
         ctx.acts, ctx.masks = acts, masks
         ctx.save_for_backward(feats, *weights, *biases)
         return update
@@ -118,12 +131,12 @@ class GCNStackFn(torch.autograd.Function):
         gw = [torch.empty_like(w) for w in weights]
         gb = [torch.empty_like(b) for b in biases]
         gfeats = torch.empty_like(feats)
-        nbytes = L.a3vt_gcn_stack_scratch_bytes(B, N, in_features, hidden, nl, cut_len, 1)
+        nbytes = L.a3vt_gcn_stack_scratch_bytes_mode(B, N, in_features, hidden, nl, cut_len, 1, ctx.mode)
         scratch = workspace("gcn", nbytes, feats.device)
         _lib.check(L.a3vt_gcn_stack_bwd(_lib.ptr(feats), ld, in_features, _ptr_array(weights), _ptr_array(biases), nl,
                                         hidden, cut_len, _lib.ptr(adj.rowptr), _lib.ptr(adj.col), _lib.ptr(adj.val),
                                         _lib.ptr(adj.t_rowptr), _lib.ptr(adj.t_col), _lib.ptr(adj.t_val),
-                                        adj.t_max_degree, N, B, 1 if ctx.bf16 else 0,
+                                        adj.t_max_degree, N, B, ctx.mode,
                                         _lib.ptr(ctx.acts), _lib.ptr(ctx.masks), _lib.ptr(grad_update), _ptr_array(gw),
                                         _ptr_array(gb),
                                         _lib.ptr(gfeats), _lib.ptr(scratch), _stream()), "gcn_stack_bwd")
@@ -135,12 +148,13 @@ class GCNStackFn(torch.autograd.Function):
 
 
 def gcn_stack(feats, adj, in_features, hidden, cut_len, weights, biases, bf16=False):
-    """``bf16``: round the operands of the per-vertex products to bf16 on their way into the matrix pipe (BASELINE
-    configs[3]/[4]); the default is the exact fp32 path."""
+    """``bf16``: gemm mode of the per-vertex products (:func:`gemm_mode`): False / 0 = exact fp32 (default, the parity
+    mode); True / 1 / "bf16" = operands rounded to bf16 on their way into the matrix pipe; 2 / "bf16s" = bf16 storage of
+    activations and gradients as well (BASELINE configs[3]/[4])."""
     params = []
     for w, b in zip(weights, biases):
         params += [w, b]
-    return GCNStackFn.apply(feats, adj, in_features, hidden, cut_len, bf16, _wants_grad(feats, *params), *params)
+    return GCNStackFn.apply(feats, adj, in_features, hidden, cut_len, gemm_mode(bf16), _wants_grad(feats, *params), *params)
 
 
 class GCNLayerFn(torch.autograd.Function):

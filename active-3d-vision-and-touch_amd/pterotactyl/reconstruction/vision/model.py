@@ -171,9 +171,11 @@ class GCN(nn.Module):
         self.input_features = input_features
         self.hidden = args.hidden_GCN_size
         self.cut = args.cut
-        # new knob (no reference counterpart): "bf16" rounds the operands of the per-vertex products to bf16 on their
-        # way into the matrix pipe (BASELINE configs[3]/[4]); everything stored stays fp32.  Default: exact fp32.
-        self.gemm_bf16 = getattr(args, "gemm_precision", "fp32") == "bf16"
+        # new knob (no reference counterpart), BASELINE configs[3]/[4]: "bf16" rounds the operands of the per-vertex
+        # products to bf16 on their way into the matrix pipe (everything stored stays fp32); "bf16s" also stores the
+        # activations, their gradients and the weight images as bf16 (fp32 accumulation, fp32 master weights / Adam).
+        # Default "fp32": exact fp32 MFMA, the parity mode.
+        self.gemm_bf16 = _ops.gemm_mode(getattr(args, "gemm_precision", "fp32"))
         dims = [input_features] + [self.hidden] * (self.num_layers - 1) + [3]
         self.layers = nn.ModuleList(
             [GCN_layer(dims[i], dims[i + 1], args.cut, do_cut=i < self.num_layers - 1) for i in range(self.num_layers)])

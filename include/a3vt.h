@@ -47,7 +47,8 @@ int a3vt_csr_validate(const int32_t *rowptr_host, const int32_t *col_host, int n
  * `weights`, `biases`, `grad_weights`, `grad_biases` are HOST arrays of L DEVICE pointers.
  * `cut_len` = round(hidden * cut) (model.py:355; 99 for 300 * 0.33).
  * csr_* is A (row-normalised), csrT_* is its transpose (A is not symmetric after normalisation).
- * gemm_bf16 (every GCN entry point and a3vt_rowgemm): 0 = the per-vertex products run as exact fp32 MFMA (the parity
+ * gemm_bf16 (every GCN entry point and a3vt_rowgemm; 2 = bf16 storage, stack entry points only, see below): 0 = the
+ * per-vertex products run as exact fp32 MFMA (the parity
  * mode, BASELINE configs[1]/[2]); 1 = "bf16 + MFMA feature MLP" (configs[3]/[4]): the operands of X W, dZ W^T and
  * X^T dZ are rounded to bf16 on their way into the matrix pipe (v_mfma_f32_16x16x16_bf16, fp32 accumulation); every
  * stored tensor stays fp32.  Vertex positions then agree with the fp32 reference to ~2e-3 relative instead of 3e-7.
@@ -66,13 +67,21 @@ int a3vt_csr_validate(const int32_t *rowptr_host, const int32_t *col_host, int n
 size_t a3vt_gcn_stack_scratch_bytes(int batch, int n_vert, int in_features, int hidden, int num_layers,
                                     int cut_len, int need_backward);
 size_t a3vt_gcn_stack_mask_bytes(int batch, int n_vert, int hidden, int num_layers, int cut_len);
+/* gemm_bf16 == 2, "bf16 storage" (BASELINE configs[3]/[4]): activations, their gradients and the weight images are kept
+ * as bf16 in HBM (fp32 accumulation; fp32 weights, gradients of the weights, features and update at this boundary).
+ * `acts` then holds bf16 rows of pad8(hidden) elements and the sign bytes use another row length: query both sizes
+ * with a3vt_gcn_stack_stash_bytes, and the scratch size with a3vt_gcn_stack_scratch_bytes_mode.  Needs >= 2 layers. */
+size_t a3vt_gcn_stack_scratch_bytes_mode(int batch, int n_vert, int in_features, int hidden, int num_layers,
+                                         int cut_len, int need_backward, int gemm_bf16);
+int a3vt_gcn_stack_stash_bytes(int batch, int n_vert, int hidden, int num_layers, int cut_len, int gemm_bf16,
+                               size_t *acts_bytes, size_t *mask_bytes);
 
 int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features,
                        const float *const *weights, const float *const *biases,
                        int num_layers, int hidden, int cut_len,
                        const int32_t *csr_rowptr, const int32_t *csr_col, const float *csr_val, int csr_max_degree,
                        int n_vert, int batch, int gemm_bf16,
-                       float *acts, uint8_t *masks, float *scratch, float *update, void *stream);
+                       void *acts, uint8_t *masks, float *scratch, float *update, void *stream);
 
 /* Backward of the stack.  grad_update [M][3] -> grad_feats [M][ld_feats] (pad columns written as 0),
  * grad_weights[i] [in_i][out_i], grad_biases[i] [out_i] (overwritten; channels >= cut_len of hidden
@@ -83,7 +92,7 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features,
                        const int32_t *csr_rowptr, const int32_t *csr_col, const float *csr_val,
                        const int32_t *csrT_rowptr, const int32_t *csrT_col, const float *csrT_val, int csrT_max_degree,
                        int n_vert, int batch, int gemm_bf16,
-                       const float *acts, const uint8_t *masks, const float *grad_update,
+                       const void *acts, const uint8_t *masks, const float *grad_update,
                        float *const *grad_weights, float *const *grad_biases, float *grad_feats,
                        float *scratch, void *stream);
 

@@ -40,24 +40,33 @@ def bf16_round(t):
 
 
 def gcn_layer(x, weight, bias, adj, cut=0.33, do_cut=True, relu=True, bf16=False):
-    """model.py:351-363.  x (B,N,in), weight (1,in,out), bias (out,).  ``bf16``: emulate the product's bf16 operand
-    mode (operands of X W rounded to bf16, exact products, wide accumulation) — not a reference feature."""
+    """model.py:351-363.  x (B,N,in), weight (1,in,out), bias (out,).  ``bf16`` emulates the product's reduced-precision
+    modes (not a reference feature): True = operand mode (operands of X W rounded to bf16, exact products, wide
+    accumulation); "storage" = bf16 storage mode (additionally the raw aggregated channels Z[:, :c] and the layer output
+    are rounded to bf16 where the device stores them)."""
+    storage = bf16 == "storage"
     z = torch.matmul(bf16_round(x), bf16_round(weight)) if bf16 else torch.matmul(x, weight)
     if do_cut:
         length = cut_length(z.shape[-1], cut)
-        agg = adj_matmul(adj, z[:, :, :length]) + bias[:length]
+        za = bf16_round(z[:, :, :length]) if storage else z[:, :, :length]
+        agg = adj_matmul(adj, za) + bias[:length]
         out = torch.cat((agg, z[:, :, length:]), dim=-1)
     else:
         out = adj_matmul(adj, z) + bias
-    return torch.relu(out) if relu else out
+    out = torch.relu(out) if relu else out
+    return bf16_round(out) if storage else out
 
 
 def gcn(x, state, prefix, adj, num_layers, cut=0.33, collect=None, bf16=False):
-    """model.py:316-331 — ``num_layers`` layers, ReLU on all but the last, last layer aggregates all channels."""
+    """model.py:316-331 — ``num_layers`` layers, ReLU on all but the last, last layer aggregates all channels.
+    ``bf16``: see :func:`gcn_layer`; the 3-channel output layer always runs in full precision (in "storage" mode on the
+    bf16-stored activations, and the stack's input features are rounded once at entry, as the device does)."""
+    if bf16 == "storage":
+        x = bf16_round(x)
     for i in range(num_layers):
         last = i == num_layers - 1
         x = gcn_layer(x, state[f"{prefix}.layers.{i}.weight"], state[f"{prefix}.layers.{i}.bias"],
-                      adj, cut, do_cut=not last, relu=not last, bf16=bf16 and not last)
+                      adj, cut, do_cut=not last, relu=not last, bf16=bf16 if not last else False)
         if collect is not None:
             collect.append(x)
     return x
