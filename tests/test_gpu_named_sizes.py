@@ -195,17 +195,19 @@ def test_forward_only_callers_do_not_stash_activations(cuda):
 
 
 # ---- (c) configs[3] composite: image + 4 touch charts + bf16 operands + 25 000-point Chamfer --------------------------
-def test_config3_composite_bs2(cuda):
+@pytest.mark.parametrize("precision,emul", [("bf16", True), ("bf16s", "storage")])
+def test_config3_composite_bs2(cuda, precision, emul):
     """BASELINE.json configs[3] at bs 2: ``use_img`` (default CNNs, 448-wide features), ``use_touch`` with
-    ``num_grasps=1, finger=False`` (4 chart slots fused into the atlas: N = 1924), the full 20 x 300 GCNs with bf16 GEMM
-    operands, 25 000-point Chamfer x 3 draws.  Vertex positions against ``oracle.gcn.deformation_forward_img`` with the
-    bf16 emulation (tolerance 5e-3 relative: bf16 rounding after every layer); the Chamfer loss of THESE
-    positions against the oracle's Chamfer on the same injected samples (1e-4)."""
+    ``num_grasps=1, finger=False`` (4 chart slots fused into the atlas: N = 1924), the full 20 x 300 GCNs in both bf16
+    modes (operands only / bf16 storage), 25 000-point Chamfer x 3 draws.  Vertex positions against
+    ``oracle.gcn.deformation_forward_img`` with the matching bf16 emulation (tolerance 5e-3 relative: bf16 rounding after
+    every layer); the Chamfer loss of THESE positions against the oracle's Chamfer on the same injected
+    samples (1e-4)."""
     from a3vt_amd import mesh as amesh
     from a3vt_amd.pterotactyl.reconstruction.vision import model
     from a3vt_amd.pterotactyl.utility import utils
     from oracle import chamfer as och, gcn as og, mesh as omesh
-    args = make_args(use_img=True, use_touch=True, num_grasps=1, finger=False, gemm_precision="bf16",
+    args = make_args(use_img=True, use_touch=True, num_grasps=1, finger=False, gemm_precision=precision,
                      CNN_ker_size=5, num_CNN_blocks=6, layers_per_block=3, number_points=25000)
     info, verts = utils.load_mesh_vision(args, "vision_charts")
     torch.manual_seed(0)
@@ -230,7 +232,7 @@ def test_config3_composite_bs2(cuda):
     st = {k: t.detach().cpu() for k, t in net.state_dict().items()}
     ch = og.prepare_mesh(tc, torch.from_numpy(v), B, True)
     with torch.no_grad():
-        out_o, mask_o = og.deformation_forward_img(st, adj, ch, img, True, 20, 0.33, training=False, bf16=True)
+        out_o, mask_o = og.deformation_forward_img(st, adj, ch, img, True, 20, 0.33, training=False, bf16=emul)
         out_f, _ = og.deformation_forward_img(st, adj, ch, img, True, 20, 0.33, training=False, bf16=False)
     assert torch.equal(mask.cpu(), mask_o)
     e_bf, e_fp = rel_err(out, out_o), rel_err(out, out_f)
@@ -277,12 +279,13 @@ def _repeatable_training_step(cuda, net, forward, faces, gt, P, n_faces, bitwise
     return outs
 
 
-def test_config4_shard_fullsize_is_finite_and_repeatable(cuda):
-    """configs[4] per-GPU shard: 10 242-vertex template, bs 8, 50 000-point Chamfer, 20 x 300 GCNs, bf16 operands: finite,
+@pytest.mark.parametrize("precision", ["bf16", "bf16s"])
+def test_config4_shard_fullsize_is_finite_and_repeatable(cuda, precision):
+    """configs[4] per-GPU shard: 10 242-vertex template, bs 8, 50 000-point Chamfer, 20 x 300 GCNs, both bf16 modes: finite,
     forward + loss bitwise repeatable, GCN weight gradients bitwise repeatable (deterministic backward scatter)."""
     from a3vt_amd.pterotactyl.reconstruction.vision import model
     from a3vt_amd.pterotactyl.utility import utils
-    args = make_args(gemm_precision="bf16", number_points=50000)
+    args = make_args(gemm_precision=precision, number_points=50000)
     v, f = template("ico5")
     vt, ft = torch.from_numpy(v).to(cuda), torch.from_numpy(f).to(cuda)
     info = utils.adj_init(vt, ft, args)
@@ -296,14 +299,14 @@ def test_config4_shard_fullsize_is_finite_and_repeatable(cuda):
 
 
 def test_config3_fullsize_is_finite_and_repeatable(cuda):
-    """configs[3] at its full batch: image model + 4 touch charts, bs 64, 25 000-point Chamfer, bf16 operands.  The whole
+    """configs[3] at its full batch: image model + 4 touch charts, bs 64, 25 000-point Chamfer, bf16 storage.  The whole
     step (MIOpen convolutions included) is finite and repeats to rounding — MIOpen may pick another convolution algorithm
     from one call to the next —; with the image feature maps held fixed, everything this library computes (pooling,
     encoders, 448-wide GCN stacks, sampling, Chamfer and all their backward kernels) repeats bit for bit."""
     from a3vt_amd.pterotactyl.reconstruction.vision import model
     from a3vt_amd.pterotactyl.utility import utils
     from a3vt_amd.synthetic import touch_charts
-    args = make_args(use_img=True, use_touch=True, num_grasps=1, finger=False, gemm_precision="bf16",
+    args = make_args(use_img=True, use_touch=True, num_grasps=1, finger=False, gemm_precision="bf16s",
                      CNN_ker_size=5, num_CNN_blocks=6, layers_per_block=3, number_points=25000)
     info, verts = utils.load_mesh_vision(args, "vision_charts")
     torch.manual_seed(0)
