@@ -147,45 +147,55 @@ __global__ __launch_bounds__(256) void pool_bwd_verts_kernel(PoolArgs a) {
 }
 
 // ---- backward, maps: workgroup = (sample, map, block of CB channels); the block's gradient image [H*W][CB] lives in
-// LDS, every vertex of the sample adds its four weighted corners, then the image is written once.
-constexpr int kPoolLdsFloats = 10240;  // 40 KB: 23*23 pixels x 16 channels, 7*7 x 128, 3*3 x 256 all fit
+// LDS, every vertex of the sample adds its four weighted corners, then the image is written once.  The accumulators
+// are 64-bit fixed point (common.h): integer sums do not depend on the order in which the vertices arrive, so the map
+// gradients — and with them the CNN weight gradients — are reproducible bit for bit (float LDS atomics plus a
+// float-atomic combine of vertex slices, as before, were not).  Scale: the bilinear weights are <= 1, so the largest
+// |grad_feats| of the block's channels over the sample's vertices bounds every term (a first pass over the same values),
+// and a pixel receives at most one term per vertex and corner.
+constexpr int kPoolLdsCells = 8192;  // 64 KB of accumulators: 23*23 pixels x 8 channels, 7*7 x 128, 3*3 x 256 all fit
 __global__ __launch_bounds__(256) void pool_bwd_maps_kernel(PoolArgs a, int k, int CB) {
-  extern __shared__ float img[];
+  extern __shared__ long long img[];
+  __shared__ float red[4];
   const int C = a.C[k], H = a.H[k], W = a.W[k];
   const int nblk = (C + CB - 1) / CB;
   const int b = blockIdx.x / nblk, c0 = (blockIdx.x % nblk) * CB;
   const int cb = min(CB, C - c0);
-  for (int i = threadIdx.x; i < H * W * CB; i += 256) img[i] = 0.f;
-  __syncthreads();
   const int lanes_c = CB >> 2;               // float4 groups per vertex
   const int vpar = 256 / lanes_c;            // vertices in flight
   const int cl = (threadIdx.x % lanes_c) * 4, vs = threadIdx.x / lanes_c;
-  // vertices of this sample are split over gridDim.y workgroups (small maps have few channel blocks: without the
-  // split a handful of workgroups would walk every vertex)
-  const int vper = (a.n_vert + gridDim.y - 1) / gridDim.y;
-  const int vbeg = blockIdx.y * vper, vend = min(a.n_vert, vbeg + vper);
-  for (int v = vbeg + vs; v < vend && vs < vpar; v += vpar) {
+  const bool lane_on = cl < cb && vs < vpar;
+  float mx = 0.f;
+  for (int v = vs; v < a.n_vert && lane_on; v += vpar) {
+    const f32x4 gv = *reinterpret_cast<const f32x4 *>(a.gfeats + ((long long)b * a.n_vert + v) * a.ld + a.off[k] + c0 + cl);
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(gv[0]), fabsf(gv[1]))), fmaxf(fabsf(gv[2]), fabsf(gv[3])));
+  }
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  for (int i = threadIdx.x; i < H * W * CB; i += 256) img[i] = 0;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const bool finite = mx < 3.0e38f;
+  const FixScale fs = fix_scale(finite ? mx : 0.f, a.n_vert);
+  for (int v = vs; v < a.n_vert && lane_on; v += vpar) {
     const long long row = (long long)b * a.n_vert + v;
     const Projected p = project(a.verts + row * 3, a.proj);
     const Bilinear bl = bilinear_setup(p.gx, p.gy, H, W);
-    if (cl >= cb) continue;
     const f32x4 gv = *reinterpret_cast<const f32x4 *>(a.gfeats + row * a.ld + a.off[k] + c0 + cl);
-    float *nw = img + (bl.y0 * W + bl.x0) * CB + cl;
+    long long *nw = img + (bl.y0 * W + bl.x0) * CB + cl;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      if (bl.in_nw) atomicAdd(nw + t, bl.wnw * gv[t]);
-      if (bl.in_ne) atomicAdd(nw + CB + t, bl.wne * gv[t]);
-      if (bl.in_sw) atomicAdd(nw + W * CB + t, bl.wsw * gv[t]);
-      if (bl.in_se) atomicAdd(nw + (W + 1) * CB + t, bl.wse * gv[t]);
+      if (bl.in_nw) fix_add(nw + t, fix_from(bl.wnw * gv[t], fs));
+      if (bl.in_ne) fix_add(nw + CB + t, fix_from(bl.wne * gv[t], fs));
+      if (bl.in_sw) fix_add(nw + W * CB + t, fix_from(bl.wsw * gv[t], fs));
+      if (bl.in_se) fix_add(nw + (W + 1) * CB + t, fix_from(bl.wse * gv[t], fs));
     }
   }
   __syncthreads();
   float *gm = a.gmaps[k] + (long long)b * H * W * C;
   for (int i = threadIdx.x; i < H * W * cb; i += 256) {
     const int px = i / cb, c = i - px * cb;
-    const float val = img[px * CB + c];
-    if (gridDim.y == 1) gm[(long long)px * C + c0 + c] = val;
-    else if (val != 0.f) atomicAdd(gm + (long long)px * C + c0 + c, val);  // gm zeroed by the launcher
+    gm[(long long)px * C + c0 + c] = finite ? fix_to(img[px * CB + c], fs) : __builtin_nanf("");
   }
 }
 
@@ -220,17 +230,13 @@ int launch_pool_bwd(PoolArgs a, hipStream_t s) {
   A3VT_CHECK_LAUNCH();
   for (int k = 0; k < a.n_maps; ++k) {
     const int px = a.H[k] * a.W[k];
-    int CB = a.C[k];                                   // channel block: largest power-of-two split that fits LDS
-    while (CB > 4 && (px * CB > kPoolLdsFloats || CB > 256)) CB >>= 1;
-    if (px * CB > kPoolLdsFloats) { set_error("image_pool: map %d x %d too large for the LDS image", a.H[k], a.W[k]); return -1; }
+    int CB = a.C[k];                                   // channel block: largest power-of-two split that fits LDS ...
+    while (CB > 4 && (px * CB > kPoolLdsCells || CB > 256)) CB >>= 1;
+    if (px * CB > kPoolLdsCells) { set_error("image_pool: map %d x %d too large for the LDS image", a.H[k], a.W[k]); return -1; }
+    while (CB > 8 && a.batch * cdiv(a.C[k], CB) < 512) CB >>= 1;   // ... and leaves every CU a couple of workgroups
     CB = (CB + 3) & ~3;
     const int nblk = cdiv(a.C[k], CB);
-    int vsplit = cdiv(1024, a.batch * nblk);
-    vsplit = vsplit < 1 ? 1 : (vsplit > 16 ? 16 : vsplit);
-    if (vsplit > 1)
-      if (int rc = launch_fill_zero(a.gmaps[k], (size_t)a.batch * px * a.C[k], s)) return rc;
-    A3VT_LAUNCH(pool_bwd_maps_kernel, dim3(a.batch * nblk, vsplit), dim3(256), (size_t)px * CB * sizeof(float), s, a, k,
-                CB);
+    A3VT_LAUNCH(pool_bwd_maps_kernel, dim3(a.batch * nblk), dim3(256), (size_t)px * CB * sizeof(long long), s, a, k, CB);
     A3VT_CHECK_LAUNCH();
   }
   return 0;

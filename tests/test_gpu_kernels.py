@@ -223,6 +223,11 @@ def test_image_pool_fwd_bwd(cuda):
     # channels_last input is consumed as is, and the result does not depend on the input memory format
     f2 = ops.image_pool(vd.detach(), matrix, [m.detach().contiguous(memory_format=torch.channels_last) for m in md])
     assert torch.equal(f2, f.detach())
+    # the backward scatter into the maps accumulates in fixed point: a second evaluation reproduces every bit
+    vd2 = verts.to(cuda).requires_grad_(True)
+    md2 = [m.to(cuda).requires_grad_(True) for m in maps]
+    (ops.image_pool(vd2, matrix, md2) * gout.to(cuda)).sum().backward()
+    assert torch.equal(vd2.grad, vd.grad) and all(torch.equal(a.grad, b.grad) for a, b in zip(md, md2))
 
 
 @pytest.mark.parametrize("m,k,n", [(1000, 52, 300), (4099, 300, 300), (33000, 300, 300), (777, 300, 52)])
