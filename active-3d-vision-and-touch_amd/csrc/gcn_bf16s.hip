@@ -121,16 +121,18 @@ int launch_weight_images16(const WeightImages &w, int max_rows, int max_ld, hipS
 // A stage is 32 rows: the X window and this column group's dZa / G windows are DMA'd into compact [32][w] images.  The
 // MFMA sums over ROWS, so both operands are needed column-wise: lane 16 g + i of v_mfma_f32_16x16x32_bf16 holds
 // A[m = i][k = 8 g + j] = X[row 8 g + j][channel i] — eight rows of one channel.  ds_read_b64_tr_b16 delivers exactly
-// that from the row-major image: per 16-lane group a 4-row x 16-column block comes back column-major, so two reads (rows
-// 8 g .. 8 g + 3 and 8 g + 4 .. 8 g + 7) fill an operand.
+// that from the row-major image: per 16-lane group a 4-row x 16-column block comes back column-major, so two reads fill
+// an operand.  Which eight rows of the stage a k-group takes is free as long as both operands agree (a sum over rows):
+// group g takes rows 4 g .. 4 g + 3 and 16 + 4 g .. 16 + 4 g + 3, so that the two groups of a 32-lane half read ADJACENT
+// 4-row blocks — with 608-byte rows (24 banks mod 64) rows r and r + 8 would land on the same banks, rows r and r + 4 do not.
 // ------------------------------------------------------------------------------------------------
 constexpr int DW16_MAXI = 5, DW16_MAXO = 3;
 
 __device__ __forceinline__ bf16x8 tr_operand(const u16 *lds_row0_col, int row_stride_elems) {
-  // address of (row 0 of the lane's block, the lane's 4-column quad); the second block sits 4 rows further
+  // address of (the lane's row of its first block, the lane's 4-column quad); the second block sits 16 rows further
   const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(lds_row0_col));
   const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (__attribute__((address_space(3))) s16x4 *)(lds_row0_col + 4 * row_stride_elems));
+      (__attribute__((address_space(3))) s16x4 *)(lds_row0_col + 16 * row_stride_elems));
   return __builtin_bit_cast(bf16x8, (s16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]});
 }
 
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(1024, 1) void dw16_kernel(Dw16Args p) {
   extern __shared__ __attribute__((aligned(16))) u16 lds16[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int l16 = lane & 15, g = lane >> 4;      // MFMA k-group g: rows 8 g .. 8 g + 7 of the stage
+  const int l16 = lane & 15, g = lane >> 4;      // MFMA k-group g: rows 4 g .. 4 g + 3 and 16 + 4 g .. of the stage
   const int bq = l16 >> 2, bp = l16 & 3;         // transposed-read address role: block row bq, column quad bp
   const int wi = wave & 3, wo = wave >> 2;
 
@@ -207,12 +209,12 @@ __global__ __launch_bounds__(1024, 1) void dw16_kernel(Dw16Args p) {
 #pragma unroll
     for (int j = 0; j < DW16_MAXO; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // per-lane element offsets (inside a stage) of the transposed reads: block row (8 g + bq), column quad 4 bp of the tile
+  // per-lane element offsets (inside a stage) of the transposed reads: block row (4 g + bq), column quad 4 bp of the tile
   int xoff[DW16_MAXI], zoff[DW16_MAXO], zld[DW16_MAXO];
 #pragma unroll
   for (int i = 0; i < DW16_MAXI; ++i) {
     const int ch = min((i0 + i) * 16 + 4 * bp, wx - 4);  // tiles past ni are clamped (read, never used)
-    xoff[i] = (8 * g + bq) * wx + ch;
+    xoff[i] = (4 * g + bq) * wx + ch;
   }
 #pragma unroll
   for (int j = 0; j < DW16_MAXO; ++j) {
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(1024, 1) void dw16_kernel(Dw16Args p) {
     const int w = in_a ? wa : wg;
     const int c = in_a ? min(col - a0, max(wa - 4, 0)) : min(max(col - g0, 0), max(wg - 4, 0));
     zld[j] = w;
-    zoff[j] = (in_a ? offA : offG) + (8 * g + bq) * w + c;
+    zoff[j] = (in_a ? offA : offG) + (4 * g + bq) * w + c;
   }
 
   const int nst = p.nstage;

@@ -378,7 +378,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
       constexpr int G0 = (NT + 1) / 2;  // n-tiles in the first column group (second gets NT - G0)
       static_assert(16 * (G0 * 16 + 4) <= (NSTAGE * STAGE) / WAVES, "epilogue slice too small");
       const bool vec_ok = (p.ldc % 4 == 0) && (EPI != EPI_FWD_HIDDEN || p.ldc2 % 4 == 0);
-      const uint8_t *mslot = reinterpret_cast<const uint8_t *>(lds + NSTAGE * STAGE + wave * MSLOT);
+      uint8_t *mslot = reinterpret_cast<uint8_t *>(lds + NSTAGE * STAGE + wave * MSLOT);
+      // EPI_FWD_HIDDEN: the ReLU-sign bytes of this wave's rows are collected in its LDS slot and leave as whole rows
+      // with 16-byte stores (the rows of a round are contiguous: 16 nm mld bytes from row0 * mld) instead of one
+      // scattered byte store per 4 columns.  Only when this workgroup covers all columns (no column blocks) and the slot
+      // holds the rows.
+      const bool mask_rows = EPI == EPI_FWD_HIDDEN && p.maskb != nullptr && gridDim.y == 1 && 32 * p.mld <= 4 * MSLOT;
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         if (i >= nm) continue;
@@ -419,7 +424,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
                       bits |= ((g4 + t >= p.csplit && g4 + t < p.n_store && v[h][t] > 0.f) ? 1u : 0u) << t;
-                    p.maskb[(size_t)row * p.mld + p.moff + (g4 >> 2)] = (uint8_t)bits;
+                    if (mask_rows) mslot[(i * 16 + rl) * p.mld + p.moff + (g4 >> 2)] = (uint8_t)bits;
+                    else p.maskb[(size_t)row * p.mld + p.moff + (g4 >> 2)] = (uint8_t)bits;
                   }
                 }
                 u16 *zo = reinterpret_cast<u16 *>(p.c2) + (size_t)row * p.ldc2 + col;
@@ -481,7 +487,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
                   bits |= ((col + t >= p.csplit && col + t < p.n_store && v[t] > 0.f) ? 1u : 0u) << t;
-                p.maskb[(size_t)row * p.mld + p.moff + (col >> 2)] = (uint8_t)bits;
+                if (mask_rows) mslot[(i * 16 + rl) * p.mld + p.moff + (col >> 2)] = (uint8_t)bits;
+                else p.maskb[(size_t)row * p.mld + p.moff + (col >> 2)] = (uint8_t)bits;
               }
               if (full && col + 3 < p.csplit) {  // aggregated channels: raw Z for the neighbour gather
                 *reinterpret_cast<f32x4 *>(p.c2 + (size_t)row * p.ldc2 + col) = v;
@@ -516,6 +523,14 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
           }
         }
       }
+      if (mask_rows) {  // sign bytes of this wave's 16 nm rows: one contiguous block, 16 bytes per lane
+        wait_lgkm0();
+        __builtin_amdgcn_wave_barrier();
+        const int nbytes = 16 * nm * p.mld;
+        uint8_t *dstm = p.maskb + (size_t)row0 * p.mld;
+        for (int o = lane * 16; o < nbytes; o += 1024)
+          *reinterpret_cast<f32x4 *>(dstm + o) = *reinterpret_cast<const f32x4 *>(mslot + o);
+      }
     }
     wait_lgkm0();
     __builtin_amdgcn_s_barrier();  // epilogue slices are free again before the next round's DMA
@@ -545,7 +560,7 @@ template <int NT, int EPI>
 static int launch_rowgemm_nt(const RowGemmArgs &a, int grid_y, hipStream_t s) {
   using C = RowGemmCfg<NT>;
   constexpr size_t shmem = (C::NSTAGE * (size_t)(C::WAVES * 2 * 256 + C::BROWS * 16) +
-                            (EPI == EPI_DX_MASK ? C::WAVES * 1024 : 0)) * sizeof(float);
+                            (EPI != EPI_PLAIN ? C::WAVES * 1024 : 0)) * sizeof(float);   // + a sign-byte slot per wave
   static_assert(shmem * C::WG_PER_CU <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
