@@ -437,15 +437,17 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) v[h][t] = (v[h][t] > 0.f || p.no_relu) ? v[h][t] : 0.f;
                   *reinterpret_cast<f32x4 *>(yo) = pack_bf16x8(v[0], v[1]);
-                } else {  // the group that straddles the cut
+                } else {
+                  // The group that straddles the cut goes to BOTH outputs whole: the raw copy's columns >= csplit are
+                  // never gathered (the aggregation stops at csplit), and the activation's columns < csplit are
+                  // overwritten by the aggregation kernel that runs next.  (Element-wise stores here cost 16 divergent
+                  // store instructions per 64 groups for 3 of them.)
+                  *reinterpret_cast<f32x4 *>(zo) = pack_bf16x8(v[0], v[1]);
 #pragma unroll
                   for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                      const int cc = col + 4 * h + t;
-                      if (cc < p.csplit) zo[4 * h + t] = to_bf16(v[h][t]);
-                      else yo[4 * h + t] = to_bf16((v[h][t] > 0.f || p.no_relu) ? v[h][t] : 0.f);
-                    }
+                    for (int t = 0; t < 4; ++t) v[h][t] = (v[h][t] > 0.f || p.no_relu) ? v[h][t] : 0.f;
+                  *reinterpret_cast<f32x4 *>(yo) = pack_bf16x8(v[0], v[1]);
                 }
               } else {  // EPI_DX_MASK
                 const int ur = i * 16 + rl;
@@ -493,6 +495,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
               if (full && col + 3 < p.csplit) {  // aggregated channels: raw Z for the neighbour gather
                 *reinterpret_cast<f32x4 *>(p.c2 + (size_t)row * p.ldc2 + col) = v;
               } else if (full && col >= p.csplit) {  // pass-through channels: ReLU(Z), no bias
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = (v[t] > 0.f || p.no_relu) ? v[t] : 0.f;
+                *reinterpret_cast<f32x4 *>(p.c + (size_t)row * p.ldc + col) = v;
+              } else if (full && col + 4 <= p.ldc2) {
+                // the group that straddles the cut goes to BOTH outputs whole: the raw copy's columns >= csplit are never
+                // gathered, the activation's columns < csplit are overwritten by the aggregation kernel that runs next
+                *reinterpret_cast<f32x4 *>(p.c2 + (size_t)row * p.ldc2 + col) = v;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) v[t] = (v[t] > 0.f || p.no_relu) ? v[t] : 0.f;
                 *reinterpret_cast<f32x4 *>(p.c + (size_t)row * p.ldc + col) = v;
