@@ -21,14 +21,19 @@ void set_error(const char *fmt, ...) {
 
 // 256 bytes of zeros in the code object: source for out-of-range LDS-DMA lanes.
 __device__ float g_zero_page[64];
-static const float *zero_page() {
-  static const float *ptr = nullptr;
-  if (!ptr) {
+static const float *zero_page() {  // the symbol has one address per device
+  static const float *ptr[64] = {};
+  static std::mutex mu;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  const float *&slot = ptr[dev & 63];
+  if (!slot) {
     void *p = nullptr;
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_zero_page)) != hipSuccess) return nullptr;
-    ptr = static_cast<const float *>(p);
+    slot = static_cast<const float *>(p);
   }
-  return ptr;
+  return slot;
 }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

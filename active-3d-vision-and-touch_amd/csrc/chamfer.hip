@@ -510,12 +510,11 @@ __global__ __launch_bounds__(1024) void chamfer_bwd_kernel(const float *__restri
 
 int launch_chamfer_bwd(const float *x, const float *y, int draws, int batch, int p, int q, const int32_t *ixy,
                        const int32_t *iyx, const float *gcd, float *gx, float *gy, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static OncePerDevice once;
+  once.run([] {
     (void)hipFuncSetAttribute((const void *)chamfer_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               kBwdTile * 3 * sizeof(long long));
-    attr_set = true;
-  }
+  });
   const float inv_draws = 1.0f / (float)draws;
   {  // grad_x: targets = the draws*batch predicted clouds, one source each (y[b])
     const int tiles = cdiv(p, kBwdTile), tile = cdiv(p, tiles);

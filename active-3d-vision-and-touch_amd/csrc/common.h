@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <mutex>
+
 namespace a3vt {
 
 void set_error(const char *fmt, ...);
@@ -33,6 +35,24 @@ void set_error(const char *fmt, ...);
       return -2;                                                                          \
     }                                                                                     \
   } while (0)
+
+// Runs `f` once per DEVICE (kernel attributes such as the dynamic-LDS limit belong to the current device's copy of
+// the code object): safe for a process that drives several GPUs from several threads.
+struct OncePerDevice {
+  std::mutex mu;
+  unsigned long long done = 0;
+  template <class F>
+  void run(F &&f) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    std::lock_guard<std::mutex> lock(mu);
+    if (!(done & bit)) {
+      f();
+      done |= bit;
+    }
+  }
+};
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline int pad4(int n) { return (n + 3) & ~3; }

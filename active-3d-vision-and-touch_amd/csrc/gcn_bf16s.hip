@@ -315,11 +315,8 @@ int launch_dw16(const Dw16Args &a, hipStream_t s) {
     return -1;
   }
   const size_t shmem = (size_t)args.nstage * worst * 1024;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void *)dw16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  static OncePerDevice once;
+  once.run([] { (void)hipFuncSetAttribute((const void *)dw16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
   A3VT_LAUNCH(dw16_kernel, dim3(dw16_num_slabs(a.n_out), ngrp), dim3(1024), shmem, s, args);
   A3VT_CHECK_LAUNCH();
   return 0;
@@ -412,10 +409,8 @@ __device__ __forceinline__ void csr16_fwd_store(const F8 &acc, int ch, int c, co
     for (int t = 0; t < 8; ++t)
       if (ch + t < c) yo[t] = bf16_of(f8_get(o, t));
   }
-  if (mrow) {
-    mrow[ch >> 2] = (uint8_t)(bits & 15u);
-    mrow[(ch >> 2) + 1] = (uint8_t)(bits >> 4);
-  }
+  // two sign bytes (4 channels each) in one 2-byte store: ch is a multiple of 8 and the mask rows have even length
+  if (mrow) *reinterpret_cast<u16 *>(mrow + (ch >> 2)) = (u16)((bits & 15u) | ((bits >> 4) << 8));
 }
 
 __global__ __launch_bounds__(256) void csr16_fwd_kernel(const u16 *__restrict__ za, int ldza,

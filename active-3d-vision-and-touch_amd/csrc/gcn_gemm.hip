@@ -571,16 +571,15 @@ static int launch_rowgemm_nt(const RowGemmArgs &a, int grid_y, hipStream_t s) {
   constexpr size_t shmem = (C::NSTAGE * (size_t)(C::WAVES * 2 * 256 + C::BROWS * 16) +
                             (EPI != EPI_PLAIN ? C::WAVES * 1024 : 0)) * sizeof(float);   // + a sign-byte slot per wave
   static_assert(shmem * C::WG_PER_CU <= 160 * 1024, "LDS budget");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static OncePerDevice once;
+  once.run([] {
     (void)hipFuncSetAttribute((const void *)rowgemm_kernel<NT, EPI, C::NSTAGE, C::WAVES, 0>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     (void)hipFuncSetAttribute((const void *)rowgemm_kernel<NT, EPI, C::NSTAGE, C::WAVES, 1>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     (void)hipFuncSetAttribute((const void *)rowgemm_kernel<NT, EPI, C::NSTAGE, C::WAVES, 2>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    attr_set = true;
-  }
+  });
   const int tiles = cdiv(a.m, 16);
   const int max_wg = 256 * C::WG_PER_CU;
   // one tile per wave until every CU has a workgroup; beyond that the kernel deals tiles evenly (two per wave per round)
@@ -1126,13 +1125,12 @@ int launch_dw(const DwArgs &a, hipStream_t s) {
     return -1;
   }
   const size_t shmem = (size_t)args.nstage * worst * 1024;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static OncePerDevice once;
+  once.run([] {
     (void)hipFuncSetAttribute((const void *)dw_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)dw_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)dw_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  });
   // fast path: every wave owns 4-5 input tiles and 2-3 output tiles (true for 300 x 300)
   const int tin = cdiv(a.k_in, 16), tout = cdiv(a.n_out, 16), groups = dw_col_groups(a.n_out);
   const bool fast = tin / 4 >= 4 && tin <= 20 && (tout / groups) / 4 >= 2 && cdiv(tout, groups) <= 12;

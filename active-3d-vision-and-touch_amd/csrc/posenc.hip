@@ -435,12 +435,11 @@ int launch_posenc_bwd(const float *verts, const float *mask, int m, int input_si
     return -1;
   }
   const int nslab = posenc_num_slabs(m);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static OncePerDevice once;
+  once.run([] {
     (void)hipFuncSetAttribute((const void *)posenc_bwd_kernel<50>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)posenc_bwd_smem<50>());
-    attr_set = true;
-  }
+  });
   A3VT_LAUNCH((posenc_bwd_kernel<50>), dim3(nslab), dim3(kPEBwdThreads), posenc_bwd_smem<50>(), s, verts, mask, m,
               params, gfeats, ld, gverts, scratch);
   A3VT_CHECK_LAUNCH();

@@ -222,12 +222,11 @@ __global__ __launch_bounds__(1024) void sample_bwd_kernel(const int32_t *__restr
 int launch_sample_bwd(const int32_t *faces, int batch, int n_vert, int n_faces, int draws, int num, const int32_t *fi,
                       const float *u, const float *v, const float *gpoints, float *gverts, hipStream_t s) {
   (void)n_faces;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static OncePerDevice once;
+  once.run([] {
     (void)hipFuncSetAttribute((const void *)sample_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               kSampleBwdTile * 3 * sizeof(long long));
-    attr_set = true;
-  }
+  });
   const int tiles = cdiv(n_vert, kSampleBwdTile), tile = cdiv(n_vert, tiles);
   A3VT_LAUNCH(sample_bwd_kernel, dim3(batch, tiles), dim3(1024), (size_t)tile * 3 * sizeof(long long), s, faces, batch,
               n_vert, draws, num, fi, u, v, gpoints, gverts);

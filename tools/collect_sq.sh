@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ-level PMC counters of the hot kernels (run on the GPU box):  tools/collect_sq.sh
+# SQ-level PMC counters of the hot kernels (run on the GPU box):  tools/collect_sq.sh [--precision bf16s]
 # One --pmc pass with the 8 SQ slots + GRBM_GUI_ACTIVE (MI355X_MICROARCH.md "rocprofv3 PMC slots"); kernel-trace only.
 # Writes gpurun_out/sq/*.csv and gpurun_out/sq/summary.json (copy to profiles/ to keep).
 set -e
@@ -9,14 +9,14 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
   SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pass \
-  -- python $ROOT/tools/stack_bench.py --layers 4 --reps 2 > $OUT/run.log 2>&1 || { tail -5 $OUT/run.log; exit 1; }
+  -- python $ROOT/tools/stack_bench.py --layers 4 --reps 2 "$@" > $OUT/run.log 2>&1 || { tail -5 $OUT/run.log; exit 1; }
 python - <<PY
 import csv, glob, collections, json
 f = glob.glob("$OUT/pass/*/*counter_collection.csv")[0]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"].split("(")[0]
-    if any(t in k for t in ("rowgemm", "dw_kernel", "csr_", "slab", "thin_")):
+    if any(t in k for t in ("rowgemm", "dw_kernel", "dw16", "csr", "slab", "thin")):
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for k, d in agg.items():
