@@ -48,7 +48,12 @@ __device__ __forceinline__ s16x4 cvt_bf16x4(f32x4 v) {
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using u16 = unsigned short;
 __device__ __forceinline__ f32x4 mfma_bf16s(f32x4 a, f32x4 b, f32x4 c) {
+#ifdef A3VT_DBG_RG_NOMFMA
+  c[0] += a[0] * b[0];   // one VALU op instead of the matrix instruction (operands stay live)
+  return c;
+#else
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#endif
 }
 __device__ __forceinline__ u16 to_bf16(float v) {  // round to nearest even (v_cvt_pk_bf16_f32)
   const bf16x2 r = __builtin_convertvector((f32x2){v, 0.f}, bf16x2);
@@ -232,6 +237,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
     // One DMA wave-instruction of a chunk: pieces [0, A_INSTR) are this wave's A tiles, the rest its share of Bt.
     auto issue_piece = [&](int chunk, int buf, int piece) {
       const int kk = chunk * 16 + kpiece;
+#ifdef A3VT_DBG_RG_NOA   // timing-only ablations (tools/build_variants.sh rowgemm): results are wrong by design
+      if (piece < A_INSTR) return;
+#endif
+#ifdef A3VT_DBG_RG_NOB
+      if (piece >= A_INSTR) return;
+#endif
       if (piece < A_INSTR) {
         float *sA = lds + buf * STAGE + wave * (MT * 256);
         const float *src =
@@ -373,7 +384,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
     // of one column, so direct stores would be 64-byte fragments.  Each wave transposes its accumulators through
     // a private slice of the idle ring and moves whole rows with 16-byte accesses; the fused ReLU / raw-Z split
     // (forward) and the ReLU-sign multiply (backward, bytes already in LDS) happen on the way out.
+#ifdef A3VT_DBG_RG_NOEPI
+    if (active && acc[0][0][0] == 1.2345e-33f) {   // never true in practice: keeps the accumulators alive, skips the epilogue
+#else
     if (active) {
+#endif
       float *ep = lds + wave * ((NSTAGE * STAGE) / WAVES);
       constexpr int G0 = (NT + 1) / 2;  // n-tiles in the first column group (second gets NT - G0)
       static_assert(16 * (G0 * 16 + 4) <= (NSTAGE * STAGE) / WAVES, "epilogue slice too small");
@@ -413,6 +428,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
               if (row >= p.m || col >= p.ldc) continue;
               f32x4 v[2] = {*reinterpret_cast<const f32x4 *>(ep + rl * stride + c8 * 8),
                             *reinterpret_cast<const f32x4 *>(ep + rl * stride + c8 * 8 + 4)};
+#ifdef A3VT_DBG_RG_NOSTORE   // timing-only: the LDS transposition runs, the global stores do not
+              if (v[0][0] != 1.2345e-33f) continue;
+#endif
               u16 *yo = reinterpret_cast<u16 *>(p.c) + (size_t)row * p.ldc + col;
               if (EPI == EPI_FWD_HIDDEN) {
                 if (p.maskb) {
@@ -474,6 +492,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
             const int col = col0 + j0 * 16 + c4 * 4;
             if (row >= p.m || col >= p.n_store) continue;
             f32x4 v = *reinterpret_cast<const f32x4 *>(ep + rl * stride + c4 * 4);
+#ifdef A3VT_DBG_RG_NOSTORE
+            if (v[0] != 1.2345e-33f) continue;
+#endif
             const bool full = vec_ok && col + 3 < p.n_store;
             if (EPI == EPI_PLAIN) {
               float *dst = p.c + (size_t)row * p.ldc + col;
@@ -581,7 +602,8 @@ static int launch_rowgemm_nt(const RowGemmArgs &a, int grid_y, hipStream_t s) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
   });
   const int tiles = cdiv(a.m, 16);
-  const int max_wg = 256 * C::WG_PER_CU;
+  static const int env_wg = getenv("A3VT_RG_MAXWG") ? atoi(getenv("A3VT_RG_MAXWG")) : 0;  // developer override (experiments)
+  const int max_wg = env_wg > 0 ? env_wg : 256 * C::WG_PER_CU;
   // one tile per wave until every CU has a workgroup; beyond that the kernel deals tiles evenly (two per wave per round)
   const int grid = cdiv(tiles, C::WAVES) < max_wg ? cdiv(tiles, C::WAVES) : max_wg;
   if (a.bf16 == 2)

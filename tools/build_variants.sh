@@ -5,11 +5,23 @@ cd "$(dirname "$0")/../active-3d-vision-and-touch_amd/csrc"
 mkdir -p ../../gpurun_variants
 build() { # name flags...
   local name=$1; shift
-  hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared "$@" capi.hip gcn_gemm.hip gcn_csr.hip posenc.hip sample.hip chamfer.hip pooling.hip -o ../../gpurun_variants/liba3vt_$name.so
+  hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared "$@" capi.hip gcn_gemm.hip gcn_csr.hip gcn_bf16s.hip posenc.hip sample.hip -fno-slp-vectorize chamfer.hip pooling.hip -o ../../gpurun_variants/liba3vt_$name.so
 }
+if [ "$1" = "rowgemm" ]; then   # rowgemm_kernel ablations (all gemm modes): python tools/stack_bench.py with A3VT_LIB=...
+  build RG_NOEPI -DA3VT_DBG_RG_NOEPI &
+  build RG_NOA -DA3VT_DBG_RG_NOA &
+  build RG_NOB -DA3VT_DBG_RG_NOB &
+  build RG_NODMA -DA3VT_DBG_RG_NOA -DA3VT_DBG_RG_NOB &
+  wait
+  build RG_NOMFMA -DA3VT_DBG_RG_NOMFMA &
+  build RG_NOSTORE -DA3VT_DBG_RG_NOSTORE &
+  build RG_NODMA_NOEPI -DA3VT_DBG_RG_NOA -DA3VT_DBG_RG_NOB -DA3VT_DBG_RG_NOEPI &
+  wait
+else
 build V1 -DA3VT_DBG_NODMA &
 build V2 -DA3VT_DBG_NOLDSREAD &
 build V3 -DA3VT_DBG_NOBARRIER &
 build V4 -DA3VT_DBG_NODMA -DA3VT_DBG_NOEPI -DA3VT_DBG_NOLDSREAD -DA3VT_DBG_NOBARRIER &
 wait
+fi
 ls ../../gpurun_variants

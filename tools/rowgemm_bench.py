@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 from a3vt_amd import lib, ops  # noqa: E402
 
-M, K, N = 64 * 2562, 300, 300
+M, K, N = int(os.environ.get('ROWS', 64 * 2562)), 300, 300
 dev = torch.device("cuda", 0)
 zero = os.environ.get("ZERO", "0") == "1"
 BF16 = 1 if os.environ.get("BF16", "0") == "1" else 0   # operand mode (a3vt.h: gemm_bf16)
