@@ -11,7 +11,6 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -24,7 +23,7 @@ def main():
     p.add_argument("--batch", type=int, default=64)
     p.add_argument("--points", type=int, default=10000)
     a = p.parse_args()
-    from helpers import make_args
+    from a3vt_amd.synthetic import make_args
     from a3vt_amd import distributed as adist, mesh as amesh
     from a3vt_amd.pterotactyl.reconstruction.vision import model
     from a3vt_amd.pterotactyl.utility import utils

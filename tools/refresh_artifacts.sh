@@ -1,11 +1,25 @@
+#!/bin/bash
+# One pass over everything under profiles/ that a kernel change can move (run on the GPU box from the repo root; ~6 min):
+#   tools/refresh_artifacts.sh r02      -> gpurun_out/refresh/r02_*   (copy what should be kept into profiles/)
 set -x
+R=${1:-r02}
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/refresh
-python bench.py > gpurun_out/refresh/bench.json 2> gpurun_out/refresh/bench.err
-tail -c 600 gpurun_out/refresh/bench.json
-python tools/measure_protocol.py > gpurun_out/refresh/protocol.log 2>&1; tail -3 gpurun_out/refresh/protocol.log
-(cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/bstats && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bstats -- python $GRAFT_REPO_ROOT/bench.py --steps 15 > /tmp/bstats.log 2>&1; cp $(find /tmp/bstats -name '*kernel_stats.csv' | head -1) $GRAFT_REPO_ROOT/gpurun_out/refresh/kernel_stats.csv; tail -c 300 /tmp/bstats.log)
-python bench.py --gemm-precision bf16 --no-cpu-baseline > gpurun_out/refresh/bench_bf16.json 2>/dev/null; tail -c 400 gpurun_out/refresh/bench_bf16.json
-python tools/named_configs.py > gpurun_out/refresh/named.jsonl 2> gpurun_out/refresh/named.err; cat gpurun_out/refresh/named.jsonl | cut -c 1-300
-python tools/touch_bench.py > gpurun_out/refresh/touch.log 2>&1; tail -3 gpurun_out/refresh/touch.log
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 2>/dev/null | tail -c 400
+O=$GRAFT_REPO_ROOT/gpurun_out/refresh
+mkdir -p $O
+python bench.py > $O/${R}_bench_default.json 2> $O/bench.err
+tail -c 700 $O/${R}_bench_default.json
+python bench.py --gemm-precision bf16s --no-cpu-baseline > $O/${R}_bench_bf16s.json 2>/dev/null; tail -c 400 $O/${R}_bench_bf16s.json
+python bench.py --gemm-precision bf16 --no-cpu-baseline > $O/${R}_bench_bf16_operand_mode.json 2>/dev/null; tail -c 400 $O/${R}_bench_bf16_operand_mode.json
+python tools/measure_protocol.py > $O/${R}_timing_protocol.json 2> $O/protocol.err; tail -c 400 $O/${R}_timing_protocol.json
+python tools/named_configs.py > $O/${R}_named_configs.jsonl 2> $O/named.err; cut -c 1-300 $O/${R}_named_configs.jsonl
+python tools/named_configs.py --precision bf16 >> $O/${R}_named_configs.jsonl 2>> $O/named.err
+python tools/touch_bench.py > $O/${R}_touch_topology_step.log 2>&1; tail -3 $O/${R}_touch_topology_step.log
+(cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/bstats && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bstats -- python $GRAFT_REPO_ROOT/bench.py --steps 15 --warmup 5 --no-cpu-baseline --no-traffic > /tmp/bstats.log 2>&1; cp $(find /tmp/bstats -name '*kernel_stats.csv' | head -1) $O/${R}_bench_kernel_stats.csv; tail -c 300 /tmp/bstats.log)
+(cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/bstats2 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bstats2 -- python $GRAFT_REPO_ROOT/bench.py --steps 15 --warmup 5 --no-cpu-baseline --no-traffic --gemm-precision bf16s > /tmp/bstats2.log 2>&1; cp $(find /tmp/bstats2 -name '*kernel_stats.csv' | head -1) $O/${R}_bench_bf16s_kernel_stats.csv)
+(cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/c3 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/c3 -- python $GRAFT_REPO_ROOT/tools/named_configs.py --only 3 --steps 5 > /tmp/c3.log 2>&1; cp $(find /tmp/c3 -name '*kernel_stats.csv' | head -1) $O/${R}_config3_bf16s_kernel_stats.csv)
+bash tools/collect_traffic.sh > $O/traffic.log 2>&1; cp gpurun_out/traffic/summary.json $O/${R}_pmc_traffic_summary.json
+bash tools/collect_sq.sh > $O/sq.log 2>&1; cp gpurun_out/sq/summary.json $O/${R}_pmc_sq_summary.json
+bash tools/collect_sq.sh --precision bf16s > $O/sq16.log 2>&1; cp gpurun_out/sq/summary.json $O/${R}_pmc_sq_summary_bf16s.json
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-traffic 2>/dev/null | tail -c 400
+python tools/kstats_summary.py $O/${R}_bench_kernel_stats.csv 22 16
+python tools/kstats_summary.py $O/${R}_bench_bf16s_kernel_stats.csv 22 12

@@ -10,7 +10,6 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import torch  # noqa: E402
 
@@ -22,7 +21,7 @@ def main():
     p.add_argument("--points", type=int, default=10000)
     p.add_argument("--reps", type=int, default=3)
     a = p.parse_args()
-    from helpers import make_args, random_cloud
+    from a3vt_amd.synthetic import gt_cloud, make_args
     from a3vt_amd.pterotactyl.policies import scoring
     from a3vt_amd.pterotactyl.reconstruction.vision import model
     from a3vt_amd.pterotactyl.utility import utils
@@ -34,7 +33,7 @@ def main():
     E, K = a.env, a.candidates
     g = torch.Generator().manual_seed(1)
     img = torch.zeros(E, 1)
-    gt = random_cloud(E, a.points, 3).to(dev)
+    gt = gt_cloud(E, a.points, 3).to(dev)
     charts_list = []
     for k in range(K):
         tc = torch.zeros(E, 5, 25, 4)

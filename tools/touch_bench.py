@@ -8,12 +8,11 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 
 
 def main():
-    from helpers import make_args
+    from a3vt_amd.synthetic import make_args
     from a3vt_amd import distributed as adist
     from a3vt_amd.pterotactyl.reconstruction.vision import model
     from a3vt_amd.pterotactyl.utility import utils
