@@ -389,14 +389,15 @@ __device__ __forceinline__ F8 gather_row16(const u16 *__restrict__ base, long lo
   return acc;
 }
 
-// forward epilogue of one vertex's 8-channel group: bias, ReLU, sign bytes, bf16 store of the channels < c
-__device__ __forceinline__ void csr16_fwd_store(const F8 &acc, int ch, int c, const float *__restrict__ bias, int relu,
+// forward epilogue of one vertex's 8-channel group: bias (this lane's 8 values, zero past c), ReLU, sign bytes, bf16
+// store of the channels < c
+__device__ __forceinline__ void csr16_fwd_store(const F8 &acc, int ch, int c, const F8 &bs, int relu,
                                                 u16 *__restrict__ yo, uint8_t *__restrict__ mrow) {
   F8 o;
   unsigned bits = 0;
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
-    const float pre = ch + t < c ? f8_get(acc, t) + bias[ch + t] : 0.f;
+    const float pre = ch + t < c ? f8_get(acc, t) + f8_get(bs, t) : 0.f;
     const float out = (pre > 0.f || !relu) ? pre : 0.f;
     bits |= (pre > 0.f ? 1u : 0u) << t;
     if (t < 4) o.lo[t] = out;
@@ -412,6 +413,16 @@ __device__ __forceinline__ void csr16_fwd_store(const F8 &acc, int ch, int c, co
   // two sign bytes (4 channels each) in one 2-byte store: ch is a multiple of 8 and the mask rows have even length
   if (mrow) *reinterpret_cast<u16 *>(mrow + (ch >> 2)) = (u16)((bits & 15u) | ((bits >> 4) << 8));
 }
+__device__ __forceinline__ F8 csr16_load_bias(const float *__restrict__ bias, int ch, int c) {
+  F8 b;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const float v = ch + t < c ? bias[ch + t] : 0.f;
+    if (t < 4) b.lo[t] = v;
+    else b.hi[t - 4] = v;
+  }
+  return b;
+}
 
 __global__ __launch_bounds__(256) void csr16_fwd_kernel(const u16 *__restrict__ za, int ldza,
                                                         const float *__restrict__ bias, int c,
@@ -422,6 +433,9 @@ __global__ __launch_bounds__(256) void csr16_fwd_kernel(const u16 *__restrict__ 
                                                         int mld, int relu, int heavy_thresh) {
   const int hl = threadIdx.x & 15, sub = threadIdx.x >> 4;
   const XcdWalk16 w(batch, n_vert);
+  // this lane's bias values stay in registers (c <= 128: one channel pass): loading them per vertex put 8 loads and a
+  // full vmcnt wait — which also waits for the previous vertex's stores — behind every gather
+  const F8 bs0 = csr16_load_bias(bias, hl * 8, c);
   for (long long g = w.nloc; g < w.ngroups; g += w.stride) {
     long long b;
     int v;
@@ -434,7 +448,13 @@ __global__ __launch_bounds__(256) void csr16_fwd_kernel(const u16 *__restrict__ 
       const int ch = ch0 + hl * 8;
       const bool on = ch < c;
       const F8 acc = gather_row16(zb, ldza, ch, on, e0, e1, hl, colidx, val);
-      if (on) csr16_fwd_store(acc, ch, c, bias, relu, y + row * ldy + ch, maskb ? maskb + row * mld : nullptr);
+#ifdef A3VT_DBG_CSR_NOSTORE   // timing-only ablation (tools/build_variants.sh csr): every gathered value stays live, nothing is stored
+      if (on && acc.lo[0] + acc.lo[1] + acc.lo[2] + acc.lo[3] + acc.hi[0] + acc.hi[1] + acc.hi[2] + acc.hi[3] == 1.2345e-33f)
+#else
+      if (on)
+#endif
+        csr16_fwd_store(acc, ch, c, c <= 128 ? bs0 : csr16_load_bias(bias, ch, c), relu, y + row * ldy + ch,
+                        maskb ? maskb + row * mld : nullptr);
     }
   }
 }
@@ -473,7 +493,7 @@ __global__ __launch_bounds__(256) void csr16_heavy_kernel(const u16 *__restrict_
         }
         u16 *o = dst + row * ld_dst + ch;
         if (MODE == 0) {
-          csr16_fwd_store(acc, ch, c, bias, relu, o, maskb ? maskb + row * mld : nullptr);
+          csr16_fwd_store(acc, ch, c, csr16_load_bias(bias, ch, c), relu, o, maskb ? maskb + row * mld : nullptr);
         } else {
           const F8 own = unpack8(*reinterpret_cast<const u32x4 *>(sb + (long long)v * ld_src + ch));
           F8 out;

@@ -193,6 +193,9 @@ __global__ __launch_bounds__(256) void csr_fwd_kernel(const float *__restrict__ 
       const bool on = ch < c;
       const f32x4 acc = gather_row(zb, ldza, ch, on, e0, e1, hl, colidx, val);
       if (!on) continue;
+#ifdef A3VT_DBG_CSR_NOSTORE   // timing-only ablation (tools/build_variants.sh csr): every gathered value stays live, nothing is stored
+      if (acc[0] + acc[1] + acc[2] + acc[3] != 1.2345e-33f) continue;
+#endif
       float *yo = y + row * ldy + ch;
       unsigned bits = 0;
       f32x4 o;
