@@ -15,7 +15,7 @@ root).  Layout:
 """
 from . import lib, mesh  # noqa: F401
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"
 
 
 def install_as_pterotactyl():

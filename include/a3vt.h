@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define A3VT_VERSION 100 /* 0.1.0 */
+#define A3VT_VERSION 110 /* 0.2.0: bf16 storage mode (gemm_bf16 = 2), a3vt_gcn_stack_stash_bytes / _scratch_bytes_mode, deterministic backward scatters */
 
 int a3vt_version(void);
 const char *a3vt_last_error(void);
