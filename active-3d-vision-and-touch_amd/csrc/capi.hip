@@ -995,8 +995,22 @@ size_t a3vt_chamfer_scratch_bytes(int draws, int batch, int p, int q) {
 int a3vt_chamfer_fwd(const float *x, const float *y, int draws, int batch, int p, int q, float *dist_xy,
                      int32_t *idx_xy, float *dist_yx, int32_t *idx_yx, float *cd, void *scratch, void *stream) {
   A3VT_CHECK_ARG(x && y && dist_xy && idx_xy && dist_yx && idx_yx && cd);
+  // brute force only: the scratch of this entry point is a3vt_chamfer_scratch_bytes() (the column minima of the sweep)
   return launch_chamfer_fwd(x, y, draws, batch, p, q, dist_xy, idx_xy, dist_yx, idx_yx, cd, scratch,
-                            static_cast<hipStream_t>(stream));
+                            scratch ? a3vt_chamfer_scratch_bytes(draws, batch, p, q) : 0,
+                            scratch ? NN_BRUTE_SWEEP : NN_BRUTE_TWO_PASS, static_cast<hipStream_t>(stream));
+}
+
+size_t a3vt_chamfer_workspace_bytes(int draws, int batch, int p, int q) {
+  return draws > 0 && batch > 0 && p > 0 && q > 0 ? chamfer_workspace_bytes(draws, batch, p, q) : 0;
+}
+
+int a3vt_chamfer_fwd_ws(const float *x, const float *y, int draws, int batch, int p, int q, float *dist_xy,
+                        int32_t *idx_xy, float *dist_yx, int32_t *idx_yx, float *cd, void *workspace,
+                        size_t workspace_bytes, int algo, void *stream) {
+  A3VT_CHECK_ARG(x && y && dist_xy && idx_xy && dist_yx && idx_yx && cd);
+  return launch_chamfer_fwd(x, y, draws, batch, p, q, dist_xy, idx_xy, dist_yx, idx_yx, cd, workspace,
+                            workspace ? workspace_bytes : 0, algo, static_cast<hipStream_t>(stream));
 }
 
 int a3vt_chamfer_bwd(const float *x, const float *y, int draws, int batch, int p, int q, const int32_t *idx_xy,

@@ -412,13 +412,37 @@ __global__ __launch_bounds__(1024) void chamfer_reduce_kernel(const float *__res
   if (threadIdx.x == 0) cd[b] = total / (float)draws;
 }
 
+size_t chamfer_workspace_bytes(int draws, int batch, int p, int q) {
+  const size_t a = chamfer_scratch_bytes(draws, batch, q), b = nn_pruned_workspace_bytes(draws, batch, p, q);
+  return a > b ? a : b;
+}
+
 int launch_chamfer_fwd(const float *x, const float *y, int draws, int batch, int p, int q, float *dxy, int32_t *ixy,
-                       float *dyx, int32_t *iyx, float *cd, void *scratch, hipStream_t s) {
+                       float *dyx, int32_t *iyx, float *cd, void *scratch, size_t scratch_bytes, int algo, hipStream_t s) {
   if (p <= 0 || q <= 0 || draws <= 0 || batch <= 0) {
     set_error("chamfer_fwd: empty input (draws=%d batch=%d p=%d q=%d)", draws, batch, p, q);
     return -1;
   }
-  if (scratch && (long long)cdiv(p, 256 * 3) * 4 < (1 << 26)) {
+  if (algo < NN_AUTO || algo > NN_PRUNED) {
+    set_error("chamfer_fwd: unknown search algorithm %d", algo);
+    return -1;
+  }
+  const bool fits_pruned = scratch && scratch_bytes >= nn_pruned_workspace_bytes(draws, batch, p, q);
+  const bool fits_sweep = scratch && scratch_bytes >= chamfer_scratch_bytes(draws, batch, q) &&
+                          (long long)cdiv(p, 256 * 3) * 4 < (1 << 26);
+  if ((algo == NN_PRUNED && !fits_pruned) || (algo == NN_BRUTE_SWEEP && !fits_sweep)) {
+    set_error("chamfer_fwd: workspace of %zu bytes is too small for search algorithm %d", scratch_bytes, algo);
+    return -1;
+  }
+  if (algo == NN_AUTO) {
+    // the sort and the per-wave block scan pay for themselves from a couple of thousand points per cloud on
+    static const int env = getenv("A3VT_NN_ALGO") ? atoi(getenv("A3VT_NN_ALGO")) : 0;   // developer override
+    if (env == NN_BRUTE_TWO_PASS || (env == NN_BRUTE_SWEEP && fits_sweep) || (env == NN_PRUNED && fits_pruned)) algo = env;
+    else algo = (fits_pruned && p >= 2048 && q >= 2048) ? NN_PRUNED : fits_sweep ? NN_BRUTE_SWEEP : NN_BRUTE_TWO_PASS;
+  }
+  if (algo == NN_PRUNED) {
+    if (int rc = launch_nn_pruned(x, y, draws, batch, p, q, dxy, ixy, dyx, iyx, scratch, s)) return rc;
+  } else if (algo == NN_BRUTE_SWEEP) {
     // one pass over the distance matrix for both directions (rows = predicted clouds, columns = ground truth)
     if (int rc = launch_nn2(x, p, y, q, batch, draws * batch, dxy, ixy, dyx, iyx, scratch, s)) return rc;
   } else {

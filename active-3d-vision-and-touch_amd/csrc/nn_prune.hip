@@ -1,0 +1,356 @@
+// nn_prune.hip — EXACT squared-L2 nearest neighbour with spatial pruning (gfx950).
+//
+// Same results, bit for bit, as the brute-force searches of chamfer.hip (every distance is the same fma chain
+// fma(dz,dz, fma(dy,dy, dx*dx)) with d = query - candidate, and ties go to the lowest candidate index), i.e. as
+// pytorch3d.ops.knn_points(K=1) behind pytorch3d.loss.chamfer_distance (utility/utils.py:207,212) — but a query only
+// meets the candidates that can still beat what it has:
+//
+//   1. nn_sort_kernel   one workgroup per cloud: bounding box, a G^3 grid over it (G = 16, 32 above 20k points), a counting
+//                       sort of the points by the Morton code of their cell (histogram and cursors in LDS).  The sorted
+//                       cloud is stored as float4 (x, y, z, original index): 64 consecutive points — a "block" — are a
+//                       compact patch of the surface.
+//   2. nn_boxes_kernel  the axis-aligned bounding box of every block (one wave each); pads the last block.
+//   3. nn_query_kernel  one wave per block of 64 sorted QUERIES (one per lane, so the lanes of a wave ask about the same
+//                       neighbourhood).  The wave tests the candidate blocks 64 at a time, lane-parallel, box against
+//                       box; a block survives if its box-to-box lower bound does not exceed the worst "best so far" of
+//                       the wave, is then tested per lane (point to box) and evaluated — 64 candidates broadcast through
+//                       the scalar cache, 6.5 VALU operations per pair as in the brute-force loop — only if some lane can
+//                       still improve.  Every bound is computed with the same monotone floating-point operations as the
+//                       distances themselves (differences, products, fma), so bound <= distance holds for the COMPUTED
+//                       values and pruning with "bound > best" can never drop a candidate that ties or wins.
+//                       The arg-min is kept per 16-candidate group in the hot loop and resolved afterwards by rescanning
+//                       that group for the lowest original index; if another group tied the minimum exactly (duplicate
+//                       points), the wave rescans every block that can hold the distance — rare, and exact.
+//
+// Work per query is roughly constant (a dozen blocks) instead of proportional to the cloud: 10k-point clouds 4x fewer
+// instructions than the single-sweep brute force, 25k / 50k points 10-20x.  All kernels are deterministic in their
+// outputs (the order of points inside a grid cell depends on LDS atomics, the minima do not).
+#include <stdlib.h>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace a3vt {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kPB = 64;                 // points per block = lanes per wave
+constexpr float kPadCoord = 1.0e18f;    // coordinates of the pad entries of a cloud's last block (never a minimum)
+constexpr int kSortThreads = 1024;
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+// (__builtin_bit_cast applied directly to an element of an ext_vector reads element 0 with this compiler: go through
+// a by-value argument)
+__device__ __forceinline__ int as_int(float v) { return __builtin_bit_cast(int, v); }
+__device__ __forceinline__ float sq3(float dx, float dy, float dz) {
+  return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));   // the distance arithmetic of chamfer.hip
+}
+// distance between the intervals [qlo, qhi] and [tlo, thi] (0 if they overlap); <= |q - c| for q, c inside them, also
+// as computed: fp subtraction is monotone
+__device__ __forceinline__ float gap(float qlo, float qhi, float tlo, float thi) {
+  return fmaxf(fmaxf(tlo - qhi, qlo - thi), 0.f);
+}
+__device__ __forceinline__ unsigned spread3(unsigned v) {   // 10 bits -> every third bit
+  v &= 0x3ffu;
+  v = (v | (v << 16)) & 0x030000ffu;
+  v = (v | (v << 8)) & 0x0300f00fu;
+  v = (v | (v << 4)) & 0x030c30c3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+
+struct NNClouds {   // the clouds of one Chamfer call: nx predicted clouds of p points, ny ground-truth clouds of q
+  const float *x, *y;
+  int p, q, nx, ny;
+  int npx, npy;     // padded points per cloud (multiple of 64)
+  f32x4 *sx, *sy;   // sorted clouds  [n?][np?]
+  f32x4 *bx, *by;   // block boxes    [n?][np?/64][2]  (min xyz 0, max xyz 0)
+};
+
+__host__ __device__ inline int nn_grid_bits(int n) { return n > 20000 ? 5 : 4; }
+
+__global__ __launch_bounds__(kSortThreads) void nn_sort_kernel(NNClouds c) {
+  extern __shared__ unsigned hist[];   // G^3 counters, then cursors
+  __shared__ float red[6][16];
+  __shared__ unsigned wsum[16];
+  const int cloud = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool isx = cloud < c.nx;
+  const int n = isx ? c.p : c.q;
+  const float *P = isx ? c.x + (size_t)cloud * c.p * 3 : c.y + (size_t)(cloud - c.nx) * c.q * 3;
+  f32x4 *out = isx ? c.sx + (size_t)cloud * c.npx : c.sy + (size_t)(cloud - c.nx) * c.npy;
+  const int bits = nn_grid_bits(n), G = 1 << bits, cells = G * G * G;
+
+  float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (int i = tid; i < n; i += kSortThreads) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const float v = P[i * 3 + d];
+      mn[d] = fminf(mn[d], v);
+      mx[d] = fmaxf(mx[d], v);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    mn[d] = wave_min(mn[d]);
+    mx[d] = wave_max(mx[d]);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) red[d][wave] = mn[d], red[3 + d][wave] = mx[d];
+  }
+  for (int i = tid; i < cells; i += kSortThreads) hist[i] = 0;
+  __syncthreads();
+  float scale[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    float a = red[d][0], b = red[3 + d][0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) a = fminf(a, red[d][w]), b = fmaxf(b, red[3 + d][w]);
+    mn[d] = a;
+    const float ext = b - a;
+    scale[d] = (ext > 0.f && ext < 3.0e38f) ? (float)G / ext : 0.f;   // degenerate / non-finite extent: one cell
+  }
+  auto key_of = [&](int i) {
+    unsigned k = 0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const float t = fminf(fmaxf((P[i * 3 + d] - mn[d]) * scale[d], 0.f), (float)(G - 1));   // NaN -> 0
+      k |= spread3((unsigned)(int)t) << d;
+    }
+    return k;
+  };
+  for (int i = tid; i < n; i += kSortThreads) atomicAdd(&hist[key_of(i)], 1u);
+  __syncthreads();
+  // exclusive scan of the counters: `per` consecutive cells per thread, then a scan of the 1024 partial sums
+  const int per = cells / kSortThreads;   // 4 or 32
+  unsigned local = 0;
+  for (int k = 0; k < per; ++k) local += hist[tid * per + k];
+  unsigned incl = local;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned o = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += o;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  unsigned base = incl - local;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  for (int k = 0; k < per; ++k) {
+    const unsigned t = hist[tid * per + k];
+    hist[tid * per + k] = base;
+    base += t;
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += kSortThreads) {
+    const unsigned pos = atomicAdd(&hist[key_of(i)], 1u);
+    out[pos] = f32x4{P[i * 3 + 0], P[i * 3 + 1], P[i * 3 + 2], __builtin_bit_cast(float, i)};
+  }
+}
+
+// grid = (ceil(blocks / 16), clouds), 16 waves per workgroup, one block of 64 sorted points per wave
+__global__ __launch_bounds__(1024) void nn_boxes_kernel(NNClouds c) {
+  const int cloud = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool isx = cloud < c.nx;
+  const int n = isx ? c.p : c.q, np = isx ? c.npx : c.npy;
+  const int blk = blockIdx.x * 16 + wave;
+  if (blk * kPB >= np) return;
+  f32x4 *pts = isx ? c.sx + (size_t)cloud * c.npx : c.sy + (size_t)(cloud - c.nx) * c.npy;
+  f32x4 *box = (isx ? c.bx + (size_t)cloud * (c.npx / kPB) * 2 : c.by + (size_t)(cloud - c.nx) * (c.npy / kPB) * 2) + blk * 2;
+  const int i = blk * kPB + lane;
+  const bool valid = i < n;
+  f32x4 v = {kPadCoord, kPadCoord, kPadCoord, __builtin_bit_cast(float, -1)};
+  if (valid) v = pts[i];
+  else pts[i] = v;
+  const float lo0 = wave_min(valid ? v[0] : 3.0e38f), lo1 = wave_min(valid ? v[1] : 3.0e38f), lo2 = wave_min(valid ? v[2] : 3.0e38f);
+  const float hi0 = wave_max(valid ? v[0] : -3.0e38f), hi1 = wave_max(valid ? v[1] : -3.0e38f), hi2 = wave_max(valid ? v[2] : -3.0e38f);
+  if (lane == 0) {
+    box[0] = f32x4{lo0, lo1, lo2, 0.f};
+    box[1] = f32x4{hi0, hi1, hi2, 0.f};
+  }
+}
+
+struct NNQuery {
+  const f32x4 *sx, *sy, *bx, *by;
+  int p, q, npx, npy, nz, batch;   // nz = draws * batch cloud pairs; pair z = (x cloud z, y cloud z % batch)
+  float *dxy, *dyx;
+  int32_t *ixy, *iyx;
+};
+
+// grid = (ceil(query blocks / 4), 2 nz): y < nz: the x cloud asks the y cloud; y >= nz: the y cloud asks the x cloud
+__global__ __launch_bounds__(256) void nn_query_kernel(NNQuery a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool fwd = (int)blockIdx.y < a.nz;
+  const int z = fwd ? blockIdx.y : blockIdx.y - a.nz;
+  const int zx = z, zy = z % a.batch;
+  const int nbx = a.npx / kPB, nby = a.npy / kPB;
+  const int nqb = fwd ? nbx : nby, ntb = fwd ? nby : nbx;
+  const int qblk = blockIdx.x * 4 + wave;
+  if (qblk >= nqb) return;
+  const f32x4 *__restrict__ qpts = fwd ? a.sx + (size_t)zx * a.npx : a.sy + (size_t)zy * a.npy;
+  const f32x4 *__restrict__ qbox = fwd ? a.bx + (size_t)zx * nbx * 2 : a.by + (size_t)zy * nby * 2;
+  const f32x4 *__restrict__ tpts = fwd ? a.sy + (size_t)zy * a.npy : a.sx + (size_t)zx * a.npx;
+  const f32x4 *__restrict__ tbox = fwd ? a.by + (size_t)zy * nby * 2 : a.bx + (size_t)zx * nbx * 2;
+  float *od = fwd ? a.dxy + (size_t)z * a.p : a.dyx + (size_t)z * a.q;
+  int32_t *oi = fwd ? a.ixy + (size_t)z * a.p : a.iyx + (size_t)z * a.q;
+
+  const f32x4 me = qpts[(size_t)qblk * kPB + lane];
+  const int qidx = as_int(me[3]);
+  // pad lanes (last block of the cloud) ask for lane 0's point and write nothing
+  const float qx = qidx < 0 ? __shfl(me[0], 0, 64) : me[0];
+  const float qy = qidx < 0 ? __shfl(me[1], 0, 64) : me[1];
+  const float qz = qidx < 0 ? __shfl(me[2], 0, 64) : me[2];
+  const f32x4 qb0 = qbox[qblk * 2], qb1 = qbox[qblk * 2 + 1];
+
+  float best = 3.0e38f;
+  int bsub = 0;        // 16-candidate group (block * 4 + quarter) that gave `best`
+  bool tie = false;    // another group reproduced `best` exactly
+  auto eval = [&](int blk) {   // blk is wave-uniform: the candidates go through the scalar cache
+    const f32x4 *__restrict__ tp = tpts + (size_t)blk * kPB;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float m = 3.0e38f;
+#pragma unroll
+      for (int j = 0; j < 16; j += 4) {
+        float d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const f32x4 cnd = tp[s * 16 + j + u];
+          d[u] = sq3(qx - cnd[0], qy - cnd[1], qz - cnd[2]);
+        }
+        m = __builtin_fminf(__builtin_fminf(m, d[0]), d[1]);
+        m = __builtin_fminf(__builtin_fminf(m, d[2]), d[3]);
+      }
+      if (m < best) {
+        best = m;
+        bsub = blk * 4 + s;
+        tie = false;
+      } else if (m == best) {
+        tie = true;
+      }
+    }
+  };
+  auto point_box = [&](int blk) {   // lower bound of this lane's distance to any point of candidate block blk (uniform)
+    const f32x4 t0 = tbox[blk * 2], t1 = tbox[blk * 2 + 1];
+    return sq3(gap(qx, qx, t0[0], t1[0]), gap(qy, qy, t0[1], t1[1]), gap(qz, qz, t0[2], t1[2]));
+  };
+  auto box_box = [&](int blk) {     // per lane: lower bound between the query block's box and candidate block blk's
+    const f32x4 t0 = tbox[blk * 2], t1 = tbox[blk * 2 + 1];
+    return sq3(gap(qb0[0], qb1[0], t0[0], t1[0]), gap(qb0[1], qb1[1], t0[1], t1[1]), gap(qb0[2], qb1[2], t0[2], t1[2]));
+  };
+
+  // seed: the candidate block nearest to the query block, box to box (lowest index among equals)
+  float sb = 3.0e38f;
+  int sblk = 0x7fffffff;
+  for (int it = 0; it < ntb; it += 64) {
+    const int b = it + lane;
+    if (b < ntb) {
+      const float l = box_box(b);
+      if (l < sb) sb = l, sblk = b;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float o = __shfl_xor(sb, off, 64);
+    const int ob = __shfl_xor(sblk, off, 64);
+    if (o < sb || (o == sb && ob < sblk)) sb = o, sblk = ob;
+  }
+  const int seed = min(__builtin_amdgcn_readfirstlane(sblk), ntb - 1);
+  eval(seed);
+  float T = wave_max(best);   // a block whose box-to-box bound exceeds this cannot help any lane
+
+  for (int it = 0; it < ntb; it += 64) {
+    const int b = it + lane;
+    const float lbb = b < ntb ? box_box(b) : 3.0e38f;
+    unsigned long long mask = __builtin_amdgcn_ballot_w64(lbb <= T && b < ntb && b != seed);
+    while (mask) {
+      const int bit = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      const int blk = it + bit;
+      const float lb = point_box(blk);
+      if (__builtin_amdgcn_ballot_w64(lb <= best) == 0) continue;   // <=: a candidate that TIES must still be seen
+      eval(blk);
+      T = wave_max(best);
+      mask &= __builtin_amdgcn_ballot_w64(lbb <= T);
+    }
+  }
+
+  // lowest original index among the candidates of the winning group that reproduce the minimum
+  int bidx = 0x7fffffff;
+  {
+    const f32x4 *rp = tpts + (size_t)bsub * 16;
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+      const f32x4 cnd = rp[j];
+      const int ci = as_int(cnd[3]);
+      if (sq3(qx - cnd[0], qy - cnd[1], qz - cnd[2]) == best && ci >= 0) bidx = min(bidx, ci);
+    }
+  }
+  if (__builtin_amdgcn_ballot_w64(tie) != 0) {   // duplicates of the minimum in other groups: look everywhere it can be
+    for (int blk = 0; blk < ntb; ++blk) {
+      const float lb = point_box(blk);
+      if (__builtin_amdgcn_ballot_w64(tie && lb <= best) == 0) continue;
+      const f32x4 *__restrict__ tp = tpts + (size_t)blk * kPB;
+      for (int j = 0; j < kPB; ++j) {
+        const f32x4 cnd = tp[j];
+        const int ci = as_int(cnd[3]);
+        if (tie && ci >= 0 && sq3(qx - cnd[0], qy - cnd[1], qz - cnd[2]) == best) bidx = min(bidx, ci);
+      }
+    }
+  }
+  if (bidx == 0x7fffffff) bidx = 0;   // only with non-finite coordinates (no distance ever compared equal)
+  if (qidx >= 0) {
+    od[qidx] = best;
+    oi[qidx] = bidx;
+  }
+}
+
+static NNClouds nn_layout(const float *x, const float *y, int draws, int batch, int p, int q, void *ws) {
+  NNClouds c{};
+  c.x = x, c.y = y, c.p = p, c.q = q, c.nx = draws * batch, c.ny = batch;
+  c.npx = cdiv(p, kPB) * kPB, c.npy = cdiv(q, kPB) * kPB;
+  char *w = static_cast<char *>(ws);
+  c.sx = reinterpret_cast<f32x4 *>(w);
+  w += (size_t)c.nx * c.npx * sizeof(f32x4);
+  c.sy = reinterpret_cast<f32x4 *>(w);
+  w += (size_t)c.ny * c.npy * sizeof(f32x4);
+  c.bx = reinterpret_cast<f32x4 *>(w);
+  w += (size_t)c.nx * (c.npx / kPB) * 2 * sizeof(f32x4);
+  c.by = reinterpret_cast<f32x4 *>(w);
+  return c;
+}
+
+size_t nn_pruned_workspace_bytes(int draws, int batch, int p, int q) {
+  const size_t nx = (size_t)draws * batch, ny = batch;
+  const size_t npx = (size_t)cdiv(p, kPB) * kPB, npy = (size_t)cdiv(q, kPB) * kPB;
+  return (nx * npx + ny * npy) * sizeof(f32x4) + (nx * (npx / kPB) + ny * (npy / kPB)) * 2 * sizeof(f32x4);
+}
+
+int launch_nn_pruned(const float *x, const float *y, int draws, int batch, int p, int q, float *dxy, int32_t *ixy,
+                     float *dyx, int32_t *iyx, void *ws, hipStream_t s) {
+  const NNClouds c = nn_layout(x, y, draws, batch, p, q, ws);
+  const int bits = nn_grid_bits(p > q ? p : q);
+  const size_t shmem = (size_t)(1 << (3 * bits)) * sizeof(unsigned);
+  static OncePerDevice once;
+  once.run([] {
+    (void)hipFuncSetAttribute((const void *)nn_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (1 << 15) * 4);
+  });
+  static const int stages = getenv("A3VT_NN_STAGES") ? atoi(getenv("A3VT_NN_STAGES")) : 3;   // developer aid: stop early
+  A3VT_LAUNCH(nn_sort_kernel, dim3(c.nx + c.ny), dim3(kSortThreads), shmem, s, c);
+  A3VT_CHECK_LAUNCH();
+  if (stages < 2) return 0;
+  const int nbmax = (c.npx > c.npy ? c.npx : c.npy) / kPB;
+  A3VT_LAUNCH(nn_boxes_kernel, dim3(cdiv(nbmax, 16), c.nx + c.ny), dim3(1024), 0, s, c);
+  A3VT_CHECK_LAUNCH();
+  if (stages < 3) return 0;
+  NNQuery a{c.sx, c.sy, c.bx, c.by, p, q, c.npx, c.npy, c.nx, batch, dxy, dyx, ixy, iyx};
+  A3VT_LAUNCH(nn_query_kernel, dim3(cdiv(nbmax, 4), 2 * c.nx), dim3(256), 0, s, a);
+  A3VT_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace a3vt

@@ -10,13 +10,13 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("A3VT_LIB", os.path.join(_HERE, "liba3vt.so"))  # A3VT_LIB: developer override (variant builds)
-SOURCES = ["capi.hip", "gcn_gemm.hip", "gcn_csr.hip", "gcn_bf16s.hip", "posenc.hip", "sample.hip", "chamfer.hip",
+SOURCES = ["capi.hip", "gcn_gemm.hip", "gcn_csr.hip", "gcn_bf16s.hip", "posenc.hip", "sample.hip", "chamfer.hip", "nn_prune.hip",
            "pooling.hip"]
 # Per-file extra flags (none at present; sample.hip / gcn_csr.hip rely on IEEE NaN semantics — the reference's NaN
 # scrubs, a3vt_check_finite — so fast-math style flags must never be applied globally).
 # chamfer.hip: keep the nearest-neighbour loop on scalar fp32 ops (the SLP vectoriser would re-pack it into v_pk_*_f32,
 # which issues at half the rate on gfx950 and needs s_nop hazard padding)
-EXTRA_FLAGS = {"chamfer.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"chamfer.hip": ["-fno-slp-vectorize"], "nn_prune.hip": ["-fno-slp-vectorize"]}
 
 _vp, _i, _sz, _u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_uint64
 
@@ -53,6 +53,8 @@ SIGNATURES = {
     "a3vt_sample_points_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "a3vt_chamfer_scratch_bytes": (_sz, [_i, _i, _i, _i]),
     "a3vt_chamfer_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "a3vt_chamfer_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "a3vt_chamfer_fwd_ws": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     "a3vt_chamfer_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "a3vt_check_finite": (_i, [_vp, _sz, _vp, _vp]),
     "a3vt_profile_enable": (_i, [_i]),

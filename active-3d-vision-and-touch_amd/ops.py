@@ -393,9 +393,10 @@ class ChamferFn(torch.autograd.Function):
         dyx = torch.empty((draws, B, Q), dtype=torch.float32, device=dev)
         iyx = torch.empty((draws, B, Q), dtype=torch.int32, device=dev)
         cd = torch.empty((B,), dtype=torch.float32, device=dev)
-        scratch = torch.empty((L.a3vt_chamfer_scratch_bytes(draws, B, P, Q),), dtype=torch.uint8, device=dev)
-        _lib.check(L.a3vt_chamfer_fwd(_lib.ptr(x), _lib.ptr(y), draws, B, P, Q, _lib.ptr(dxy), _lib.ptr(ixy),
-                                      _lib.ptr(dyx), _lib.ptr(iyx), _lib.ptr(cd), _lib.ptr(scratch), _stream()),
+        nbytes = L.a3vt_chamfer_workspace_bytes(draws, B, P, Q)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        _lib.check(L.a3vt_chamfer_fwd_ws(_lib.ptr(x), _lib.ptr(y), draws, B, P, Q, _lib.ptr(dxy), _lib.ptr(ixy),
+                                         _lib.ptr(dyx), _lib.ptr(iyx), _lib.ptr(cd), _lib.ptr(ws), nbytes, 0, _stream()),
                    "chamfer_fwd")
         ctx.save_for_backward(x, y, ixy, iyx)
         ctx.aux = (dxy, dyx)
@@ -415,9 +416,13 @@ class ChamferFn(torch.autograd.Function):
         return gx, gy
 
 
-def chamfer_nn(x, y, single_pass=True):
+NN_ALGOS = {"auto": 0, "two_pass": 1, "sweep": 2, "pruned": 3}
+
+
+def chamfer_nn(x, y, single_pass=True, algo=None):
     """Raw nearest-neighbour outputs (dist_xy, idx_xy, dist_yx, idx_yx, cd) — used by tests and scoring.
-    ``single_pass=False`` runs the two-pass search (no scratch); the results are identical."""
+    ``algo``: "auto" | "two_pass" | "sweep" | "pruned" (include/a3vt.h: a3vt_chamfer_fwd_ws); by default the brute-force
+    sweep, or with ``single_pass=False`` the two-pass search (no scratch).  The results are identical bit for bit."""
     L = _lib.load()
     x, y = _req(x, "x"), _req(y, "y")
     draws, B, P, _ = x.shape
@@ -428,11 +433,13 @@ def chamfer_nn(x, y, single_pass=True):
     dyx = torch.empty((draws, B, Q), dtype=torch.float32, device=dev)
     iyx = torch.empty((draws, B, Q), dtype=torch.int32, device=dev)
     cd = torch.empty((B,), dtype=torch.float32, device=dev)
-    scratch = torch.empty((L.a3vt_chamfer_scratch_bytes(draws, B, P, Q),), dtype=torch.uint8, device=dev) \
-        if single_pass else None
-    _lib.check(L.a3vt_chamfer_fwd(_lib.ptr(x), _lib.ptr(y), draws, B, P, Q, _lib.ptr(dxy), _lib.ptr(ixy),
-                                  _lib.ptr(dyx), _lib.ptr(iyx), _lib.ptr(cd), _lib.ptr(scratch), _stream()),
-               "chamfer_fwd")
+    if algo is None:
+        algo = "sweep" if single_pass else "two_pass"
+    nbytes = L.a3vt_chamfer_workspace_bytes(draws, B, P, Q) if algo != "two_pass" else 0
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev) if nbytes else None
+    _lib.check(L.a3vt_chamfer_fwd_ws(_lib.ptr(x), _lib.ptr(y), draws, B, P, Q, _lib.ptr(dxy), _lib.ptr(ixy),
+                                     _lib.ptr(dyx), _lib.ptr(iyx), _lib.ptr(cd), _lib.ptr(ws), nbytes, NN_ALGOS[algo],
+                                     _stream()), "chamfer_fwd")
     return dxy, ixy, dyx, iyx, cd
 
 

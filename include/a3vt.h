@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define A3VT_VERSION 110 /* 0.2.0: bf16 storage mode (gemm_bf16 = 2), a3vt_gcn_stack_stash_bytes / _scratch_bytes_mode, deterministic backward scatters */
+#define A3VT_VERSION 120 /* 0.2.x: bf16 storage mode (gemm_bf16 = 2), a3vt_gcn_stack_stash_bytes / _scratch_bytes_mode, deterministic backward scatters; 120: a3vt_chamfer_fwd_ws (pruned exact search) */
 
 int a3vt_version(void);
 const char *a3vt_last_error(void);
@@ -203,6 +203,17 @@ size_t a3vt_chamfer_scratch_bytes(int draws, int batch, int p, int q);
 int a3vt_chamfer_fwd(const float *x, const float *y, int draws, int batch, int p, int q,
                      float *dist_xy, int32_t *idx_xy, float *dist_yx, int32_t *idx_yx, float *cd,
                      void *scratch, void *stream);
+/* The same with a sized workspace and a choice of search.  a3vt_chamfer_workspace_bytes() holds every algorithm.
+ * algo: 0 = automatic (the pruned search from 2048 points per cloud on, else the sweep), 1 = brute force, one launch
+ *       per direction (workspace may be NULL), 2 = brute force, one sweep, 3 = pruned exact search: each cloud is
+ *       sorted into blocks of 64 neighbouring points with bounding boxes, and a wave of 64 neighbouring queries only
+ *       evaluates the blocks whose box can still hold a nearer (or equally near) point.
+ * All algorithms return the same distances and indices bit for bit (same fma chain, ties to the lowest index).
+ * <0 if the workspace is too small for the algorithm asked for. */
+size_t a3vt_chamfer_workspace_bytes(int draws, int batch, int p, int q);
+int a3vt_chamfer_fwd_ws(const float *x, const float *y, int draws, int batch, int p, int q,
+                        float *dist_xy, int32_t *idx_xy, float *dist_yx, int32_t *idx_yx, float *cd,
+                        void *workspace, size_t workspace_bytes, int algo, void *stream);
 /* grad_cd [batch].  grad_x [draws][batch][p][3] overwritten; grad_y [batch][q][3] overwritten, may be
  * NULL (the trainer's ground truth needs no gradient, vision/train.py:141-143). */
 int a3vt_chamfer_bwd(const float *x, const float *y, int draws, int batch, int p, int q,

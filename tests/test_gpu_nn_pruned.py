@@ -1,0 +1,154 @@
+"""The pruned exact nearest-neighbour search (csrc/nn_prune.hip, ``a3vt_chamfer_fwd_ws`` algo 3) against the brute-force
+searches and the C oracle: integer / bit-exact bar — every distance and every index identical, ties to the lowest index.
+Covers what the domain offers as edge cases: ragged sizes (last block padded), single-point clouds, duplicated points
+(exact ties inside a block, across blocks and across the pad), surfaces far apart (pruning degenerates towards brute
+force), degenerate extents (all points equal, planar and collinear clouds: grid cells collapse), unequal cloud sizes,
+clouds above 20k points (the 32^3 grid), and the trainer's call through ``ChamferFn`` (automatic choice)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ("dist_xy", "idx_xy", "dist_yx", "idx_yx", "cd")
+
+
+def _surface(gen, n, kind, shift=0.0):
+    """n points on a closed surface (what the trainer samples), float32."""
+    u = torch.randn(n, 3, generator=gen)
+    u = u / u.norm(dim=1, keepdim=True)
+    if kind == "sphere":
+        p = 0.4 * u
+    elif kind == "ellipsoid":
+        p = u * torch.tensor([0.5, 0.3, 0.2])
+    elif kind == "cube":
+        p = 0.35 * u / u.abs().max(dim=1, keepdim=True).values
+    elif kind == "volume":
+        p = torch.rand(n, 3, generator=gen) - 0.5
+    else:
+        raise ValueError(kind)
+    return (p + shift).float()
+
+
+def _both(x, y, cuda):
+    from a3vt_amd import ops
+    xd, yd = x.to(cuda), y.to(cuda)
+    return ops.chamfer_nn(xd, yd, algo="pruned"), ops.chamfer_nn(xd, yd, algo="sweep")
+
+
+def _assert_same(a, b):
+    for name, u, v in zip(NAMES, a, b):
+        assert torch.equal(u, v), f"{name}: {(u != v).sum().item()} of {u.numel()} differ"
+
+
+@pytest.mark.parametrize("draws,B,P,Q,kx,ky,shift", [
+    (1, 1, 1, 1, "sphere", "sphere", 0.0),
+    (1, 2, 63, 65, "sphere", "cube", 0.0),
+    (2, 3, 64, 128, "volume", "volume", 0.0),
+    (1, 2, 100, 37, "ellipsoid", "sphere", 0.0),
+    (3, 2, 1000, 2176, "sphere", "ellipsoid", 0.0),
+    (2, 1, 4099, 5000, "cube", "sphere", 0.0),
+    (1, 1, 5, 3000, "sphere", "sphere", 0.0),
+    (1, 1, 3000, 5, "sphere", "sphere", 0.0),
+    (1, 4, 2600, 700, "volume", "sphere", 0.0),
+    (2, 2, 2048, 2048, "sphere", "sphere", 3.0),        # surfaces far apart: every block is about equally far
+    (1, 2, 3001, 2999, "ellipsoid", "cube", 0.05),
+])
+def test_pruned_equals_brute_force(cuda, draws, B, P, Q, kx, ky, shift):
+    g = torch.Generator().manual_seed(P * 31 + Q)
+    x = torch.stack([torch.stack([_surface(g, P, kx, shift) for _ in range(B)]) for _ in range(draws)])
+    y = torch.stack([_surface(g, Q, ky) for _ in range(B)])
+    _assert_same(*_both(x, y, cuda))
+
+
+@pytest.mark.parametrize("P,Q", [(777, 1025), (2176, 1000), (4096, 4096)])
+def test_pruned_ties_go_to_the_lowest_index(cuda, P, Q):
+    """Every candidate exists twice (and some three times, at indices far apart, so the copies land in one sorted block
+    next to each other AND — for the copies of the cloud's last points — next to the pad), queries are duplicated too,
+    a few coincide with candidates (zero distance)."""
+    g = torch.Generator().manual_seed(P + Q)
+    x = torch.stack([torch.stack([_surface(g, P, "sphere") for _ in range(3)]) for _ in range(2)])
+    y = torch.stack([_surface(g, Q, "ellipsoid") for _ in range(3)])
+    y[:, Q // 2:] = y[:, :Q - Q // 2]
+    y[:, -5:] = y[:, 10:15]
+    x[:, :, P // 2:] = x[:, :, :P - P // 2]
+    x[0, :, :3] = y[:, :3]
+    pruned, brute = _both(x, y, cuda)
+    _assert_same(pruned, brute)
+    assert (pruned[1] < Q // 2 + 1).all()          # of identical candidates the first one
+
+
+def test_pruned_degenerate_extents(cuda):
+    """All points equal; all on a plane; all on a line; one cloud a single repeated point: the grid collapses to one
+    cell / one layer and the block boxes are flat — results unchanged."""
+    g = torch.Generator().manual_seed(5)
+    P = Q = 2500
+    x = torch.rand(1, 4, P, 3, generator=g) - 0.5
+    y = torch.rand(4, Q, 3, generator=g) - 0.5
+    x[0, 0] = 0.25                                   # one point, P times
+    y[1, :, 2] = 0.125                               # planar
+    x[0, 2, :, 1:] = -0.5                            # collinear
+    y[3] = y[3, :1]                                  # one point, Q times
+    _assert_same(*_both(x.float(), y.float(), cuda))
+
+
+def test_pruned_against_the_c_oracle(cuda):
+    """Bit for bit against oracle/chamfer_nn.c with the device's contraction (fma=True), both directions."""
+    from a3vt_amd import ops
+    from oracle import chamfer as ochamfer
+    g = torch.Generator().manual_seed(11)
+    P, Q = 6000, 5000
+    x = _surface(g, P, "sphere")
+    y = _surface(g, Q, "ellipsoid")
+    dxy, ixy, dyx, iyx, _ = ops.chamfer_nn(x[None, None].to(cuda), y[None].to(cuda), algo="pruned")
+    d1, i1 = ochamfer.nn_sqdist_c(x.numpy(), y.numpy(), fma=True)
+    d2, i2 = ochamfer.nn_sqdist_c(y.numpy(), x.numpy(), fma=True)
+    assert np.array_equal(dxy[0, 0].cpu().numpy(), d1) and np.array_equal(ixy[0, 0].cpu().numpy(), i1)
+    assert np.array_equal(dyx[0, 0].cpu().numpy(), d2) and np.array_equal(iyx[0, 0].cpu().numpy(), i2)
+
+
+@pytest.mark.parametrize("P,Q,B", [(25000, 25000, 2), (50000, 50000, 1), (30000, 9000, 2)])
+def test_pruned_large_clouds(cuda, P, Q, B):
+    """BASELINE configs[3] / configs[4] cloud sizes (the 32^3 grid above 20k points), unequal sizes."""
+    g = torch.Generator().manual_seed(P // 1000 + Q)
+    x = torch.stack([_surface(g, P, "sphere", 0.02) for _ in range(B)])[None]
+    y = torch.stack([_surface(g, Q, "ellipsoid") for _ in range(B)])
+    _assert_same(*_both(x, y, cuda))
+
+
+def test_automatic_choice_and_workspace_checks(cuda):
+    """ChamferFn (the trainer's call) lets the library choose: the result equals the brute-force one either side of the
+    2048-point threshold.  A workspace too small for the algorithm asked for is an error, not a silent fallback."""
+    from a3vt_amd import lib, ops
+    g = torch.Generator().manual_seed(3)
+    for P, Q in ((1500, 1500), (2500, 2500)):
+        x = _surface(g, P, "sphere")[None, None].to(cuda)
+        y = _surface(g, Q, "cube")[None].to(cuda)
+        auto = ops.chamfer_nn(x, y, algo="auto")
+        _assert_same(auto, ops.chamfer_nn(x, y, algo="two_pass"))
+        cd = ops.ChamferFn.apply(x, y)
+        assert torch.equal(cd, auto[4])
+    L = lib.load()
+    x = torch.rand(1, 1, 4096, 3, device=cuda)
+    y = torch.rand(1, 4096, 3, device=cuda)
+    out = [torch.empty(4096, device=cuda) for _ in range(2)] + [torch.empty(4096, dtype=torch.int32, device=cuda) for _ in range(2)]
+    cd = torch.empty(1, device=cuda)
+    ws = torch.empty(1024, dtype=torch.uint8, device=cuda)
+    rc = L.a3vt_chamfer_fwd_ws(lib.ptr(x), lib.ptr(y), 1, 1, 4096, 4096, lib.ptr(out[0]), lib.ptr(out[2]), lib.ptr(out[1]),
+                               lib.ptr(out[3]), lib.ptr(cd), lib.ptr(ws), 1024, 3, None)
+    assert rc < 0 and b"too small" in L.a3vt_last_error()
+    rc = L.a3vt_chamfer_fwd_ws(lib.ptr(x), lib.ptr(y), 1, 1, 4096, 4096, lib.ptr(out[0]), lib.ptr(out[2]), lib.ptr(out[1]),
+                               lib.ptr(out[3]), lib.ptr(cd), lib.ptr(ws), 1024, 7, None)
+    assert rc < 0 and b"unknown search algorithm" in L.a3vt_last_error()
+    torch.cuda.synchronize()
+
+
+def test_pruned_repeats_bit_for_bit(cuda):
+    """The order of points inside a grid cell depends on LDS atomics; the outputs must not."""
+    from a3vt_amd import ops
+    g = torch.Generator().manual_seed(9)
+    x = torch.stack([_surface(g, 10000, "sphere") for _ in range(4)])[None].to(cuda)
+    y = torch.stack([_surface(g, 10000, "ellipsoid") for _ in range(4)]).to(cuda)
+    first = ops.chamfer_nn(x, y, algo="pruned")
+    for _ in range(3):
+        _assert_same(first, ops.chamfer_nn(x, y, algo="pruned"))

@@ -1,6 +1,8 @@
 #!/usr/bin/env python
-"""Time the Chamfer forward (two nearest-neighbour launches + reduce) at the headline shape: 3 draws x 64 clouds x
-10,000 points against 64 x 10,000.  Development aid:  python tools/chamfer_bench.py"""
+"""Time the Chamfer forward (nearest neighbour both ways + reduce) for each search algorithm on surface-like clouds:
+the headline shape (3 draws x 64 clouds x 10,000 points) and the configs[3] / configs[4] cloud sizes.  Development aid:
+python tools/chamfer_bench.py [--algos sweep,pruned] [--shapes 3x64x10000,3x64x25000,3x8x50000] [--gap 0.05]"""
+import argparse
 import os
 import sys
 
@@ -9,21 +11,37 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 from a3vt_amd import ops  # noqa: E402
 
+ap = argparse.ArgumentParser()
+ap.add_argument("--algos", default="sweep,pruned")
+ap.add_argument("--shapes", default="3x64x10000,3x64x25000,3x8x50000")
+ap.add_argument("--gap", type=float, default=0.05, help="offset between the predicted and the ground-truth surface")
+ap.add_argument("--reps", type=int, default=5)
+args = ap.parse_args()
+
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
-x = torch.randn(3, 64, 10000, 3, device=dev) * 0.1
-y = torch.randn(64, 10000, 3, device=dev) * 0.1
-single = os.environ.get("SINGLE", "1") == "1"   # 0: the two-pass search
-out = ops.chamfer_nn(x, y, single_pass=single)
-torch.cuda.synchronize()
-reps = int(os.environ.get("REPS", "10"))
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(reps):
-    ops.chamfer_nn(x, y, single_pass=single)
-e1.record()
-torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / reps
-pairs = 2.0 * 3 * 64 * 10000 * 10000
-print(f"chamfer fwd {ms:.3f} ms per call  ({pairs / ms / 1e9:.1f} T pair evaluations/s)  checksum {out[4].sum().item():.6f} "
-      f"{out[1].sum().item()} {out[3].sum().item()}")
+
+
+def surface(*shape, radii):
+    u = torch.randn(*shape, 3, device=dev)
+    return u / u.norm(dim=-1, keepdim=True) * torch.tensor(radii, device=dev)
+
+
+for shape in args.shapes.split(","):
+    draws, B, N = (int(v) for v in shape.split("x"))
+    x = surface(draws, B, N, radii=(0.4, 0.4, 0.4)) + args.gap         # the predicted surface: a sphere, a little off
+    y = surface(B, N, radii=(0.5, 0.3, 0.2))                            # ground truth: an ellipsoid
+    ref = None
+    for algo in args.algos.split(","):
+        out = ops.chamfer_nn(x, y, algo=algo)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.reps):
+            ops.chamfer_nn(x, y, algo=algo)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / args.reps
+        same = "" if ref is None else ("  == first" if all(torch.equal(a, b) for a, b in zip(ref, out)) else "  DIFFERS")
+        ref = ref or out
+        print(f"{shape:>14s} {algo:9s} {ms:9.3f} ms per call   cd sum {out[4].sum().item():.6f}{same}", flush=True)
