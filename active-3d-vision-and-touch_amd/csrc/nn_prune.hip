@@ -6,7 +6,7 @@
 // meets the candidates that can still beat what it has:
 //
 //   1. nn_sort_kernel   one workgroup per cloud: bounding box, a G^3 grid over it (G = 16, 32 above 20k points), a counting
-//                       sort of the points by the Morton code of their cell (histogram and cursors in LDS).  The sorted
+//                       sort of the points by the Hilbert-curve position of their cell (histogram and cursors in LDS).  The sorted
 //                       cloud is stored as float4 (x, y, z, original index): 64 consecutive points — a "block" — are a
 //                       compact patch of the surface.
 //   2. nn_boxes_kernel  the axis-aligned bounding box of every block (one wave each); pads the last block.
@@ -63,12 +63,40 @@ __device__ __forceinline__ unsigned spread3(unsigned v) {   // 10 bits -> every 
   return v;
 }
 
+// Position of grid cell (x, y, z) along the 3-D Hilbert curve of 2^bits cells per axis (Skilling's transposition).  The
+// curve is continuous, so 64 consecutive sorted points form a connected patch; consecutive Morton cells jump, which made
+// the blocks' boxes a quarter longer and nearly twice as large in surface (measured on 10k-point ellipsoids).
+__device__ __forceinline__ unsigned hilbert3(unsigned x, unsigned y, unsigned z, int bits) {
+  unsigned X[3] = {x, y, z};
+  const unsigned M = 1u << (bits - 1);
+  for (unsigned Q = M; Q > 1; Q >>= 1) {
+    const unsigned P = Q - 1;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (X[i] & Q) {
+        X[0] ^= P;
+      } else {
+        const unsigned t = (X[0] ^ X[i]) & P;
+        X[0] ^= t;
+        X[i] ^= t;
+      }
+    }
+  }
+  X[1] ^= X[0];
+  X[2] ^= X[1];
+  unsigned t = 0;
+  for (unsigned Q = M; Q > 1; Q >>= 1)
+    if (X[2] & Q) t ^= Q - 1;
+  return (spread3(X[0] ^ t) << 2) | (spread3(X[1] ^ t) << 1) | spread3(X[2] ^ t);
+}
+
 struct NNClouds {   // the clouds of one Chamfer call: nx predicted clouds of p points, ny ground-truth clouds of q
   const float *x, *y;
   int p, q, nx, ny;
   int npx, npy;     // padded points per cloud (multiple of 64)
   f32x4 *sx, *sy;   // sorted clouds  [n?][np?]
   f32x4 *bx, *by;   // block boxes    [n?][np?/64][2]  (min xyz 0, max xyz 0)
+  f32x4 *ux, *uy;   // group boxes    [n?][np?/16][2]  one per 16 consecutive sorted points (4 per block)
 };
 
 __host__ __device__ inline int nn_grid_bits(int n) { return n > 20000 ? 5 : 4; }
@@ -115,13 +143,13 @@ __global__ __launch_bounds__(kSortThreads) void nn_sort_kernel(NNClouds c) {
     scale[d] = (ext > 0.f && ext < 3.0e38f) ? (float)G / ext : 0.f;   // degenerate / non-finite extent: one cell
   }
   auto key_of = [&](int i) {
-    unsigned k = 0;
+    unsigned cell[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       const float t = fminf(fmaxf((P[i * 3 + d] - mn[d]) * scale[d], 0.f), (float)(G - 1));   // NaN -> 0
-      k |= spread3((unsigned)(int)t) << d;
+      cell[d] = (unsigned)(int)t;
     }
-    return k;
+    return hilbert3(cell[0], cell[1], cell[2], bits);
   };
   for (int i = tid; i < n; i += kSortThreads) atomicAdd(&hist[key_of(i)], 1u);
   __syncthreads();
@@ -165,16 +193,73 @@ __global__ __launch_bounds__(1024) void nn_boxes_kernel(NNClouds c) {
   f32x4 v = {kPadCoord, kPadCoord, kPadCoord, __builtin_bit_cast(float, -1)};
   if (valid) v = pts[i];
   else pts[i] = v;
-  const float lo0 = wave_min(valid ? v[0] : 3.0e38f), lo1 = wave_min(valid ? v[1] : 3.0e38f), lo2 = wave_min(valid ? v[2] : 3.0e38f);
-  const float hi0 = wave_max(valid ? v[0] : -3.0e38f), hi1 = wave_max(valid ? v[1] : -3.0e38f), hi2 = wave_max(valid ? v[2] : -3.0e38f);
+  float lo[3], hi[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    lo[d] = valid ? v[d] : 3.0e38f;
+    hi[d] = valid ? v[d] : -3.0e38f;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {   // the 16 points of this lane's group
+      lo[d] = fminf(lo[d], __shfl_xor(lo[d], off, 64));
+      hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], off, 64));
+    }
+  }
+  f32x4 *sub = (isx ? c.ux + (size_t)cloud * (c.npx / 16) * 2 : c.uy + (size_t)(cloud - c.nx) * (c.npy / 16) * 2) + blk * 8;
+  if ((lane & 15) == 0) {   // a group without valid points keeps (3e38, -3e38): every bound against it is +inf
+    sub[(lane >> 4) * 2] = f32x4{lo[0], lo[1], lo[2], 0.f};
+    sub[(lane >> 4) * 2 + 1] = f32x4{hi[0], hi[1], hi[2], 0.f};
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+#pragma unroll
+    for (int off = 16; off < 64; off <<= 1) {
+      lo[d] = fminf(lo[d], __shfl_xor(lo[d], off, 64));
+      hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], off, 64));
+    }
+  }
   if (lane == 0) {
-    box[0] = f32x4{lo0, lo1, lo2, 0.f};
-    box[1] = f32x4{hi0, hi1, hi2, 0.f};
+    box[0] = f32x4{lo[0], lo[1], lo[2], 0.f};
+    box[1] = f32x4{hi[0], hi[1], hi[2], 0.f};
   }
 }
 
+#ifdef A3VT_DBG_NN_STATS   // developer counters (tools/build_variants.sh nn): waves, blocks evaluated, point-box tests, slow paths
+__device__ unsigned long long nn_stats[6];
+#define NN_STAT(i, v) do { if (lane == 0) atomicAdd(&nn_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define NN_STAT(i, v) do { } while (0)
+#endif
+
+// Wave-uniform maximum / minimum of NON-NEGATIVE floats through their bit patterns (they order like unsigned integers):
+// four DPP steps inside each 16-lane row, then the four row results through v_readlane and scalar min / max — a dozen
+// instructions and no LDS round trip, where six __shfl_xor steps cost six dependent ds_bpermute.
+template <int CTRL>
+__device__ __forceinline__ unsigned nn_dpp(unsigned x) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, false);
+}
+__device__ __forceinline__ float wave_umax(float v) {
+  unsigned x = __builtin_bit_cast(unsigned, v);
+  x = max(x, nn_dpp<0xB1>(x));    // quad_perm [1,0,3,2]
+  x = max(x, nn_dpp<0x4E>(x));    // quad_perm [2,3,0,1]
+  x = max(x, nn_dpp<0x124>(x));   // row_ror:4
+  x = max(x, nn_dpp<0x128>(x));   // row_ror:8
+  const unsigned a = __builtin_amdgcn_readlane((int)x, 0), b = __builtin_amdgcn_readlane((int)x, 16),
+                 c = __builtin_amdgcn_readlane((int)x, 32), d = __builtin_amdgcn_readlane((int)x, 48);
+  return __builtin_bit_cast(float, max(max(a, b), max(c, d)));
+}
+__device__ __forceinline__ float wave_umin(float v) {
+  unsigned x = __builtin_bit_cast(unsigned, v);
+  x = min(x, nn_dpp<0xB1>(x));
+  x = min(x, nn_dpp<0x4E>(x));
+  x = min(x, nn_dpp<0x124>(x));
+  x = min(x, nn_dpp<0x128>(x));
+  const unsigned a = __builtin_amdgcn_readlane((int)x, 0), b = __builtin_amdgcn_readlane((int)x, 16),
+                 c = __builtin_amdgcn_readlane((int)x, 32), d = __builtin_amdgcn_readlane((int)x, 48);
+  return __builtin_bit_cast(float, min(min(a, b), min(c, d)));
+}
+
 struct NNQuery {
-  const f32x4 *sx, *sy, *bx, *by;
+  const f32x4 *sx, *sy, *bx, *by, *ux, *uy;
   int p, q, npx, npy, nz, batch;   // nz = draws * batch cloud pairs; pair z = (x cloud z, y cloud z % batch)
   float *dxy, *dyx;
   int32_t *ixy, *iyx;
@@ -195,6 +280,7 @@ __global__ __launch_bounds__(256) void nn_query_kernel(NNQuery a) {
   const f32x4 *__restrict__ qbox = fwd ? a.bx + (size_t)zx * nbx * 2 : a.by + (size_t)zy * nby * 2;
   const f32x4 *__restrict__ tpts = fwd ? a.sy + (size_t)zy * a.npy : a.sx + (size_t)zx * a.npx;
   const f32x4 *__restrict__ tbox = fwd ? a.by + (size_t)zy * nby * 2 : a.bx + (size_t)zx * nbx * 2;
+  const f32x4 *__restrict__ tsub = fwd ? a.uy + (size_t)zy * nby * 8 : a.ux + (size_t)zx * nbx * 8;
   float *od = fwd ? a.dxy + (size_t)z * a.p : a.dyx + (size_t)z * a.q;
   int32_t *oi = fwd ? a.ixy + (size_t)z * a.p : a.iyx + (size_t)z * a.q;
 
@@ -209,10 +295,17 @@ __global__ __launch_bounds__(256) void nn_query_kernel(NNQuery a) {
   float best = 3.0e38f;
   int bsub = 0;        // 16-candidate group (block * 4 + quarter) that gave `best`
   bool tie = false;    // another group reproduced `best` exactly
-  auto eval = [&](int blk) {   // blk is wave-uniform: the candidates go through the scalar cache
+  int n_grp = 0;       // (developer counter) 16-candidate groups evaluated
+  auto eval = [&](int blk) {   // blk is wave-uniform: boxes and candidates go through the scalar cache
     const f32x4 *__restrict__ tp = tpts + (size_t)blk * kPB;
+    const f32x4 *__restrict__ sb = tsub + (size_t)blk * 8;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
+      // the group's own box first: a quarter of the block's points sit in a box far smaller than the block's
+      const f32x4 t0 = sb[2 * s], t1 = sb[2 * s + 1];
+      const float lbs = sq3(gap(qx, qx, t0[0], t1[0]), gap(qy, qy, t0[1], t1[1]), gap(qz, qz, t0[2], t1[2]));
+      if (__builtin_amdgcn_ballot_w64(lbs <= best) == 0) continue;
+      ++n_grp;
       float m = 3.0e38f;
 #pragma unroll
       for (int j = 0; j < 16; j += 4) {
@@ -260,21 +353,28 @@ __global__ __launch_bounds__(256) void nn_query_kernel(NNQuery a) {
     if (o < sb || (o == sb && ob < sblk)) sb = o, sblk = ob;
   }
   const int seed = min(__builtin_amdgcn_readfirstlane(sblk), ntb - 1);
+  int n_eval = 1, n_test = 0;
   eval(seed);
-  float T = wave_max(best);   // a block whose box-to-box bound exceeds this cannot help any lane
+  float T = wave_umax(best);   // (wave-uniform) a block whose box-to-box bound exceeds this cannot help any lane
 
   for (int it = 0; it < ntb; it += 64) {
     const int b = it + lane;
     const float lbb = b < ntb ? box_box(b) : 3.0e38f;
     unsigned long long mask = __builtin_amdgcn_ballot_w64(lbb <= T && b < ntb && b != seed);
     while (mask) {
-      const int bit = __builtin_ctzll(mask);
-      mask &= mask - 1;
+      // nearest surviving block first (box to box): the minima tighten early and the later blocks fail their tests
+      const float mine = ((mask >> lane) & 1ull) ? lbb : 3.0e38f;
+      const float nearest = wave_umin(mine);
+      const unsigned long long pick = __builtin_amdgcn_ballot_w64(mine == nearest) & mask;
+      const int bit = __builtin_ctzll(pick ? pick : mask);
+      mask &= ~(1ull << bit);
       const int blk = it + bit;
       const float lb = point_box(blk);
+      ++n_test;
       if (__builtin_amdgcn_ballot_w64(lb <= best) == 0) continue;   // <=: a candidate that TIES must still be seen
       eval(blk);
-      T = wave_max(best);
+      ++n_eval;
+      T = wave_umax(best);
       mask &= __builtin_amdgcn_ballot_w64(lbb <= T);
     }
   }
@@ -290,6 +390,24 @@ __global__ __launch_bounds__(256) void nn_query_kernel(NNQuery a) {
       if (sq3(qx - cnd[0], qy - cnd[1], qz - cnd[2]) == best && ci >= 0) bidx = min(bidx, ci);
     }
   }
+  NN_STAT(0, 1);
+  NN_STAT(1, n_eval);
+  NN_STAT(2, n_test);
+  NN_STAT(5, n_grp);
+#ifdef A3VT_DBG_NN_STATS
+  {   // blocks that HAD to be evaluated given the final minima (slot 3), blocks some lane needs on average (slot 2 reused below)
+    int need = 0, lane_need = 0;
+    for (int blk = 0; blk < ntb; ++blk) {
+      const float lb = point_box(blk);
+      need += __builtin_amdgcn_ballot_w64(lb <= best) != 0;
+      lane_need += lb <= best;
+    }
+    NN_STAT(3, need);
+    if (lane == 0) atomicAdd(&nn_stats[2], 0ull);
+    lane_need = (int)wave_sum((float)lane_need);
+    if (lane == 0) atomicAdd(&nn_stats[4], (unsigned long long)lane_need);
+  }
+#endif
   if (__builtin_amdgcn_ballot_w64(tie) != 0) {   // duplicates of the minimum in other groups: look everywhere it can be
     for (int blk = 0; blk < ntb; ++blk) {
       const float lb = point_box(blk);
@@ -321,13 +439,18 @@ static NNClouds nn_layout(const float *x, const float *y, int draws, int batch, 
   c.bx = reinterpret_cast<f32x4 *>(w);
   w += (size_t)c.nx * (c.npx / kPB) * 2 * sizeof(f32x4);
   c.by = reinterpret_cast<f32x4 *>(w);
+  w += (size_t)c.ny * (c.npy / kPB) * 2 * sizeof(f32x4);
+  c.ux = reinterpret_cast<f32x4 *>(w);
+  w += (size_t)c.nx * (c.npx / 16) * 2 * sizeof(f32x4);
+  c.uy = reinterpret_cast<f32x4 *>(w);
   return c;
 }
 
 size_t nn_pruned_workspace_bytes(int draws, int batch, int p, int q) {
   const size_t nx = (size_t)draws * batch, ny = batch;
   const size_t npx = (size_t)cdiv(p, kPB) * kPB, npy = (size_t)cdiv(q, kPB) * kPB;
-  return (nx * npx + ny * npy) * sizeof(f32x4) + (nx * (npx / kPB) + ny * (npy / kPB)) * 2 * sizeof(f32x4);
+  return (nx * npx + ny * npy) * sizeof(f32x4) + (nx * (npx / kPB) + ny * (npy / kPB)) * 2 * sizeof(f32x4) +
+         (nx * (npx / 16) + ny * (npy / 16)) * 2 * sizeof(f32x4);
 }
 
 int launch_nn_pruned(const float *x, const float *y, int draws, int batch, int p, int q, float *dxy, int32_t *ixy,
@@ -347,10 +470,18 @@ int launch_nn_pruned(const float *x, const float *y, int draws, int batch, int p
   A3VT_LAUNCH(nn_boxes_kernel, dim3(cdiv(nbmax, 16), c.nx + c.ny), dim3(1024), 0, s, c);
   A3VT_CHECK_LAUNCH();
   if (stages < 3) return 0;
-  NNQuery a{c.sx, c.sy, c.bx, c.by, p, q, c.npx, c.npy, c.nx, batch, dxy, dyx, ixy, iyx};
+  NNQuery a{c.sx, c.sy, c.bx, c.by, c.ux, c.uy, p, q, c.npx, c.npy, c.nx, batch, dxy, dyx, ixy, iyx};
   A3VT_LAUNCH(nn_query_kernel, dim3(cdiv(nbmax, 4), 2 * c.nx), dim3(256), 0, s, a);
   A3VT_CHECK_LAUNCH();
   return 0;
 }
 
 }  // namespace a3vt
+
+#ifdef A3VT_DBG_NN_STATS
+extern "C" int a3vt_dbg_nn_stats(unsigned long long *out5) {   // reads and clears the counters
+  unsigned long long z[6] = {0, 0, 0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(out5, HIP_SYMBOL(a3vt::nn_stats), sizeof(z)) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(a3vt::nn_stats), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif

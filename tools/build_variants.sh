@@ -5,10 +5,12 @@ cd "$(dirname "$0")/../active-3d-vision-and-touch_amd/csrc"
 mkdir -p ../../gpurun_variants
 build() { # name flags...
   local name=$1; shift
-  hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared "$@" capi.hip gcn_gemm.hip gcn_csr.hip gcn_bf16s.hip posenc.hip sample.hip -fno-slp-vectorize chamfer.hip pooling.hip -o ../../gpurun_variants/liba3vt_$name.so
+  hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared "$@" capi.hip gcn_gemm.hip gcn_csr.hip gcn_bf16s.hip posenc.hip sample.hip -fno-slp-vectorize chamfer.hip nn_prune.hip pooling.hip -o ../../gpurun_variants/liba3vt_$name.so
 }
 if [ "$1" = "csr" ]; then   # csr_fwd / csr16_fwd without their stores: tools/kstats.sh with A3VT_LIB=...
   build CSR_NOSTORE -DA3VT_DBG_CSR_NOSTORE
+elif [ "$1" = "nn" ]; then   # pruned nearest-neighbour search with its counters (tools/nn_stats.py)
+  build NN_STATS -DA3VT_DBG_NN_STATS
 elif [ "$1" = "rowgemm" ]; then   # rowgemm_kernel ablations (all gemm modes): python tools/stack_bench.py with A3VT_LIB=...
   build RG_NOEPI -DA3VT_DBG_RG_NOEPI &
   build RG_NOA -DA3VT_DBG_RG_NOA &
