@@ -22,9 +22,13 @@
 //                       that group for the lowest original index; if another group tied the minimum exactly (duplicate
 //                       points), the wave rescans every block that can hold the distance — rare, and exact.
 //
-// Work per query is roughly constant (a dozen blocks) instead of proportional to the cloud: 10k-point clouds 4x fewer
-// instructions than the single-sweep brute force, 25k / 50k points 10-20x.  All kernels are deterministic in their
-// outputs (the order of points inside a grid cell depends on LDS atomics, the minima do not).
+// Work per query grows slowly with the cloud instead of in proportion to it.  Measured (3 draws x 64 clouds, sphere against
+// ellipsoid, tools/chamfer_bench.py): 10k points 0.9 ms against 3.8 ms for the single-sweep brute force, 25k 2.5 against
+// 20.4, 50k (3 x 8 clouds) 1.7 against 12.0.  What bounds the query kernel now is the miss path of the scalar cache, not
+// VALU issue (SQ counters: 0.19 VALU instructions per SIMD-cycle, half the brute-force loop's rate; a persistent grid
+// that interleaves the clouds across CUs is 1.8x SLOWER whatever the occupancy; workgroups of 1 - 16 waves make no
+// difference) — DESIGN.md §4.  All kernels are deterministic in their outputs (the order of points inside a grid cell
+// depends on LDS atomics, the minima do not).
 #include <stdlib.h>
 
 #include "common.h"
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(1024) void nn_boxes_kernel(NNClouds c) {
 }
 
 #ifdef A3VT_DBG_NN_STATS   // developer counters (tools/build_variants.sh nn): waves, blocks evaluated, point-box tests, slow paths
-__device__ unsigned long long nn_stats[6];
+__device__ unsigned long long nn_stats[8];
 #define NN_STAT(i, v) do { if (lane == 0) atomicAdd(&nn_stats[i], (unsigned long long)(v)); } while (0)
 #else
 #define NN_STAT(i, v) do { } while (0)
@@ -265,16 +269,13 @@ struct NNQuery {
   int32_t *ixy, *iyx;
 };
 
-// grid = (ceil(query blocks / 4), 2 nz): y < nz: the x cloud asks the y cloud; y >= nz: the y cloud asks the x cloud
-__global__ __launch_bounds__(256) void nn_query_kernel(NNQuery a) {
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const bool fwd = (int)blockIdx.y < a.nz;
-  const int z = fwd ? blockIdx.y : blockIdx.y - a.nz;
+// One wave = one block of 64 sorted queries.  y < nz: the x cloud asks the y cloud; y >= nz: the y cloud asks the x cloud.
+__device__ __forceinline__ void nn_query_wave(const NNQuery &a, int y, int qblk, int lane) {
+  const bool fwd = y < a.nz;
+  const int z = fwd ? y : y - a.nz;
   const int zx = z, zy = z % a.batch;
   const int nbx = a.npx / kPB, nby = a.npy / kPB;
   const int nqb = fwd ? nbx : nby, ntb = fwd ? nby : nbx;
-  const int qblk = blockIdx.x * 4 + wave;
   if (qblk >= nqb) return;
   const f32x4 *__restrict__ qpts = fwd ? a.sx + (size_t)zx * a.npx : a.sy + (size_t)zy * a.npy;
   const f32x4 *__restrict__ qbox = fwd ? a.bx + (size_t)zx * nbx * 2 : a.by + (size_t)zy * nby * 2;
@@ -296,25 +297,36 @@ __global__ __launch_bounds__(256) void nn_query_kernel(NNQuery a) {
   int bsub = 0;        // 16-candidate group (block * 4 + quarter) that gave `best`
   bool tie = false;    // another group reproduced `best` exactly
   int n_grp = 0;       // (developer counter) 16-candidate groups evaluated
-  auto eval = [&](int blk) {   // blk is wave-uniform: boxes and candidates go through the scalar cache
-    const f32x4 *__restrict__ tp = tpts + (size_t)blk * kPB;
+  // Scalar loads return out of order, so a wave can only wait for ALL of them: every batch of loads below is issued
+  // back to back and waited for once (block box + the four group boxes; then the 16 candidates of a group).
+  struct GroupBoxes { f32x4 g[8]; };
+  auto load_groups = [&](int blk) {
+    GroupBoxes r;
     const f32x4 *__restrict__ sb = tsub + (size_t)blk * 8;
 #pragma unroll
+    for (int i = 0; i < 8; ++i) r.g[i] = sb[i];
+    return r;
+  };
+  auto eval = [&](int blk, const GroupBoxes &gb) {   // blk is wave-uniform: boxes and candidates go through the scalar cache
+    const f32x4 *__restrict__ tp = tpts + (size_t)blk * kPB;
+    float lbs[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)   // the group's own box: a quarter of the block's points sit in a box far smaller than the block's
+      lbs[s] = sq3(gap(qx, qx, gb.g[2 * s][0], gb.g[2 * s + 1][0]), gap(qy, qy, gb.g[2 * s][1], gb.g[2 * s + 1][1]),
+                   gap(qz, qz, gb.g[2 * s][2], gb.g[2 * s + 1][2]));
+#pragma unroll
     for (int s = 0; s < 4; ++s) {
-      // the group's own box first: a quarter of the block's points sit in a box far smaller than the block's
-      const f32x4 t0 = sb[2 * s], t1 = sb[2 * s + 1];
-      const float lbs = sq3(gap(qx, qx, t0[0], t1[0]), gap(qy, qy, t0[1], t1[1]), gap(qz, qz, t0[2], t1[2]));
-      if (__builtin_amdgcn_ballot_w64(lbs <= best) == 0) continue;
+      if (__builtin_amdgcn_ballot_w64(lbs[s] <= best) == 0) continue;
       ++n_grp;
+      f32x4 cnd[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) cnd[j] = tp[s * 16 + j];
       float m = 3.0e38f;
 #pragma unroll
       for (int j = 0; j < 16; j += 4) {
         float d[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const f32x4 cnd = tp[s * 16 + j + u];
-          d[u] = sq3(qx - cnd[0], qy - cnd[1], qz - cnd[2]);
-        }
+        for (int u = 0; u < 4; ++u) d[u] = sq3(qx - cnd[j + u][0], qy - cnd[j + u][1], qz - cnd[j + u][2]);
         m = __builtin_fminf(__builtin_fminf(m, d[0]), d[1]);
         m = __builtin_fminf(__builtin_fminf(m, d[2]), d[3]);
       }
@@ -354,7 +366,7 @@ __global__ __launch_bounds__(256) void nn_query_kernel(NNQuery a) {
   }
   const int seed = min(__builtin_amdgcn_readfirstlane(sblk), ntb - 1);
   int n_eval = 1, n_test = 0;
-  eval(seed);
+  eval(seed, load_groups(seed));
   float T = wave_umax(best);   // (wave-uniform) a block whose box-to-box bound exceeds this cannot help any lane
 
   for (int it = 0; it < ntb; it += 64) {
@@ -369,10 +381,11 @@ __global__ __launch_bounds__(256) void nn_query_kernel(NNQuery a) {
       const int bit = __builtin_ctzll(pick ? pick : mask);
       mask &= ~(1ull << bit);
       const int blk = it + bit;
+      const GroupBoxes gb = load_groups(blk);   // issued together with the block's own box: one wait for both
       const float lb = point_box(blk);
       ++n_test;
       if (__builtin_amdgcn_ballot_w64(lb <= best) == 0) continue;   // <=: a candidate that TIES must still be seen
-      eval(blk);
+      eval(blk, gb);
       ++n_eval;
       T = wave_umax(best);
       mask &= __builtin_amdgcn_ballot_w64(lbb <= T);
@@ -394,6 +407,9 @@ __global__ __launch_bounds__(256) void nn_query_kernel(NNQuery a) {
   NN_STAT(1, n_eval);
   NN_STAT(2, n_test);
   NN_STAT(5, n_grp);
+#ifdef A3VT_DBG_NN_STATS
+  if (lane == 0) atomicMax(&nn_stats[6], (unsigned long long)n_grp), atomicMax(&nn_stats[7], (unsigned long long)n_test);
+#endif
 #ifdef A3VT_DBG_NN_STATS
   {   // blocks that HAD to be evaluated given the final minima (slot 3), blocks some lane needs on average (slot 2 reused below)
     int need = 0, lane_need = 0;
@@ -425,6 +441,13 @@ __global__ __launch_bounds__(256) void nn_query_kernel(NNQuery a) {
     od[qidx] = best;
     oi[qidx] = bidx;
   }
+}
+
+// grid = (ceil(query blocks / waves per workgroup), 2 nz)
+__global__ __launch_bounds__(1024) void nn_query_kernel(NNQuery a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  nn_query_wave(a, blockIdx.y, blockIdx.x * (blockDim.x >> 6) + wave, lane);
 }
 
 static NNClouds nn_layout(const float *x, const float *y, int draws, int batch, int p, int q, void *ws) {
@@ -471,7 +494,8 @@ int launch_nn_pruned(const float *x, const float *y, int draws, int batch, int p
   A3VT_CHECK_LAUNCH();
   if (stages < 3) return 0;
   NNQuery a{c.sx, c.sy, c.bx, c.by, c.ux, c.uy, p, q, c.npx, c.npy, c.nx, batch, dxy, dyx, ixy, iyx};
-  A3VT_LAUNCH(nn_query_kernel, dim3(cdiv(nbmax, 4), 2 * c.nx), dim3(256), 0, s, a);
+  static const int wg_waves = getenv("A3VT_NN_WG") ? atoi(getenv("A3VT_NN_WG")) : 4;   // developer override
+  A3VT_LAUNCH(nn_query_kernel, dim3(cdiv(nbmax, wg_waves), 2 * c.nx), dim3(64 * wg_waves), 0, s, a);
   A3VT_CHECK_LAUNCH();
   return 0;
 }
@@ -480,7 +504,7 @@ int launch_nn_pruned(const float *x, const float *y, int draws, int batch, int p
 
 #ifdef A3VT_DBG_NN_STATS
 extern "C" int a3vt_dbg_nn_stats(unsigned long long *out5) {   // reads and clears the counters
-  unsigned long long z[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (hipMemcpyFromSymbol(out5, HIP_SYMBOL(a3vt::nn_stats), sizeof(z)) != hipSuccess) return -1;
   return hipMemcpyToSymbol(HIP_SYMBOL(a3vt::nn_stats), z, sizeof(z)) == hipSuccess ? 0 : -1;
 }

@@ -6,16 +6,16 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/nn
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-REPS=2 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
-  SQ_INSTS_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pass \
-  -- python $ROOT/tools/chamfer_bench.py > $OUT/run.log 2>&1 || { tail -5 $OUT/run.log; exit 1; }
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
+  SQ_INSTS_SALU SQ_INSTS_SMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/pass \
+  -- python $ROOT/tools/chamfer_bench.py --reps 2 --shapes ${SHAPES:-3x64x10000} > $OUT/run.log 2>&1 || { tail -5 $OUT/run.log; exit 1; }
 python - <<PY
 import csv, glob, collections, json
 f = glob.glob("$OUT/pass/*/*counter_collection.csv")[0]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"].split("(")[0]
-    if "nn_kernel" in k or "nn2_kernel" in k:
+    if "nn_kernel" in k or "nn2_kernel" in k or "nn_query" in k or "nn_sort" in k or "nn_boxes" in k:
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for k, d in agg.items():

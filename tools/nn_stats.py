@@ -31,7 +31,7 @@ for shape in args.shapes.split(","):
     draws, B, N = (int(v) for v in shape.split("x"))
     x = surface(draws, B, N, radii=(0.4, 0.4, 0.4)) + args.gap
     y = surface(B, N, radii=(0.5, 0.3, 0.2))
-    out = (ctypes.c_ulonglong * 6)()
+    out = (ctypes.c_ulonglong * 8)()
     torch.cuda.synchronize()
     L.a3vt_dbg_nn_stats(out)
     ops.chamfer_nn(x, y, algo="pruned")
@@ -39,4 +39,4 @@ for shape in args.shapes.split(","):
     L.a3vt_dbg_nn_stats(out)
     w = max(out[0], 1)
     print(f"{shape:>14s} gap {args.gap}: {out[0]} waves, {out[1] / w:.1f} blocks ({out[5] / w:.1f} groups of 16) evaluated and {out[2] / w:.1f} point-box tests per wave "
-          f"(of {(N + 63) // 64} blocks); {out[3] / w:.1f} blocks needed by some lane given the final minima, {out[4] / w / 64:.1f} by a lane on average")
+          f"(of {(N + 63) // 64} blocks); {out[3] / w:.1f} blocks needed by some lane given the final minima, {out[4] / w / 64:.1f} by a lane on average; worst wave: {out[6]} groups, {out[7]} tests")
