@@ -200,11 +200,16 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
   const int t1 = t0 + tbase + ((int)blockIdx.x < trem ? 1 : 0);
 
   const int col0 = p.col0 + blockIdx.y * (NT * 16);  // column block of this workgroup (remainder launches)
+  // The NT 16-row pieces of a Bt chunk are dealt round-robin to the waves (piece j * WAVES + wave): every wave carries
+  // B_INSTR or B_INSTR - 1 of them and none is fetched for rows past the last n-tile (a blocked deal of the padded
+  // BROWS = 384 rows made 5 of the 24 pieces of every chunk pure waste at NT = 19, all of them on the last two waves).
+  const int nbp = (B_INSTR - 1) * WAVES + wave < NT ? B_INSTR : B_INSTR - 1;   // wave-uniform
+  const bool full_per = nbp == B_INSTR;
   const float *brow[B_INSTR];
 #pragma unroll
   for (int j = 0; j < B_INSTR; ++j) {
-    int br = col0 + (wave * B_INSTR + j) * 16 + (lane >> 2);
-    br = br < p.bt_rows ? br : p.bt_rows - 1;  // rows past the buffer are never consumed
+    int br = col0 + (j * WAVES + wave) * 16 + (lane >> 2);
+    br = br < p.bt_rows ? br : p.bt_rows - 1;
     brow[j] = p.bt + (size_t)br * p.ldb;
   }
 
@@ -250,8 +255,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
         glds16(src, sA + piece * 256);
       } else {
         const int j = piece - A_INSTR;
+        if (j >= nbp) return;
         float *sB = lds + buf * STAGE + A_FLOATS;
-        glds16(brow[j] + kk, sB + (wave * B_INSTR + j) * 256);
+        glds16(brow[j] + kk, sB + (j * WAVES + wave) * 256);
       }
     };
     auto issue = [&](int chunk, int buf) {
@@ -278,11 +284,19 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
     for (int t = 0; t < nchunks; ++t) {
       // chunk t landed; up to DIST-1 younger chunks may still be in flight
       const int younger = nchunks - 1 - t < DIST - 1 ? nchunks - 1 - t : DIST - 1;
-      if (younger >= 4) wait_vmcnt<(DIST > 4 ? 4 : 0) * PER>();
-      else if (younger == 3) wait_vmcnt<(DIST > 3 ? 3 : 0) * PER>();
-      else if (younger == 2) wait_vmcnt<(DIST > 2 ? 2 : 0) * PER>();
-      else if (younger == 1) wait_vmcnt<(DIST > 1 ? 1 : 0) * PER>();
-      else wait_vmcnt<0>();
+      if (full_per) {   // this wave issues PER instructions per chunk ...
+        if (younger >= 4) wait_vmcnt<(DIST > 4 ? 4 : 0) * PER>();
+        else if (younger == 3) wait_vmcnt<(DIST > 3 ? 3 : 0) * PER>();
+        else if (younger == 2) wait_vmcnt<(DIST > 2 ? 2 : 0) * PER>();
+        else if (younger == 1) wait_vmcnt<(DIST > 1 ? 1 : 0) * PER>();
+        else wait_vmcnt<0>();
+      } else {          // ... or one fewer (the deal of the Bt pieces above)
+        if (younger >= 4) wait_vmcnt<(DIST > 4 ? 4 : 0) * (PER - 1)>();
+        else if (younger == 3) wait_vmcnt<(DIST > 3 ? 3 : 0) * (PER - 1)>();
+        else if (younger == 2) wait_vmcnt<(DIST > 2 ? 2 : 0) * (PER - 1)>();
+        else if (younger == 1) wait_vmcnt<(DIST > 1 ? 1 : 0) * (PER - 1)>();
+        else wait_vmcnt<0>();
+      }
       __builtin_amdgcn_s_barrier();  // chunk t visible to all waves; everyone is done with chunk t-1's stage
       // Chunk t+DIST goes to stage (t-1) % NSTAGE, free since the barrier above.  With enough n-tile pairs its DMA
       // instructions are spread through the MFMA stream below so their issue cost hides under the matrix pipe.
