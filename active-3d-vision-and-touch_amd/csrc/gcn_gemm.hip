@@ -301,7 +301,11 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
       // Chunk t+DIST goes to stage (t-1) % NSTAGE, free since the barrier above.  With enough n-tile pairs its DMA
       // instructions are spread through the MFMA stream below so their issue cost hides under the matrix pipe.
       constexpr int NPAIR = (NT + 1) / 2;
+#ifdef A3VT_DBG_RG_NOSPREAD   // timing experiment: the whole next chunk is issued right after the barrier
+      constexpr bool SPREAD = false;
+#else
       constexpr bool SPREAD = NPAIR >= 2 * PER;
+#endif
       const bool prefetch = t + DIST < nchunks;
       const int nbuf = buf >= 1 ? buf - 1 : NSTAGE - 1;
       if (prefetch && (!SPREAD || !active)) issue(t + DIST, nbuf);
@@ -600,9 +604,19 @@ struct RowGemmCfg {
   static constexpr int BROWS = ((NT * 16 + 16 * WAVES - 1) / (16 * WAVES)) * (16 * WAVES);
 };
 
+#ifdef A3VT_DBG_RG_NSTAGE4   // timing experiment (plain epilogue only: the sign-byte slots do not fit beside a 4-stage ring)
+template <int NT, int EPI>
+struct RowGemmCfgE : RowGemmCfg<NT> {
+  static constexpr int NSTAGE = (EPI == EPI_PLAIN && NT == 19) ? 4 : RowGemmCfg<NT>::NSTAGE;
+};
+#else
+template <int NT, int EPI>
+struct RowGemmCfgE : RowGemmCfg<NT> {};
+#endif
+
 template <int NT, int EPI>
 static int launch_rowgemm_nt(const RowGemmArgs &a, int grid_y, hipStream_t s) {
-  using C = RowGemmCfg<NT>;
+  using C = RowGemmCfgE<NT, EPI>;
   constexpr size_t shmem = (C::NSTAGE * (size_t)(C::WAVES * 2 * 256 + C::BROWS * 16) +
                             (EPI != EPI_PLAIN ? C::WAVES * 1024 : 0)) * sizeof(float);   // + a sign-byte slot per wave
   static_assert(shmem * C::WG_PER_CU <= 160 * 1024, "LDS budget");

@@ -11,6 +11,11 @@ if [ "$1" = "csr" ]; then   # csr_fwd / csr16_fwd without their stores: tools/ks
   build CSR_NOSTORE -DA3VT_DBG_CSR_NOSTORE
 elif [ "$1" = "nn" ]; then   # pruned nearest-neighbour search with its counters (tools/nn_stats.py)
   build NN_STATS -DA3VT_DBG_NN_STATS
+elif [ "$1" = "prefetch" ]; then   # rowgemm prefetch-depth experiments: tools/rowgemm_bench.py / stack_bench.py with A3VT_LIB=...
+  build RG_NOSPREAD -DA3VT_DBG_RG_NOSPREAD &
+  build RG_NSTAGE4 -DA3VT_DBG_RG_NSTAGE4 &
+  build RG_NSTAGE4_NOSPREAD -DA3VT_DBG_RG_NSTAGE4 -DA3VT_DBG_RG_NOSPREAD &
+  wait
 elif [ "$1" = "rowgemm" ]; then   # rowgemm_kernel ablations (all gemm modes): python tools/stack_bench.py with A3VT_LIB=...
   build RG_NOEPI -DA3VT_DBG_RG_NOEPI &
   build RG_NOA -DA3VT_DBG_RG_NOA &

@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 
-def run(name, net, info, charts, img, gt, args, steps=5):
+def run(name, net, info, charts, img, gt, args, steps=10, warm=8):
     from a3vt_amd import distributed as adist
     from a3vt_amd.pterotactyl.utility import utils
     params = list(net.parameters())
@@ -31,7 +31,7 @@ def run(name, net, info, charts, img, gt, args, steps=5):
         opt.step()
         return loss
 
-    for _ in range(2):
+    for _ in range(warm):   # MIOpen's find mode and the allocator's growth take several steps to settle (image mode)
         loss = step()
     torch.cuda.synchronize()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
@@ -53,7 +53,7 @@ def main():
     p.add_argument("--batch4", type=int, default=8)
     p.add_argument("--precision", default="bf16s", choices=["fp32", "bf16", "bf16s"])
     p.add_argument("--only", type=int, default=0, choices=[0, 3, 4])
-    p.add_argument("--steps", type=int, default=5)
+    p.add_argument("--steps", type=int, default=10)
     a = p.parse_args()
     from a3vt_amd import mesh as amesh
     from a3vt_amd.pterotactyl.reconstruction.vision import model

@@ -16,7 +16,11 @@ python tools/named_configs.py --precision bf16 >> $O/${R}_named_configs.jsonl 2>
 python tools/touch_bench.py > $O/${R}_touch_topology_step.log 2>&1; tail -3 $O/${R}_touch_topology_step.log
 (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/bstats && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bstats -- python $GRAFT_REPO_ROOT/bench.py --steps 15 --warmup 5 --no-cpu-baseline --no-traffic > /tmp/bstats.log 2>&1; cp $(find /tmp/bstats -name '*kernel_stats.csv' | head -1) $O/${R}_bench_kernel_stats.csv; tail -c 300 /tmp/bstats.log)
 (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/bstats2 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bstats2 -- python $GRAFT_REPO_ROOT/bench.py --steps 15 --warmup 5 --no-cpu-baseline --no-traffic --gemm-precision bf16s > /tmp/bstats2.log 2>&1; cp $(find /tmp/bstats2 -name '*kernel_stats.csv' | head -1) $O/${R}_bench_bf16s_kernel_stats.csv)
-(cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/c3 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/c3 -- python $GRAFT_REPO_ROOT/tools/named_configs.py --only 3 --steps 5 > /tmp/c3.log 2>&1; cp $(find /tmp/c3 -name '*kernel_stats.csv' | head -1) $O/${R}_config3_bf16s_kernel_stats.csv)
+# configs[3]: the first steps run MIOpen's find mode, so the table is cut from the kernel TRACE after 5 steps (tools/trace_steady.py)
+(cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/c3 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/c3 -- python $GRAFT_REPO_ROOT/tools/named_configs.py --only 3 --steps 10 > /tmp/c3.log 2>&1; python $GRAFT_REPO_ROOT/tools/trace_steady.py $(find /tmp/c3 -name '*kernel_trace.csv' | head -1) --skip 5 --top 60 > $O/${R}_config3_bf16s_steady_kernels.txt; head -8 $O/${R}_config3_bf16s_steady_kernels.txt)
+python tools/chamfer_bench.py > $O/${R}_chamfer_search.txt 2>/dev/null; cat $O/${R}_chamfer_search.txt
+[ -f gpurun_variants/liba3vt_NN_STATS.so ] && A3VT_LIB=gpurun_variants/liba3vt_NN_STATS.so python tools/nn_stats.py > $O/${R}_nn_pruning_stats.txt 2>/dev/null
+bash tools/collect_nn.sh > $O/nn.log 2>&1; cp gpurun_out/nn/summary.json $O/${R}_pmc_nn_summary.json
 bash tools/collect_traffic.sh > $O/traffic.log 2>&1; cp gpurun_out/traffic/summary.json $O/${R}_pmc_traffic_summary.json
 bash tools/collect_sq.sh > $O/sq.log 2>&1; cp gpurun_out/sq/summary.json $O/${R}_pmc_sq_summary.json
 bash tools/collect_sq.sh --precision bf16s > $O/sq16.log 2>&1; cp gpurun_out/sq/summary.json $O/${R}_pmc_sq_summary_bf16s.json
