@@ -183,12 +183,14 @@ __global__ __launch_bounds__(kSortThreads) void nn_sort_kernel(NNClouds c) {
   }
 }
 
-// grid = (ceil(blocks / 16), clouds), 16 waves per workgroup, one block of 64 sorted points per wave
-__global__ __launch_bounds__(1024) void nn_boxes_kernel(NNClouds c) {
-  const int cloud = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// grid = ceil(blocks / 16) x clouds (flattened: gridDim.y stops at 65 535 clouds), 16 waves per workgroup, one block of
+// 64 sorted points per wave
+__global__ __launch_bounds__(1024) void nn_boxes_kernel(NNClouds c, int wgs_per_cloud) {
+  const int cloud = blockIdx.x / wgs_per_cloud, bx = blockIdx.x % wgs_per_cloud;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool isx = cloud < c.nx;
   const int n = isx ? c.p : c.q, np = isx ? c.npx : c.npy;
-  const int blk = blockIdx.x * 16 + wave;
+  const int blk = bx * 16 + wave;
   if (blk * kPB >= np) return;
   f32x4 *pts = isx ? c.sx + (size_t)cloud * c.npx : c.sy + (size_t)(cloud - c.nx) * c.npy;
   f32x4 *box = (isx ? c.bx + (size_t)cloud * (c.npx / kPB) * 2 : c.by + (size_t)(cloud - c.nx) * (c.npy / kPB) * 2) + blk * 2;
@@ -443,11 +445,13 @@ __device__ __forceinline__ void nn_query_wave(const NNQuery &a, int y, int qblk,
   }
 }
 
-// grid = (ceil(query blocks / waves per workgroup), 2 nz)
-__global__ __launch_bounds__(1024) void nn_query_kernel(NNQuery a) {
+// grid = ceil(query blocks / waves per workgroup) x 2 nz, flattened (the query blocks of one cloud pair are consecutive
+// workgroups: they run at about the same time and share the candidate cloud in L2 and in the scalar caches)
+__global__ __launch_bounds__(1024) void nn_query_kernel(NNQuery a, int wgs_per_pair) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  nn_query_wave(a, blockIdx.y, blockIdx.x * (blockDim.x >> 6) + wave, lane);
+  const int y = blockIdx.x / wgs_per_pair, bx = blockIdx.x % wgs_per_pair;
+  nn_query_wave(a, y, bx * (blockDim.x >> 6) + wave, lane);
 }
 
 static NNClouds nn_layout(const float *x, const float *y, int draws, int batch, int p, int q, void *ws) {
@@ -478,6 +482,10 @@ size_t nn_pruned_workspace_bytes(int draws, int batch, int p, int q) {
 
 int launch_nn_pruned(const float *x, const float *y, int draws, int batch, int p, int q, float *dxy, int32_t *ixy,
                      float *dyx, int32_t *iyx, void *ws, hipStream_t s) {
+  if (reinterpret_cast<uintptr_t>(ws) & 15) {
+    set_error("chamfer_fwd: the workspace of the pruned search must be 16-byte aligned");
+    return -1;
+  }
   const NNClouds c = nn_layout(x, y, draws, batch, p, q, ws);
   const int bits = nn_grid_bits(p > q ? p : q);
   const size_t shmem = (size_t)(1 << (3 * bits)) * sizeof(unsigned);
@@ -490,12 +498,18 @@ int launch_nn_pruned(const float *x, const float *y, int draws, int batch, int p
   A3VT_CHECK_LAUNCH();
   if (stages < 2) return 0;
   const int nbmax = (c.npx > c.npy ? c.npx : c.npy) / kPB;
-  A3VT_LAUNCH(nn_boxes_kernel, dim3(cdiv(nbmax, 16), c.nx + c.ny), dim3(1024), 0, s, c);
+  const long long box_wgs = (long long)cdiv(nbmax, 16) * (c.nx + c.ny);
+  const int wg_waves_q = 4;
+  const long long query_wgs = (long long)cdiv(nbmax, wg_waves_q) * 2 * c.nx;
+  if (box_wgs >= (1ll << 31) || query_wgs >= (1ll << 31)) {
+    set_error("chamfer_fwd: %d x %d clouds of %d / %d points exceed the grid of the pruned search", draws, batch, p, q);
+    return -1;
+  }
+  A3VT_LAUNCH(nn_boxes_kernel, dim3((unsigned)box_wgs), dim3(1024), 0, s, c, cdiv(nbmax, 16));
   A3VT_CHECK_LAUNCH();
   if (stages < 3) return 0;
   NNQuery a{c.sx, c.sy, c.bx, c.by, c.ux, c.uy, p, q, c.npx, c.npy, c.nx, batch, dxy, dyx, ixy, iyx};
-  static const int wg_waves = getenv("A3VT_NN_WG") ? atoi(getenv("A3VT_NN_WG")) : 4;   // developer override
-  A3VT_LAUNCH(nn_query_kernel, dim3(cdiv(nbmax, wg_waves), 2 * c.nx), dim3(64 * wg_waves), 0, s, a);
+  A3VT_LAUNCH(nn_query_kernel, dim3((unsigned)query_wgs), dim3(64 * wg_waves_q), 0, s, a, cdiv(nbmax, wg_waves_q));
   A3VT_CHECK_LAUNCH();
   return 0;
 }

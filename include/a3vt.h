@@ -209,7 +209,7 @@ int a3vt_chamfer_fwd(const float *x, const float *y, int draws, int batch, int p
  *       sorted into blocks of 64 neighbouring points with bounding boxes, and a wave of 64 neighbouring queries only
  *       evaluates the blocks whose box can still hold a nearer (or equally near) point.
  * All algorithms return the same distances and indices bit for bit (same fma chain, ties to the lowest index).
- * <0 if the workspace is too small for the algorithm asked for. */
+ * <0 if the workspace is too small for the algorithm asked for (or, for the pruned search, not 16-byte aligned). */
 size_t a3vt_chamfer_workspace_bytes(int draws, int batch, int p, int q);
 int a3vt_chamfer_fwd_ws(const float *x, const float *y, int draws, int batch, int p, int q,
                         float *dist_xy, int32_t *idx_xy, float *dist_yx, int32_t *idx_yx, float *cd,

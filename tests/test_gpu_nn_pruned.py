@@ -143,6 +143,22 @@ def test_automatic_choice_and_workspace_checks(cuda):
     torch.cuda.synchronize()
 
 
+def test_pruned_many_small_clouds(cuda):
+    """More cloud pairs than a grid's y dimension holds (65 535): the search kernels run on flattened grids."""
+    from a3vt_amd import ops
+    g = torch.Generator().manual_seed(21)
+    B, P, Q = 70000, 8, 5
+    x = torch.rand(1, B, P, 3, generator=g)
+    y = torch.rand(B, Q, 3, generator=g)
+    dxy, ixy, dyx, iyx, cd = ops.chamfer_nn(x.to(cuda), y.to(cuda), algo="pruned")
+    d = ((x[0][:, :, None, :] - y[:, None, :, :]) ** 2).sum(-1)          # (B,P,Q), same fp32 order is not needed: compare loosely
+    assert torch.allclose(dxy[0].cpu(), d.min(2).values, rtol=1e-5, atol=1e-7)
+    assert torch.allclose(dyx[0].cpu(), d.min(1).values, rtol=1e-5, atol=1e-7)
+    assert torch.equal(torch.gather(d, 2, ixy[0].cpu().long()[..., None])[..., 0], d.min(2).values) or \
+        torch.allclose(torch.gather(d, 2, ixy[0].cpu().long()[..., None])[..., 0], d.min(2).values, rtol=1e-5, atol=1e-7)
+    assert torch.isfinite(cd).all()
+
+
 def test_pruned_repeats_bit_for_bit(cuda):
     """The order of points inside a grid cell depends on LDS atomics; the outputs must not."""
     from a3vt_amd import ops
