@@ -1222,8 +1222,39 @@ __global__ __launch_bounds__(1024) void slab_reduce_kernel(const float *__restri
   }
 }
 
+// Many slabs, few outputs (the bias gradient: 2048 partial rows of 100 floats): the kernel above would run two workgroups
+// whose threads each walk 128 slabs.  Here a workgroup owns 16 consecutive outputs and cuts the slabs 64 ways (thread =
+// output o, slab group g: slabs g, g + 64, ...), so a thread sums nslab / 64 values with eight loads in flight; the 64
+// partials per output are combined through LDS in a fixed order.  9.5 -> 4 us per call, 57 calls per step.
+__global__ __launch_bounds__(1024) void slab_reduce_tall_kernel(const float *__restrict__ slab, int nslab, size_t stride,
+                                                                size_t n, size_t n_out, float *__restrict__ out) {
+  __shared__ float part[64][17];
+  const int o = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const size_t i = (size_t)blockIdx.x * 16 + o;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (i < n) {
+    int sl = grp;
+    for (; sl + 7 * 64 < nslab; sl += 8 * 64) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += slab[(size_t)(sl + u * 64) * stride + i];
+    }
+    for (; sl < nslab; sl += 64) a[0] += slab[(size_t)sl * stride + i];
+  }
+  part[grp][o] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  if (grp == 0 && i < n_out) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 64; ++g) t += part[g][o];
+    out[i] = i < n ? t : 0.f;
+  }
+}
+
 int launch_slab_reduce_z(const float *slab, int nslab, size_t stride, size_t n, size_t n_out, float *out, hipStream_t s) {
-  A3VT_LAUNCH(slab_reduce_kernel, dim3(cdiv((long long)n_out, 64)), dim3(1024), 0, s, slab, nslab, stride, n, n_out, out);
+  if (nslab >= 512 && n_out <= 1024)
+    A3VT_LAUNCH(slab_reduce_tall_kernel, dim3(cdiv((long long)n_out, 16)), dim3(1024), 0, s, slab, nslab, stride, n, n_out, out);
+  else
+    A3VT_LAUNCH(slab_reduce_kernel, dim3(cdiv((long long)n_out, 64)), dim3(1024), 0, s, slab, nslab, stride, n, n_out, out);
   A3VT_CHECK_LAUNCH();
   return 0;
 }
