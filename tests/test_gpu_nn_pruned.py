@@ -159,6 +159,31 @@ def test_pruned_many_small_clouds(cuda):
     assert torch.isfinite(cd).all()
 
 
+def test_pruned_nonfinite_coordinates_stay_in_bounds(cuda):
+    """NaN / Inf coordinates (a diverged network): no hang, no out-of-range index — the backward kernel gathers through
+    these indices — and the clouds that are finite are unaffected."""
+    from a3vt_amd import ops
+    g = torch.Generator().manual_seed(13)
+    P = Q = 3000
+    x = torch.stack([_surface(g, P, "sphere") for _ in range(3)])[None]
+    y = torch.stack([_surface(g, Q, "ellipsoid") for _ in range(3)])
+    clean = ops.chamfer_nn(x.to(cuda), y.to(cuda), algo="pruned")
+    x[0, 1, ::7] = float("nan")
+    x[0, 1, 5] = float("inf")
+    y[2, 100:200] = float("nan")
+    y[2, 7, 1] = -float("inf")
+    dxy, ixy, dyx, iyx, cd = ops.chamfer_nn(x.to(cuda), y.to(cuda), algo="pruned")
+    torch.cuda.synchronize()
+    assert ixy.min() >= 0 and ixy.max() < Q and iyx.min() >= 0 and iyx.max() < P
+    assert torch.equal(dxy[0, 0], clean[0][0, 0]) and torch.equal(ixy[0, 0], clean[1][0, 0])
+    assert torch.equal(dyx[0, 0], clean[2][0, 0]) and torch.equal(iyx[0, 0], clean[3][0, 0])
+    # the gradient kernel runs on these indices without faulting
+    xg = x.to(cuda).requires_grad_(True)
+    ops.ChamferFn.apply(xg, y.to(cuda)).sum().backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(xg.grad[0, 0]).all()
+
+
 def test_pruned_repeats_bit_for_bit(cuda):
     """The order of points inside a grid cell depends on LDS atomics; the outputs must not."""
     from a3vt_amd import ops
