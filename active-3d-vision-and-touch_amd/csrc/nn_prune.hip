@@ -24,11 +24,10 @@
 //
 // Work per query grows slowly with the cloud instead of in proportion to it.  Measured (3 draws x 64 clouds, sphere against
 // ellipsoid, tools/chamfer_bench.py): 10k points 0.9 ms against 3.8 ms for the single-sweep brute force, 25k 2.5 against
-// 20.4, 50k (3 x 8 clouds) 1.7 against 12.0.  What bounds the query kernel now is the latency of each wave's dependent chain
-// (pick a block, fetch its boxes, test, fetch a group of candidates) through the miss path of the scalar cache, not VALU
-// issue (SQ counters: 0.19 VALU instructions per SIMD-cycle, half the brute-force loop's rate, waves waiting half their
-// cycles; a persistent grid that interleaves the clouds across CUs is 1.8x SLOWER whatever the occupancy; workgroups of
-// 1 - 16 waves make no difference; two query blocks per wave are slower) — DESIGN.md §4, §8.  All kernels are deterministic in their outputs (the order of points inside a grid cell
+// 20.4, 50k (3 x 8 clouds) 1.7 against 12.0.  The query kernel issues 0.19 VALU instructions per SIMD-cycle (the brute-force
+// loop 0.32) in bursts of ~100 between wave-uniform decisions; variants that halve the scalar fetches per query (two query
+// blocks per wave) or remove them (candidates through vector loads + DPP row_newbcast, next block prefetched) are not
+// faster, a persistent grid is slower — DESIGN.md §4, §8.  All kernels are deterministic in their outputs (the order of points inside a grid cell
 // depends on LDS atomics, the minima do not).
 #include <stdlib.h>
 
