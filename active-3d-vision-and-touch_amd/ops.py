@@ -375,6 +375,11 @@ def sample_points(verts, faces, num, draws, seed=0, offset=0, return_samples=Fal
     return (points, fi, uu, vv) if return_samples else points
 
 
+# Search algorithm ChamferFn asks the library for (include/a3vt.h: a3vt_chamfer_fwd_ws): 0 = let it choose.  All of them
+# return the same bits; tests flip this to prove it end to end.
+CHAMFER_ALGO = 0
+
+
 class ChamferFn(torch.autograd.Function):
     """pytorch3d chamfer_distance(x, y, batch_reduction=None) averaged over draws (utility/utils.py:204-217).
     x (draws,B,P,3), y (B,Q,3) -> cd (B,)."""
@@ -396,8 +401,8 @@ class ChamferFn(torch.autograd.Function):
         nbytes = L.a3vt_chamfer_workspace_bytes(draws, B, P, Q)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
         _lib.check(L.a3vt_chamfer_fwd_ws(_lib.ptr(x), _lib.ptr(y), draws, B, P, Q, _lib.ptr(dxy), _lib.ptr(ixy),
-                                         _lib.ptr(dyx), _lib.ptr(iyx), _lib.ptr(cd), _lib.ptr(ws), nbytes, 0, _stream()),
-                   "chamfer_fwd")
+                                         _lib.ptr(dyx), _lib.ptr(iyx), _lib.ptr(cd), _lib.ptr(ws), nbytes, CHAMFER_ALGO,
+                                         _stream()), "chamfer_fwd")
         ctx.save_for_backward(x, y, ixy, iyx)
         ctx.aux = (dxy, dyx)
         return cd

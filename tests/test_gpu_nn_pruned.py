@@ -184,6 +184,45 @@ def test_pruned_nonfinite_coordinates_stay_in_bounds(cuda):
     assert torch.isfinite(xg.grad[0, 0]).all()
 
 
+def test_training_is_bit_identical_whichever_search_runs(cuda):
+    """Five optimiser steps of the 3-stage network (icosphere-4, bs 4, 4 000-point Chamfer, fresh Philox draws per step)
+    with the pruned search and with the brute-force sweep: every loss and every weight identical bit for bit — the
+    searches return the same neighbours and every other kernel of the step is deterministic."""
+    from a3vt_amd import ops
+    from a3vt_amd.pterotactyl.reconstruction.vision import model
+    from a3vt_amd.pterotactyl.utility import utils
+    from a3vt_amd.synthetic import gt_cloud, make_args
+    from helpers import template
+    args = make_args(number_points=4000)
+    v, f = template("ico4")
+    vt, ft = torch.from_numpy(v).to(cuda), torch.from_numpy(f).to(cuda)
+    info = utils.adj_init(vt, ft, args)
+    B = 4
+    charts = model.prepare_mesh({"img": torch.zeros(B, 1)}, vt, args)
+    gt = gt_cloud(B, 4000, 7).to(cuda)
+    runs = {}
+    try:
+        for name, algo in (("pruned", ops.NN_ALGOS["pruned"]), ("sweep", ops.NN_ALGOS["sweep"])):
+            ops.CHAMFER_ALGO = algo
+            torch.manual_seed(0)
+            net = model.Deformation(info, vt, args).to(cuda)
+            opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+            losses = []
+            for _ in range(5):
+                opt.zero_grad()
+                out = net(torch.zeros(B, 1), charts)[0]
+                loss = args.loss_coeff * utils.chamfer_distance(out, info["faces"], gt, num=4000).mean()
+                loss.backward()
+                opt.step()
+                losses.append(loss.item())
+            runs[name] = (losses, torch.cat([p.detach().reshape(-1) for p in net.parameters()]).clone())
+    finally:
+        ops.CHAMFER_ALGO = 0
+    assert runs["pruned"][0] == runs["sweep"][0], (runs["pruned"][0], runs["sweep"][0])
+    assert torch.equal(runs["pruned"][1], runs["sweep"][1])
+    assert runs["pruned"][0][-1] < runs["pruned"][0][0]          # and it trains
+
+
 def test_pruned_repeats_bit_for_bit(cuda):
     """The order of points inside a grid cell depends on LDS atomics; the outputs must not."""
     from a3vt_amd import ops
