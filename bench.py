@@ -129,12 +129,18 @@ def cpu_baseline(level, layers, hidden, points, budget_s, seed=0):
     variants[f"csr_bs2_{some}threads"] = leg("csr", 2, adj_csr, some, 4.0, warm=False)
     variants["faithful_bs8_allcores"] = leg("faithful", 8, dense, all_cores, 12.0, warm=False)
     variants["csr_bs8_allcores"] = leg("csr", 8, adj_csr, all_cores, 12.0, warm=False)
-    head = variants["faithful_bs2_allcores"]
+    # headline = the FASTEST reference-faithful variant measured (the CPU at its best thread count, not "all cores":
+    # torch's CPU kernels get slower past a few dozen threads on tensors this small), `cores` = the threads it used
+    cands = {k: v for k, v in variants.items() if k.startswith("faithful") and "iters_per_s_at_bs64" in v}
+    best = max(cands, key=lambda k: cands[k]["iters_per_s_at_bs64"]) if cands else "faithful_bs2_allcores"
+    head = variants[best]
     spent = time.perf_counter() - t_start
-    return {"value": head.get("iters_per_s_at_bs64"), "unit": "iters/s at bs=64", "cores": all_cores, "kind": "port",
+    return {"value": head.get("iters_per_s_at_bs64"), "unit": "iters/s at bs=64", "cores": head.get("threads", all_cores),
+            "kind": "port",
             "sample": f"oracle (CPU restatement of the reference path), reference-faithful variant: dense (N,N) adjacency "
-                      f"products + compiled brute-force NN, bs=2 of the bs=64 workload, median of {head.get('iters_timed')} "
-                      f"fwd+bwd iterations after 1 warm-up (no optimizer), all {all_cores} threads; scaled by 2/64. "
+                      f"products + compiled brute-force NN; fastest of the thread counts tried ({best}: bs={head.get('bs')} of "
+                      f"the bs=64 workload on {head.get('threads')} of {all_cores} threads, median of "
+                      f"{head.get('iters_timed')} fwd+bwd iterations, no optimizer; scaled by bs/64). "
                       f"{spent:.0f} s of CPU wall time for all variants",
             "variants": variants}
 
