@@ -72,6 +72,17 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+#ifdef A3VT_DBG_RG_STAMPS   // diagnostic build (tools/build_variants.sh stamps): s_memrealtime (100 MHz) at the phase boundaries
+__device__ unsigned long long g_rg_stamps[256 * 64];   // [workgroup][round (<= 8)][8]; read with a3vt_dbg_rg_stamps
+#define RG_STAMP(round, k)                                                                                   \
+  do {                                                                                                       \
+    if (threadIdx.x == 0 && blockIdx.x < 256 && blockIdx.y == 0 && (round) < 8)                              \
+      g_rg_stamps[blockIdx.x * 64 + (round) * 8 + (k)] = __builtin_amdgcn_s_memrealtime();                   \
+  } while (0)
+#else
+#define RG_STAMP(round, k) do { } while (0)
+#endif
+
 // One 16 x 16 output tile — rows row_base + 16 mt .., columns n0 .. — with its operands pulled straight from global
 // memory into registers: all loads of up to 19 K-chunks in flight at once, no LDS, no barrier, then the MFMA chain (one
 // round trip instead of nineteen).  Same arithmetic order along K as rowgemm_kernel.  Used for the handful of rows the
@@ -213,7 +224,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
     brow[j] = p.bt + (size_t)br * p.ldb;
   }
 
-  for (int tb = t0; tb < t1; tb += MT * WAVES) {
+  int rnd_ = 0;
+  for (int tb = t0; tb < t1; tb += MT * WAVES, ++rnd_) {
+    RG_STAMP(rnd_, 0);
     // tiles of this round for this wave: two each when the round is full, an even split otherwise
     const int cnt = t1 - tb < MT * WAVES ? t1 - tb : MT * WAVES;
     const int base = cnt / WAVES, extra = cnt % WAVES;
@@ -298,6 +311,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
         else wait_vmcnt<0>();
       }
       __builtin_amdgcn_s_barrier();  // chunk t visible to all waves; everyone is done with chunk t-1's stage
+      if (t == 0) RG_STAMP(rnd_, 1);
+      if (t == 1) RG_STAMP(rnd_, 5);
       // Chunk t+DIST goes to stage (t-1) % NSTAGE, free since the barrier above.  With enough n-tile pairs its DMA
       // instructions are spread through the MFMA stream below so their issue cost hides under the matrix pipe.
       constexpr int NPAIR = (NT + 1) / 2;
@@ -397,6 +412,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
     }
     wait_lgkm0();
     __builtin_amdgcn_s_barrier();  // all waves finished reading the ring -> reuse it for the epilogue
+    RG_STAMP(rnd_, 2);
 
     // Epilogue.  C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg — a lane holds 4 rows
     // of one column, so direct stores would be 64-byte fragments.  Each wave transposes its accumulators through
@@ -580,8 +596,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
           *reinterpret_cast<f32x4 *>(dstm + o) = *reinterpret_cast<const f32x4 *>(mslot + o);
       }
     }
+    RG_STAMP(rnd_, 3);
     wait_lgkm0();
     __builtin_amdgcn_s_barrier();  // epilogue slices are free again before the next round's DMA
+    RG_STAMP(rnd_, 4);
   }
   // Leftover rows of the load-balanced split (a few 16-row tiles): one 16 x 16 output tile per wave, dealt across the
   // workgroups, operands straight from global memory (rowtile_unit) — a couple of microseconds at the end of this launch
@@ -719,6 +737,12 @@ static int launch_rowgemm_epi(const RowGemmArgs &a0, hipStream_t s) {
   if (a.maskb) r.maskb = a.maskb + r0 * a.mld;
   return launch_rowtile<EPI>(r, s);
 }
+
+#ifdef A3VT_DBG_RG_STAMPS
+extern "C" int a3vt_dbg_rg_stamps(unsigned long long *host_dst) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_rg_stamps), sizeof(unsigned long long) * 256 * 64);
+}
+#endif
 
 // Rows of Bt the kernel stages for a given n (must exist, zero padded, in the Bt buffer).
 int rowgemm_bt_rows(int n_store) {

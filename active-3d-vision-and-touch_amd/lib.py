@@ -64,20 +64,28 @@ SIGNATURES = {
 _LIB = None
 
 
-def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 -shared → liba3vt.so next to this file (cross-compiles without a GPU)."""
+def build(force=False, verbose=False, defines=(), out=None):
+    """hipcc --offload-arch=gfx950 -shared → liba3vt.so next to this file (cross-compiles without a GPU).
+
+    ``defines`` / ``out``: developer variants (tools/build_variants.sh) — the same per-file flags as the shipped
+    library plus ``-D`` switches, written to another path (always rebuilt, objects in their own directory)."""
+    if out is not None:
+        return _build(True, verbose, list(defines), out, os.path.join(_HERE, "build", "variant_" + os.path.basename(out)))
+    return _build(force, verbose, [], LIB_PATH, os.path.join(_HERE, "build"))
+
+
+def _build(force, verbose, defines, lib_path, objdir):
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.join(CSRC, h) for h in ("common.h", "kernels.h")] + \
         [os.path.join(_HERE, "..", "include", "a3vt.h")]
     force = force or os.environ.get("A3VT_FORCE_BUILD", "0") not in ("", "0")   # prove on any box that it compiles
-    if not force and os.path.exists(LIB_PATH) and all(
-            os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps if os.path.exists(d)):
-        return LIB_PATH
+    if not force and os.path.exists(lib_path) and all(
+            os.path.getmtime(lib_path) >= os.path.getmtime(d) for d in deps if os.path.exists(d)):
+        return lib_path
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    common = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
-    objdir = os.path.join(_HERE, "build")
+    common = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", *[f"-D{d}" for d in defines]]
     os.makedirs(objdir, exist_ok=True)
     procs = []
     for name in SOURCES:
@@ -91,11 +99,11 @@ def build(force=False, verbose=False):
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
         objs.append(obj)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib_path]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB_PATH
+    return lib_path
 
 
 def load():
