@@ -2,6 +2,7 @@
 // (the layer loop of reconstruction/vision/model.py:316-331 lives here so that Python makes one call
 // per refinement stage and nothing syncs the host).
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/a3vt.h"
@@ -78,8 +79,23 @@ struct StackLayout {
   size_t panel;          // bwd, inputs wider than 304 columns only: [M][300] contiguous column block of X_0 for dW_0
   size_t dw_slab, db_slab, thin_dw_slab, thin_db_slab;
   size_t heavy;          // int32 list of hub rows (csr_heavy_scratch_ints)
+  size_t gq;             // bwd: quad-major gradient columns [0, cpad) for the channel-sliced aggregation, [M][cpad]
+  size_t ell;            // slot-major index image of the adjacency (csrq_ell_ints)
   size_t total;
 };
+
+// Channel-sliced aggregation (gcn_csr.hip "csrq") for the hidden layers of a stack: the mesh slice must fit LDS and the
+// product kernel must run the shape as one column block so that its epilogues can write quad-major.  Forward and backward
+// decide from the same arguments (the backward reads the sign bytes the forward left).  A3VT_CSR_ALGO=rows is a developer
+// switch back to the half-wave-per-vertex kernels (both paths give the same outputs).
+static bool use_csrq(int batch, int n_vert, int hidden, int cut_len) {
+  const char *algo = getenv("A3VT_CSR_ALGO");   // read per call: the parity tests run both paths in one process
+  if ((algo && strcmp(algo, "rows") == 0) || cut_len <= 0) return false;
+  return csrq_fits(n_vert, cut_len) && rowgemm_quad_major_ok(batch * n_vert, hidden, pad4(cut_len));
+}
+// sign bytes of the aggregated channels, quad-major [batch][Q][n_vert] per hidden layer, kept behind the row-major
+// sign bytes in the caller's `masks` buffer
+static inline size_t signq_stride(size_t m, int cut_len) { return align_up(m * (size_t)(pad4(cut_len) / 4), 256); }
 
 static StackLayout stack_layout(int batch, int n_vert, int in_features, int hidden, int num_layers, int cut_len,
                                 int need_backward) {
@@ -100,12 +116,15 @@ static StackLayout stack_layout(int batch, int n_vert, int in_features, int hidd
   L.ping[0] = take(m * hidden);
   L.ping[1] = take(m * hidden);
   L.heavy = take(csr_heavy_scratch_ints(n_vert));
+  L.ell = take(csrq_ell_ints(n_vert));
   if (need_backward) {
     const size_t kin = kmax;
     // its own region: with hidden < 300 a ping buffer ([M][hidden]) is smaller than a 300-column block of X_0
     L.panel = take(pad4(in_features) > 304 ? m * 300 : 0);
     L.dw_slab = take((size_t)dw_num_slabs(hidden) * kin * hidden);
-    L.db_slab = take((size_t)csr_bwd_num_slabs(batch, n_vert) * cpad);
+    const size_t nslab = (size_t)csr_bwd_num_slabs(batch, n_vert) > (size_t)batch ? csr_bwd_num_slabs(batch, n_vert) : batch;
+    L.db_slab = take(nslab * cpad);
+    L.gq = take(m * (cpad > 4 ? cpad : 4));
     L.thin_dw_slab = take((size_t)thin_num_slabs() * kin * 3);
     L.thin_db_slab = take((size_t)thin_num_slabs() * 3);
   }
@@ -437,7 +456,8 @@ static inline int mask_ld(int hidden, int cut_len) { return pad4(cut_len) / 4 + 
 size_t a3vt_gcn_stack_mask_bytes(int batch, int n_vert, int hidden, int num_layers, int cut_len) {
   if (num_layers < 2) return 0;
   const size_t mpad = ((size_t)batch * n_vert + 31) / 32 * 32;
-  return (size_t)(num_layers - 1) * mpad * mask_ld(hidden, cut_len);
+  // row-major sign bytes, then the quad-major signs of the aggregated channels (channel-sliced aggregation)
+  return (size_t)(num_layers - 1) * (mpad * mask_ld(hidden, cut_len) + signq_stride((size_t)batch * n_vert, cut_len));
 }
 
 size_t a3vt_gcn_stack_scratch_bytes(int batch, int n_vert, int in_features, int hidden, int num_layers, int cut_len,
@@ -514,6 +534,10 @@ int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const 
     if (int rc = launch_weight_images(wi, rowgemm_bt_rows(hidden), pad16(ld_feats > hidden ? ld_feats : hidden), s)) return rc;
   }
 
+  const bool quad = use_csrq(batch, n_vert, hidden, cut_len) && num_layers > 1;
+  int32_t *ell = reinterpret_cast<int32_t *>(scratch + L.ell);
+  if (quad)
+    if (int rc = launch_csrq_ell(rowptr, col, val, n_vert, ell, s)) return rc;
   const float *x = feats;
   int ldx = ld_feats;
   for (int i = 0; i + 1 < num_layers; ++i) {
@@ -543,13 +567,23 @@ int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const 
     g.mld = mld;
     g.moff = cpad / 4;
     g.bf16 = gemm_bf16 ? 1 : 0;
+    if (quad) {   // raw aggregated channels leave the product quad-major, for the channel-sliced aggregation
+      g.zq_nvert = n_vert;
+      g.zq_quads = cpad / 4;
+    }
     {
       ProfScope ps(PROF_GEMM_FWD, s);
       if (int rc = launch_rowgemm(g, EPI_FWD_HIDDEN, s)) return rc;
     }
-    if (cut_len > 0)
-      if (int rc = launch_csr_fwd(scratch + L.za, cpad, biases[i], cut_len, rowptr, col, val, heavy, n_vert, batch, y, hidden, mk, mld, 1, s))
+    if (cut_len > 0) {
+      if (quad) {
+        uint8_t *sq = masks ? masks + (size_t)(num_layers - 1) * mpad * mld + (size_t)i * signq_stride(m, cut_len) : nullptr;
+        if (int rc = launch_csrq_fwd(scratch + L.za, biases[i], cut_len, rowptr, col, val, heavy, ell, n_vert, batch, y, hidden, sq, 1, s))
+          return rc;
+      } else if (int rc = launch_csr_fwd(scratch + L.za, cpad, biases[i], cut_len, rowptr, col, val, heavy, n_vert, batch, y, hidden, mk, mld, 1, s)) {
         return rc;
+      }
+    }
     x = y;
     ldx = hidden;
   }
@@ -593,6 +627,10 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
     if (int rc = launch_csr_heavy_list(rowptrT, n_vert, heavyT, s)) return rc;
   }
 
+  const bool quad = masks != nullptr && num_layers > 1 && use_csrq(batch, n_vert, hidden, cut_len);   // same rule as the forward (which left the quad-major signs in `masks`)
+  int32_t *ellT = reinterpret_cast<int32_t *>(scratch + L.ell);
+  if (quad)
+    if (int rc = launch_csrq_ell(rowptrT, colT, valT, n_vert, ellT, s)) return rc;
   // ---- output layer
   {
     const float *x = num_layers == 1 ? feats : acts + (size_t)(last - 1) * m * hidden;
@@ -601,7 +639,7 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
     float *gprev = num_layers == 1 ? grad_feats : scratch + L.ping[0];
     if (int rc = launch_thin_bwd(x, ldx, k, weights[last], rowptrT, colT, valT, heavyT, n_vert, batch, grad_update,
                                  scratch + L.z3, num_layers > 1, gprev, ldx, ldx, scratch + L.thin_dw_slab,
-                                 scratch + L.thin_db_slab, s))
+                                 scratch + L.thin_db_slab, quad ? scratch + L.gq : nullptr, cpad / 4, s))
       return rc;
     if (int rc = launch_slab_reduce(scratch + L.thin_dw_slab, thin_num_slabs(), (size_t)k * 3, (size_t)k * 3,
                                     grad_weights[last], s))
@@ -639,7 +677,13 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
     const int kin = i == 0 ? in_features : hidden;
 
     // bias gradient + A^T gather on the aggregated channels
-    if (cut_len > 0) {
+    if (cut_len > 0 && quad) {
+      const uint8_t *sq = masks + (size_t)(num_layers - 1) * mpad * mld + (size_t)i * signq_stride(m, cut_len);
+      if (int rc = launch_csrq_bwd(scratch + L.gq, cut_len, rowptrT, colT, valT, heavyT, ellT, n_vert, batch, dza, cpad, sq,
+                                   scratch + L.db_slab, s))
+        return rc;
+      if (int rc = launch_slab_reduce_z(scratch + L.db_slab, batch, cpad, cut_len, hidden, grad_biases[i], s)) return rc;
+    } else if (cut_len > 0) {
       if (int rc = launch_csr_bwd(g, hidden, cut_len, rowptrT, colT, valT, heavyT, n_vert, batch, dza, cpad,
                                   scratch + L.db_slab, s))
         return rc;
@@ -720,6 +764,11 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
       r.mld = mld;
       r.moff = cpad / 4;
       r.csplit = cut_len;
+      if (quad) {   // gradient columns [0, cpad) go quad-major (unmasked below cut_len) to the next aggregation
+        r.c2 = scratch + L.gq;
+        r.zq_nvert = n_vert;
+        r.zq_quads = cpad / 4;
+      }
       {
         ProfScope ps(PROF_GEMM_DX, s);
         if (int rc = launch_rowgemm(r, EPI_DX_MASK, s)) return rc;

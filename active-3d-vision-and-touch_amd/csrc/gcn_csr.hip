@@ -468,7 +468,8 @@ __global__ __launch_bounds__(256) void thin_bwd_kernel(const float *__restrict__
                                                        const float *__restrict__ du, long long m, int apply_mask,
                                                        float *__restrict__ gprev, int ldg, int n_store,
                                                        float *__restrict__ dw_slab,
-                                                       float *__restrict__ db_slab) {
+                                                       float *__restrict__ db_slab, float *__restrict__ gq, int nq,
+                                                       int n_vert) {
   __shared__ float red[16][kThinPieces * 64 * 3 / 16 + 1];  // [row group][this lane-column's 60 partials] per l16 pass
   const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
   float wr[kThinPieces][4][3], dwp[kThinPieces][4][3];
@@ -493,6 +494,9 @@ __global__ __launch_bounds__(256) void thin_bwd_kernel(const float *__restrict__
     }
     const float *xr = x + row * ldx;
     float *gr = gprev + row * ldg;
+    // quad-major copy of the aggregated-channel columns for csrq_kernel<1> (launch_csrq_bwd), when asked for
+    const long long bq = gq ? row / n_vert : 0;
+    float *gqr = gq ? gq + ((size_t)bq * nq * n_vert + (size_t)(row - bq * n_vert)) * 4 : nullptr;
 #pragma unroll
     for (int p = 0; p < kThinPieces; ++p) {
       const int kk = (p * 16 + l16) * 4;
@@ -507,7 +511,9 @@ __global__ __launch_bounds__(256) void thin_bwd_kernel(const float *__restrict__
           dwp[p][t][1] += xv[t] * d[1];
           dwp[p][t][2] += xv[t] * d[2];
         }
-        if (kk + 3 < n_store) {
+        if (gq && kk < nq * 4) {
+          *reinterpret_cast<f32x4 *>(gqr + (size_t)(kk >> 2) * n_vert * 4) = o;
+        } else if (kk + 3 < n_store) {
           *reinterpret_cast<f32x4 *>(gr + kk) = o;
         } else {
 #pragma unroll
@@ -568,7 +574,7 @@ int launch_pad3to4(const float *in, long long m, float *out, hipStream_t s) {
 int launch_thin_bwd(const float *x, int ldx, int k, const float *w, const int32_t *rowptrT, const int32_t *colT,
                     const float *valT, const int32_t *heavyT, int n_vert, int batch, const float *grad_update,
                     float *dz3, int apply_mask, float *g_prev, int ldg, int n_store, float *dw_slab, float *db_slab,
-                    hipStream_t s) {
+                    float *gq, int nq, hipStream_t s) {
   if (k > kThinPieces * 64 || ldx % 4 != 0 || ldg % 4 != 0) {
     set_error("thin_bwd: k=%d ldx=%d ldg=%d unsupported", k, ldx, ldg);
     return -1;
@@ -581,7 +587,7 @@ int launch_thin_bwd(const float *x, int ldx, int k, const float *w, const int32_
   if (int rc = launch_pad3to4(grad_update, m, du4, s)) return rc;
   if (int rc = launch_csr3(du4, nullptr, rowptrT, colT, valT, heavyT, n_vert, batch, res, 4, s)) return rc;
   A3VT_LAUNCH(thin_bwd_kernel, dim3(kThinBlocks), dim3(256), 0, s, x, ldx, k, w, res, grad_update, m, apply_mask,
-                     g_prev, ldg, n_store, dw_slab, db_slab);
+                     g_prev, ldg, n_store, dw_slab, db_slab, gq, nq, n_vert);
   A3VT_CHECK_LAUNCH();
   return 0;
 }

@@ -73,11 +73,13 @@ __device__ __forceinline__ void wait_vmcnt() {
 __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 #ifdef A3VT_DBG_RG_STAMPS   // diagnostic build (tools/build_variants.sh stamps): s_memrealtime (100 MHz) at the phase boundaries
-__device__ unsigned long long g_rg_stamps[256 * 64];   // [workgroup][round (<= 8)][8]; read with a3vt_dbg_rg_stamps
+__device__ unsigned long long g_rg_stamps[2 * 256 * 64];   // [real time | shader cycles][workgroup][round (<= 8)][8]; a3vt_dbg_rg_stamps
 #define RG_STAMP(round, k)                                                                                   \
   do {                                                                                                       \
-    if (threadIdx.x == 0 && blockIdx.x < 256 && blockIdx.y == 0 && (round) < 8)                              \
+    if (threadIdx.x == 0 && blockIdx.x < 256 && blockIdx.y == 0 && (round) < 8) {                            \
       g_rg_stamps[blockIdx.x * 64 + (round) * 8 + (k)] = __builtin_amdgcn_s_memrealtime();                   \
+      g_rg_stamps[256 * 64 + blockIdx.x * 64 + (round) * 8 + (k)] = __builtin_amdgcn_s_memtime();            \
+    }                                                                                                        \
   } while (0)
 #else
 #define RG_STAMP(round, k) do { } while (0)
@@ -142,8 +144,16 @@ __device__ __forceinline__ void rowtile_unit(const RowGemmArgs &p, int row_base,
           else reinterpret_cast<u16 *>(p.c)[(size_t)row * p.ldc + col] = to_bf16((v > 0.f || p.no_relu) ? v : 0.f);
         }
       } else if (row_ok && col_ok) {
-        if (col < p.csplit) p.c2[(size_t)row * p.ldc2 + col] = v;
-        else p.c[(size_t)row * p.ldc + col] = (v > 0.f || p.no_relu) ? v : 0.f;
+        if (col < p.csplit) {
+          if (p.zq_nvert > 0) {
+            const int bq = row / p.zq_nvert;
+            p.c2[(((size_t)bq * p.zq_quads + (col >> 2)) * p.zq_nvert + (row - bq * p.zq_nvert)) * 4 + (col & 3)] = v;
+          } else {
+            p.c2[(size_t)row * p.ldc2 + col] = v;
+          }
+        } else {
+          p.c[(size_t)row * p.ldc + col] = (v > 0.f || p.no_relu) ? v : 0.f;
+        }
       }
     } else {  // EPI_DX_MASK
       if (MODE == 2) {
@@ -152,8 +162,18 @@ __device__ __forceinline__ void rowtile_unit(const RowGemmArgs &p, int row_base,
           reinterpret_cast<u16 *>(p.c)[(size_t)row * p.ldc + col] = to_bf16(((byte >> (col & 3)) & 1u) ? v : 0.f);
         }
       } else if (row_ok && col_ok) {
-        const unsigned byte = p.maskb[(size_t)row * p.mld + (col < p.csplit ? 0 : p.moff) + (col >> 2)];
-        p.c[(size_t)row * p.ldc + col] = ((byte >> (col & 3)) & 1u) ? v : 0.f;
+        if (p.zq_nvert > 0 && col < p.zq_quads * 4) {   // quad-major gradient columns: unmasked below csplit (RowGemmArgs)
+          float o = v;
+          if (col >= p.csplit) {
+            const unsigned byte = p.maskb[(size_t)row * p.mld + p.moff + (col >> 2)];
+            o = ((byte >> (col & 3)) & 1u) ? v : 0.f;
+          }
+          const int bq = row / p.zq_nvert;
+          p.c2[(((size_t)bq * p.zq_quads + (col >> 2)) * p.zq_nvert + (row - bq * p.zq_nvert)) * 4 + (col & 3)] = o;
+        } else {
+          const unsigned byte = p.maskb[(size_t)row * p.mld + (col < p.csplit ? 0 : p.moff) + (col >> 2)];
+          p.c[(size_t)row * p.ldc + col] = ((byte >> (col & 3)) & 1u) ? v : 0.f;
+        }
       }
     }
   }
@@ -519,9 +539,36 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
             }
             continue;
           }
-          const int nf4 = 16 * f4row;
+          // Quad-major side output (RowGemmArgs::zq_nvert; one column block, so col0 == 0): the first zq_quads column
+          // quads of this tile leave as 16 consecutive rows x 16 B per quad (lane & 15 = row: 256 contiguous bytes of one
+          // quad plane per 16 lanes) instead of as pieces of row-major rows.
+          const bool zq_mode = EPI != EPI_PLAIN && p.zq_nvert > 0;
+          int qlo = 0;
+          if (zq_mode && grp == 0) {
+            const int nqz = p.zq_quads;
+            const int rl = lane & 15;
+            const int row = row0 + i * 16 + rl;
+            const int bq = row / p.zq_nvert;
+            float *qbase = p.c2 + ((size_t)bq * nqz * p.zq_nvert + (size_t)(row - bq * p.zq_nvert)) * 4;
+            for (int c4 = lane >> 4; c4 < nqz; c4 += 4) {
+              f32x4 v = *reinterpret_cast<const f32x4 *>(ep + rl * stride + c4 * 4);
+              if (EPI == EPI_DX_MASK && c4 * 4 + 3 >= p.csplit) {   // pass-through columns inside the last quad: masked here
+                const unsigned bb = mslot[(i * 16 + rl) * p.mld + p.moff + c4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                  if (c4 * 4 + t >= p.csplit) v[t] = ((bb >> t) & 1u) ? v[t] : 0.f;
+              }
+#ifdef A3VT_DBG_RG_NOSTORE
+              if (v[0] != 1.2345e-33f) continue;
+#endif
+              if (row < p.m) *reinterpret_cast<f32x4 *>(qbase + (size_t)c4 * p.zq_nvert * 4) = v;
+            }
+            // forward: the quad that straddles the cut still goes (activated) to the row-major output below
+            qlo = EPI == EPI_FWD_HIDDEN ? p.csplit >> 2 : nqz;
+          }
+          const int wq = f4row - qlo, nf4 = 16 * wq;
           for (int f = lane; f < nf4; f += 64) {
-            const int rl = f / f4row, c4 = f - rl * f4row;
+            const int rl = f / wq, c4 = qlo + (f - rl * wq);
             const int row = row0 + i * 16 + rl;
             const int col = col0 + j0 * 16 + c4 * 4;
             if (row >= p.m || col >= p.n_store) continue;
@@ -547,24 +594,28 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
                 if (mask_rows) mslot[(i * 16 + rl) * p.mld + p.moff + (col >> 2)] = (uint8_t)bits;
                 else p.maskb[(size_t)row * p.mld + p.moff + (col >> 2)] = (uint8_t)bits;
               }
-              if (full && col + 3 < p.csplit) {  // aggregated channels: raw Z for the neighbour gather
+              if (!zq_mode && full && col + 3 < p.csplit) {  // aggregated channels: raw Z for the neighbour gather
                 *reinterpret_cast<f32x4 *>(p.c2 + (size_t)row * p.ldc2 + col) = v;
               } else if (full && col >= p.csplit) {  // pass-through channels: ReLU(Z), no bias
 #pragma unroll
                 for (int t = 0; t < 4; ++t) v[t] = (v[t] > 0.f || p.no_relu) ? v[t] : 0.f;
                 *reinterpret_cast<f32x4 *>(p.c + (size_t)row * p.ldc + col) = v;
-              } else if (full && col + 4 <= p.ldc2) {
+              } else if (full && (zq_mode || col + 4 <= p.ldc2)) {
                 // the group that straddles the cut goes to BOTH outputs whole: the raw copy's columns >= csplit are never
                 // gathered, the activation's columns < csplit are overwritten by the aggregation kernel that runs next
-                *reinterpret_cast<f32x4 *>(p.c2 + (size_t)row * p.ldc2 + col) = v;
+                // (quad-major mode: the raw copy has left above)
+                if (!zq_mode) *reinterpret_cast<f32x4 *>(p.c2 + (size_t)row * p.ldc2 + col) = v;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) v[t] = (v[t] > 0.f || p.no_relu) ? v[t] : 0.f;
                 *reinterpret_cast<f32x4 *>(p.c + (size_t)row * p.ldc + col) = v;
               } else {
                 for (int t = 0; t < 4; ++t) {
                   if (col + t >= p.n_store) break;
-                  if (col + t < p.csplit) p.c2[(size_t)row * p.ldc2 + col + t] = v[t];
-                  else p.c[(size_t)row * p.ldc + col + t] = (v[t] > 0.f || p.no_relu) ? v[t] : 0.f;
+                  if (col + t < p.csplit) {
+                    if (!zq_mode) p.c2[(size_t)row * p.ldc2 + col + t] = v[t];
+                  } else {
+                    p.c[(size_t)row * p.ldc + col + t] = (v[t] > 0.f || p.no_relu) ? v[t] : 0.f;
+                  }
                 }
               }
             } else {  // EPI_DX_MASK: gradient through the ReLU of the producing layer (sign bytes from LDS)
@@ -740,7 +791,7 @@ static int launch_rowgemm_epi(const RowGemmArgs &a0, hipStream_t s) {
 
 #ifdef A3VT_DBG_RG_STAMPS
 extern "C" int a3vt_dbg_rg_stamps(unsigned long long *host_dst) {
-  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_rg_stamps), sizeof(unsigned long long) * 256 * 64);
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_rg_stamps), sizeof(unsigned long long) * 2 * 256 * 64);
 }
 #endif
 
@@ -752,7 +803,20 @@ int rowgemm_bt_rows(int n_store) {
   return ((tnt * 16 + 127) / 128) * 128;
 }
 
+bool rowgemm_quad_major_ok(int m, int n_store, int cpad) {
+  const int nt = cdiv(n_store, 16);
+  if (nt < 14 || nt > 19 || cpad <= 0 || cpad > 160 || cpad % 4 != 0) return false;   // NT = 19, first column group = 160 columns
+  const int tiles = cdiv(m, 16), full = tiles / 2048 * 2048, rem = tiles - full;     // as launch_rowgemm_epi
+  const int main_m = (full == 0 || rem == 0 || rem * nt > 1024) ? m : full * 16;
+  return cdiv(cdiv(main_m, 16), 8) >= 96;                                             // as launch_rowgemm_cols: no column blocks
+}
+
 int launch_rowgemm(const RowGemmArgs &a, int epi, hipStream_t s) {
+  if (a.zq_nvert > 0 && (epi == EPI_PLAIN || a.bf16 == 2 || a.c2 == nullptr || a.m % a.zq_nvert != 0 ||
+                         a.zq_quads * 4 != pad4(a.csplit) || !rowgemm_quad_major_ok(a.m, a.n_store, a.zq_quads * 4))) {
+    set_error("rowgemm: quad-major output unsupported for m=%d n=%d csplit=%d epi=%d mode=%d", a.m, a.n_store, a.csplit, epi, a.bf16);
+    return -1;
+  }
   if (epi == EPI_DX_MASK && (a.maskb == nullptr || 32 * a.mld > 4096)) {
     set_error("rowgemm: EPI_DX_MASK needs sign bytes with 32*mld <= 4096 (mld=%d)", a.mld);
     return -1;

@@ -34,6 +34,12 @@ struct RowGemmArgs {
   // rows [rem_row0, rem_row0 + rem_rows) beyond the m rows of the main loop: the few leftover tiles of the load-balanced
   // split, done by the tail of the same launch (set by launch_rowgemm; 0 = none)
   int rem_row0, rem_rows;
+  // Quad-major side output (round 3, fp32 storage only; 0 = off).  With zq_nvert = vertices per mesh and zq_quads = Q,
+  // c2 is the quad-major array [m / zq_nvert][Q][zq_nvert] float4 of columns [0, 4 Q):
+  //   EPI_FWD_HIDDEN: raw Z of the aggregated channels (instead of the row-major [M][ldc2] copy);
+  //   EPI_DX_MASK   : the gradient columns [0, 4 Q), columns < csplit UNMASKED (csrq_kernel<1> applies the signs it
+  //                   keeps itself), columns in [csplit, 4 Q) masked as usual; they are then NOT written to c.
+  int zq_nvert, zq_quads;
 };
 int rowgemm_bt_rows(int n_store);
 int launch_rowgemm(const RowGemmArgs &a, int epi, hipStream_t s);
@@ -88,6 +94,23 @@ int csr_bwd_num_slabs(int batch, int n_vert);
 int launch_csr_bwd(const float *g, int ldg, int c, const int32_t *rowptrT, const int32_t *colT, const float *valT,
                    const int32_t *heavyT, int n_vert, int batch, float *dza, int lddza, float *db_slab, hipStream_t s);
 
+// Channel-sliced aggregation, whole mesh resident in LDS (gcn_csr.hip "csrq"): inputs quad-major
+// [batch][Q = pad4(c)/4][n_vert] float4, ReLU signs of the aggregated channels quad-major bytes [batch][Q][n_vert]
+// (written by the forward, applied by the backward), outputs row-major.  db_slab: [batch][pad4(c)].
+// `ell`: the slot-major index image launch_csrq_ell builds from the same CSR (csrq_ell_ints(n_vert) ints, 256-B aligned).
+bool csrq_fits(int n_vert, int cut_len);
+size_t csrq_ell_ints(int n_vert);
+int launch_csrq_ell(const int32_t *rowptr, const int32_t *col, const float *val, int n_vert, int32_t *ell, hipStream_t s);
+int launch_csrq_fwd(const float *zq, const float *bias, int c, const int32_t *rowptr, const int32_t *col,
+                    const float *val, const int32_t *heavy, const int32_t *ell, int n_vert, int batch, float *y, int ldy,
+                    uint8_t *signq, int relu, hipStream_t s);
+int launch_csrq_bwd(const float *gq, int c, const int32_t *rowptrT, const int32_t *colT, const float *valT,
+                    const int32_t *heavyT, const int32_t *ellT, int n_vert, int batch, float *dza, int lddza,
+                    const uint8_t *signq, float *db_slab, hipStream_t s);
+// True when launch_rowgemm will run (m, n_store) as ONE column block of 19-tile rows whose first epilogue column group
+// holds the cpad aggregated columns — the shape for which the epilogues can write quad-major (RowGemmArgs::zq_nvert).
+bool rowgemm_quad_major_ok(int m, int n_store, int cpad);
+
 // Last layer (out = 3 channels, all aggregated, no activation), model.py:359-361.
 int thin_num_slabs();
 int launch_thin_fwd(const float *x, int ldx, int k, const float *w /*[k][3]*/, const float *bias /*[3]*/,
@@ -97,7 +120,8 @@ int launch_thin_bwd(const float *x, int ldx, int k, const float *w, const int32_
                     const float *valT, const int32_t *heavyT, int n_vert, int batch,
                     const float *grad_update /*[M][3]*/, float *dz3 /*[2][M][4] scratch*/, int apply_mask,
                     float *g_prev /*[M][ldg]*/, int ldg, int n_store, float *dw_slab /*[thin_num_slabs()][k*3]*/,
-                    float *db_slab /*[thin_num_slabs()][3]*/, hipStream_t s);
+                    float *db_slab /*[thin_num_slabs()][3]*/, float *gq /*quad-major columns [0, 4 nq) or nullptr*/, int nq,
+                    hipStream_t s);
 
 int launch_vertex_update(const float *vin, const float *upd, int batch, int n_vert, int n_vision, float *vout,
                          hipStream_t s);

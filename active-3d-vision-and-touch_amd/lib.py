@@ -10,13 +10,15 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("A3VT_LIB", os.path.join(_HERE, "liba3vt.so"))  # A3VT_LIB: developer override (variant builds)
-SOURCES = ["capi.hip", "gcn_gemm.hip", "gcn_csr.hip", "gcn_bf16s.hip", "posenc.hip", "sample.hip", "chamfer.hip", "nn_prune.hip",
+SOURCES = ["capi.hip", "gcn_gemm.hip", "gcn_csr.hip", "gcn_csrq.hip", "gcn_bf16s.hip", "posenc.hip", "sample.hip", "chamfer.hip", "nn_prune.hip",
            "pooling.hip"]
 # Per-file extra flags (none at present; sample.hip / gcn_csr.hip rely on IEEE NaN semantics — the reference's NaN
 # scrubs, a3vt_check_finite — so fast-math style flags must never be applied globally).
 # chamfer.hip: keep the nearest-neighbour loop on scalar fp32 ops (the SLP vectoriser would re-pack it into v_pk_*_f32,
 # which issues at half the rate on gfx950 and needs s_nop hazard padding)
-EXTRA_FLAGS = {"chamfer.hip": ["-fno-slp-vectorize"], "nn_prune.hip": ["-fno-slp-vectorize"]}
+# gcn_csrq.hip: scalar fma chains keep one register per edge weight (v_pk_fma_f32 wants (w, w) pairs): see the file header
+EXTRA_FLAGS = {"chamfer.hip": ["-fno-slp-vectorize"], "nn_prune.hip": ["-fno-slp-vectorize"],
+               "gcn_csrq.hip": ["-fno-slp-vectorize"]}
 
 _vp, _i, _sz, _u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_uint64
 

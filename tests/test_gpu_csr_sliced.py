@@ -1,0 +1,105 @@
+"""-m gpu: the channel-sliced, LDS-resident neighbour aggregation (csrc/gcn_csr.hip ``csrq_kernel``; replaces the dense
+adjacency products of reconstruction/vision/model.py:356,360 for the hidden layers of a stack) against (i) the
+half-wave-per-vertex kernels it replaces — bit for bit, the summation order per element is the same — and (ii) the fp64
+oracle, on shapes that take the new path (>= 12 288 rows, hidden 300): plain icospheres, the reference atlas, and the
+fused vision + touch graph whose hub rows (~1150 neighbours) go through ``csrq_heavy_kernel``."""
+import os
+
+import pytest
+import torch
+
+from helpers import assert_grad_close, make_args, oracle_adj, rel_err, template
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(cuda, adj, st, feats, gup, L, H, cut_len):
+    from a3vt_amd import ops
+    ws = [st[f"mesh_deform_1.layers.{i}.weight"].to(cuda).requires_grad_(True) for i in range(L)]
+    bs = [st[f"mesh_deform_1.layers.{i}.bias"].to(cuda).requires_grad_(True) for i in range(L)]
+    fd = torch.nn.functional.pad(feats, (0, 2)).to(cuda).requires_grad_(True)
+    out = ops.gcn_stack(fd, adj, 50, H, cut_len, ws, bs)
+    (out * gup.to(cuda)).sum().backward()
+    torch.cuda.synchronize()
+    return out.detach(), fd.grad, [w.grad for w in ws], [b.grad for b in bs]
+
+
+@pytest.mark.parametrize("tname,use_touch,L,B,cut", [("ico3", False, 4, 24, 0.33), ("ico4", False, 3, 6, 0.33),
+                                                      ("atlas", False, 3, 8, 0.33), ("atlas", True, 3, 8, 0.33),
+                                                      ("ico3", False, 3, 20, 0.5), ("ico3", False, 3, 20, 0.04)])
+def test_channel_sliced_aggregation_equals_row_kernels_and_oracle(cuda, tname, use_touch, L, B, cut):
+    from a3vt_amd import mesh as amesh, ops
+    from oracle import gcn as og
+    H = 300
+    args = make_args(use_touch=use_touch, num_GCN_layers=L, hidden_GCN_size=H, num_grasps=1, cut=cut)
+    verts, faces = template(tname)
+    adj_o, _ = oracle_adj(verts, faces, args)
+    n = adj_o[0].numel() - 1
+    assert B * n >= 12288                       # the shape takes the channel-sliced path (capi.hip use_csrq)
+    st = og.init_state(50, H, L, seed=5)
+    g = torch.Generator().manual_seed(21)
+    feats = torch.randn(B, n, 50, generator=g) * 0.5
+    gup = torch.randn(B, n, 3, generator=g)
+    if use_touch:
+        sv, sf = amesh.load_asset("touch_chart")
+        r, c, nn_, _ = amesh.fused_pairs(verts, faces, sf, 1, False)
+    else:
+        r, c = amesh.vision_pairs(faces, verts.shape[0])
+        nn_ = verts.shape[0]
+    adj = ops.DeviceCSR(amesh.CSRAdjacency.from_pairs(r, c, nn_), cuda)
+    cut_len = og.cut_length(H, cut)
+    old = os.environ.get("A3VT_CSR_ALGO")
+    try:
+        os.environ["A3VT_CSR_ALGO"] = "rows"
+        ref = _run(cuda, adj, st, feats, gup, L, H, cut_len)
+        os.environ.pop("A3VT_CSR_ALGO")
+        new = _run(cuda, adj, st, feats, gup, L, H, cut_len)
+        again = _run(cuda, adj, st, feats, gup, L, H, cut_len)
+    finally:
+        if old is None:
+            os.environ.pop("A3VT_CSR_ALGO", None)
+        else:
+            os.environ["A3VT_CSR_ALGO"] = old
+    # (i) same bits as the kernels it replaces: outputs, input gradient, every weight gradient
+    assert torch.equal(new[0], ref[0])
+    assert torch.equal(new[1], ref[1])
+    for i in range(L):
+        assert torch.equal(new[2][i], ref[2][i]), f"dW layer {i}"
+        # bias gradients are sums over all rows: the partial sums are grouped per mesh here, per workgroup there
+        assert rel_err(new[3][i], ref[3][i]) < 2e-5, f"db layer {i}"
+        assert new[3][i][cut_len:].abs().max().item() == 0.0 or i == L - 1     # dead bias channels stay exactly zero
+    # repeatable bit for bit
+    for a, b in zip([new[0], new[1], *new[2], *new[3]], [again[0], again[1], *again[2], *again[3]]):
+        assert torch.equal(a, b)
+    # (ii) the fp64 oracle
+    st64 = {k: v.double().requires_grad_(True) for k, v in st.items() if k.startswith("mesh_deform_1")}
+    f64 = feats.double().requires_grad_(True)
+    out_o = og.gcn(f64, st64, "mesh_deform_1", (adj_o[0], adj_o[1], adj_o[2].double()), L, cut)
+    (out_o * gup.double()).sum().backward()
+    assert rel_err(new[0], out_o) < 1e-4
+    assert_grad_close(new[1][..., :50], f64.grad, "grad_feats")
+    for i in range(L):
+        assert_grad_close(new[2][i], st64[f"mesh_deform_1.layers.{i}.weight"].grad, f"dW layer {i}")
+        assert_grad_close(new[3][i], st64[f"mesh_deform_1.layers.{i}.bias"].grad, f"db layer {i}")
+
+
+def test_forward_only_call_takes_the_sliced_path_without_a_stash(cuda):
+    """No saved activations / sign bytes (policy scoring path): the sliced kernels run with a null sign array."""
+    from a3vt_amd import mesh as amesh, ops
+    from oracle import gcn as og
+    L, H, B = 3, 300, 24
+    verts, faces = template("ico3")
+    args = make_args(num_GCN_layers=L, hidden_GCN_size=H)
+    adj_o, _ = oracle_adj(verts, faces, args)
+    st = og.init_state(50, H, L, seed=9)
+    g = torch.Generator().manual_seed(2)
+    feats = torch.randn(B, verts.shape[0], 50, generator=g) * 0.5
+    r, c = amesh.vision_pairs(faces, verts.shape[0])
+    adj = ops.DeviceCSR(amesh.CSRAdjacency.from_pairs(r, c, verts.shape[0]), cuda)
+    ws = [st[f"mesh_deform_1.layers.{i}.weight"].to(cuda) for i in range(L)]
+    bs = [st[f"mesh_deform_1.layers.{i}.bias"].to(cuda) for i in range(L)]
+    with torch.no_grad():
+        out = ops.gcn_stack(torch.nn.functional.pad(feats, (0, 2)).to(cuda), adj, 50, H, 99, ws, bs)
+        out_o = og.gcn(feats.double(), {k: v.double() for k, v in st.items()}, "mesh_deform_1",
+                       (adj_o[0], adj_o[1], adj_o[2].double()), L, 0.33)
+    assert rel_err(out, out_o) < 1e-4

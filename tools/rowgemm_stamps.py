@@ -26,10 +26,11 @@ for _ in range(5):
     lib.check(L.a3vt_rowgemm(lib.ptr(a), K, M, K, lib.ptr(wt), N, 0, lib.ptr(c), N, None), "g")
 torch.cuda.synchronize()
 raw = ctypes.CDLL(lib.LIB_PATH)
-buf = np.zeros(256 * 64, dtype=np.uint64)
+buf = np.zeros(2 * 256 * 64, dtype=np.uint64)
 rc = raw.a3vt_dbg_rg_stamps(buf.ctypes.data_as(ctypes.c_void_p))
 assert rc == 0, rc
-st = buf.reshape(256, 8, 8).astype(np.float64) * 0.01   # us
+st = buf[:256 * 64].reshape(256, 8, 8).astype(np.float64) * 0.01   # us
+cyc = buf[256 * 64:].reshape(256, 8, 8).astype(np.float64)     # shader cycles (s_memtime)
 t00 = st[:, 0, 0].min()
 rounds = int(os.environ.get("ROUNDS", 3))
 print(f"rows {M}: launch spread of round-0 starts {st[:, 0, 0].max() - t00:.2f} us")
@@ -40,5 +41,8 @@ for r in range(rounds):
     print(f"round {r}: starts at {np.median(s[:, 0]) - t00:7.2f} (p10 {np.percentile(s[:, 0], 10) - t00:.2f}, p90 {np.percentile(s[:, 0], 90) - t00:.2f})")
     for n, x in zip(names, d):
         print(f"    {n:26s} median {np.median(x):7.2f}  p10 {np.percentile(x, 10):7.2f}  p90 {np.percentile(x, 90):7.2f}  max {x.max():7.2f}")
+    kc = cyc[:, r, 2] - cyc[:, r, 1]
+    kt = s[:, 2] - s[:, 1]
+    print(f"    K loop: {np.median(kc):.0f} shader cycles -> clock {np.median(kc / kt) / 1e3:.3f} GHz (p10 {np.percentile(kc / kt, 10) / 1e3:.3f}, p90 {np.percentile(kc / kt, 90) / 1e3:.3f})")
 end = st[:, rounds - 1, 4]
 print(f"last barrier: median {np.median(end) - t00:.2f}, max {end.max() - t00:.2f} us after the first start")
