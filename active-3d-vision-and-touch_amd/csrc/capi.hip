@@ -88,10 +88,13 @@ struct StackLayout {
 // product kernel must run the shape as one column block so that its epilogues can write quad-major.  Forward and backward
 // decide from the same arguments (the backward reads the sign bytes the forward left).  A3VT_CSR_ALGO=rows is a developer
 // switch back to the half-wave-per-vertex kernels (both paths give the same outputs).
-static bool use_csrq(int batch, int n_vert, int hidden, int cut_len) {
+constexpr int kQuadCols = 160;   // quad-major columns of a hybrid layer output: the first column group of rowgemm's epilogue
+static bool use_csrq(int batch, int n_vert, int hidden, int cut_len, int gemm_bf16) {
+  if (gemm_bf16) return false;   // the bf16 operand / storage modes keep the half-wave kernels
   const char *algo = getenv("A3VT_CSR_ALGO");   // read per call: the parity tests run both paths in one process
   if ((algo && strcmp(algo, "rows") == 0) || cut_len <= 0) return false;
-  return csrq_fits(n_vert, cut_len) && rowgemm_quad_major_ok(batch * n_vert, hidden, pad4(cut_len));
+  return hidden % 4 == 0 && hidden >= kQuadCols + 16 && csrq_fits(n_vert, cut_len) && dw_quad_major_ok(hidden, kQuadCols / 4) &&
+         rowgemm_quad_major_ok(batch * n_vert, hidden, pad4(cut_len));
 }
 // sign bytes of the aggregated channels, quad-major [batch][Q][n_vert] per hidden layer, kept behind the row-major
 // sign bytes in the caller's `masks` buffer
@@ -534,11 +537,19 @@ int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const 
     if (int rc = launch_weight_images(wi, rowgemm_bt_rows(hidden), pad16(ld_feats > hidden ? ld_feats : hidden), s)) return rc;
   }
 
-  const bool quad = use_csrq(batch, n_vert, hidden, cut_len) && num_layers > 1;
+  const bool quad = use_csrq(batch, n_vert, hidden, cut_len, gemm_bf16) && num_layers > 1;
   int32_t *ell = reinterpret_cast<int32_t *>(scratch + L.ell);
   if (quad)
     if (int rc = launch_csrq_ell(rowptr, col, val, n_vert, ell, s)) return rc;
-  const float *x = feats;
+  // Layer outputs.  Row-major [M][hidden] on the half-wave path; on the channel-sliced path ("hybrid" rows) the block of
+  // M * hidden floats holds columns [0, 160) quad-major [batch][40][n_vert] float4 — the aggregated channels written by
+  // the aggregation kernel, the rest of the product kernel's first column group by its epilogue — followed by columns
+  // [160, hidden) row-major [M][hidden - 160].  160 = ten 16-column tiles = the input tiles of two waves of dw_kernel
+  // and ten whole K chunks of rowgemm_kernel: no tile or chunk straddles the two parts.  Every consumer reads either.
+  const int qcols = quad ? kQuadCols : 0;                    // columns of a layer's output kept quad-major
+  const int rm_ld = hidden - qcols;                          // row stride of the row-major part
+  const size_t rm_off = m * qcols;                           // its offset inside a layer's block
+  const float *x = feats, *xq = nullptr;                     // x: pre-offset so that x + row * ldx + col is column col
   int ldx = ld_feats;
   for (int i = 0; i + 1 < num_layers; ++i) {
     const int k = i == 0 ? ld_feats : hidden;       // K walked by the kernel (pad columns of feats are zero)
@@ -551,14 +562,20 @@ int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const 
     g.a0 = g.a1 = x;
     g.lda0 = g.lda1 = ldx;
     g.ksplit = k;
+    if (xq) {   // hybrid input rows: columns [0, 160) from the quad-major part
+      g.a0 = xq;
+      g.ksplit = qcols;
+      g.a0q_nvert = n_vert;
+      g.a0q_quads = qcols / 4;
+    }
     g.bt = wt;
     g.ldb = pad16(k);
     g.zeros = zeros;
     g.m = (int)m;
     g.k = k;
     g.n_store = hidden;
-    g.c = y;
-    g.ldc = hidden;
+    g.c = y + rm_off - qcols;
+    g.ldc = rm_ld;
     g.c2 = scratch + L.za;
     g.ldc2 = cpad;
     g.csplit = cut_len;
@@ -567,29 +584,31 @@ int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const 
     g.mld = mld;
     g.moff = cpad / 4;
     g.bf16 = gemm_bf16 ? 1 : 0;
-    if (quad) {   // raw aggregated channels leave the product quad-major, for the channel-sliced aggregation
-      g.zq_nvert = n_vert;
+    if (quad) {   // raw columns [0, cpad) leave the product quad-major, for the channel-sliced aggregation;
+      g.zq_nvert = n_vert;   // activated columns [cpad, 160) quad-major into the layer's output
       g.zq_quads = cpad / 4;
+      g.yq = y;
+      g.yq_quads = qcols / 4;
     }
     {
       ProfScope ps(PROF_GEMM_FWD, s);
       if (int rc = launch_rowgemm(g, EPI_FWD_HIDDEN, s)) return rc;
     }
-    if (cut_len > 0) {
-      if (quad) {
-        uint8_t *sq = masks ? masks + (size_t)(num_layers - 1) * mpad * mld + (size_t)i * signq_stride(m, cut_len) : nullptr;
-        if (int rc = launch_csrq_fwd(scratch + L.za, biases[i], cut_len, rowptr, col, val, heavy, ell, n_vert, batch, y, hidden, sq, 1, s))
-          return rc;
-      } else if (int rc = launch_csr_fwd(scratch + L.za, cpad, biases[i], cut_len, rowptr, col, val, heavy, n_vert, batch, y, hidden, mk, mld, 1, s)) {
+    if (quad) {
+      uint8_t *sq = masks ? masks + (size_t)(num_layers - 1) * mpad * mld + (size_t)i * signq_stride(m, cut_len) : nullptr;
+      if (int rc = launch_csrq_fwd(scratch + L.za, biases[i], cut_len, rowptr, col, val, heavy, ell, n_vert, batch, y, qcols / 4, sq, 1, s))
         return rc;
-      }
+      xq = y;
+    } else if (cut_len > 0) {
+      if (int rc = launch_csr_fwd(scratch + L.za, cpad, biases[i], cut_len, rowptr, col, val, heavy, n_vert, batch, y, hidden, mk, mld, 1, s))
+        return rc;
     }
-    x = y;
-    ldx = hidden;
+    x = y + rm_off - qcols;
+    ldx = rm_ld;
   }
   const int klast = num_layers == 1 ? in_features : hidden;
   return launch_thin_fwd(x, ldx, klast, weights[num_layers - 1], biases[num_layers - 1], rowptr, col, val, heavy, n_vert,
-                         batch, scratch + L.z3, update, s);
+                         batch, scratch + L.z3, update, xq, qcols / 4, s);
 }
 
 int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const float *const *weights,
@@ -627,19 +646,25 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
     if (int rc = launch_csr_heavy_list(rowptrT, n_vert, heavyT, s)) return rc;
   }
 
-  const bool quad = masks != nullptr && num_layers > 1 && use_csrq(batch, n_vert, hidden, cut_len);   // same rule as the forward (which left the quad-major signs in `masks`)
+  const bool quad = masks != nullptr && num_layers > 1 && use_csrq(batch, n_vert, hidden, cut_len, gemm_bf16);   // same rule as the forward (which left the quad-major signs in `masks`)
   int32_t *ellT = reinterpret_cast<int32_t *>(scratch + L.ell);
   if (quad)
     if (int rc = launch_csrq_ell(rowptrT, colT, valT, n_vert, ellT, s)) return rc;
+  const int qcols = quad ? kQuadCols : 0;            // hybrid activation rows (a3vt_gcn_stack_fwd)
+  const int rm_ld = hidden - qcols;
+  const size_t rm_off = m * qcols;
   // ---- output layer
   {
-    const float *x = num_layers == 1 ? feats : acts + (size_t)(last - 1) * m * hidden;
-    const int ldx = num_layers == 1 ? ld_feats : hidden;
+    const float *xl = num_layers == 1 ? feats : acts + (size_t)(last - 1) * m * hidden;
+    const float *x = xl + rm_off - qcols;                 // hybrid rows: see a3vt_gcn_stack_fwd (qcols = 0: plain rows)
+    const int ldx = num_layers == 1 ? ld_feats : rm_ld;
     const int k = num_layers == 1 ? in_features : hidden;
     float *gprev = num_layers == 1 ? grad_feats : scratch + L.ping[0];
+    const int ldg = num_layers == 1 ? ld_feats : hidden;
     if (int rc = launch_thin_bwd(x, ldx, k, weights[last], rowptrT, colT, valT, heavyT, n_vert, batch, grad_update,
-                                 scratch + L.z3, num_layers > 1, gprev, ldx, ldx, scratch + L.thin_dw_slab,
-                                 scratch + L.thin_db_slab, quad ? scratch + L.gq : nullptr, cpad / 4, s))
+                                 scratch + L.z3, num_layers > 1, gprev, ldg, ldg, scratch + L.thin_dw_slab,
+                                 scratch + L.thin_db_slab, quad ? scratch + L.gq : nullptr, cpad / 4, quad ? xl : nullptr,
+                                 qcols / 4, s))
       return rc;
     if (int rc = launch_slab_reduce(scratch + L.thin_dw_slab, thin_num_slabs(), (size_t)k * 3, (size_t)k * 3,
                                     grad_weights[last], s))
@@ -672,14 +697,16 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
   for (int i = last - 1; i >= 0; --i) {
     float *g = scratch + L.ping[cur];
     float *dza = scratch + L.za;
-    const float *x = i == 0 ? feats : acts + (size_t)(i - 1) * m * hidden;
-    const int ldx = i == 0 ? ld_feats : hidden;
+    const float *xl = i == 0 ? feats : acts + (size_t)(i - 1) * m * hidden;
+    const bool xhyb = quad && i > 0;                  // X_i = output of layer i-1: hybrid rows on the channel-sliced path
+    const float *x = xhyb ? xl + rm_off - qcols : xl;
+    const int ldx = i == 0 ? ld_feats : (xhyb ? rm_ld : hidden);
     const int kin = i == 0 ? in_features : hidden;
 
     // bias gradient + A^T gather on the aggregated channels
     if (cut_len > 0 && quad) {
       const uint8_t *sq = masks + (size_t)(num_layers - 1) * mpad * mld + (size_t)i * signq_stride(m, cut_len);
-      if (int rc = launch_csrq_bwd(scratch + L.gq, cut_len, rowptrT, colT, valT, heavyT, ellT, n_vert, batch, dza, cpad, sq,
+      if (int rc = launch_csrq_bwd(scratch + L.gq, cut_len, rowptrT, colT, valT, heavyT, ellT, n_vert, batch, dza, sq,
                                    scratch + L.db_slab, s))
         return rc;
       if (int rc = launch_slab_reduce_z(scratch + L.db_slab, batch, cpad, cut_len, hidden, grad_biases[i], s)) return rc;
@@ -714,6 +741,17 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
       DwArgs d{};
       d.x = xs;
       d.ldx = ldxs;
+      if (xhyb) {   // (kin = hidden <= 304 here: no panels) staged image [16][hidden], sources: quad-major + row-major parts
+        d.ldx = hidden;
+        d.ldx_src = rm_ld;
+        d.xq = xl;
+        d.xq_nvert = n_vert;
+        d.xq_quads = qcols / 4;
+      }
+      if (quad) {
+        d.z0q_nvert = n_vert;
+        d.z0q_quads = cpad / 4;
+      }
       d.z0 = dza;
       d.ldz0 = cpad > 0 ? cpad : 4;
       d.z1 = g;
@@ -742,6 +780,10 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
     RowGemmArgs r{};
     r.a0 = dza;
     r.lda0 = cpad > 0 ? cpad : 4;
+    if (quad) {   // dZa is quad-major (csrq_kernel<1>)
+      r.a0q_nvert = n_vert;
+      r.a0q_quads = cpad / 4;
+    }
     r.a1 = g;
     r.lda1 = hidden;
     r.ksplit = cpad;

@@ -328,9 +328,21 @@ constexpr int kThinBlocks = 768;
 constexpr int kThinFwdBlocks = 1280;
 int thin_num_slabs() { return kThinBlocks; }
 
+// Hybrid rows (the stack's channel-sliced path): columns [0, 4 xq_quads) of X come from the quad-major array xq
+// [m / n_vert][xq_quads][n_vert] float4 (the aggregation kernel's output), the rest from x (pre-offset, row stride ldx).
+__device__ __forceinline__ const float *hybrid_piece(const float *x, int ldx, const float *xq, int xq_quads, int n_vert,
+                                                     long long row, int kk) {
+  if (xq != nullptr && kk < xq_quads * 4) {
+    const long long bq = row / n_vert;
+    return xq + (((size_t)bq * xq_quads + (kk >> 2)) * n_vert + (size_t)(row - bq * n_vert)) * 4;
+  }
+  return x + row * ldx + kk;
+}
+
 __global__ __launch_bounds__(256) void thin_fwd_kernel(const float *__restrict__ x, int ldx, int k,
                                                        const float *__restrict__ w, long long m,
-                                                       float *__restrict__ z3) {
+                                                       float *__restrict__ z3, const float *__restrict__ xq,
+                                                       int xq_quads, int n_vert) {
   const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;  // 16 row groups per block
   float wr[kThinPieces][4][3];
 #pragma unroll
@@ -342,13 +354,12 @@ __global__ __launch_bounds__(256) void thin_fwd_kernel(const float *__restrict__
       for (int j = 0; j < 3; ++j) wr[p][t][j] = kk < k ? w[kk * 3 + j] : 0.f;
     }
   for (long long row = (long long)blockIdx.x * 16 + grp; row < m; row += (long long)gridDim.x * 16) {
-    const float *xr = x + row * ldx;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int p = 0; p < kThinPieces; ++p) {
       const int kk = (p * 16 + l16) * 4;
       if (kk < k) {
-        const f32x4 xv = *reinterpret_cast<const f32x4 *>(xr + kk);
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(hybrid_piece(x, ldx, xq, xq_quads, n_vert, row, kk));
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           s0 += xv[t] * wr[p][t][0];
@@ -446,14 +457,14 @@ int launch_csr3(const float *z, const float *bias, const int32_t *rowptr, const 
 
 int launch_thin_fwd(const float *x, int ldx, int k, const float *w, const float *bias, const int32_t *rowptr,
                     const int32_t *col, const float *val, const int32_t *heavy, int n_vert, int batch, float *z3,
-                    float *update, hipStream_t s) {
+                    float *update, const float *xq, int xq_quads, hipStream_t s) {
   if (k > kThinPieces * 64 || ldx % 4 != 0) {
     set_error("thin_fwd: k=%d (max %d) ldx=%d unsupported", k, kThinPieces * 64, ldx);
     return -1;
   }
   const long long m = (long long)batch * n_vert;
   const int grid = (int)(cdiv(m, 16) < kThinFwdBlocks ? cdiv(m, 16) : kThinFwdBlocks);
-  A3VT_LAUNCH(thin_fwd_kernel, dim3(grid), dim3(256), 0, s, x, ldx, k, w, m, z3);
+  A3VT_LAUNCH(thin_fwd_kernel, dim3(grid), dim3(256), 0, s, x, ldx, k, w, m, z3, xq, xq_quads, n_vert);
   A3VT_CHECK_LAUNCH();
   return launch_csr3(z3, bias, rowptr, col, val, heavy, n_vert, batch, update, 3, s);
 }
@@ -469,7 +480,7 @@ __global__ __launch_bounds__(256) void thin_bwd_kernel(const float *__restrict__
                                                        float *__restrict__ gprev, int ldg, int n_store,
                                                        float *__restrict__ dw_slab,
                                                        float *__restrict__ db_slab, float *__restrict__ gq, int nq,
-                                                       int n_vert) {
+                                                       int n_vert, const float *__restrict__ xq, int xq_quads) {
   __shared__ float red[16][kThinPieces * 64 * 3 / 16 + 1];  // [row group][this lane-column's 60 partials] per l16 pass
   const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
   float wr[kThinPieces][4][3], dwp[kThinPieces][4][3];
@@ -492,7 +503,6 @@ __global__ __launch_bounds__(256) void thin_bwd_kernel(const float *__restrict__
       db1 += du[row * 3 + 1];
       db2 += du[row * 3 + 2];
     }
-    const float *xr = x + row * ldx;
     float *gr = gprev + row * ldg;
     // quad-major copy of the aggregated-channel columns for csrq_kernel<1> (launch_csrq_bwd), when asked for
     const long long bq = gq ? row / n_vert : 0;
@@ -501,7 +511,7 @@ __global__ __launch_bounds__(256) void thin_bwd_kernel(const float *__restrict__
     for (int p = 0; p < kThinPieces; ++p) {
       const int kk = (p * 16 + l16) * 4;
       if (kk < k) {
-        const f32x4 xv = *reinterpret_cast<const f32x4 *>(xr + kk);
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(hybrid_piece(x, ldx, xq, xq_quads, n_vert, row, kk));
         f32x4 o;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -574,7 +584,7 @@ int launch_pad3to4(const float *in, long long m, float *out, hipStream_t s) {
 int launch_thin_bwd(const float *x, int ldx, int k, const float *w, const int32_t *rowptrT, const int32_t *colT,
                     const float *valT, const int32_t *heavyT, int n_vert, int batch, const float *grad_update,
                     float *dz3, int apply_mask, float *g_prev, int ldg, int n_store, float *dw_slab, float *db_slab,
-                    float *gq, int nq, hipStream_t s) {
+                    float *gq, int nq, const float *xq, int xq_quads, hipStream_t s) {
   if (k > kThinPieces * 64 || ldx % 4 != 0 || ldg % 4 != 0) {
     set_error("thin_bwd: k=%d ldx=%d ldg=%d unsupported", k, ldx, ldg);
     return -1;
@@ -587,7 +597,7 @@ int launch_thin_bwd(const float *x, int ldx, int k, const float *w, const int32_
   if (int rc = launch_pad3to4(grad_update, m, du4, s)) return rc;
   if (int rc = launch_csr3(du4, nullptr, rowptrT, colT, valT, heavyT, n_vert, batch, res, 4, s)) return rc;
   A3VT_LAUNCH(thin_bwd_kernel, dim3(kThinBlocks), dim3(256), 0, s, x, ldx, k, w, res, grad_update, m, apply_mask,
-                     g_prev, ldg, n_store, dw_slab, db_slab, gq, nq, n_vert);
+                     g_prev, ldg, n_store, dw_slab, db_slab, gq, nq, n_vert, xq, xq_quads);
   A3VT_CHECK_LAUNCH();
   return 0;
 }

@@ -27,8 +27,10 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 //   backward: the UNMASKED gradient columns [0, cpad) from the EPI_DX_MASK epilogue / thin_bwd; the ReLU signs of the
 //             aggregated channels never leave this pair of kernels: csrq<0> writes them quad-major (one byte per vertex
 //             and quad, coalesced), csrq<1> applies them while it fills LDS.
-// Outputs stay row-major (the next product's A operand): 16-byte pieces of 1200- / 400-byte rows; all quads of a mesh
-// run on one XCD (blockIdx % 8) at about the same time, so the pieces of a cache line meet in that XCD's L2.
+// Outputs are quad-major too — the activations' / dZa's columns [0, 4 Q) live in that layout for the whole stack and the
+// consumers (rowgemm's A operand, dw's X / dZa images, the output layer) fetch their 16-byte pieces from it: written
+// row-major, as 16-byte pieces of 1200- / 400-byte rows, the stores alone cost 45 us per launch (measured; 35 us with
+// quad-major stores, profiles/r03_csrq_ablation.txt).
 // Arithmetic and summation order per output element are those of csr_fwd / csr_bwd (acc += w * r in CSR order).
 // ------------------------------------------------------------------------------------------------
 constexpr int kCsrqThreads = 512;
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(kCsrqThreads) void csrq_kernel(const float *__restr
                                                             const int32_t *__restrict__ rowptr,
                                                             const int32_t *__restrict__ colidx,
                                                             const float *__restrict__ val, int n_vert, int batch,
-                                                            float *__restrict__ dst, int ld_dst,
+                                                            float *__restrict__ dst, int nq_dst,
                                                             uint8_t *__restrict__ signq, int relu, int heavy_thresh,
                                                             float *__restrict__ db_slab,
                                                             const int32_t *__restrict__ ellbuf) {
@@ -124,11 +126,11 @@ __global__ __launch_bounds__(kCsrqThreads) void csrq_kernel(const float *__restr
     bits = MODE == 1 ? signq[plane + vv[k]] : 0u;
   };
   auto park = [&](f32x4 *tile, int q, int k, f32x4 v4, unsigned bits) {
-    if (MODE == 1) {
+    if (MODE == 1) {   // all four channels of the quad: the forward kept a sign bit for the pass-through ones too
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-        if (q * 4 + t < c) v4[t] = ((bits >> t) & 1u) ? v4[t] : 0.f;
+      for (int t = 0; t < 4; ++t) v4[t] = ((bits >> t) & 1u) ? v4[t] : 0.f;
     }
+    (void)q;
     tile[vv[k]] = v4;   // (the copies of the last vertex all write the same value)
   };
 
@@ -198,39 +200,24 @@ __global__ __launch_bounds__(kCsrqThreads) void csrq_kernel(const float *__restr
         }
       }
       if (!on[k] || dg[k] > heavy_thresh) continue;   // hub rows: csrq_heavy_kernel (their bias share is counted above)
-      const size_t row = (size_t)b * n_vert + v;
+      f32x4 o;
       if (MODE == 0) {
         unsigned bits = 0;
-        f32x4 o;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const float pre = ch + t < c ? acc[t] + bs[t] : 0.f;
+          // aggregated channels: neighbour sum + bias; the pass-through channels of the last quad (model.py:358: no
+          // bias): the raw value itself
+          const float pre = ch + t < c ? acc[t] + bs[t] : own[t];
           o[t] = (pre > 0.f || !relu) ? pre : 0.f;
           bits |= (pre > 0.f ? 1u : 0u) << t;
         }
-#ifdef A3VT_DBG_CSRQ_QSTORE   // timing-only (tools/build_variants.sh csrq): outputs leave quad-major, i.e. coalesced — wrong results
-        float *yo = dst + (plane + v) * 4;
-#else
-        float *yo = dst + row * ld_dst + ch;
-#endif
-        if (ch + 3 < c && (ld_dst & 3) == 0) {
-          *reinterpret_cast<f32x4 *>(yo) = o;
-        } else {
-#pragma unroll
-          for (int t = 0; t < 4; ++t)
-            if (ch + t < c) yo[t] = o[t];
-        }
         if (signq) signq[plane + v] = (uint8_t)bits;
       } else {
-        f32x4 o;
 #pragma unroll
         for (int t = 0; t < 4; ++t) o[t] = ch + t < c ? acc[t] : own[t];
-#ifdef A3VT_DBG_CSRQ_QSTORE
-        *reinterpret_cast<f32x4 *>(dst + (plane + v) * 4) = o;
-#else
-        *reinterpret_cast<f32x4 *>(dst + row * ld_dst + ch) = o;
-#endif
       }
+      // quad-major like the input (1 KiB per wave-instruction); the output array may hold more planes per mesh (nq_dst)
+      *reinterpret_cast<f32x4 *>(dst + ((((size_t)b * nq_dst + q) * n_vert) + v) * 4) = o;
     }
     __builtin_amdgcn_sched_barrier(0);
     if (MODE == 1) {   // bias-gradient partial of this (mesh, quad), fixed order; red[par] is read behind the barrier below
@@ -264,7 +251,7 @@ __global__ __launch_bounds__(256) void csrq_heavy_kernel(const float *__restrict
                                                          const int32_t *__restrict__ colidx,
                                                          const float *__restrict__ val, int n_vert, int batch,
                                                          const int32_t *__restrict__ heavy, float *__restrict__ dst,
-                                                         int ld_dst, uint8_t *__restrict__ signq, int relu) {
+                                                         int nq_dst, uint8_t *__restrict__ signq, int relu) {
   __shared__ f32x4 red[8][32];
   const int hl = threadIdx.x & 31, sub = threadIdx.x >> 5;
   const int count = heavy[0];
@@ -272,7 +259,7 @@ __global__ __launch_bounds__(256) void csrq_heavy_kernel(const float *__restrict
   const int ch = hl * 4;
   for (long long item = blockIdx.x; item < (long long)count * batch; item += gridDim.x) {
     const int v = heavy[64 + (int)(item % count)];
-    const long long b = item / count, row = b * n_vert + v;
+    const long long b = item / count;
     const size_t plane = ((size_t)b * nq + (on ? hl : 0)) * n_vert;
     const f32x4 *src = reinterpret_cast<const f32x4 *>(srcq) + plane;
     const int e0 = rowptr[v], e1 = rowptr[v + 1];
@@ -286,8 +273,7 @@ __global__ __launch_bounds__(256) void csrq_heavy_kernel(const float *__restrict
         if (MODE == 1) {
           const unsigned bits = signq[plane + cc];
 #pragma unroll
-          for (int t = 0; t < 4; ++t)
-            if (ch + t < c) r[t] = ((bits >> t) & 1u) ? r[t] : 0.f;
+          for (int t = 0; t < 4; ++t) r[t] = ((bits >> t) & 1u) ? r[t] : 0.f;
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = __builtin_fmaf(val[e], r[t], acc[t]);
@@ -299,22 +285,26 @@ __global__ __launch_bounds__(256) void csrq_heavy_kernel(const float *__restrict
       f32x4 a = red[0][hl];
 #pragma unroll
       for (int r = 1; r < 8; ++r) a += red[r][hl];
-      float *o = dst + row * ld_dst + ch;
+      f32x4 own = src[v];   // columns >= c pass the row's own value through
+      f32x4 o;
       if (MODE == 0) {
         unsigned bits = 0;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const float pre = ch + t < c ? a[t] + bias[ch + t] : 0.f;
-          const float out = (pre > 0.f || !relu) ? pre : 0.f;
+          const float pre = ch + t < c ? a[t] + bias[ch + t] : own[t];
+          o[t] = (pre > 0.f || !relu) ? pre : 0.f;
           bits |= (pre > 0.f ? 1u : 0u) << t;
-          if (ch + t < c) o[t] = out;
         }
         if (signq) signq[plane + v] = (uint8_t)bits;
       } else {
-        const f32x4 own = src[v];   // columns >= c: the row's own (already masked) gradient passes through
+        const unsigned bits = signq[plane + v];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) o[t] = ch + t < c ? a[t] : own[t];
+        for (int t = 0; t < 4; ++t) {
+          own[t] = ((bits >> t) & 1u) ? own[t] : 0.f;
+          o[t] = ch + t < c ? a[t] : own[t];
+        }
       }
+      *reinterpret_cast<f32x4 *>(dst + ((((size_t)b * nq_dst + hl) * n_vert) + v) * 4) = o;
     }
     __syncthreads();
   }
@@ -329,7 +319,7 @@ bool csrq_fits(int n_vert, int cut_len) {
 template <int MODE, int VPT>
 static int launch_csrq_vpt(const float *srcq, int nq, const float *bias, int c, const int32_t *rowptr, const int32_t *col,
                            const float *val, const int32_t *heavy, const int32_t *ell, int n_vert, int batch, float *dst,
-                           int ld_dst, uint8_t *signq, int relu, float *db_slab, hipStream_t s) {
+                           int nq_dst, uint8_t *signq, int relu, float *db_slab, hipStream_t s) {
   const size_t shmem = ((size_t)n_vert + 1) * 32;
   static OncePerDevice once;
   once.run([] {
@@ -340,7 +330,7 @@ static int launch_csrq_vpt(const float *srcq, int nq, const float *bias, int c, 
   parts = parts < 1 ? 1 : parts > nq ? nq : parts;
   const int grid = 8 * ((batch + 7) / 8) * parts;   // (XCD group, mesh of the group, part): the parts of a mesh share an XCD
   A3VT_LAUNCH((csrq_kernel<MODE, VPT>), dim3(grid), dim3(kCsrqThreads), shmem, s, srcq, nq, parts, bias, c, rowptr, col, val,
-              n_vert, batch, dst, ld_dst, signq, relu, heavy ? kHeavyDegQ : 0x7fffffff, db_slab, ell);
+              n_vert, batch, dst, nq_dst, signq, relu, heavy ? kHeavyDegQ : 0x7fffffff, db_slab, ell);
   A3VT_CHECK_LAUNCH();
   return 0;
 }
@@ -348,35 +338,35 @@ static int launch_csrq_vpt(const float *srcq, int nq, const float *bias, int c, 
 template <int MODE>
 static int launch_csrq(const float *srcq, const float *bias, int c, const int32_t *rowptr, const int32_t *col,
                        const float *val, const int32_t *heavy, const int32_t *ell, int n_vert, int batch, float *dst,
-                       int ld_dst, uint8_t *signq, int relu, float *db_slab, hipStream_t s) {
+                       int nq_dst, uint8_t *signq, int relu, float *db_slab, hipStream_t s) {
   const int nq = pad4(c) / 4;
-  if (!csrq_fits(n_vert, c) || (MODE == 1 && (ld_dst % 4 != 0 || !signq || !db_slab))) {
-    set_error("csrq: n_vert=%d c=%d ld_dst=%d unsupported", n_vert, c, ld_dst);
+  if (!csrq_fits(n_vert, c) || nq_dst < nq || (MODE == 1 && (!signq || !db_slab))) {
+    set_error("csrq: n_vert=%d c=%d output planes=%d unsupported", n_vert, c, nq_dst);
     return -1;
   }
   int rc;
   if (n_vert <= 4 * kCsrqThreads)
-    rc = launch_csrq_vpt<MODE, 4>(srcq, nq, bias, c, rowptr, col, val, heavy, ell, n_vert, batch, dst, ld_dst, signq, relu, db_slab, s);
+    rc = launch_csrq_vpt<MODE, 4>(srcq, nq, bias, c, rowptr, col, val, heavy, ell, n_vert, batch, dst, nq_dst, signq, relu, db_slab, s);
   else
-    rc = launch_csrq_vpt<MODE, 6>(srcq, nq, bias, c, rowptr, col, val, heavy, ell, n_vert, batch, dst, ld_dst, signq, relu, db_slab, s);
+    rc = launch_csrq_vpt<MODE, 6>(srcq, nq, bias, c, rowptr, col, val, heavy, ell, n_vert, batch, dst, nq_dst, signq, relu, db_slab, s);
   if (rc) return rc;
   if (heavy) {
     A3VT_LAUNCH(csrq_heavy_kernel<MODE>, dim3(2048), dim3(256), 0, s, srcq, nq, bias, c, rowptr, col, val, n_vert, batch,
-                heavy, dst, ld_dst, signq, relu);
+                heavy, dst, nq_dst, signq, relu);
     A3VT_CHECK_LAUNCH();
   }
   return 0;
 }
 
 int launch_csrq_fwd(const float *zq, const float *bias, int c, const int32_t *rowptr, const int32_t *col,
-                    const float *val, const int32_t *heavy, const int32_t *ell, int n_vert, int batch, float *y, int ldy,
-                    uint8_t *signq, int relu, hipStream_t s) {
-  return launch_csrq<0>(zq, bias, c, rowptr, col, val, heavy, ell, n_vert, batch, y, ldy, signq, relu, nullptr, s);
+                    const float *val, const int32_t *heavy, const int32_t *ell, int n_vert, int batch, float *yq,
+                    int yq_quads, uint8_t *signq, int relu, hipStream_t s) {
+  return launch_csrq<0>(zq, bias, c, rowptr, col, val, heavy, ell, n_vert, batch, yq, yq_quads, signq, relu, nullptr, s);
 }
 int launch_csrq_bwd(const float *gq, int c, const int32_t *rowptrT, const int32_t *colT, const float *valT,
-                    const int32_t *heavyT, const int32_t *ellT, int n_vert, int batch, float *dza, int lddza,
+                    const int32_t *heavyT, const int32_t *ellT, int n_vert, int batch, float *dzaq,
                     const uint8_t *signq, float *db_slab, hipStream_t s) {
-  return launch_csrq<1>(gq, nullptr, c, rowptrT, colT, valT, heavyT, ellT, n_vert, batch, dza, lddza,
+  return launch_csrq<1>(gq, nullptr, c, rowptrT, colT, valT, heavyT, ellT, n_vert, batch, dzaq, pad4(c) / 4,
                         const_cast<uint8_t *>(signq), 0, db_slab, s);
 }
 

@@ -95,7 +95,16 @@ __device__ __forceinline__ void rowtile_unit(const RowGemmArgs &p, int row_base,
   const int l16 = lane & 15, q = lane >> 4;
   const int ar = min(row_base + mt * 16 + l16, row_end - 1);  // A row of this lane (ragged tail: duplicate, never stored)
   const int br = min(n0 + l16, p.bt_rows - 1);                 // Bt row (= output column) of this lane
-  const float *a0r = p.a0 + (size_t)ar * p.lda0, *a1r = p.a1 + (size_t)ar * p.lda1;
+  // a0 may be quad-major (RowGemmArgs::a0q_nvert): element (row, k) at ((b Q + k / 4) N + v) * 4 + k % 4 -> k * N past the
+  // row's base for the 4-aligned k a lane reads
+  const float *a1r = p.a1 + (size_t)ar * p.lda1;
+  const float *a0r = p.a0 + (size_t)ar * p.lda0;
+  size_t a0mul = 1;
+  if (p.a0q_nvert > 0) {
+    const int bq = ar / p.a0q_nvert;
+    a0r = p.a0 + ((size_t)bq * p.a0q_quads * p.a0q_nvert + (size_t)(ar - bq * p.a0q_nvert)) * 4;
+    a0mul = (size_t)p.a0q_nvert;
+  }
   const float *btr = p.bt + (size_t)br * p.ldb;
   const int nch = (p.k + 15) >> 4;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -105,7 +114,7 @@ __device__ __forceinline__ void rowtile_unit(const RowGemmArgs &p, int row_base,
     for (int c = 0; c < KB; ++c) {
       const int kk = (c0 + c) * 16 + q * 4;
       const bool on = c0 + c < nch && kk < p.k;
-      af[c] = on ? *reinterpret_cast<const f32x4 *>((kk < p.ksplit ? a0r : a1r) + kk) : f32x4{0.f, 0.f, 0.f, 0.f};
+      af[c] = on ? *reinterpret_cast<const f32x4 *>(kk < p.ksplit ? a0r + (size_t)kk * a0mul : a1r + kk) : f32x4{0.f, 0.f, 0.f, 0.f};
       bf[c] = on ? *reinterpret_cast<const f32x4 *>(btr + kk) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
@@ -144,13 +153,15 @@ __device__ __forceinline__ void rowtile_unit(const RowGemmArgs &p, int row_base,
           else reinterpret_cast<u16 *>(p.c)[(size_t)row * p.ldc + col] = to_bf16((v > 0.f || p.no_relu) ? v : 0.f);
         }
       } else if (row_ok && col_ok) {
-        if (col < p.csplit) {
-          if (p.zq_nvert > 0) {
-            const int bq = row / p.zq_nvert;
-            p.c2[(((size_t)bq * p.zq_quads + (col >> 2)) * p.zq_nvert + (row - bq * p.zq_nvert)) * 4 + (col & 3)] = v;
-          } else {
-            p.c2[(size_t)row * p.ldc2 + col] = v;
-          }
+        if (p.zq_nvert > 0 && col < p.zq_quads * 4) {   // quad-major raw columns (RowGemmArgs::zq_nvert)
+          const int bq = row / p.zq_nvert;
+          p.c2[(((size_t)bq * p.zq_quads + (col >> 2)) * p.zq_nvert + (row - bq * p.zq_nvert)) * 4 + (col & 3)] = v;
+        } else if (p.zq_nvert > 0 && col < p.yq_quads * 4) {   // quad-major pass-through columns of the activations
+          const int bq = row / p.zq_nvert;
+          p.yq[(((size_t)bq * p.yq_quads + (col >> 2)) * p.zq_nvert + (row - bq * p.zq_nvert)) * 4 + (col & 3)] =
+              (v > 0.f || p.no_relu) ? v : 0.f;
+        } else if (p.zq_nvert == 0 && col < p.csplit) {
+          p.c2[(size_t)row * p.ldc2 + col] = v;
         } else {
           p.c[(size_t)row * p.ldc + col] = (v > 0.f || p.no_relu) ? v : 0.f;
         }
@@ -162,14 +173,9 @@ __device__ __forceinline__ void rowtile_unit(const RowGemmArgs &p, int row_base,
           reinterpret_cast<u16 *>(p.c)[(size_t)row * p.ldc + col] = to_bf16(((byte >> (col & 3)) & 1u) ? v : 0.f);
         }
       } else if (row_ok && col_ok) {
-        if (p.zq_nvert > 0 && col < p.zq_quads * 4) {   // quad-major gradient columns: unmasked below csplit (RowGemmArgs)
-          float o = v;
-          if (col >= p.csplit) {
-            const unsigned byte = p.maskb[(size_t)row * p.mld + p.moff + (col >> 2)];
-            o = ((byte >> (col & 3)) & 1u) ? v : 0.f;
-          }
+        if (p.zq_nvert > 0 && col < p.zq_quads * 4) {   // quad-major gradient columns: unmasked (RowGemmArgs::zq_nvert)
           const int bq = row / p.zq_nvert;
-          p.c2[(((size_t)bq * p.zq_quads + (col >> 2)) * p.zq_nvert + (row - bq * p.zq_nvert)) * 4 + (col & 3)] = o;
+          p.c2[(((size_t)bq * p.zq_quads + (col >> 2)) * p.zq_nvert + (row - bq * p.zq_nvert)) * 4 + (col & 3)] = v;
         } else {
           const unsigned byte = p.maskb[(size_t)row * p.mld + (col < p.csplit ? 0 : p.moff) + (col >> 2)];
           p.c[(size_t)row * p.ldc + col] = ((byte >> (col & 3)) & 1u) ? v : 0.f;
@@ -258,11 +264,16 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
     // this wave's A source rows (ragged tail: duplicate the last row, never stored)
     const float *a0row[A_INSTR];
     const float *a1row[A_INSTR];
+    const size_t a0mul = p.a0q_nvert > 0 ? (size_t)p.a0q_nvert : 1;   // quad-major a0: k -> k * N floats past the row's base
 #pragma unroll
     for (int j = 0; j < A_INSTR; ++j) {
       int r = row0 + j * 16 + (lane >> 2);
       r = r < p.m ? r : p.m - 1;
       a0row[j] = p.a0 + (size_t)r * p.lda0;
+      if (p.a0q_nvert > 0) {
+        const int bq = r / p.a0q_nvert;
+        a0row[j] = p.a0 + ((size_t)bq * p.a0q_quads * p.a0q_nvert + (size_t)(r - bq * p.a0q_nvert)) * 4;
+      }
       a1row[j] = p.a1 + (size_t)r * p.lda1;
     }
 
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
       if (piece < A_INSTR) {
         float *sA = lds + buf * STAGE + wave * (MT * 256);
         const float *src =
-            (piece >= nm || kk >= p.k) ? p.zeros : (kk < p.ksplit ? a0row[piece] + kk : a1row[piece] + kk);
+            (piece >= nm || kk >= p.k) ? p.zeros : (kk < p.ksplit ? a0row[piece] + (size_t)kk * a0mul : a1row[piece] + kk);
         glds16(src, sA + piece * 256);
       } else {
         const int j = piece - A_INSTR;
@@ -551,20 +562,37 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
             const int bq = row / p.zq_nvert;
             float *qbase = p.c2 + ((size_t)bq * nqz * p.zq_nvert + (size_t)(row - bq * p.zq_nvert)) * 4;
             for (int c4 = lane >> 4; c4 < nqz; c4 += 4) {
-              f32x4 v = *reinterpret_cast<const f32x4 *>(ep + rl * stride + c4 * 4);
-              if (EPI == EPI_DX_MASK && c4 * 4 + 3 >= p.csplit) {   // pass-through columns inside the last quad: masked here
-                const unsigned bb = mslot[(i * 16 + rl) * p.mld + p.moff + c4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                  if (c4 * 4 + t >= p.csplit) v[t] = ((bb >> t) & 1u) ? v[t] : 0.f;
-              }
+              const f32x4 v = *reinterpret_cast<const f32x4 *>(ep + rl * stride + c4 * 4);
 #ifdef A3VT_DBG_RG_NOSTORE
               if (v[0] != 1.2345e-33f) continue;
 #endif
               if (row < p.m) *reinterpret_cast<f32x4 *>(qbase + (size_t)c4 * p.zq_nvert * 4) = v;
             }
-            // forward: the quad that straddles the cut still goes (activated) to the row-major output below
-            qlo = EPI == EPI_FWD_HIDDEN ? p.csplit >> 2 : nqz;
+            qlo = nqz;   // the quad-major columns [0, 4 Q) belong to the aggregation kernels alone (RowGemmArgs::zq_nvert)
+            if (EPI == EPI_FWD_HIDDEN && p.yq_quads > nqz) {
+              // forward: the pass-through columns [4 Q, 4 yq_quads) — the rest of this column group — are part of the
+              // quad-major region of the activations too (RowGemmArgs::yq): ReLU, sign bits, same row-fastest stores
+              float *ybase = p.yq + ((size_t)bq * p.yq_quads * p.zq_nvert + (size_t)(row - bq * p.zq_nvert)) * 4;
+              for (int c4 = nqz + (lane >> 4); c4 < p.yq_quads; c4 += 4) {
+                f32x4 v = *reinterpret_cast<const f32x4 *>(ep + rl * stride + c4 * 4);
+                unsigned bits = 0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                  bits |= (v[t] > 0.f ? 1u : 0u) << t;
+                  v[t] = (v[t] > 0.f || p.no_relu) ? v[t] : 0.f;
+                }
+                if (row >= p.m) continue;
+                if (p.maskb) {
+                  if (mask_rows) mslot[(i * 16 + rl) * p.mld + p.moff + c4] = (uint8_t)bits;
+                  else p.maskb[(size_t)row * p.mld + p.moff + c4] = (uint8_t)bits;
+                }
+#ifdef A3VT_DBG_RG_NOSTORE
+                if (v[0] != 1.2345e-33f) continue;
+#endif
+                *reinterpret_cast<f32x4 *>(ybase + (size_t)c4 * p.zq_nvert * 4) = v;
+              }
+              qlo = p.yq_quads;
+            }
           }
           const int wq = f4row - qlo, nf4 = 16 * wq;
           for (int f = lane; f < nf4; f += 64) {
@@ -812,6 +840,15 @@ bool rowgemm_quad_major_ok(int m, int n_store, int cpad) {
 }
 
 int launch_rowgemm(const RowGemmArgs &a, int epi, hipStream_t s) {
+  if (a.a0q_nvert > 0 && (a.bf16 == 2 || a.m % a.a0q_nvert != 0 || a.ksplit != a.a0q_quads * 4)) {
+    set_error("rowgemm: quad-major a0 needs ksplit = 4 * quads (ksplit=%d quads=%d) and whole meshes (m=%d)", a.ksplit, a.a0q_quads, a.m);
+    return -1;
+  }
+  if (a.yq_quads > 0 && (a.zq_nvert <= 0 || a.yq == nullptr || epi != EPI_FWD_HIDDEN || a.yq_quads < a.zq_quads || a.yq_quads * 4 > 160 ||
+                         a.yq_quads * 4 > a.n_store)) {
+    set_error("rowgemm: quad-major activations need the quad-major forward epilogue and at most 160 columns (yq_quads=%d)", a.yq_quads);
+    return -1;
+  }
   if (a.zq_nvert > 0 && (epi == EPI_PLAIN || a.bf16 == 2 || a.c2 == nullptr || a.m % a.zq_nvert != 0 ||
                          a.zq_quads * 4 != pad4(a.csplit) || !rowgemm_quad_major_ok(a.m, a.n_store, a.zq_quads * 4))) {
     set_error("rowgemm: quad-major output unsupported for m=%d n=%d csplit=%d epi=%d mode=%d", a.m, a.n_store, a.csplit, epi, a.bf16);
@@ -946,13 +983,13 @@ constexpr int DW_MAXO = 3;   // output-channel tiles per wave
 // One 16-row stage: 4 k-steps of up to NI x NO MFMAs.  NI/NO < 0 selects the guarded generic form.
 template <int NI, int NO>
 __device__ __forceinline__ void dw_stage(const float *__restrict__ sb, int ldx, int ldz0, int ldz1, int offG,
-                                         int xoff, const int (&zoff)[DW_MAXO], int q, int ni, int no,
+                                         int xoff, const int (&zoff)[DW_MAXO], int q, int ni, int no, bool z0q, int rot,
                                          f32x4 (&acc)[DW_MAXI][DW_MAXO]) {
 #pragma unroll 1
   for (int ks = 0; ks < 4; ++ks) {
     const int r = q * 4 + ks;  // see dw_stage_fast
     const float *xr = sb + r * ldx + xoff;
-    const int ra = r * ldz0, rg = r * ldz1;
+    const int ra = z0q ? ((r + rot) & 15) * 4 : r * ldz0, rg = r * ldz1;   // z0q: blocked dZa window, see dw_kernel
     float a[DW_MAXI], b[DW_MAXO];
 #ifdef A3VT_DBG_NOLDSREAD
 #pragma unroll
@@ -983,9 +1020,14 @@ __device__ __forceinline__ void dw_stage(const float *__restrict__ sb, int ldx, 
 // Common shape (ni in {4,5}, no in {2,3} — e.g. 19 x 10 tiles over 4 x 4 waves): the 4 x 2 core block runs
 // unconditionally, the 5th row / 3rd column / corner behind three wave-uniform branches, and the operand
 // reads of k-step ks+1 are issued before the MFMAs of k-step ks (register double buffer).
+// HYB (quad-major sources, see dw_kernel): the leading blocks of X and (z0q) the dZa window are staged as 16-column
+// blocks [4 quads][16 slots][4 floats], row r of quad qd in slot (r + qd) & 15 (rot = this lane's qd); xo = offset of this
+// lane's column in the block of its first input tile (< 0: this wave's tiles are columns of the row-major image), xoff =
+// the same in the row-major image of the remaining columns (row stride ldx).
+template <bool HYB, bool BLK>
 __device__ __forceinline__ void dw_stage_fast(const float *__restrict__ sb, int ldx, int ldz0, int ldz1, int offG,
                                               int xoff, const int (&zoff)[DW_MAXO], int q, bool row5, bool col3,
-                                              f32x4 (&acc)[DW_MAXI][DW_MAXO]) {
+                                              int xo, bool z0q, int rot, f32x4 (&acc)[DW_MAXI][DW_MAXO]) {
   float a[DW_MAXI], b[DW_MAXO], an[DW_MAXI], bn[DW_MAXO];
   auto load = [&](int ks, float (&av)[DW_MAXI], float (&bv)[DW_MAXO]) {
     // k-step ks takes rows {ks, 4+ks, 8+ks, 12+ks} of the stage (lane group q reads row 4q+ks) rather than four
@@ -994,7 +1036,8 @@ __device__ __forceinline__ void dw_stage_fast(const float *__restrict__ sb, int 
     // Adjacent rows (ld mod 32 = 12 or 4) overlapped: 2-way conflicts on every operand read.
     const int r = q * 4 + ks;
     const float *xr = sb + r * ldx + xoff;
-    const int ra = r * ldz0, rg = r * ldz1;
+    const int rq = ((r + rot) & 15) * 4;   // row term inside a 16-column block (dw_kernel: row r of quad qd at slot (r + qd) & 15)
+    const int ra = HYB && z0q ? rq : r * ldz0, rg = r * ldz1;
 #ifdef A3VT_DBG_NOLDSREAD
 #pragma unroll
     for (int i = 0; i < DW_MAXI; ++i) av[i] = (float)(r + i);
@@ -1007,8 +1050,14 @@ __device__ __forceinline__ void dw_stage_fast(const float *__restrict__ sb, int 
     // ("i < 4 || row5 ? i : 3") made the compiler reuse the loaded a[3] through a v_mov, i.e. wait for the NEXT
     // k-step's ds_reads (s_waitcnt lgkmcnt(0)) before the current k-step's MFMAs — 19 % of the launch.
     (void)row5; (void)col3;
+    if (HYB && BLK) {   // this wave's five input tiles are 1 KiB blocks: tile stride 256 floats, slot row rq
+      const float *xb = sb + xo + rq;
 #pragma unroll
-    for (int i = 0; i < DW_MAXI; ++i) av[i] = xr[i * 16];
+      for (int i = 0; i < DW_MAXI; ++i) av[i] = xb[i * 256];
+    } else {
+#pragma unroll
+      for (int i = 0; i < DW_MAXI; ++i) av[i] = xr[i * 16];
+    }
 #pragma unroll
     for (int j = 0; j < DW_MAXO; ++j) bv[j] = sb[zoff[j] + (zoff[j] < offG ? ra : rg)];
 #endif
@@ -1074,7 +1123,16 @@ __device__ __forceinline__ void dw_stage_bf16(const float *__restrict__ sb, int 
   }
 }
 
-template <bool FAST, bool BF16>
+// Input tiles of X staged as blocks when its first 4 * quads columns are quad-major: up to the end of the wave (wi) that
+// holds the last of them — waves own tin / 4 (+1) consecutive tiles each, as in dw_kernel.
+__host__ __device__ static inline int dw_blocked_tiles(int k_in, int quads) {
+  const int tin = (k_in + 15) >> 4, need = (quads * 4 + 15) >> 4;
+  int end = 0;
+  for (int wi = 0; wi < 4 && end < need; ++wi) end += tin / 4 + (wi < tin % 4 ? 1 : 0);
+  return end < tin ? end : tin;
+}
+
+template <bool FAST, bool BF16, bool HYB>
 __global__ __launch_bounds__(1024, 1) void dw_kernel(DwArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63;
@@ -1101,9 +1159,20 @@ __global__ __launch_bounds__(1024, 1) void dw_kernel(DwArgs p) {
   const int g0 = max(gcol0, p.zsplit) & ~3, g1 = min((max(gcol1, p.zsplit) + 3) & ~3, p.ldz1);
   const int wa = max(a1 - a0, 0), wg = max(g1 - g0, 0);
 
-  // 16-row images: floats, DMA wave-instructions (1 KiB each), LDS offsets
-  const int xfl = 16 * p.ldx, afl = 16 * wa, gfl = 16 * wg;
-  const int xin = (xfl + 255) >> 8, ain = (afl + 255) >> 8, gin = (gfl + 255) >> 8;
+  // 16-row images: floats, DMA wave-instructions (1 KiB each), LDS offsets.
+  // Quad-major sources (HYB; DwArgs::xq / z0q_nvert: the outputs of the channel-sliced aggregation kernels) are staged as
+  // 16-COLUMN BLOCKS of 1 KiB, one DMA instruction each: lane l fetches 16 bytes of column quad l >> 4 of the block, the
+  // 16 lanes of a quad walking its 16 rows — 256 contiguous bytes of that quad's plane, so the instruction touches eight
+  // cache lines like a contiguous one (pieces taken in compact row-major order are 64 different lines per instruction:
+  // +14-24 us per launch, measured).  In LDS the block is [4 quads][16 slots][4 floats] with row r of quad qd in slot
+  // (r + qd) & 15: the ds_read_b32 of a k-step (rows 4 q + ks, 16 columns) then hits 64 different banks.
+  // X: blocks for its quad-major columns [0, 4 xq_quads) (a multiple of 16, and whole waves' tiles: launch_dw), a compact
+  // row-major image for the other wrm columns.  dZa window: blocks when z0q.  G window: compact row-major image.
+  const bool z0q = HYB && p.z0q_nvert > 0;
+  const int nbq = HYB && p.xq_nvert > 0 ? p.xq_quads >> 2 : 0;
+  const int wrm = p.ldx - nbq * 16;
+  const int afl = 16 * wa, gfl = 16 * wg;
+  const int xin = nbq + ((16 * wrm + 255) >> 8), ain = z0q ? (wa + 15) >> 4 : (afl + 255) >> 8, gin = (gfl + 255) >> 8;
   const int offA = xin * 256, offG = offA + ain * 256, offD = offG + gin * 256;
   const int stage = offD + 256;  // + one dummy 1 KiB slot for idle DMA slots
 
@@ -1116,47 +1185,89 @@ __global__ __launch_bounds__(1024, 1) void dw_kernel(DwArgs p) {
   // DMA slot s = wave*3 + j (wave-uniform): [0,xin) -> X, [xin,xin+ain) -> dZa window, [..,+gin) -> G window, else
   // dummy.  A lane's piece is float4 number f4 of the compact [16][w] image: row f4 / (w/4), column c0 + 4 (f4 % (w/4))
   // of the source; the source advances by 16 rows per unit, so each lane just bumps a pointer.
+  // Quad-major sources (DwArgs::xq / z0q_nvert: the outputs of the channel-sliced aggregation kernels): the LDS images
+  // stay the same compact row-major [16][w] — only where a lane's 16-byte piece comes from changes.  Piece (row, column
+  // quad) of mesh b lies at ((b Q + quad) N + v) * 4; 16 rows further it is 64 floats on, plus (Q - 1) N * 4 when the row
+  // has crossed into the next mesh.
   const float *sp[3];   // this lane's source for the next unit (zeros for idle lanes)
   int sstep[3];         // floats to advance per unit (0 for idle lanes)
   int sdst[3];          // LDS float offset of the slot inside a stage (wave-uniform)
   int srow[3];          // image row of this lane's piece (ragged-tail test); huge for idle lanes
+  const int qn = p.xq_nvert > 0 ? p.xq_nvert : p.z0q_nvert;   // vertices per mesh (the same for X and dZa)
+  int sjq[3];           // that further step (wave-uniform: a slot is X or dZa for the whole wave)
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     const int s = wave * 3 + j;
-    const float *img = nullptr;
-    int ld = 0, w = 4, c0 = 0, li = 0;
+    const float *img = nullptr, *imgq = nullptr;   // row-major source; quad-major source of the columns below 4 nquad
+    int ld = 0, w = 4, c0 = 0, li = 0, nquad = 0, cend = 0;
+    bool blocked = false;
     sdst[j] = offD;
-    if (s < xin) {
-      img = p.x; ld = p.ldx; w = p.ldx; c0 = 0; li = s; sdst[j] = li * 256;
-    } else if (s < xin + ain) {
-      img = p.z0; ld = p.ldz0; w = wa; c0 = a0; li = s - xin; sdst[j] = offA + li * 256;
-    } else if (s < xin + ain + gin) {
+    if (s < nbq) {                       // X, blocked part
+      img = p.x; ld = p.ldx_src; c0 = 0; cend = p.ldx; li = s; sdst[j] = li * 256;
+      imgq = p.xq; nquad = p.xq_quads; blocked = true;
+    } else if (s < xin) {                // X, row-major image of the columns [16 nbq, ldx)
+      img = p.x; ld = p.ldx_src; w = wrm; c0 = nbq * 16; li = s - nbq; sdst[j] = s * 256;
+    } else if (s < xin + ain) {          // dZa window
+      li = s - xin; sdst[j] = offA + li * 256;
+      if (z0q) { imgq = p.z0; nquad = p.z0q_quads; c0 = a0; cend = a0 + wa; blocked = true; }
+      else { img = p.z0; ld = p.ldz0; w = wa; c0 = a0; }
+    } else if (s < xin + ain + gin) {    // G window
       img = p.z1; ld = p.ldz1; w = wg; c0 = g0; li = s - xin - ain; sdst[j] = offG + li * 256;
     }
-    const int wq = w >> 2, f4 = li * 64 + lane;
-    const int row = f4 / wq, c4 = f4 - row * wq;
-    const bool valid = img != nullptr && row < 16;
-    sp[j] = valid ? img + ((size_t)u0 * 16 + row) * ld + c0 + c4 * 4 : p.zeros;
+    int row, col;
+    bool valid;
+    if (blocked) {
+      const int qd = lane >> 4;
+      row = ((lane & 15) - qd) & 15;
+      col = c0 + li * 16 + qd * 4;
+      valid = col < cend && (img != nullptr || col < nquad * 4);
+    } else {
+      const int wq = w >> 2, f4 = li * 64 + lane;
+      row = f4 / wq;
+      col = c0 + (f4 - row * wq) * 4;
+      valid = img != nullptr && row < 16;
+    }
+    const size_t grow = (size_t)u0 * 16 + row;
+    sp[j] = valid && img != nullptr ? img + grow * ld + col : p.zeros;
     sstep[j] = valid ? 16 * ld : 0;
     srow[j] = valid ? row : 0x7fffffff;
+    sjq[j] = (nquad - 1) * qn * 4;
+    if (valid && imgq != nullptr && col < nquad * 4) {
+      const int bq = (int)(grow / qn), vq = (int)(grow - (size_t)bq * qn);
+      sp[j] = imgq + (((size_t)bq * nquad + (col >> 2)) * qn + vq) * 4;
+      sstep[j] = 64;   // marks a quad-major lane (launch_dw: no row-major source has a 4-float row)
+    }
   }
 
+  // After the pieces of `unit` are on their way every pointer moves 16 rows on.  A quad-major lane whose row thereby
+  // crosses into the next mesh steps (Q - 1) N * 4 floats further; `next_mesh` (scalar) is the first row of the next mesh,
+  // so the per-lane test runs only in the one or two units per mesh (of ~160) that touch a boundary.
+  int next_mesh = qn > 0 ? (int)((((size_t)u0 * 16) / qn + 1) * qn) : 0x7fffffff;
+  auto advance = [&](int unit) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) sp[j] += sstep[j];
+#ifndef A3VT_DBG_DW_NOWRAP   // timing-only ablation: no mesh-boundary bookkeeping (wrong addresses past the first mesh)
+    if (HYB && unit * 16 + 31 >= next_mesh) {   // wave-uniform
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int g = unit * 16 + (srow[j] & 15);
+        if (sstep[j] == 64 && g < next_mesh && g + 16 >= next_mesh) sp[j] += sjq[j];
+      }
+      if (unit * 16 + 16 >= next_mesh) next_mesh += qn;
+    }
+#endif
+  };
   auto issue = [&](int unit, int buf) {
     float *base = lds + buf * stage;
     const int rows_left = p.m - unit * 16;
     if (rows_left >= 16) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        glds16(sp[j], base + sdst[j]);
-        sp[j] += sstep[j];
-      }
+      for (int j = 0; j < 3; ++j) glds16(sp[j], base + sdst[j]);
     } else {  // ragged global tail: rows >= m contribute zeros
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        glds16(srow[j] < rows_left ? sp[j] : p.zeros, base + sdst[j]);
-        sp[j] += sstep[j];
-      }
+      for (int j = 0; j < 3; ++j) glds16(srow[j] < rows_left ? sp[j] : p.zeros, base + sdst[j]);
     }
+    advance(unit);
   };
 
   f32x4 acc[DW_MAXI][DW_MAXO];
@@ -1170,13 +1281,16 @@ __global__ __launch_bounds__(1024, 1) void dw_kernel(DwArgs p) {
 #pragma unroll
   for (int j = 0; j < DW_MAXO; ++j) {
     const int col = (o0 + j) * 16 + l16;
-    zoff[j] = col < p.zsplit ? offA + (col - a0) : offG + (col - g0);
+    const int ca = col - a0;   // blocked dZa window: block ca / 16, column ca % 16 of its 16-float slot rows
+    zoff[j] = col < p.zsplit ? offA + (z0q ? (ca >> 4) * 256 + ((ca & 15) >> 2) * 64 + (ca & 3) : ca) : offG + (col - g0);
   }
+  const int xo = i0 < nbq ? i0 * 256 + (l16 >> 2) * 64 + (l16 & 3) : -1;   // HYB: this lane's column in its first input tile's block; < 0: row-major image
+  const int rot = l16 >> 2;   // this lane's quad inside a block (a0 and the tiles are multiples of 16 columns)
 
   // NST-stage ring, one barrier per 16-row stage; unit t+NST-1 is issued right after the barrier of iteration t (into
   // the stage everyone finished reading before that barrier).  NST comes from the launcher: as many stages as the
   // windowed images leave room for in LDS (4 at 300 x 300), at least 3.
-  const int xoff = i0 * 16 + l16;
+  const int xoff = HYB ? nbq * 256 + (i0 - nbq) * 16 + l16 : i0 * 16 + l16;   // in the row-major image (behind the blocks)
   const int nst = p.nstage;
   for (int d = 0; d < nst - 1; ++d)
     if (d < nu) issue(u0 + d, d);
@@ -1198,8 +1312,13 @@ __global__ __launch_bounds__(1024, 1) void dw_kernel(DwArgs p) {
     // every wave runs five row tiles: the one SIMD whose waves own four (19 = 5+5+5+4) would otherwise idle for that
     // fifth of the time anyway, its extra tile reads finite neighbouring data and is dropped at the slab write, and the
     // k-step loop loses two of its three wave-uniform branches
-    else if (FAST) dw_stage_fast(sb, p.ldx, wa, wg, offG, xoff, zoff, q, true, no == 3, acc);
-    else dw_stage<-1, -1>(sb, p.ldx, wa, wg, offG, xoff, zoff, q, ni, no, acc);
+    else if (FAST && HYB) {
+      // a wave's five input tiles are all blocks or all columns of the row-major image (launch_dw): two copies of the stage
+      // so that every operand read keeps an immediate tile offset
+      if (xo >= 0) dw_stage_fast<true, true>(sb, wrm, wa, wg, offG, xoff, zoff, q, true, no == 3, xo, z0q, rot, acc);
+      else dw_stage_fast<true, false>(sb, wrm, wa, wg, offG, xoff, zoff, q, true, no == 3, xo, z0q, rot, acc);
+    } else if (FAST) dw_stage_fast<false, false>(sb, p.ldx, wa, wg, offG, xoff, zoff, q, true, no == 3, xo, z0q, rot, acc);
+    else dw_stage<-1, -1>(sb, p.ldx, wa, wg, offG, xoff, zoff, q, ni, no, z0q, rot, acc);
     buf = buf == nst - 1 ? 0 : buf + 1;
   }
   wait_lgkm0();
@@ -1223,19 +1342,42 @@ __global__ __launch_bounds__(1024, 1) void dw_kernel(DwArgs p) {
   }
 }
 
+bool dw_quad_major_ok(int k_in, int quads) { return quads % 4 == 0 && dw_blocked_tiles(k_in, quads) == quads / 4; }
+
 static int dw_col_groups(int n_out) { return cdiv(cdiv(n_out, 16), 4 * DW_MAXO); }
 int dw_num_slabs(int n_out) {
   const int g = dw_col_groups(n_out);
   return 256 / g > 0 ? 256 / g : 1;
 }
 
-int launch_dw(const DwArgs &a, hipStream_t s) {
+int launch_dw(const DwArgs &a0, hipStream_t s) {
+  DwArgs a = a0;
+#ifdef A3VT_DBG_DW_NOHYB   // timing-only: the plain kernel on the same buffers (wrong results)
+  a.xq = nullptr; a.xq_nvert = a.xq_quads = a.z0q_nvert = a.z0q_quads = 0; a.ldx_src = 0;
+  if (a.ldz0 < a.zsplit) a.ldz0 = a.zsplit;
+#endif
+  if (a.ldx_src == 0) a.ldx_src = a.ldx;
+  if ((a.xq_nvert > 0 && (a.xq == nullptr || a.xq_quads * 4 > a.k_in || a.m % a.xq_nvert != 0)) ||
+      (a.z0q_nvert > 0 && (a.z0q_quads * 4 != a.zsplit || a.m % a.z0q_nvert != 0)) ||
+      (a.xq_nvert > 0 && a.z0q_nvert > 0 && a.xq_nvert != a.z0q_nvert) || a.bf16 == 2 ||
+      (a.xq_nvert > 0 && a.xq_nvert < 32) || (a.z0q_nvert > 0 && a.z0q_nvert < 32) ||
+      ((a.xq_nvert > 0 || a.z0q_nvert > 0) && (a.ldx_src == 4 || a.ldz1 == 4 || a.ldz0 == 4))) {
+    set_error("dw: quad-major operands unsupported (xq %d x %d, z0q %d x %d, m=%d)", a.xq_nvert, a.xq_quads, a.z0q_nvert,
+              a.z0q_quads, a.m);
+    return -1;
+  }
   if (a.ldx % 4 || a.ldz0 % 4 || a.ldz1 % 4 || a.k_in > DW_MAXI * 64 || a.k_in > a.ldx ||
       a.n_out > a.ldz1 || a.zsplit > a.ldz0) {
     set_error("dw: unsupported dims k_in=%d n_out=%d ldx=%d ldz0=%d ldz1=%d", a.k_in, a.n_out, a.ldx, a.ldz0, a.ldz1);
     return -1;
   }
-  const int xin = (16 * a.ldx + 255) / 256, ain = (16 * a.ldz0 + 255) / 256, gin = (16 * a.ldz1 + 255) / 256;
+  const bool hyb = a.xq_nvert > 0 || a.z0q_nvert > 0;
+  const int nbq = a.xq_nvert > 0 ? a.xq_quads / 4 : 0, wrm = a.ldx - nbq * 16;   // as dw_kernel
+  if (a.xq_nvert > 0 && (a.xq_quads % 4 != 0 || dw_blocked_tiles(a.k_in, a.xq_quads) != nbq)) {
+    set_error("dw: quad-major X columns (%d) must end where a wave's input tiles end (k_in=%d)", a.xq_quads * 4, a.k_in);
+    return -1;
+  }
+  const int xin = nbq + (16 * wrm + 255) / 256, ain = (16 * a.ldz0 + 255) / 256, gin = (16 * a.ldz1 + 255) / 256;
   if (xin + ain + gin > 48) {
     set_error("dw: rows too wide (%d + %d + %d floats)", a.ldx, a.ldz0, a.ldz1);
     return -1;
@@ -1252,7 +1394,7 @@ int launch_dw(const DwArgs &a, hipStream_t s) {
     int g1 = ((c1 > a.zsplit ? c1 : a.zsplit) + 3) & ~3;
     g1 = g1 < a.ldz1 ? g1 : a.ldz1;
     const int wa = a1 > a0 ? a1 - a0 : 0, wg = g1 > g0 ? g1 - g0 : 0;
-    const int units = xin + (16 * wa + 255) / 256 + (16 * wg + 255) / 256 + 1;
+    const int units = xin + (a.z0q_nvert > 0 ? (wa + 15) / 16 : (16 * wa + 255) / 256) + (16 * wg + 255) / 256 + 1;
     worst = units > worst ? units : worst;
   }
   DwArgs args = a;
@@ -1265,17 +1407,26 @@ int launch_dw(const DwArgs &a, hipStream_t s) {
   const size_t shmem = (size_t)args.nstage * worst * 1024;
   static OncePerDevice once;
   once.run([] {
-    (void)hipFuncSetAttribute((const void *)dw_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)dw_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)dw_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)dw_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)dw_kernel<false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)dw_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)dw_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)dw_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   // fast path: every wave owns 4-5 input tiles and 2-3 output tiles (true for 300 x 300)
   const int tin = cdiv(a.k_in, 16), tout = cdiv(a.n_out, 16), groups = dw_col_groups(a.n_out);
   const bool fast = tin / 4 >= 4 && tin <= 20 && (tout / groups) / 4 >= 2 && cdiv(tout, groups) <= 12;
+  if (hyb && (a.bf16 || (a.xq_nvert > 0 && !fast))) {
+    set_error("dw: quad-major operands need the fp32 kernels (and quad-major X the 300-wide shape): k_in=%d n_out=%d mode=%d",
+              a.k_in, a.n_out, a.bf16);
+    return -1;
+  }
   const dim3 grid(dw_num_slabs(a.n_out), groups);
-  if (a.bf16) A3VT_LAUNCH((dw_kernel<false, true>), grid, dim3(1024), shmem, s, args);
-  else if (fast) A3VT_LAUNCH((dw_kernel<true, false>), grid, dim3(1024), shmem, s, args);
-  else A3VT_LAUNCH((dw_kernel<false, false>), grid, dim3(1024), shmem, s, args);
+  if (a.bf16) A3VT_LAUNCH((dw_kernel<false, true, false>), grid, dim3(1024), shmem, s, args);
+  else if (fast && hyb) A3VT_LAUNCH((dw_kernel<true, false, true>), grid, dim3(1024), shmem, s, args);
+  else if (fast) A3VT_LAUNCH((dw_kernel<true, false, false>), grid, dim3(1024), shmem, s, args);
+  else if (hyb) A3VT_LAUNCH((dw_kernel<false, false, true>), grid, dim3(1024), shmem, s, args);
+  else A3VT_LAUNCH((dw_kernel<false, false, false>), grid, dim3(1024), shmem, s, args);
   A3VT_CHECK_LAUNCH();
   return 0;
 }

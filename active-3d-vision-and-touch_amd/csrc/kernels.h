@@ -35,11 +35,22 @@ struct RowGemmArgs {
   // split, done by the tail of the same launch (set by launch_rowgemm; 0 = none)
   int rem_row0, rem_rows;
   // Quad-major side output (round 3, fp32 storage only; 0 = off).  With zq_nvert = vertices per mesh and zq_quads = Q,
-  // c2 is the quad-major array [m / zq_nvert][Q][zq_nvert] float4 of columns [0, 4 Q):
-  //   EPI_FWD_HIDDEN: raw Z of the aggregated channels (instead of the row-major [M][ldc2] copy);
-  //   EPI_DX_MASK   : the gradient columns [0, 4 Q), columns < csplit UNMASKED (csrq_kernel<1> applies the signs it
-  //                   keeps itself), columns in [csplit, 4 Q) masked as usual; they are then NOT written to c.
+  // c2 is the quad-major array [m / zq_nvert][Q][zq_nvert] float4 of columns [0, 4 Q), Q = pad4(csplit) / 4.  Those
+  // columns then belong to the channel-sliced aggregation kernels (gcn_csrq.hip) alone and are NOT written to c, and no
+  // sign byte is written / read for them:
+  //   EPI_FWD_HIDDEN: raw Z (csrq_kernel<0> aggregates, adds the bias, applies the ReLU — also to the pass-through columns
+  //                   [csplit, 4 Q) — and keeps the signs); c receives columns >= 4 Q only;
+  //   EPI_DX_MASK   : the UNMASKED gradient columns (csrq_kernel<1> applies the signs); c receives columns >= 4 Q, masked.
   int zq_nvert, zq_quads;
+  // EPI_FWD_HIDDEN with zq_nvert > 0: the activations' quad-major region may extend past the aggregated columns, up to the
+  // end of the epilogue's first column group (160 columns): columns [4 zq_quads, 4 yq_quads) leave activated (ReLU, sign
+  // bytes as usual) into yq, the quad-major array [m / zq_nvert][yq_quads][zq_nvert] float4 whose first zq_quads planes the
+  // aggregation kernel fills; c then receives columns >= 4 yq_quads only.  0 = off.
+  float *yq;
+  int yq_quads;
+  // Quad-major a0 (0 = row-major): a0 is [m / a0q_nvert][a0q_quads][a0q_nvert] float4 holding A columns [0, ksplit),
+  // ksplit = 4 a0q_quads (the aggregation kernels' outputs: activations / dZa); lda0 is ignored.
+  int a0q_nvert, a0q_quads;
 };
 int rowgemm_bt_rows(int n_store);
 int launch_rowgemm(const RowGemmArgs &a, int epi, hipStream_t s);
@@ -68,8 +79,17 @@ struct DwArgs {
   int m, k_in, n_out;
   int bf16;  // as RowGemmArgs::bf16
   int nstage;  // LDS ring depth (set by launch_dw)
+  // Quad-major operands (0 = off; the outputs of the channel-sliced aggregation kernels, gcn_csrq.hip):
+  //   xq_nvert > 0 : X columns [0, 4 xq_quads) come from xq [m / xq_nvert][xq_quads][xq_nvert] float4; the other columns
+  //                  from x with row stride ldx_src (x is pre-offset so that x + row * ldx_src + col addresses column col);
+  //                  ldx stays the width of the staged image (>= k_in).  ldx_src = 0 means ldx.
+  //   z0q_nvert > 0: z0 is quad-major [m / z0q_nvert][z0q_quads][z0q_nvert] float4, zsplit = 4 z0q_quads.
+  const float *xq;
+  int ldx_src, xq_nvert, xq_quads, z0q_nvert, z0q_quads;
 };
 int dw_num_slabs(int n_out);
+// True when dw_kernel can take the first 4 * quads columns of a k_in-wide X quad-major (they must end where a wave's input tiles end).
+bool dw_quad_major_ok(int k_in, int quads);
 int launch_dw(const DwArgs &a, hipStream_t s);
 int launch_copy_cols(const float *src, int ld_src, int c0, int w, float *dst, long long m, hipStream_t s);
 int launch_slab_reduce(const float *slab, int nslab, size_t stride, size_t n, float *out, hipStream_t s);
@@ -94,19 +114,20 @@ int csr_bwd_num_slabs(int batch, int n_vert);
 int launch_csr_bwd(const float *g, int ldg, int c, const int32_t *rowptrT, const int32_t *colT, const float *valT,
                    const int32_t *heavyT, int n_vert, int batch, float *dza, int lddza, float *db_slab, hipStream_t s);
 
-// Channel-sliced aggregation, whole mesh resident in LDS (gcn_csr.hip "csrq"): inputs quad-major
-// [batch][Q = pad4(c)/4][n_vert] float4, ReLU signs of the aggregated channels quad-major bytes [batch][Q][n_vert]
-// (written by the forward, applied by the backward), outputs row-major.  db_slab: [batch][pad4(c)].
+// Channel-sliced aggregation, whole mesh resident in LDS (gcn_csrq.hip): inputs AND outputs quad-major
+// [batch][Q = pad4(c)/4][n_vert] float4 (columns [0, 4 Q) of the activations / gradients), ReLU signs of those columns
+// quad-major bytes [batch][Q][n_vert] (written by the forward, applied by the backward).  db_slab: [batch][pad4(c)].
 // `ell`: the slot-major index image launch_csrq_ell builds from the same CSR (csrq_ell_ints(n_vert) ints, 256-B aligned).
 bool csrq_fits(int n_vert, int cut_len);
 size_t csrq_ell_ints(int n_vert);
 int launch_csrq_ell(const int32_t *rowptr, const int32_t *col, const float *val, int n_vert, int32_t *ell, hipStream_t s);
 int launch_csrq_fwd(const float *zq, const float *bias, int c, const int32_t *rowptr, const int32_t *col,
-                    const float *val, const int32_t *heavy, const int32_t *ell, int n_vert, int batch, float *y, int ldy,
+                    const float *val, const int32_t *heavy, const int32_t *ell, int n_vert, int batch, float *yq,
+                    int yq_quads /* planes per mesh of yq (>= pad4(c) / 4; the first pad4(c) / 4 are written) */,
                     uint8_t *signq, int relu, hipStream_t s);
 int launch_csrq_bwd(const float *gq, int c, const int32_t *rowptrT, const int32_t *colT, const float *valT,
-                    const int32_t *heavyT, const int32_t *ellT, int n_vert, int batch, float *dza, int lddza,
-                    const uint8_t *signq, float *db_slab, hipStream_t s);
+                    const int32_t *heavyT, const int32_t *ellT, int n_vert, int batch, float *dzaq, const uint8_t *signq,
+                    float *db_slab, hipStream_t s);
 // True when launch_rowgemm will run (m, n_store) as ONE column block of 19-tile rows whose first epilogue column group
 // holds the cpad aggregated columns — the shape for which the epilogues can write quad-major (RowGemmArgs::zq_nvert).
 bool rowgemm_quad_major_ok(int m, int n_store, int cpad);
@@ -115,13 +136,15 @@ bool rowgemm_quad_major_ok(int m, int n_store, int cpad);
 int thin_num_slabs();
 int launch_thin_fwd(const float *x, int ldx, int k, const float *w /*[k][3]*/, const float *bias /*[3]*/,
                     const int32_t *rowptr, const int32_t *col, const float *val, const int32_t *heavy, int n_vert,
-                    int batch, float *z3 /*[M][4] scratch*/, float *update /*[M][3]*/, hipStream_t s);
+                    int batch, float *z3 /*[M][4] scratch*/, float *update /*[M][3]*/,
+                    const float *xq /*quad-major X columns [0, 4 xq_quads) or nullptr (then x holds them all)*/, int xq_quads,
+                    hipStream_t s);
 int launch_thin_bwd(const float *x, int ldx, int k, const float *w, const int32_t *rowptrT, const int32_t *colT,
                     const float *valT, const int32_t *heavyT, int n_vert, int batch,
                     const float *grad_update /*[M][3]*/, float *dz3 /*[2][M][4] scratch*/, int apply_mask,
                     float *g_prev /*[M][ldg]*/, int ldg, int n_store, float *dw_slab /*[thin_num_slabs()][k*3]*/,
                     float *db_slab /*[thin_num_slabs()][3]*/, float *gq /*quad-major columns [0, 4 nq) or nullptr*/, int nq,
-                    hipStream_t s);
+                    const float *xq /*as launch_thin_fwd*/, int xq_quads, hipStream_t s);
 
 int launch_vertex_update(const float *vin, const float *upd, int batch, int n_vert, int n_vision, float *vout,
                          hipStream_t s);

@@ -67,7 +67,8 @@ def test_channel_sliced_aggregation_equals_row_kernels_and_oracle(cuda, tname, u
         assert torch.equal(new[2][i], ref[2][i]), f"dW layer {i}"
         # bias gradients are sums over all rows: the partial sums are grouped per mesh here, per workgroup there
         assert rel_err(new[3][i], ref[3][i]) < 2e-5, f"db layer {i}"
-        assert new[3][i][cut_len:].abs().max().item() == 0.0 or i == L - 1     # dead bias channels stay exactly zero
+        if i < L - 1 and cut_len < H:
+            assert new[3][i][cut_len:].abs().max().item() == 0.0               # dead bias channels stay exactly zero
     # repeatable bit for bit
     for a, b in zip([new[0], new[1], *new[2], *new[3]], [again[0], again[1], *again[2], *again[3]]):
         assert torch.equal(a, b)

@@ -14,9 +14,10 @@ build() { # name defines...
 }
 if [ "$1" = "csr" ]; then   # csr_fwd / csr16_fwd without their stores: tools/kstats.sh with A3VT_LIB=...
   build CSR_NOSTORE -DA3VT_DBG_CSR_NOSTORE
-elif [ "$1" = "csrq" ]; then   # channel-sliced aggregation with coalesced (quad-major) output stores: what the scattered stores cost
-  build CSRQ_QSTORE -DA3VT_DBG_CSRQ_QSTORE
+elif [ "$1" = "csrq" ]; then   # channel-sliced aggregation without its LDS gathers (what the gathers cost)
   build CSRQ_NOGATHER -DA3VT_DBG_CSRQ_NOGATHER
+  build DW_NOWRAP -DA3VT_DBG_DW_NOWRAP   # dw without its mesh-boundary bookkeeping
+  build DW_NOHYB -DA3VT_DBG_DW_NOHYB     # the plain dw kernel on the same buffers
 elif [ "$1" = "nn" ]; then   # pruned nearest-neighbour search with its counters (tools/nn_stats.py)
   build NN_STATS -DA3VT_DBG_NN_STATS
 elif [ "$1" = "stamps" ]; then   # rowgemm with s_memrealtime stamps at its phase boundaries (tools/rowgemm_stamps.py)
