@@ -138,6 +138,7 @@ __device__ __forceinline__ void rowtile_unit(const RowGemmArgs &p, int row_base,
     const bool row_ok = row < row_end;
     float v = acc[r];
     if (EPI == EPI_PLAIN) {
+      if (p.plain_relu) v = v > 0.f ? v : 0.f;
       if (row_ok && col_ok) p.c[(size_t)row * p.ldc + col] = v;
     } else if (EPI == EPI_FWD_HIDDEN) {
       // ReLU-sign byte of 4 consecutive pass-through columns: gathered from the 4 lanes that hold them
@@ -607,6 +608,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
             const bool full = vec_ok && col + 3 < p.n_store;
             if (EPI == EPI_PLAIN) {
               float *dst = p.c + (size_t)row * p.ldc + col;
+              if (p.plain_relu) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = v[t] > 0.f ? v[t] : 0.f;
+              }
               if (full) {
                 *reinterpret_cast<f32x4 *>(dst) = v;
               } else {

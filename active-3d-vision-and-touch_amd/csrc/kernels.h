@@ -26,6 +26,7 @@ struct RowGemmArgs {
   int m, k, n_store;
   int ldc, ldc2, csplit, mld, moff;
   int no_relu;  // EPI_FWD_HIDDEN: store the pass-through channels without the ReLU (identity activation)
+  int plain_relu;  // EPI_PLAIN: C = max(A Bt^T, 0) (the wide vertex-feature encoder's layers, posenc_wide.hip)
   // 0: exact fp32 MFMA.  1: fp32 storage, operands rounded to bf16 on the way into v_mfma_f32_16x16x16_bf16.
   // 2: bf16 STORAGE — a0 / a1 / bt point at bf16 rows (lda*, ldb, k, ksplit still in 4-byte units = pairs of bf16),
   //    v_mfma_f32_16x16x32_bf16; EPI_FWD_HIDDEN / EPI_DX_MASK write bf16 (c, c2 as bf16 with ldc, ldc2 in ELEMENTS, all
@@ -187,6 +188,18 @@ int launch_posenc_fwd(const float *verts, const float *mask, int m, int input_si
                       int ld, hipStream_t s);
 int launch_posenc_bwd(const float *verts, const float *mask, int m, int input_size, const float *params,
                       const float *gfeats, int ld, float *gverts, float *gparams, float *scratch, hipStream_t s);
+
+// posenc_wide.hip — the same encoder for wide inputs (I = 448 of the image models): three augmented products on rowgemm /
+// dw_kernel; `acts` keeps E', H1', H2' for the backward (posenc_wide_acts_floats), `scratch` the operand images and the
+// backward's intermediates (posenc_wide_scratch_floats).  ld must equal input_size.
+bool posenc_wide_supported(int input_size);
+size_t posenc_wide_acts_floats(int m, int input_size);
+size_t posenc_wide_scratch_floats(int m, int input_size, int need_backward);
+int launch_posenc_wide_fwd(const float *verts, const float *mask, int m, int input_size, const float *params, float *feats,
+                           int ld, float *acts, float *scratch, const float *zeros, hipStream_t s);
+int launch_posenc_wide_bwd(const float *verts, const float *mask, int m, int input_size, const float *params,
+                           const float *gfeats, int ld, const float *acts, float *gverts, float *gparams, float *scratch,
+                           const float *zeros, hipStream_t s);
 
 // sample.hip
 int launch_face_cdf(const float *verts, const int32_t *faces, int batch, int n_vert, int n_faces, float *cdf,

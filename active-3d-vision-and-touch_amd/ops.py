@@ -217,8 +217,20 @@ class PosEncMaskFn(torch.autograd.Function):
             raise RuntimeError("a3vt: packed positional-encoder parameter count mismatch")
         B, N, _ = verts.shape
         feats = torch.empty((B, N, ld), dtype=torch.float32, device=verts.device)
-        _lib.check(L.a3vt_posenc_mask_fwd(_lib.ptr(verts), _lib.ptr(mask), B * N, input_size, _lib.ptr(packed),
-                                          _lib.ptr(feats), ld, _stream()), "posenc_mask_fwd")
+        ctx.wide_acts = None
+        if input_size == 50:
+            _lib.check(L.a3vt_posenc_mask_fwd(_lib.ptr(verts), _lib.ptr(mask), B * N, input_size, _lib.ptr(packed),
+                                              _lib.ptr(feats), ld, _stream()), "posenc_mask_fwd")
+        else:   # wide inputs (448 of the image models): three products on the matrix pipe, activations kept for the backward
+            if not L.a3vt_posenc_wide_supported(input_size) or ld != input_size:
+                raise RuntimeError(f"a3vt: vertex-feature encoder: input_size={input_size} ld={ld} unsupported")
+            acts = torch.empty(L.a3vt_posenc_wide_acts_bytes(B * N, input_size), dtype=torch.uint8, device=verts.device)
+            need_bwd = ctx.needs_input_grad[0] or ctx.needs_input_grad[2]   # (grad mode is off inside forward)
+            scratch = workspace("posenc", L.a3vt_posenc_wide_scratch_bytes(B * N, input_size, 0), verts.device)
+            _lib.check(L.a3vt_posenc_wide_fwd(_lib.ptr(verts), _lib.ptr(mask), B * N, input_size, _lib.ptr(packed),
+                                              _lib.ptr(feats), ld, _lib.ptr(acts), _lib.ptr(scratch), _stream()),
+                       "posenc_wide_fwd")
+            ctx.wide_acts = acts if need_bwd else None
         ctx.save_for_backward(verts, mask, packed)
         ctx.dims = (input_size, ld)
         return feats
@@ -232,10 +244,19 @@ class PosEncMaskFn(torch.autograd.Function):
         B, N, _ = verts.shape
         gverts = torch.empty_like(verts)
         gparams = torch.empty_like(packed)
-        scratch = workspace("posenc", L.a3vt_posenc_scratch_bytes(B * N, input_size), verts.device)
-        _lib.check(L.a3vt_posenc_mask_bwd(_lib.ptr(verts), _lib.ptr(mask), B * N, input_size, _lib.ptr(packed),
-                                          _lib.ptr(gfeats), ld, _lib.ptr(gverts), _lib.ptr(gparams),
-                                          _lib.ptr(scratch), _stream()), "posenc_mask_bwd")
+        if input_size == 50:
+            scratch = workspace("posenc", L.a3vt_posenc_scratch_bytes(B * N, input_size), verts.device)
+            _lib.check(L.a3vt_posenc_mask_bwd(_lib.ptr(verts), _lib.ptr(mask), B * N, input_size, _lib.ptr(packed),
+                                              _lib.ptr(gfeats), ld, _lib.ptr(gverts), _lib.ptr(gparams),
+                                              _lib.ptr(scratch), _stream()), "posenc_mask_bwd")
+        else:
+            if ctx.wide_acts is None:
+                raise RuntimeError("a3vt: vertex-feature encoder: backward without saved activations")
+            scratch = workspace("posenc", L.a3vt_posenc_wide_scratch_bytes(B * N, input_size, 1), verts.device)
+            _lib.check(L.a3vt_posenc_wide_bwd(_lib.ptr(verts), _lib.ptr(mask), B * N, input_size, _lib.ptr(packed),
+                                              _lib.ptr(gfeats), ld, _lib.ptr(ctx.wide_acts), _lib.ptr(gverts),
+                                              _lib.ptr(gparams), _lib.ptr(scratch), _stream()), "posenc_wide_bwd")
+            ctx.wide_acts = None
         return gverts, None, gparams, None, None
 
 

@@ -273,19 +273,27 @@ class Deformation(nn.Module):
         self.mesh_deform_2 = GCN(input_size, args)
         self.finite_flag = None  # set to an int32 device scalar to enable the deferred NaN/Inf check
 
+    def _fused_encoder(self):
+        if self.input_size == 50:
+            return True
+        from .... import lib as _alib
+        return self.ld_feats == self.input_size and bool(_alib.load().a3vt_posenc_wide_supported(self.input_size))
+
     def _packed_encoder_params(self):
         return torch.cat([p.reshape(-1) for p in self.positional_encoder.packed()] +
                          [self.mask_encoder.model[0].weight.reshape(-1)])
 
     def _vertex_features(self, vertices, mask, packed, img_maps):
-        if self.input_size == 50:
+        if packed is not None:
+            # I = 50: the LDS-resident fused kernel; wide inputs (448 of the image models): three products on the matrix
+            # pipe (csrc/posenc_wide.hip) — both behind the same C-ABI pair and autograd function
             feats = _ops.PosEncMaskFn.apply(vertices, mask, packed, self.input_size, self.ld_feats)
-        else:  # image model (I = 448): small torch ops on the GPU, padded to the 4-float row granule
+        else:  # input sizes the library does not take (not a multiple of 8): torch ops, padded to the 4-float row granule
             feats = self.positional_encoder(vertices) + self.mask_encoder(mask)
-            if img_maps is not None:
-                feats = feats + self.img_encoder_global.pooling(img_maps, vertices)   # always the global encoder's
-            if self.ld_feats != self.input_size:                                      # projection (:243,265,277)
-                feats = F.pad(feats, (0, self.ld_feats - self.input_size))
+        if img_maps is not None:
+            feats = feats + self.img_encoder_global.pooling(img_maps, vertices)       # always the global encoder's
+        if packed is None and self.ld_feats != self.input_size:                       # projection (:243,265,277)
+            feats = F.pad(feats, (0, self.ld_feats - self.input_size))
         return feats.contiguous()
 
     def forward(self, img, charts, img_features=None):
@@ -315,7 +323,7 @@ class Deformation(nn.Module):
             mask = f32(torch.cat((charts["vision_masks"], charts["touch_masks"]), dim=1))
         else:
             vertices, mask = f32(charts["vision_charts"]), f32(charts["vision_masks"])
-        packed = self._packed_encoder_params() if self.input_size == 50 else None
+        packed = self._packed_encoder_params() if self._fused_encoder() else None
         for stage in range(self.num_stages):
             if stage == 1 and use_touch and use_img:      # vision+touch models add the touch charts now (:254-259)
                 vertices = f32(torch.cat((vertices, charts["touch_charts"]), dim=1))

@@ -145,6 +145,21 @@ int a3vt_posenc_mask_bwd(const float *verts, const float *mask, int m, int input
                          const float *pe_params, const float *grad_feats, int ld_feats,
                          float *grad_verts, float *grad_params, float *scratch, void *stream);
 
+/* The same encoder for wide inputs — input_size = 448 of the image models (model.py:180-190: 64 + 128 + 256 pooled channels)
+ * — whose 133 k parameters do not fit the LDS-resident kernel above: every layer runs as one product on the fp32 matrix
+ * pipe (csrc/posenc_wide.hip).  a3vt_posenc_wide_supported: input_size % 8 == 0, 16 <= input_size <= 630.  ld_feats must
+ * equal input_size.  `acts` (a3vt_posenc_wide_acts_bytes) receives the layer activations in the forward and is read by the
+ * backward — the caller keeps it between the two calls; `scratch` (a3vt_posenc_wide_scratch_bytes) is free afterwards.
+ * pe_params / grad_params: the packing of a3vt_posenc_mask_fwd.  Replaces the same reference lines. */
+int a3vt_posenc_wide_supported(int input_size);
+size_t a3vt_posenc_wide_acts_bytes(int m, int input_size);
+size_t a3vt_posenc_wide_scratch_bytes(int m, int input_size, int need_backward);
+int a3vt_posenc_wide_fwd(const float *verts, const float *mask, int m, int input_size, const float *pe_params,
+                         float *feats, int ld_feats, float *acts, float *scratch, void *stream);
+int a3vt_posenc_wide_bwd(const float *verts, const float *mask, int m, int input_size, const float *pe_params,
+                         const float *grad_feats, int ld_feats, const float *acts, float *grad_verts,
+                         float *grad_params, float *scratch, void *stream);
+
 /* Per-vertex image features.  Replaces Image_Encoder.pooling (model.py:70-103): project the vertices with the fixed
  * camera matrix `proj` = K.RT (row-major 3 x 4, model.py:50-67; HOST pointer), z == 0 -> 0.1,
  * xs = P1/P2/256, ys = P0/P2/256, inf -> 0.5, then grid_sample(bilinear, zeros, align_corners=True) of every map at

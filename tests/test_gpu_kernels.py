@@ -325,6 +325,51 @@ def test_posenc_mask_fwd_bwd(cuda):
     assert rel_err(packed.grad, g_o) < 1e-4
 
 
+@pytest.mark.parametrize("I,B,N", [(448, 3, 1949), (448, 1, 37), (64, 2, 700), (200, 2, 333)])
+def test_posenc_mask_wide_fwd_bwd(cuda, I, B, N):
+    """The vertex-feature encoder at the image models' input size (448) and two other wide sizes:
+    a3vt_posenc_wide_fwd / _bwd (three augmented products on the fp32 matrix pipe, csrc/posenc_wide.hip) against the fp64
+    oracle of Positional_Encoder + Mask_Encoder (model.py:381-414): features, position gradient, every parameter gradient
+    (biases and the mask embedding come out of the augmented weight gradients), 1e-4; bit-reproducible."""
+    from a3vt_amd import ops
+    from oracle import gcn as og
+    st = og.init_state(I, 8, 1, seed=7)
+    g = torch.Generator().manual_seed(I + N)
+    verts = (torch.rand(B, N, 3, generator=g) - 0.5) * 0.6
+    mask = torch.randint(0, 4, (B, N, 1), generator=g).float()
+    gout = torch.randn(B, N, I, generator=g)
+    names = ["positional_encoder.model.0.weight", "positional_encoder.model.0.bias",
+             "positional_encoder.model.2.weight", "positional_encoder.model.2.bias",
+             "positional_encoder.model.4.weight", "positional_encoder.model.4.bias", "mask_encoder.model.0.weight"]
+    st64 = {k: st[k].double().requires_grad_(True) for k in names}
+    v64 = verts.double().requires_grad_(True)
+    f_o = og.positional_encoder(v64, st64) + og.mask_encoder(mask, st64)
+    (f_o * gout.double()).sum().backward()
+    g_o = torch.cat([st64[k].grad.reshape(-1) for k in names])
+    outs = []
+    for _ in range(2):
+        packed = torch.cat([st[k].reshape(-1) for k in names]).to(cuda).requires_grad_(True)
+        vd = verts.to(cuda).requires_grad_(True)
+        f = ops.PosEncMaskFn.apply(vd, mask.to(cuda), packed, I, I)
+        (f * gout.to(cuda)).sum().backward()
+        outs.append((f.detach(), vd.grad, packed.grad))
+    f, gv, gp = outs[0]
+    assert f.shape == (B, N, I)
+    assert rel_err(f, f_o) < 1e-5
+    assert rel_err(gv, v64.grad) < 1e-4
+    assert rel_err(gp, g_o) < 1e-4
+    off = 0
+    for k in names:                       # every tensor on its own scale (the embedding rows are small next to W3's)
+        n = st[k].numel()
+        assert rel_err(gp[off:off + n], st64[k].grad.reshape(-1)) < 2e-4, k
+        off += n
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    with torch.no_grad():                 # forward-only call: no activations are kept
+        f2 = ops.PosEncMaskFn.apply(verts.to(cuda), mask.to(cuda), packed.detach(), I, I)
+    assert torch.equal(f2, f)
+
+
 @pytest.mark.parametrize("P,Q,B,draws", [(1, 1, 1, 1), (100, 37, 2, 3), (1000, 2176, 2, 1), (4099, 5000, 1, 2)])
 def test_chamfer_fwd_bwd(cuda, P, Q, B, draws):
     from a3vt_amd import ops
