@@ -31,55 +31,113 @@ def init_from_env(backend=None):
 
 
 class FlatGradBucket:
-    """One contiguous buffer for the whole gradient: a single collective reduces it and the optimiser reads the
-    averaged values in place (every ``.grad`` is a view into the buffer when ``optimizer.step()`` runs).
+    """One contiguous buffer for the whole gradient: collectives reduce it in place and the optimiser reads the averaged
+    values there (every ``.grad`` is a view into the buffer when ``optimizer.step()`` runs).
 
     Step protocol: ``zero()`` -> ``loss.backward()`` -> ``all_reduce_mean()`` -> ``optimizer.step()``.
     ``zero()`` clears the ``.grad`` fields rather than memsetting the buffer, so autograd *assigns* each gradient
     instead of launching one ``grad += g`` kernel per parameter (131 launches per step on the 20 x 300 model);
-    ``all_reduce_mean()`` then gathers them into the buffer with one multi-tensor copy and re-homes ``.grad``."""
+    ``all_reduce_mean()`` then gathers them into the buffer with one multi-tensor copy and re-homes ``.grad``.
 
-    def __init__(self, params):
-        self.params = [p for p in params if p.requires_grad]
+    Two chunks: ``early`` names parameters whose gradients are final before the backward pass ends — in
+    ``Deformation`` the modules only stages 2 and 3 use (``mesh_deform_2``; ``img_encoder_local``).  They sit at the front
+    of the buffer and carry a post-accumulate hook each: when the last of them has received its gradient, ``reduce_early()``
+    starts their all-reduce asynchronously, so it overlaps with the rest of the backward pass (stage 1 and the global image
+    encoder: 95 MB of the 189 MB image model); ``all_reduce_mean()`` reduces the rest and waits for both.  If an early
+    parameter gets no gradient in some step the early reduce simply does not start and everything is reduced at the end."""
+
+    def __init__(self, params, early=()):
+        params = [p for p in params if p.requires_grad]
+        early_ids = {id(p) for p in early}
+        self.params = [p for p in params if id(p) in early_ids] + [p for p in params if id(p) not in early_ids]
+        self.n_early = sum(1 for p in params if id(p) in early_ids)
         n = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(n, dtype=self.params[0].dtype, device=self.params[0].device)
         self.views = []
         off = 0
-        for p in self.params:
+        for k, p in enumerate(self.params):
+            if k == self.n_early:
+                self.early_numel = off
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
+        if self.n_early == len(self.params):
+            self.early_numel = off
+        self._early_done = False
+        self._early_work = None
+        self._pending = self.n_early
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_early_grad) for p in self.params[:self.n_early]]
         self._rehome()
 
-    def _rehome(self):
-        for p, v in zip(self.params, self.views):
+    def _on_early_grad(self, _param):
+        self._pending -= 1
+        if self._pending == 0:
+            self.reduce_early()
+
+    def _rehome(self, lo=0, hi=None):
+        for p, v in zip(self.params[lo:hi], self.views[lo:hi]):
             p.grad = v
 
     def zero(self):
         for p in self.params:
             p.grad = None
+        self._early_done = False
+        self._early_work = None
+        self._pending = self.n_early
 
-    def gather(self):
-        """Collect the freshly assigned gradients into the flat buffer (no-op for gradients already living there)."""
+    def _gather(self, lo, hi, out):
+        """Collect the freshly assigned gradients of params[lo:hi] into ``out`` (their slice of the flat buffer); a no-op for
+        gradients that already live there."""
         pieces, fresh = [], False
-        for p, v in zip(self.params, self.views):
+        for p, v in zip(self.params[lo:hi], self.views[lo:hi]):
             g = p.grad
             if g is None:                               # parameter unused in this graph
                 g = torch.zeros_like(v)
             if g.data_ptr() != v.data_ptr():
                 fresh = True
             pieces.append(g)
-        if fresh:                                       # pieces that already live in the buffer must not alias the output
+        if fresh and pieces:                            # pieces that already live in the buffer must not alias the output
             flat_pieces = [g.reshape(-1).clone() if g.data_ptr() == v.data_ptr() else g.reshape(-1)
-                           for g, v in zip(pieces, self.views)]
-            torch.cat(flat_pieces, out=self.flat)
-        self._rehome()
+                           for g, v in zip(pieces, self.views[lo:hi])]
+            torch.cat(flat_pieces, out=out)
+        self._rehome(lo, hi)
 
-    def all_reduce_mean(self, async_op=False):
+    def gather(self):
+        """Collect every gradient into the flat buffer (the early chunk only if ``reduce_early`` has not already)."""
+        if not self._early_done:
+            self._gather(0, self.n_early, self.flat[:self.early_numel])
+        self._gather(self.n_early, len(self.params), self.flat[self.early_numel:])
+
+    @staticmethod
+    def _active():
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def reduce_early(self):
+        """Gather the early chunk and start its all-reduce (asynchronously).  Safe to call when there is no early chunk or no
+        process group (then it only gathers).  Call once per step, when those gradients are final."""
+        if self._early_done or self.n_early == 0:
+            return
+        chunk = self.flat[:self.early_numel]
+        self._gather(0, self.n_early, chunk)
+        self._early_done = True
+        if self._active():
+            chunk.div_(dist.get_world_size())
+            self._early_work = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True)
+
+    def all_reduce_mean(self):
+        """Average the whole gradient over the ranks: the early chunk's reduce may already be in flight; the rest is reduced
+        here; both are complete on return (on the current stream for RCCL)."""
         self.gather()
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not self._active():
             return None
-        self.flat.div_(dist.get_world_size())
-        return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
+        world = dist.get_world_size()
+        rest = self.flat[self.early_numel:] if self._early_done else self.flat
+        if rest.numel():
+            rest.div_(world)
+            dist.all_reduce(rest, op=dist.ReduceOp.SUM)
+        if self._early_work is not None:
+            self._early_work.wait()
+            self._early_work = None
+        return None
 
 
 def broadcast_parameters(module, src=0):
@@ -93,6 +151,27 @@ def broadcast_parameters(module, src=0):
     for p in ps:
         p.copy_(flat[off:off + p.numel()].view_as(p))
         off += p.numel()
+
+
+def broadcast_buffers(module, src=0):
+    """Make every rank hold rank `src`'s module buffers (the running statistics of the image encoders' BatchNorm layers,
+    reference vision/model.py:15-23).  The reference has no SyncBN and neither do we: in training every rank normalises with
+    its own batch statistics and updates its own running averages; before a sharded validation or a checkpoint the ranks
+    adopt rank 0's, so that every shard is scored with the statistics that are saved."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    bufs = [b for b in module.buffers() if b.numel() > 0]
+    floats = [b for b in bufs if b.is_floating_point()]
+    if floats:
+        flat = torch.cat([b.reshape(-1).float() for b in floats])
+        dist.broadcast(flat, src)
+        off = 0
+        for b in floats:
+            b.copy_(flat[off:off + b.numel()].view_as(b))
+            off += b.numel()
+    for b in bufs:
+        if not b.is_floating_point():                   # num_batches_tracked (int64)
+            dist.broadcast(b, src)
 
 
 class RankPlan:

@@ -12,8 +12,9 @@ calls ``loss.item()`` every step, :151-153); tensorboard / submitit are optional
 ``StopIteration`` instead of ``exit()`` (:284); with ``WORLD_SIZE`` > 1 each rank trains on its own shard of every
 epoch (``distributed.rank_plan``: same permutation on all ranks, every ``world``-th item; python / numpy / torch re-seeded
 with ``seed + rank`` after the weight broadcast so grasp choices and surface samples differ per rank), gradients are
-averaged with one flat-bucket RCCL all-reduce, and validation is sharded with the loss and example counts summed over
-ranks (``a3vt_amd.distributed``).  Datasets: ``get_loaders`` reads the reference's on-disk
+averaged over RCCL from one flat bucket in two chunks (the one that is final after stage 2's backward starts early and
+overlaps with the rest of the backward), BatchNorm running statistics follow rank 0 at validation / checkpoint time, and the
+validation loss and example counts are summed over ranks whatever the loader (``a3vt_amd.distributed``).  Datasets: ``get_loaders`` reads the reference's on-disk
 layout through ``utility/data_loaders.py`` (``args.data_root`` / ``PTEROTACTYL_DATA``; worker count ``args.num_workers``,
 default 16 as the reference); or pass ``loaders=(train_loader, valid_loader)`` (e.g. ``a3vt_amd.synthetic.SyntheticLoader``).
 Batches are uploaded one step ahead on a copy stream (``data_loaders.DevicePrefetcher``).
@@ -64,12 +65,17 @@ class Engine:
         self.n_vision_charts = self.initial_mesh.shape[0]
         self.encoder = model.Deformation(self.mesh_info, self.initial_mesh, self.args).to(self.initial_mesh.device)
         adist.broadcast_parameters(self.encoder)
+        adist.broadcast_buffers(self.encoder)
         if self.world > 1:   # identical weights everywhere; from here on every rank draws its own random numbers
             adist.seed_rank(self.args.seed, self.rank)
         self.bucket = None
         if not self.args.eval:
             params = list(self.encoder.parameters())
-            self.bucket = adist.FlatGradBucket(params)
+            # gradients that are final once the backward pass has left stage 2: their all-reduce starts as soon as the last of
+            # them has arrived (two chunks, FlatGradBucket)
+            early = [p for name in ("mesh_deform_2", "img_encoder_local") if hasattr(self.encoder, name)
+                     for p in getattr(self.encoder, name).parameters()] if getattr(self.encoder, "num_stages", 3) > 1 else []
+            self.bucket = adist.FlatGradBucket(params, early=early)
             try:
                 self.optimizer = optim.Adam(params, lr=self.args.lr, weight_decay=0, fused=True)
             except (RuntimeError, TypeError):
@@ -146,6 +152,7 @@ class Engine:
 
     def validate(self, valid_loader, writer):
         total_loss = torch.zeros((), device=self.initial_mesh.device)
+        adist.broadcast_buffers(self.encoder)   # BatchNorm running statistics: every shard is scored with rank 0's (the saved ones)
         self.encoder.eval()
         num_examples = 0
         dev = self.initial_mesh.device
@@ -157,7 +164,11 @@ class Engine:
             loss = utils.chamfer_distance(verts, self.mesh_info["faces_i32"], gt_points, num=self.args.number_points)
             total_loss += self.args.loss_coeff * loss.sum()
             num_examples += float(img.shape[0])
-        if self.world > 1 and hasattr(getattr(valid_loader, "sampler", None), "plan"):   # sharded validation: sum over ranks
+        if self.world > 1:
+            # Always: with a sharded loader the ranks hold disjoint parts of the set; with an injected loader (no
+            # ``sampler.plan``) they hold copies of it scored with different surface samples (per-rank seeds) — either way
+            # the sums over ranks give every rank the SAME score, so check_values() takes the same decision everywhere
+            # (a rank that stopped or saved alone would leave the others waiting in the gradient all-reduce).
             count = torch.tensor(float(num_examples), device=dev)
             adist.all_reduce_sum_(total_loss, count)
             num_examples = count.item()

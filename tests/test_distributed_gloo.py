@@ -174,3 +174,158 @@ def test_two_rank_engine_plan_bucket_and_sharded_validation():
     assert res[0]["seen"][0] != res[0]["seen"][1]
     assert sorted(res[0]["vshard"] + res[1]["vshard"]) == list(range(7))
     assert res[0]["val"] == res[1]["val"] == (28.0, 7.0)
+
+
+class _ThreeStage(torch.nn.Module):
+    """Shape of ``Deformation``: ``first`` feeds stage 1, ``shared`` stages 2 and 3 (so its gradients are final before the
+    backward pass has reached stage 1), a BatchNorm branch with running statistics (the image encoders')."""
+
+    def __init__(self):
+        super().__init__()
+        self.first = torch.nn.Linear(6, 6)
+        self.shared = torch.nn.Linear(6, 6)
+        self.bn = torch.nn.BatchNorm1d(6)
+
+    def forward(self, x):
+        x = torch.tanh(self.first(self.bn(x))) + x
+        x = torch.tanh(self.shared(x)) + x
+        return torch.tanh(self.shared(x)) + x
+
+
+def _worker_two_chunks(rank, world, port, out):
+    import sys
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from a3vt_amd import distributed as adist
+    adist.init_from_env("gloo")
+    torch.manual_seed(50 + rank)
+    net = _ThreeStage()
+    adist.broadcast_parameters(net)
+    adist.broadcast_buffers(net)
+    bucket = adist.FlatGradBucket(net.parameters(), early=list(net.shared.parameters()))
+    assert bucket.n_early == 2 and bucket.params[0] is net.shared.weight and bucket.early_numel == 42
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(16, 6, generator=g)
+    lo, hi = adist.shard_range(16, rank, world)
+    started_early = []
+    first_grad_seen = []
+    net.first.weight.register_post_accumulate_grad_hook(lambda p: first_grad_seen.append(bucket._early_done))
+    for _ in range(3):
+        bucket.zero()
+        net(x[lo:hi]).square().mean().backward()
+        # the early chunk's reduce was started from inside the backward pass, before stage 1's gradient existed
+        started_early.append(bucket._early_done and bucket._early_work is not None)
+        bucket.all_reduce_mean()
+        assert bucket._early_work is None
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views))
+        opt.step()
+    stats_before = net.bn.running_mean.clone()     # per-rank batch statistics: the ranks have drifted apart
+    adist.broadcast_buffers(net)                   # what Engine.validate does first
+    out.put((rank, dict(params=torch.cat([p.detach().reshape(-1) for p in net.parameters()]).tolist(),
+                        started_early=started_early, first_grad_seen=first_grad_seen,
+                        stats_before=stats_before.tolist(), stats_after=net.bn.running_mean.tolist(),
+                        tracked=int(net.bn.num_batches_tracked))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_chunk_async_reduce_and_batchnorm_buffers():
+    """The gradient exchange in two chunks (the early one started asynchronously by the post-accumulate hooks, inside the
+    backward pass) gives the single-process result; BatchNorm running statistics differ per rank after training and are
+    rank 0's everywhere after ``broadcast_buffers``."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_two_chunks, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert torch.equal(torch.tensor(res[0]["params"]), torch.tensor(res[1]["params"]))
+    for r in range(world):
+        assert res[r]["started_early"] == [True] * 3
+        assert res[r]["first_grad_seen"] == [True] * 3          # stage 1's gradient arrived after the early reduce had started
+    assert res[0]["stats_before"] != res[1]["stats_before"]      # no SyncBN, as the reference
+    assert res[0]["stats_after"] == res[1]["stats_after"] == res[0]["stats_before"]
+    assert res[0]["tracked"] == res[1]["tracked"] == 3
+    # single-process reference on the two half batches averaged = data-parallel step (BatchNorm normalises per shard)
+    torch.manual_seed(50)
+    net = _ThreeStage()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(16, 6, generator=g)
+    for _ in range(3):
+        opt.zero_grad()
+        (0.5 * (net(x[:8]).square().mean() + net(x[8:]).square().mean())).backward()
+        opt.step()
+    ref = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    assert torch.allclose(torch.tensor(res[0]["params"]), ref, atol=2e-6)
+
+
+def _worker_engine_validation(rank, world, port, out):
+    """Engine.validate / check_values with WORLD_SIZE = 2 and INJECTED loaders (no sharded sampler): the ranks score the
+    same batches with different surface samples (per-rank seeds), so their local scores differ; the decisions must not."""
+    import sys
+    import types
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from a3vt_amd import distributed as adist
+    from a3vt_amd.pterotactyl.reconstruction.vision import train as vtrain
+    adist.init_from_env("gloo")
+    eng = object.__new__(vtrain.Engine)            # no mesh / HIP library on this box: only the control flow is under test
+    eng.rank, eng.world, eng.local_rank = rank, world, rank
+    eng.args = types.SimpleNamespace(eval=False, loss_coeff=1.0, number_points=8, exp_id="t", patience=2)
+    eng.initial_mesh = torch.zeros(4, 3)
+    eng.mesh_info = {"faces_i32": None}
+    eng.encoder = torch.nn.Linear(1, 1)
+    eng.encoder.forward = lambda img, charts: (charts, None)
+    eng.epoch, eng.best_loss, eng.last_improvement = 0, 10000, 0
+    saves = []
+    eng.save = lambda: saves.append(eng.epoch)
+    torch.manual_seed(1000 + rank)                 # per-rank sample stream (Engine.setup seeds seed + rank)
+    scores = iter([5.0, 4.0, 4.5, 4.6, 4.7])       # epoch scores before the per-rank sampling noise
+    base = {"v": 0.0}
+    vtrain.model.prepare_mesh = lambda batch, mesh, args: batch["img"]
+    vtrain.utils.chamfer_distance = lambda verts, faces, gt, num: base["v"] + 0.2 * torch.rand(verts.shape[0])
+    vtrain.data_loaders.DevicePrefetcher = lambda loader, dev: loader
+
+    class W:
+        def add_scalars(self, *a, **k):
+            pass
+    loader = [{"img": torch.zeros(3, 1), "gt_points": torch.zeros(3, 8, 3)} for _ in range(2)]   # injected: no sampler
+    history, stopped = [], None
+    for epoch in range(5):
+        eng.epoch = epoch
+        base["v"] = next(scores)
+        eng.validate(loader, W())
+        history.append(eng.current_loss)
+        try:
+            eng.check_values()
+        except StopIteration:
+            stopped = epoch
+            break
+    out.put((rank, dict(history=history, stopped=stopped, saves=saves, best=eng.best_loss)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_validation_score_and_early_stop_agree_across_ranks_with_injected_loaders():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_engine_validation, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0]["history"] == res[1]["history"]                     # the same score on every rank, every epoch
+    assert res[0]["stopped"] == res[1]["stopped"] == 3                # 5.x, 4.x (best), 4.5+, 4.6+ -> patience 2 spent
+    assert res[0]["best"] == res[1]["best"]
+    assert res[0]["saves"] == [0, 1] and res[1]["saves"] == [0, 1]    # (save() itself writes on rank 0 only)
