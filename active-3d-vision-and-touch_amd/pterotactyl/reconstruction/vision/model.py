@@ -101,19 +101,34 @@ class Image_Encoder(nn.Module):
         self.register_buffer("matrix", torch.FloatTensor(K.dot(np.array(_CAM_RT))), persistent=False)
         self._matrix_host = [float(x) for x in self.matrix.reshape(-1).tolist()]   # fp32 values, no device sync later
 
+    def _bf16_branch(self, img):
+        """The bf16 configurations (BASELINE configs[3] "bf16"; ``args.gemm_precision`` in {"bf16", "bf16s"}, overridable with
+        ``args.cnn_precision``) run the convolution stack channels-last under bf16 autocast: fp32 master weights and
+        BatchNorm statistics, bf16 activations — MIOpen picks its bf16 NHWC kernels, the NCHW <-> NHWC transposes
+        between layers disappear and the BatchNorm passes move half the bytes.  fp32 stays the default (golden ``g8``)."""
+        prec = getattr(self.args, "cnn_precision", None) or getattr(self.args, "gemm_precision", "fp32")
+        return img.is_cuda and prec in ("bf16", "bf16s")
+
     def forward(self, img):
         """Feature maps of the three layers ``layers_per_block`` apart from the end, plus the last map reached
         before the spatial size drops below the kernel size (:147-164)."""
         n = len(self.layers)
         picks = {n - 1 - (i + 1) * self.args.layers_per_block for i in range(3)}
-        x, maps = img, []
-        for e, layer in enumerate(self.layers):
-            if x.shape[-1] < self.args.CNN_ker_size:
-                break
-            x = layer(x)
-            if e in picks:
-                maps.append(x)
-        maps.append(x)
+        low = self._bf16_branch(img)
+        if low and not getattr(self, "_channels_last", False):
+            self.layers.to(memory_format=torch.channels_last)   # (weights only change their strides: state dict untouched)
+            self._channels_last = True
+        x, maps = (img.contiguous(memory_format=torch.channels_last) if low else img), []
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=low):
+            for e, layer in enumerate(self.layers):
+                if x.shape[-1] < self.args.CNN_ker_size:
+                    break
+                x = layer(x)
+                if e in picks:
+                    maps.append(x)
+            maps.append(x)
+        if low:   # the pooling kernel reads fp32 channels-last maps (three small tensors)
+            maps = [m.float().contiguous(memory_format=torch.channels_last) for m in maps]
         return maps
 
     def pooling(self, blocks, verts_pos):
