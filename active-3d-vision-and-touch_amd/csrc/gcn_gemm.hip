@@ -1320,8 +1320,15 @@ __global__ __launch_bounds__(1024, 1) void dw_kernel(DwArgs p) {
     else if (FAST && HYB) {
       // a wave's five input tiles are all blocks or all columns of the row-major image (launch_dw): two copies of the stage
       // so that every operand read keeps an immediate tile offset
+#if defined(A3VT_DBG_DW_ARM)      // timing-only bisection: every wave reads its A operand as from the row-major image
+      dw_stage_fast<true, false>(sb, wrm, wa, wg, offG, xoff & 0xfff, zoff, q, true, no == 3, xo, z0q, rot, acc);
+#elif defined(A3VT_DBG_DW_BRM)    // timing-only bisection: B operand row term of the compact image
+      if (xo >= 0) dw_stage_fast<true, true>(sb, wrm, wa, wg, offG, xoff, zoff, q, true, no == 3, xo, false, rot, acc);
+      else dw_stage_fast<true, false>(sb, wrm, wa, wg, offG, xoff, zoff, q, true, no == 3, xo, false, rot, acc);
+#else
       if (xo >= 0) dw_stage_fast<true, true>(sb, wrm, wa, wg, offG, xoff, zoff, q, true, no == 3, xo, z0q, rot, acc);
       else dw_stage_fast<true, false>(sb, wrm, wa, wg, offG, xoff, zoff, q, true, no == 3, xo, z0q, rot, acc);
+#endif
     } else if (FAST) dw_stage_fast<false, false>(sb, p.ldx, wa, wg, offG, xoff, zoff, q, true, no == 3, xo, z0q, rot, acc);
     else dw_stage<-1, -1>(sb, p.ldx, wa, wg, offG, xoff, zoff, q, ni, no, z0q, rot, acc);
     buf = buf == nst - 1 ? 0 : buf + 1;

@@ -493,7 +493,11 @@ int launch_nn_pruned(const float *x, const float *y, int draws, int batch, int p
   once.run([] {
     (void)hipFuncSetAttribute((const void *)nn_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (1 << 15) * 4);
   });
-  static const int stages = getenv("A3VT_NN_STAGES") ? atoi(getenv("A3VT_NN_STAGES")) : 3;   // developer aid: stop early
+#ifdef A3VT_DBG_NN_STATS   // diagnostic build only (tools/build_variants.sh nn): stop after the sort / box kernels — the outputs
+  static const int stages = getenv("A3VT_NN_STAGES") ? atoi(getenv("A3VT_NN_STAGES")) : 3;   // are then NOT written
+#else
+  constexpr int stages = 3;
+#endif
   A3VT_LAUNCH(nn_sort_kernel, dim3(c.nx + c.ny), dim3(kSortThreads), shmem, s, c);
   A3VT_CHECK_LAUNCH();
   if (stages < 2) return 0;

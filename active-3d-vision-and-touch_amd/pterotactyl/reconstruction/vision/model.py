@@ -200,12 +200,14 @@ class GCN(nn.Module):
             [GCN_layer(dims[i], dims[i + 1], args.cut, do_cut=i < self.num_layers - 1) for i in range(self.num_layers)])
 
     def forward(self, features, adj_info):
-        """features (B,N,ld) with ld >= input_features (pad columns zero) -> (B,N,3)."""
+        """features (B,N,ld), ld >= input_features with zero pad columns -> (B,N,3).  The library takes rows of exactly
+        pad4(input_features) floats (a3vt.h): narrower rows are padded here, wider ones cut back to that width."""
         adj = _csr_of(adj_info, "origional" if self.ignore_touch_matrix else "adj")
-        ld = features.shape[-1]
-        if ld % 4 != 0:  # callers outside Deformation may hand in exactly input_features columns
-            pad = (-ld) % 4
-            features = torch.nn.functional.pad(features, (0, pad))
+        ld, want = features.shape[-1], (self.input_features + 3) // 4 * 4
+        if ld < want:    # callers outside Deformation may hand in exactly input_features columns
+            features = torch.nn.functional.pad(features, (0, want - ld))
+        elif ld > want:  # or rows padded further than the 4-float granule
+            features = features[..., :want].contiguous()
         ws = [l.weight for l in self.layers]
         bs = [l.bias for l in self.layers]
         return _ops.gcn_stack(features, adj, self.input_features, self.hidden, _cut_len(self.hidden, self.cut), ws, bs,

@@ -300,9 +300,12 @@ def main():
         t_ms = tot[1] / max(n_dx, 1)
         achieved = flop / (t_ms * 1e-3) / 1e12
         fp32 = a.gemm_precision == "fp32"
-        peak = 157.3 if fp32 else 2500.0
-        roof = {"bound": "mfma", "kernel": "rowgemm_kernel<19,EPI_DX_MASK> (fp32 MFMA 16x16x4, M x 300 x 300, dX = dZ W^T)"
-                if fp32 else f"dX product of the {a.gemm_precision} mode (bf16 MFMA, fp32 accumulate)",
+        # dense matrix peaks (MI355X_MICROARCH.md): fp32 157.3; bf16 2500 for v_mfma_f32_16x16x32_bf16 (the bf16s mode), half
+        # of that for the K = 16 instruction of the operand mode
+        peak = 157.3 if fp32 else (2500.0 if a.gemm_precision == "bf16s" else 1250.0)
+        instr = {"fp32": "v_mfma_f32_16x16x4_f32", "bf16": "v_mfma_f32_16x16x16_bf16", "bf16s": "v_mfma_f32_16x16x32_bf16"}
+        roof = {"bound": "mfma", "kernel": f"rowgemm_kernel<19,EPI_DX_MASK> ({instr.get(a.gemm_precision, '?')}, M x 300 x 300, "
+                                           f"dX = dZ W^T{'' if fp32 else ', fp32 accumulate'})",
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "traffic": None, "avg_launch_ms": t_ms, "launches": n_dx, "flop_per_launch": flop,
                 "other_mfma_ms": per, "mfma_ms_per_step": (tot[0] + tot[1] + tot[2]) / a.profile_steps}

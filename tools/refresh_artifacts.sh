@@ -1,8 +1,8 @@
 #!/bin/bash
 # One pass over everything under profiles/ that a kernel change can move (run on the GPU box from the repo root; ~6 min):
-#   tools/refresh_artifacts.sh r02      -> gpurun_out/refresh/r02_*   (copy what should be kept into profiles/)
+#   tools/refresh_artifacts.sh r03      -> gpurun_out/refresh/r03_*   (copy what should be kept into profiles/)
 set -x
-R=${1:-r02}
+R=${1:-r03}
 cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/refresh
 mkdir -p $O
