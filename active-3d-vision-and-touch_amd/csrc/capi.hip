@@ -89,8 +89,14 @@ struct StackLayout {
 // decide from the same arguments (the backward reads the sign bytes the forward left).  A3VT_CSR_ALGO=rows is a developer
 // switch back to the half-wave-per-vertex kernels (both paths give the same outputs).
 constexpr int kQuadCols = 160;   // quad-major columns of a hybrid layer output: the first column group of rowgemm's epilogue
-static bool use_csrq(int batch, int n_vert, int hidden, int cut_len, int gemm_bf16) {
+static bool use_csrq(int batch, int n_vert, int hidden, int cut_len, int gemm_bf16, int max_degree) {
   if (gemm_bf16) return false;   // the bf16 operand / storage modes keep the half-wave kernels
+  // Rows longer than the eight index slots a thread keeps in registers fall back to per-lane CSR walks: on the fused
+  // vision + touch graphs (mean degree 12-26, hub rows of ~1150) that made the step 108 ms where the half-wave kernels
+  // take 64 — those graphs stay on the half-wave kernels.  (The caller passes the larger of the two maximum degrees of
+  // A and A^T to both calls, so forward and backward decide alike.)
+  const char *force = getenv("A3VT_CSR_ALGO");   // "sliced": developer / test switch, long rows included (they are correct, just slow)
+  if (!(force && strcmp(force, "sliced") == 0) && (max_degree <= 0 || max_degree > csrq_max_degree())) return false;
   const char *algo = getenv("A3VT_CSR_ALGO");   // read per call: the parity tests run both paths in one process
   if ((algo && strcmp(algo, "rows") == 0) || cut_len <= 0) return false;
   return hidden % 4 == 0 && hidden >= kQuadCols + 16 && csrq_fits(n_vert, cut_len) && dw_quad_major_ok(hidden, kQuadCols / 4) &&
@@ -537,7 +543,7 @@ int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const 
     if (int rc = launch_weight_images(wi, rowgemm_bt_rows(hidden), pad16(ld_feats > hidden ? ld_feats : hidden), s)) return rc;
   }
 
-  const bool quad = use_csrq(batch, n_vert, hidden, cut_len, gemm_bf16) && num_layers > 1;
+  const bool quad = use_csrq(batch, n_vert, hidden, cut_len, gemm_bf16, max_degree) && num_layers > 1;
   int32_t *ell = reinterpret_cast<int32_t *>(scratch + L.ell);
   if (quad)
     if (int rc = launch_csrq_ell(rowptr, col, val, n_vert, ell, s)) return rc;
@@ -646,7 +652,7 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
     if (int rc = launch_csr_heavy_list(rowptrT, n_vert, heavyT, s)) return rc;
   }
 
-  const bool quad = masks != nullptr && num_layers > 1 && use_csrq(batch, n_vert, hidden, cut_len, gemm_bf16);   // same rule as the forward (which left the quad-major signs in `masks`)
+  const bool quad = masks != nullptr && num_layers > 1 && use_csrq(batch, n_vert, hidden, cut_len, gemm_bf16, max_degreeT);   // same rule as the forward (which left the quad-major signs in `masks`)
   int32_t *ellT = reinterpret_cast<int32_t *>(scratch + L.ell);
   if (quad)
     if (int rc = launch_csrq_ell(rowptrT, colT, valT, n_vert, ellT, s)) return rc;

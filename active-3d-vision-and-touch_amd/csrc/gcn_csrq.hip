@@ -310,6 +310,7 @@ __global__ __launch_bounds__(256) void csrq_heavy_kernel(const float *__restrict
   }
 }
 
+int csrq_max_degree() { return kEllW; }
 bool csrq_fits(int n_vert, int cut_len) {
   // two slices of one mesh in LDS; a thread owns at most 6 vertices (their index entries stay in registers); hub lanes
   // cover up to 32 quads

@@ -120,6 +120,7 @@ int launch_csr_bwd(const float *g, int ldg, int c, const int32_t *rowptrT, const
 // quad-major bytes [batch][Q][n_vert] (written by the forward, applied by the backward).  db_slab: [batch][pad4(c)].
 // `ell`: the slot-major index image launch_csrq_ell builds from the same CSR (csrq_ell_ints(n_vert) ints, 256-B aligned).
 bool csrq_fits(int n_vert, int cut_len);
+int csrq_max_degree();   // rows up to this many edges are served entirely from the index entries a thread keeps in registers
 size_t csrq_ell_ints(int n_vert);
 int launch_csrq_ell(const int32_t *rowptr, const int32_t *col, const float *val, int n_vert, int32_t *ell, hipStream_t s);
 int launch_csrq_fwd(const float *zq, const float *bias, int c, const int32_t *rowptr, const int32_t *col,

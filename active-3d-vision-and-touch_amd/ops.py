@@ -109,8 +109,8 @@ class GCNStackFn(torch.autograd.Function):
         update = torch.empty((B, N, 3), dtype=torch.float32, device=feats.device)
         wp, bp = _ptr_array(weights), _ptr_array(biases)
         _lib.check(L.a3vt_gcn_stack_fwd(_lib.ptr(feats), ld, in_features, wp, bp, nl, hidden, cut_len,
-                                        _lib.ptr(adj.rowptr), _lib.ptr(adj.col), _lib.ptr(adj.val), adj.max_degree, N, B,
-                                        mode,
+                                        _lib.ptr(adj.rowptr), _lib.ptr(adj.col), _lib.ptr(adj.val), max(adj.max_degree, adj.t_max_degree),
+                                        N, B, mode,
                                         _lib.ptr(acts), _lib.ptr(masks), _lib.ptr(scratch), _lib.ptr(update), _stream()),
                    "gcn_stack_fwd")
         ctx.adj, ctx.dims, ctx.mode = adj, (in_features, hidden, cut_len, nl), mode
@@ -136,7 +136,7 @@ class GCNStackFn(torch.autograd.Function):
         _lib.check(L.a3vt_gcn_stack_bwd(_lib.ptr(feats), ld, in_features, _ptr_array(weights), _ptr_array(biases), nl,
                                         hidden, cut_len, _lib.ptr(adj.rowptr), _lib.ptr(adj.col), _lib.ptr(adj.val),
                                         _lib.ptr(adj.t_rowptr), _lib.ptr(adj.t_col), _lib.ptr(adj.t_val),
-                                        adj.t_max_degree, N, B, ctx.mode,
+                                        max(adj.max_degree, adj.t_max_degree), N, B, ctx.mode,
                                         _lib.ptr(ctx.acts), _lib.ptr(ctx.masks), _lib.ptr(grad_update), _ptr_array(gw),
                                         _ptr_array(gb),
                                         _lib.ptr(gfeats), _lib.ptr(scratch), _stream()), "gcn_stack_bwd")

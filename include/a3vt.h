@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define A3VT_VERSION 120 /* 0.2.x: bf16 storage mode (gemm_bf16 = 2), a3vt_gcn_stack_stash_bytes / _scratch_bytes_mode, deterministic backward scatters; 120: a3vt_chamfer_fwd_ws (pruned exact search) */
+#define A3VT_VERSION 130 /* 0.2.x: bf16 storage mode (gemm_bf16 = 2), a3vt_gcn_stack_stash_bytes / _scratch_bytes_mode, deterministic backward scatters; 120: a3vt_chamfer_fwd_ws (pruned exact search); 130: a3vt_posenc_wide_* (448-wide vertex-feature encoder), larger a3vt_gcn_stack_mask_bytes / _scratch_bytes (channel-sliced aggregation) */
 
 int a3vt_version(void);
 const char *a3vt_last_error(void);
@@ -55,11 +55,16 @@ int a3vt_csr_validate(const int32_t *rowptr_host, const int32_t *col_host, int n
  * csr_max_degree / csrT_max_degree: the largest number of entries in a row of that matrix, or 0 if unknown.  The
  * fused vision + touch graphs have hub rows (chart centres linked to every seam vertex, ~1150 entries,
  * utility/utils.py:119-128); rows above 64 entries are aggregated by a whole workgroup in a second launch, which a
- * known small maximum lets the library skip.  Results do not depend on the value.
+ * known small maximum lets the library skip.  Results do not depend on the value — but pass the SAME value (the larger
+ * of the two maxima) to the forward and the backward call of a stack: with every row <= 8 entries (the vision templates),
+ * fp32, hidden 273-304, <= 3072 vertices per mesh and >= 12 288 rows, both calls use the channel-sliced aggregation
+ * (csrc/gcn_csrq.hip) and the backward reads sign bytes in the layout the forward wrote.
  *
  * feats  : [M][ld_feats] with ld_feats == in_features rounded up to a multiple of 4; pad columns must be zero.
- * acts   : saved inputs of layers 1..L-1, [L-1][M][hidden]   (needed by the backward pass)
- * masks  : ReLU sign bytes of those activations (1 byte per 4 channels), a3vt_gcn_stack_mask_bytes() bytes;
+ * acts   : saved inputs of layers 1..L-1, (L-1) * M * hidden floats (needed by the backward pass).  OPAQUE to the caller:
+ *          row-major [L-1][M][hidden] on the half-wave aggregation path, "hybrid" rows on the channel-sliced one (per layer
+ *          columns [0,160) quad-major [batch][40][n_vert] float4, then columns [160,hidden) row-major) — same size either way
+ * masks  : ReLU sign bytes of those activations (1 byte per 4 channels), a3vt_gcn_stack_mask_bytes() bytes (opaque);
  *          the backward pass reads these 16 MB per layer instead of re-reading the 197 MB activation
  * update : [M][3]
  * Forward-only callers (policy scoring, environment.py:221-257) may pass acts = masks = NULL: the

@@ -52,9 +52,16 @@ def test_channel_sliced_aggregation_equals_row_kernels_and_oracle(cuda, tname, u
     try:
         os.environ["A3VT_CSR_ALGO"] = "rows"
         ref = _run(cuda, adj, st, feats, gup, L, H, cut_len)
-        os.environ.pop("A3VT_CSR_ALGO")
+        # "sliced" forces the channel-sliced path on graphs with rows longer than its eight register slots too (the fused
+        # touch graph: CSR continuation of long rows, hub rows through csrq_heavy_kernel) — by default those graphs stay on
+        # the half-wave kernels, which are faster for them
+        os.environ["A3VT_CSR_ALGO"] = "sliced"
         new = _run(cuda, adj, st, feats, gup, L, H, cut_len)
         again = _run(cuda, adj, st, feats, gup, L, H, cut_len)
+        if not use_touch:
+            os.environ.pop("A3VT_CSR_ALGO")
+            default = _run(cuda, adj, st, feats, gup, L, H, cut_len)     # short rows: the default IS the sliced path
+            assert torch.equal(default[0], new[0]) and torch.equal(default[1], new[1])
     finally:
         if old is None:
             os.environ.pop("A3VT_CSR_ALGO", None)
