@@ -304,7 +304,7 @@ static int stack_bwd16(const float *feats, int ld_feats, int in_features, const 
                        int hidden, int cut_len, const int32_t *rowptrT, const int32_t *colT, const float *valT,
                        int max_degreeT, int n_vert, int batch, const void *acts, const uint8_t *masks,
                        const float *grad_update, float *const *grad_weights, float *const *grad_biases,
-                       float *grad_feats, float *scratch, hipStream_t s) {
+                       float *grad_feats, float *scratch, int acc, hipStream_t s) {
   if (int rc = check_stack16_dims(num_layers, hidden, in_features)) return rc;
   const float *zeros = zero_page();
   A3VT_CHECK_ARG(zeros != nullptr);
@@ -334,10 +334,10 @@ static int stack_bwd16(const float *feats, int ld_feats, int in_features, const 
     if (int rc = launch_thin16_bwd_main(x, L.ldh, hidden, weights[last], res, grad_update, (long long)m, 1, ping[0], L.ldh,
                                         scratch + L.thin_dw_slab, scratch + L.thin_db_slab, s))
       return rc;
-    if (int rc = launch_slab_reduce(scratch + L.thin_dw_slab, thin_num_slabs(), (size_t)hidden * 3, (size_t)hidden * 3,
-                                    grad_weights[last], s))
+    if (int rc = launch_slab_reduce_za(scratch + L.thin_dw_slab, thin_num_slabs(), (size_t)hidden * 3, (size_t)hidden * 3,
+                                       (size_t)hidden * 3, grad_weights[last], acc, s))
       return rc;
-    if (int rc = launch_slab_reduce(scratch + L.thin_db_slab, thin_num_slabs(), 3, 3, grad_biases[last], s)) return rc;
+    if (int rc = launch_slab_reduce_za(scratch + L.thin_db_slab, thin_num_slabs(), 3, 3, 3, grad_biases[last], acc, s)) return rc;
   }
   // bf16 images Bt = W_i (zero padded) for dX_i = dZ W_i^T
   {
@@ -369,10 +369,10 @@ static int stack_bwd16(const float *feats, int ld_feats, int in_features, const 
       if (int rc = launch_csr16_bwd(g, L.ldh, cut_len, cpad, rowptrT, colT, valT, heavyT, n_vert, batch, dza, ldza,
                                     scratch + L.db_slab, s))
         return rc;
-      if (int rc = launch_slab_reduce_z(scratch + L.db_slab, csr_bwd_num_slabs(batch, n_vert), cpad, cut_len, hidden,
-                                        grad_biases[i], s))
+      if (int rc = launch_slab_reduce_za(scratch + L.db_slab, csr_bwd_num_slabs(batch, n_vert), cpad, cut_len, hidden,
+                                         grad_biases[i], acc, s))
         return rc;
-    } else {
+    } else if (!acc) {
       if (int rc = launch_fill_zero(grad_biases[i], hidden, s)) return rc;
     }
     // dW_i = X_i^T dZ in panels of <= 304 input channels (windows of the rows: no copies)
@@ -397,8 +397,8 @@ static int stack_bwd16(const float *feats, int ld_feats, int in_features, const 
         ProfScope ps(PROF_DW, s);
         if (int rc = launch_dw16(d, s)) return rc;
       }
-      if (int rc = launch_slab_reduce(scratch + L.dw_slab, dw16_num_slabs(hidden), (size_t)w * hidden, (size_t)w * hidden,
-                                      grad_weights[i] + (size_t)c0 * hidden, s))
+      if (int rc = launch_slab_reduce_za(scratch + L.dw_slab, dw16_num_slabs(hidden), (size_t)w * hidden, (size_t)w * hidden,
+                                         (size_t)w * hidden, grad_weights[i] + (size_t)c0 * hidden, acc, s))
         return rc;
     }
     // dX_i = dZ W_i^T
@@ -624,6 +624,19 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
                        const void *acts_v,
                        const uint8_t *masks, const float *grad_update, float *const *grad_weights, float *const *grad_biases,
                        float *grad_feats, float *scratch, void *stream) {
+  return a3vt_gcn_stack_bwd_acc(feats, ld_feats, in_features, weights, biases, num_layers, hidden, cut_len, rowptr, col, val,
+                                rowptrT, colT, valT, max_degreeT, n_vert, batch, gemm_bf16, acts_v, masks, grad_update,
+                                grad_weights, grad_biases, grad_feats, scratch, 0, stream);
+}
+
+int a3vt_gcn_stack_bwd_acc(const float *feats, int ld_feats, int in_features, const float *const *weights,
+                           const float *const *biases, int num_layers, int hidden, int cut_len,
+                           const int32_t *rowptr, const int32_t *col, const float *val, const int32_t *rowptrT,
+                           const int32_t *colT, const float *valT, int max_degreeT, int n_vert, int batch, int gemm_bf16,
+                           const void *acts_v,
+                           const uint8_t *masks, const float *grad_update, float *const *grad_weights,
+                           float *const *grad_biases, float *grad_feats, float *scratch, int accumulate, void *stream) {
+  const int acc = accumulate ? 1 : 0;
   const float *acts = static_cast<const float *>(acts_v);
   (void)biases; (void)rowptr; (void)col; (void)val;
   A3VT_CHECK_ARG(feats && weights && rowptrT && colT && valT && grad_update && grad_weights && grad_biases);
@@ -635,7 +648,7 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
   if (gemm_bf16 == 2)
     return stack_bwd16(feats, ld_feats, in_features, weights, num_layers, hidden, cut_len, rowptrT, colT, valT,
                        max_degreeT, n_vert, batch, acts, masks, grad_update, grad_weights, grad_biases, grad_feats,
-                       scratch, s);
+                       scratch, acc, s);
   const float *zeros = zero_page();
   A3VT_CHECK_ARG(zeros != nullptr);
   const StackLayout L = stack_layout(batch, n_vert, in_features, hidden, num_layers, cut_len, 1);
@@ -672,10 +685,10 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
                                  scratch + L.thin_db_slab, quad ? scratch + L.gq : nullptr, cpad / 4, quad ? xl : nullptr,
                                  qcols / 4, s))
       return rc;
-    if (int rc = launch_slab_reduce(scratch + L.thin_dw_slab, thin_num_slabs(), (size_t)k * 3, (size_t)k * 3,
-                                    grad_weights[last], s))
+    if (int rc = launch_slab_reduce_za(scratch + L.thin_dw_slab, thin_num_slabs(), (size_t)k * 3, (size_t)k * 3, (size_t)k * 3,
+                                       grad_weights[last], acc, s))
       return rc;
-    if (int rc = launch_slab_reduce(scratch + L.thin_db_slab, thin_num_slabs(), 3, 3, grad_biases[last], s)) return rc;
+    if (int rc = launch_slab_reduce_za(scratch + L.thin_db_slab, thin_num_slabs(), 3, 3, 3, grad_biases[last], acc, s)) return rc;
   }
 
   // zero-padded weight images (Bt = W_i for dX) of all hidden layers, one launch
@@ -715,7 +728,7 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
       if (int rc = launch_csrq_bwd(scratch + L.gq, cut_len, rowptrT, colT, valT, heavyT, ellT, n_vert, batch, dza, sq,
                                    scratch + L.db_slab, s))
         return rc;
-      if (int rc = launch_slab_reduce_z(scratch + L.db_slab, batch, cpad, cut_len, hidden, grad_biases[i], s)) return rc;
+      if (int rc = launch_slab_reduce_za(scratch + L.db_slab, batch, cpad, cut_len, hidden, grad_biases[i], acc, s)) return rc;
     } else if (cut_len > 0) {
       if (int rc = launch_csr_bwd(g, hidden, cut_len, rowptrT, colT, valT, heavyT, n_vert, batch, dza, cpad,
                                   scratch + L.db_slab, s))
@@ -723,10 +736,10 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
       // channels >= cut_len are dead bias parameters (model.py:358): written as exact zeros by the same launch.
       // (Folding this reduce into the weight-gradient reduce below made that launch wait for the two long-running
       // blocks that walk the 2048 bias slabs: 19.9 us per fused launch against 9.5 + 9.5 for two.)
-      if (int rc = launch_slab_reduce_z(scratch + L.db_slab, csr_bwd_num_slabs(batch, n_vert), cpad, cut_len, hidden,
-                                        grad_biases[i], s))
+      if (int rc = launch_slab_reduce_za(scratch + L.db_slab, csr_bwd_num_slabs(batch, n_vert), cpad, cut_len, hidden,
+                                         grad_biases[i], acc, s))
         return rc;
-    } else {
+    } else if (!acc) {
       if (int rc = launch_fill_zero(grad_biases[i], hidden, s)) return rc;
     }
 
@@ -773,8 +786,8 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
         ProfScope ps(PROF_DW, s);
         if (int rc = launch_dw(d, s)) return rc;
       }
-      if (int rc = launch_slab_reduce(scratch + L.dw_slab, dw_num_slabs(hidden), (size_t)w * hidden, (size_t)w * hidden,
-                                      grad_weights[i] + (size_t)c0 * hidden, s))
+      if (int rc = launch_slab_reduce_za(scratch + L.dw_slab, dw_num_slabs(hidden), (size_t)w * hidden, (size_t)w * hidden,
+                                         (size_t)w * hidden, grad_weights[i] + (size_t)c0 * hidden, acc, s))
         return rc;
     }
 

@@ -1448,7 +1448,7 @@ int launch_dw(const DwArgs &a0, hipStream_t s) {
 // every load in flight at once (the reduce is latency-bound: 128 slabs x 360 KB per layer), then the sixteen
 // partials are combined through LDS in a fixed order.
 __global__ __launch_bounds__(1024) void slab_reduce_kernel(const float *__restrict__ slab, int nslab, size_t stride,
-                                                           size_t n, size_t n_out, float *__restrict__ out) {
+                                                           size_t n, size_t n_out, float *__restrict__ out, int accumulate) {
   __shared__ float part[16][64];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const size_t i = (size_t)blockIdx.x * 64 + lane;
@@ -1469,7 +1469,8 @@ __global__ __launch_bounds__(1024) void slab_reduce_kernel(const float *__restri
     float t = 0.f;
 #pragma unroll
     for (int g = 0; g < 16; ++g) t += part[g][lane];
-    out[i] = i < n ? t : 0.f;
+    t = i < n ? t : 0.f;
+    out[i] = accumulate ? out[i] + t : t;   // (accumulate: a gradient written where it lives, second use of shared weights)
   }
 }
 
@@ -1478,7 +1479,7 @@ __global__ __launch_bounds__(1024) void slab_reduce_kernel(const float *__restri
 // output o, slab group g: slabs g, g + 64, ...), so a thread sums nslab / 64 values with eight loads in flight; the 64
 // partials per output are combined through LDS in a fixed order.  9.5 -> 4 us per call, 57 calls per step.
 __global__ __launch_bounds__(1024) void slab_reduce_tall_kernel(const float *__restrict__ slab, int nslab, size_t stride,
-                                                                size_t n, size_t n_out, float *__restrict__ out) {
+                                                                size_t n, size_t n_out, float *__restrict__ out, int accumulate) {
   __shared__ float part[64][17];
   const int o = threadIdx.x & 15, grp = threadIdx.x >> 4;
   const size_t i = (size_t)blockIdx.x * 16 + o;
@@ -1497,20 +1498,27 @@ __global__ __launch_bounds__(1024) void slab_reduce_tall_kernel(const float *__r
     float t = 0.f;
 #pragma unroll
     for (int g = 0; g < 64; ++g) t += part[g][o];
-    out[i] = i < n ? t : 0.f;
+    t = i < n ? t : 0.f;
+    out[i] = accumulate ? out[i] + t : t;
   }
 }
 
-int launch_slab_reduce_z(const float *slab, int nslab, size_t stride, size_t n, size_t n_out, float *out, hipStream_t s) {
+int launch_slab_reduce_za(const float *slab, int nslab, size_t stride, size_t n, size_t n_out, float *out, int accumulate,
+                          hipStream_t s) {
   if (nslab >= 512 && n_out <= 1024)
-    A3VT_LAUNCH(slab_reduce_tall_kernel, dim3(cdiv((long long)n_out, 16)), dim3(1024), 0, s, slab, nslab, stride, n, n_out, out);
+    A3VT_LAUNCH(slab_reduce_tall_kernel, dim3(cdiv((long long)n_out, 16)), dim3(1024), 0, s, slab, nslab, stride, n, n_out, out,
+                accumulate);
   else
-    A3VT_LAUNCH(slab_reduce_kernel, dim3(cdiv((long long)n_out, 64)), dim3(1024), 0, s, slab, nslab, stride, n, n_out, out);
+    A3VT_LAUNCH(slab_reduce_kernel, dim3(cdiv((long long)n_out, 64)), dim3(1024), 0, s, slab, nslab, stride, n, n_out, out,
+                accumulate);
   A3VT_CHECK_LAUNCH();
   return 0;
 }
+int launch_slab_reduce_z(const float *slab, int nslab, size_t stride, size_t n, size_t n_out, float *out, hipStream_t s) {
+  return launch_slab_reduce_za(slab, nslab, stride, n, n_out, out, 0, s);
+}
 int launch_slab_reduce(const float *slab, int nslab, size_t stride, size_t n, float *out, hipStream_t s) {
-  return launch_slab_reduce_z(slab, nslab, stride, n, n, out, s);
+  return launch_slab_reduce_za(slab, nslab, stride, n, n, out, 0, s);
 }
 
 }  // namespace a3vt

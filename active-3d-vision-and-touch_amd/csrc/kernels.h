@@ -96,6 +96,9 @@ int launch_copy_cols(const float *src, int ld_src, int c0, int w, float *dst, lo
 int launch_slab_reduce(const float *slab, int nslab, size_t stride, size_t n, float *out, hipStream_t s);
 // same, and out[n .. n_out) = 0
 int launch_slab_reduce_z(const float *slab, int nslab, size_t stride, size_t n, size_t n_out, float *out, hipStream_t s);
+// same; accumulate != 0: out += the sum (the sum is formed first, in the same fixed order, then added once)
+int launch_slab_reduce_za(const float *slab, int nslab, size_t stride, size_t n, size_t n_out, float *out, int accumulate,
+                          hipStream_t s);
 
 // CSR neighbour aggregation on the first c channels (+ bias + ReLU), model.py:356-358,363.
 int launch_csr_fwd(const float *za, int ldza, const float *bias, int c, const int32_t *rowptr, const int32_t *col,

@@ -37,7 +37,9 @@ class FlatGradBucket:
     Step protocol: ``zero()`` -> ``loss.backward()`` -> ``all_reduce_mean()`` -> ``optimizer.step()``.
     ``zero()`` clears the ``.grad`` fields rather than memsetting the buffer, so autograd *assigns* each gradient
     instead of launching one ``grad += g`` kernel per parameter (131 launches per step on the 20 x 300 model);
-    ``all_reduce_mean()`` then gathers them into the buffer with one multi-tensor copy and re-homes ``.grad``.
+    ``all_reduce_mean()`` then brings them into the buffer with one multi-tensor copy and re-homes ``.grad``.  On the GPU the
+    GCN stacks' gradients — 99.9 % of the bytes — never take that detour: the library writes them into these views itself
+    (``ops.GradSink``: first use of a step overwrites, the second use of the shared ``mesh_deform_2`` accumulates).
 
     Two chunks: ``early`` names parameters whose gradients are final before the backward pass ends — in
     ``Deformation`` the modules only stages 2 and 3 use (``mesh_deform_2``; ``img_encoder_local``).  They sit at the front
@@ -46,7 +48,7 @@ class FlatGradBucket:
     encoder: 95 MB of the 189 MB image model); ``all_reduce_mean()`` reduces the rest and waits for both.  If an early
     parameter gets no gradient in some step the early reduce simply does not start and everything is reduced at the end."""
 
-    def __init__(self, params, early=()):
+    def __init__(self, params, early=(), sinks=True):
         params = [p for p in params if p.requires_grad]
         early_ids = {id(p) for p in early}
         self.params = [p for p in params if id(p) in early_ids] + [p for p in params if id(p) not in early_ids]
@@ -66,12 +68,24 @@ class FlatGradBucket:
         self._early_work = None
         self._pending = self.n_early
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_early_grad) for p in self.params[:self.n_early]]
+        # Gradients written where they live: the library's GCN backward takes these views as its output pointers (first use
+        # of a step overwrites, the second use of the shared mesh_deform_2 accumulates in the kernel), so for those
+        # parameters there is no fresh tensor for autograd to assign, no add kernel for the second use and nothing to copy
+        # in gather().  Only on the GPU (the sinks are consulted by ops.GCNStackFn).
+        self._sinks = []
+        if sinks and self.flat.is_cuda:
+            from . import ops as _ops
+            for k, (p, v) in enumerate(zip(self.params, self.views)):
+                self._sinks.append(_ops.register_grad_sink(p, v, self._on_early_grad_sink if k < self.n_early else None))
         self._rehome()
 
     def _on_early_grad(self, _param):
         self._pending -= 1
         if self._pending == 0:
             self.reduce_early()
+
+    def _on_early_grad_sink(self):
+        self._on_early_grad(None)
 
     def _rehome(self, lo=0, hi=None):
         for p, v in zip(self.params[lo:hi], self.views[lo:hi]):
@@ -83,22 +97,26 @@ class FlatGradBucket:
         self._early_done = False
         self._early_work = None
         self._pending = self.n_early
+        for k in self._sinks:
+            k.reset()
 
     def _gather(self, lo, hi, out):
-        """Collect the freshly assigned gradients of params[lo:hi] into ``out`` (their slice of the flat buffer); a no-op for
-        gradients that already live there."""
-        pieces, fresh = [], False
-        for p, v in zip(self.params[lo:hi], self.views[lo:hi]):
+        """Bring the gradients of params[lo:hi] into their slice of the flat buffer: nothing to do for those the library wrote
+        in place (ops.GradSink) or that already live there, one multi-tensor copy for the ones autograd assigned as fresh
+        tensors, zeros for parameters the graph did not use."""
+        fresh_v, fresh_g, unused = [], [], []
+        for k, (p, v) in enumerate(zip(self.params[lo:hi], self.views[lo:hi])):
             g = p.grad
-            if g is None:                               # parameter unused in this graph
-                g = torch.zeros_like(v)
-            if g.data_ptr() != v.data_ptr():
-                fresh = True
-            pieces.append(g)
-        if fresh and pieces:                            # pieces that already live in the buffer must not alias the output
-            flat_pieces = [g.reshape(-1).clone() if g.data_ptr() == v.data_ptr() else g.reshape(-1)
-                           for g, v in zip(pieces, self.views[lo:hi])]
-            torch.cat(flat_pieces, out=out)
+            if g is None:
+                if not (self._sinks and self._sinks[lo + k].written):
+                    unused.append(v)                    # parameter unused in this graph
+            elif g.data_ptr() != v.data_ptr():
+                fresh_v.append(v)
+                fresh_g.append(g.view_as(v) if g.shape != v.shape else g)
+        if fresh_v:
+            torch._foreach_copy_(fresh_v, fresh_g)
+        if unused:
+            torch._foreach_zero_(unused)
         self._rehome(lo, hi)
 
     def gather(self):

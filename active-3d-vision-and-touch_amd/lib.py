@@ -34,6 +34,8 @@ SIGNATURES = {
     "a3vt_gcn_stack_fwd": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "a3vt_gcn_stack_bwd": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "a3vt_gcn_stack_bwd_acc": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
+                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "a3vt_gcn_layer_scratch_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "a3vt_gcn_layer_fwd": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "a3vt_gcn_layer_bwd": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i,

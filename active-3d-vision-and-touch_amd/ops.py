@@ -81,6 +81,33 @@ def gemm_mode(bf16):
     return int(bf16)
 
 
+class GradSink:
+    """Where the gradient of one parameter lives (a view into a trainer's flat all-reduce bucket,
+    ``distributed.FlatGradBucket``).  Library calls that produce parameter gradients write them there directly — the first
+    use of a step overwrites, later uses (``mesh_deform_2`` serves stages 2 and 3) accumulate inside the kernel — instead of
+    returning fresh tensors for autograd to assign, add up and the bucket to copy.  ``expect`` counts the forward uses of the
+    step whose backward has not run yet; ``on_final`` fires when it returns to zero (the gradient is complete)."""
+    __slots__ = ("view", "written", "expect", "on_final")
+
+    def __init__(self, view, on_final=None):
+        self.view, self.written, self.expect, self.on_final = view, False, 0, on_final
+
+    def reset(self):
+        self.written, self.expect = False, 0
+
+
+GRAD_SINKS = {}     # id(parameter) -> GradSink; filled by FlatGradBucket, consulted by GCNStackFn
+
+
+def register_grad_sink(param, view, on_final=None):
+    GRAD_SINKS[id(param)] = GradSink(view, on_final)
+    return GRAD_SINKS[id(param)]
+
+
+def unregister_grad_sink(param):
+    GRAD_SINKS.pop(id(param), None)
+
+
 class GCNStackFn(torch.autograd.Function):
     """One GCN (reference ``GCN.forward``, vision/model.py:316-331): feats (B,N,ld) -> update (B,N,3)."""
 
@@ -115,6 +142,13 @@ class GCNStackFn(torch.autograd.Function):
                    "gcn_stack_fwd")
         ctx.adj, ctx.dims, ctx.mode = adj, (in_features, hidden, cut_len, nl), mode
         ctx.acts, ctx.masks = acts, masks
+        # gradients written where they live: every parameter of this call has a sink in the trainer's flat bucket
+        sinks = [GRAD_SINKS.get(id(p)) for p in params] if need_bwd else []
+        ctx.sinks = sinks if sinks and all(k is not None and k.view.shape == p.shape and k.view.is_contiguous()
+                                           for k, p in zip(sinks, params)) else None
+        if ctx.sinks:
+            for k in ctx.sinks:
+                k.expect += 1
         ctx.save_for_backward(feats, *weights, *biases)
         return update
 
@@ -128,19 +162,38 @@ class GCNStackFn(torch.autograd.Function):
         adj = ctx.adj
         B, N, ld = feats.shape
         grad_update = _req(grad_update, "grad_update")
-        gw = [torch.empty_like(w) for w in weights]
-        gb = [torch.empty_like(b) for b in biases]
+        sinks = ctx.sinks
+        if sinks and len({k.written for k in sinks}) != 1:     # mixed first / later uses: take the ordinary path
+            for k in sinks:
+                k.expect -= 1
+            sinks = None
+        if sinks:
+            acc = 1 if sinks[0].written else 0
+            gw = [k.view for k in sinks[0::2]]
+            gb = [k.view for k in sinks[1::2]]
+        else:
+            acc = 0
+            gw = [torch.empty_like(w) for w in weights]
+            gb = [torch.empty_like(b) for b in biases]
         gfeats = torch.empty_like(feats)
         nbytes = L.a3vt_gcn_stack_scratch_bytes_mode(B, N, in_features, hidden, nl, cut_len, 1, ctx.mode)
         scratch = workspace("gcn", nbytes, feats.device)
-        _lib.check(L.a3vt_gcn_stack_bwd(_lib.ptr(feats), ld, in_features, _ptr_array(weights), _ptr_array(biases), nl,
-                                        hidden, cut_len, _lib.ptr(adj.rowptr), _lib.ptr(adj.col), _lib.ptr(adj.val),
-                                        _lib.ptr(adj.t_rowptr), _lib.ptr(adj.t_col), _lib.ptr(adj.t_val),
-                                        max(adj.max_degree, adj.t_max_degree), N, B, ctx.mode,
-                                        _lib.ptr(ctx.acts), _lib.ptr(ctx.masks), _lib.ptr(grad_update), _ptr_array(gw),
-                                        _ptr_array(gb),
-                                        _lib.ptr(gfeats), _lib.ptr(scratch), _stream()), "gcn_stack_bwd")
+        _lib.check(L.a3vt_gcn_stack_bwd_acc(_lib.ptr(feats), ld, in_features, _ptr_array(weights), _ptr_array(biases), nl,
+                                            hidden, cut_len, _lib.ptr(adj.rowptr), _lib.ptr(adj.col), _lib.ptr(adj.val),
+                                            _lib.ptr(adj.t_rowptr), _lib.ptr(adj.t_col), _lib.ptr(adj.t_val),
+                                            max(adj.max_degree, adj.t_max_degree), N, B, ctx.mode,
+                                            _lib.ptr(ctx.acts), _lib.ptr(ctx.masks), _lib.ptr(grad_update), _ptr_array(gw),
+                                            _ptr_array(gb),
+                                            _lib.ptr(gfeats), _lib.ptr(scratch), acc, _stream()), "gcn_stack_bwd")
         ctx.acts = ctx.masks = None
+        if sinks:   # the gradients are in the bucket already: nothing for autograd to assign or add
+            for k in sinks:
+                k.written = True
+                k.expect -= 1
+            for k in sinks:
+                if k.expect == 0 and k.on_final is not None:
+                    k.on_final()
+            return (gfeats, None, None, None, None, None, None, *([None] * (2 * nl)))
         grads = []
         for w, b in zip(gw, gb):
             grads += [w, b]

@@ -101,6 +101,20 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features,
                        float *const *grad_weights, float *const *grad_biases, float *grad_feats,
                        float *scratch, void *stream);
 
+/* The same with `accumulate` != 0: the weight and bias gradients are ADDED to what grad_weights[i] / grad_biases[i] hold
+ * (each sum is formed first, in the usual fixed order, then added once) — for trainers that let the library write every
+ * gradient where it lives (a flat all-reduce bucket) and whose stages share weights (mesh_deform_2, model.py:268,281:
+ * the first backward call of a step overwrites, the second accumulates).  grad_feats is always overwritten. */
+int a3vt_gcn_stack_bwd_acc(const float *feats, int ld_feats, int in_features,
+                           const float *const *weights, const float *const *biases,
+                           int num_layers, int hidden, int cut_len,
+                           const int32_t *csr_rowptr, const int32_t *csr_col, const float *csr_val,
+                           const int32_t *csrT_rowptr, const int32_t *csrT_col, const float *csrT_val, int csrT_max_degree,
+                           int n_vert, int batch, int gemm_bf16,
+                           const void *acts, const uint8_t *masks, const float *grad_update,
+                           float *const *grad_weights, float *const *grad_biases, float *grad_feats,
+                           float *scratch, int accumulate, void *stream);
+
 /* One GCN layer on its own — GCN_layer.forward(features, adj, activation), model.py:351-363, for callers
  * that run their own layer loop (the copies in reconstruction/autoencoder/model.py:96-137 and
  * policies/DDQN/model.py:132-168 have layer shapes the stack entry points do not cover:

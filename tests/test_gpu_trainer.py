@@ -335,3 +335,57 @@ def test_bench_under_torchrun_single_rank(cuda):
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True,
                          text=True, timeout=300)
     assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
+
+
+def test_gradients_written_into_the_bucket_equal_the_autograd_path(cuda, tmp_path):
+    """``Engine.train_step`` lets the library write the GCN gradients straight into the flat all-reduce bucket
+    (``ops.GradSink``; the second use of the shared ``mesh_deform_2`` accumulates inside ``a3vt_gcn_stack_bwd_acc``) instead
+    of returning tensors for autograd to assign / add and the bucket to copy.  Same bits as the autograd path
+    (``FlatGradBucket(..., sinks=False)``: the sum of a step is formed first and added once, as autograd's add does), the
+    early chunk still triggers from inside the backward pass, and a second step starts clean."""
+    from a3vt_amd import distributed as adist, ops
+    from a3vt_amd.pterotactyl.reconstruction.vision import model, train
+    args = make_args(exp_type="t", exp_id="sink", eval=False, epochs=1, patience=70, batch_size=3, log_interval=0,
+                     number_points=1500, num_GCN_layers=4, hidden_GCN_size=64)
+    os.chdir(tmp_path)
+    eng = train.Engine(args, loaders=((), ()))
+    eng.setup()
+    charts = model.prepare_mesh({"img": torch.zeros(3, 1)}, eng.initial_mesh, args)
+    gt = random_cloud(3, 1500, 4).to(cuda)
+    g = torch.Generator().manual_seed(5)
+    nf = eng.mesh_info["faces"].shape[0]
+    samples = (torch.randint(0, nf, (3, 3, 1500), generator=g).to(torch.int32).to(cuda),
+               torch.rand(3, 3, 1500, generator=g).to(cuda), torch.rand(3, 3, 1500, generator=g).to(cuda))
+    params = list(eng.encoder.parameters())
+
+    def grads_of(bucket):
+        bucket.zero()
+        verts = eng.encoder(torch.zeros(3, 1), charts)[0]
+        from a3vt_amd.pterotactyl.utility import utils
+        loss = 9000.0 * utils.chamfer_distance(verts, eng.mesh_info["faces_i32"], gt, num=1500, samples=samples).mean()
+        loss.backward()
+        early_started = bucket._early_done
+        bucket.all_reduce_mean()
+        return bucket.flat.clone(), early_started
+
+    assert eng.bucket._sinks and all(id(p) in ops.GRAD_SINKS for p in eng.bucket.params)
+    stash0 = ops.STATS["stack_stash_calls"]
+    flat_sink, early = grads_of(eng.bucket)
+    assert ops.STATS["stack_stash_calls"] - stash0 == 3
+    assert early                                                  # mesh_deform_2's chunk was complete inside the backward
+    w = eng.encoder.mesh_deform_2.layers[1].weight
+    assert ops.GRAD_SINKS[id(w)].written and ops.GRAD_SINKS[id(w)].expect == 0
+    assert w.grad.data_ptr() == ops.GRAD_SINKS[id(w)].view.data_ptr()
+    flat_sink2, _ = grads_of(eng.bucket)                          # second step: flags were reset, nothing left over
+    assert torch.equal(flat_sink, flat_sink2)
+    # the autograd path on the same parameters, same order in the buffer
+    early = list(eng.encoder.mesh_deform_2.parameters())
+    for p in params:
+        ops.unregister_grad_sink(p)
+    for h in eng.bucket._hooks:
+        h.remove()
+    plain = adist.FlatGradBucket(params, early=early, sinks=False)
+    assert [id(p) for p in plain.params] == [id(p) for p in eng.bucket.params] and not plain._sinks
+    flat_plain, early_plain = grads_of(plain)
+    assert early_plain
+    assert torch.equal(flat_sink, flat_plain)
