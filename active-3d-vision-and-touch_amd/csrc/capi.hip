@@ -1205,6 +1205,21 @@ int a3vt_image_pool_bwd(const float *verts, int batch, int n_vert, const float *
   return launch_pool_bwd(a, static_cast<hipStream_t>(stream));
 }
 
+size_t a3vt_bias_grad_scratch_bytes(long long rows, int channels) {
+  if (rows <= 0 || channels <= 0) return 0;
+  return (size_t)bias_grad_wgs(rows * channels, channels) * channels * sizeof(float);
+}
+
+int a3vt_bias_grad_nhwc(const void *grad, int bf16, long long rows, int channels, float *out, void *scratch,
+                        size_t scratch_bytes, void *stream) {
+  A3VT_CHECK_ARG(grad && out && scratch);
+  A3VT_CHECK_ARG(rows > 0 && channels > 0 && (bf16 == 0 || bf16 == 1));
+  A3VT_CHECK_ARG((reinterpret_cast<uintptr_t>(grad) & 15) == 0);
+  const size_t need = a3vt_bias_grad_scratch_bytes(rows, channels);
+  A3VT_CHECK_ARG(need > 0 && scratch_bytes >= need);
+  return launch_bias_grad(grad, bf16, rows, channels, out, static_cast<float *>(scratch), static_cast<hipStream_t>(stream));
+}
+
 int a3vt_profile_enable(int on) {
   g_prof.on = on != 0;
   g_prof.used = 0;

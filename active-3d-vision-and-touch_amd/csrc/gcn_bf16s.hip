@@ -330,10 +330,11 @@ int launch_dw16(const Dw16Args &a, hipStream_t s) {
 struct XcdWalk16 {
   int xcd, nloc, stride, gps, nmesh;
   long long ngroups;
-  __device__ XcdWalk16(int batch, int n_vert) {
-    xcd = blockIdx.x & 7;
-    nloc = blockIdx.x >> 3;
-    stride = (gridDim.x + 7 - xcd) >> 3;
+  __device__ XcdWalk16(int batch, int n_vert, int skip = 0) {   // skip: workgroups in front that do other work (% 8 == 0)
+    const int bid = blockIdx.x - skip, grid = gridDim.x - skip;
+    xcd = bid & 7;
+    nloc = bid >> 3;
+    stride = (grid + 7 - xcd) >> 3;
     gps = (n_vert + 15) >> 4;  // 16 vertices per workgroup pass
     nmesh = batch > xcd ? (batch - xcd + 7) >> 3 : 0;
     ngroups = (long long)nmesh * gps;
@@ -424,15 +425,80 @@ __device__ __forceinline__ F8 csr16_load_bias(const float *__restrict__ bias, in
   return b;
 }
 
+// Hub rows (see gcn_csr.hip): one workgroup per (mesh, row); its 16 lane groups take a sixteenth of the edge list each.
+// Runs in the FIRST kCsr16HubWgs workgroups of the aggregation launch itself (they start first and finish under the
+// row walk of the others): as a launch of its own the hub pass cost 16-18 us per layer and direction on the
+// vision + touch topology (profiles/r03_config3_bf16s_steady_kernels.txt) for a few thousand short items.
+constexpr int kCsr16HubWgs = 256;   // multiple of 8: the row walk's blockIdx -> XCD mapping is unchanged behind them
+
+template <int MODE>  // 0 forward epilogue, 1 backward (A^T gather, channels [c, cpad) pass the own gradient through)
+__device__ __forceinline__ void csr16_hub_rows(F8 (*red)[16], const u16 *__restrict__ src, int ld_src,
+                                               const float *__restrict__ bias, int c, int cpad,
+                                               const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+                                               const float *__restrict__ val, int n_vert, int batch,
+                                               const int32_t *__restrict__ heavy, u16 *__restrict__ dst, int ld_dst,
+                                               uint8_t *__restrict__ maskb, int mld, int relu) {
+  const int hl = threadIdx.x & 15, sub = threadIdx.x >> 4;
+  const int count = heavy[0];
+  const int width = MODE == 0 ? c : cpad;
+  for (long long item = blockIdx.x; item < (long long)count * batch; item += kCsr16HubWgs) {
+    const int v = heavy[64 + (int)(item % count)];
+    const long long b = item / count, row = b * n_vert + v;
+    const u16 *sb = src + b * n_vert * (long long)ld_src;
+    const int e0 = rowptr[v], e1 = rowptr[v + 1];
+    const int per = ((e1 - e0 + 15) / 16 + 3) & ~3;
+    const int s0 = min(e1, e0 + sub * per), s1 = min(e1, s0 + per);
+    for (int ch0 = 0; ch0 < width; ch0 += 128) {
+      const int ch = ch0 + hl * 8;
+      const bool on = ch < width;
+      red[sub][hl] = gather_row16(sb, ld_src, ch, on, s0, s1, hl, colidx, val);
+      __syncthreads();
+      if (sub == 0 && on) {
+        F8 acc = red[0][hl];
+#pragma unroll 1   // (fully unrolled, the 15 staged rows held 120 registers and set the whole kernel's allocation)
+        for (int r = 1; r < 16; ++r) {
+          acc.lo += red[r][hl].lo;
+          acc.hi += red[r][hl].hi;
+        }
+        u16 *o = dst + row * ld_dst + ch;
+        if (MODE == 0) {
+          csr16_fwd_store(acc, ch, c, csr16_load_bias(bias, ch, c), relu, o, maskb ? maskb + row * mld : nullptr);
+        } else {
+          const F8 own = unpack8(*reinterpret_cast<const u32x4 *>(sb + (long long)v * ld_src + ch));
+          F8 out;
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            const float x = ch + t < c ? f8_get(acc, t) : f8_get(own, t);
+            if (t < 4) out.lo[t] = x;
+            else out.hi[t - 4] = x;
+          }
+          *reinterpret_cast<u32x4 *>(o) = pack8(out);
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <bool HUB>   // HUB: the first kCsr16HubWgs workgroups take the hub rows (a second instantiation: the hub body's
+                      // registers would otherwise cost the plain graphs a quarter of their resident waves)
 __global__ __launch_bounds__(256) void csr16_fwd_kernel(const u16 *__restrict__ za, int ldza,
                                                         const float *__restrict__ bias, int c,
                                                         const int32_t *__restrict__ rowptr,
                                                         const int32_t *__restrict__ colidx,
                                                         const float *__restrict__ val, int n_vert, int batch,
                                                         u16 *__restrict__ y, int ldy, uint8_t *__restrict__ maskb,
-                                                        int mld, int relu, int heavy_thresh) {
+                                                        int mld, int relu, int heavy_thresh,
+                                                        const int32_t *__restrict__ heavy) {
+  constexpr int hub = HUB ? kCsr16HubWgs : 0;
+  if (HUB && (int)blockIdx.x < hub) {
+    __shared__ F8 red[16][16];
+    csr16_hub_rows<0>(red, za, ldza, bias, c, (c + 7) & ~7, rowptr, colidx, val, n_vert, batch, heavy, y, ldy, maskb, mld,
+                      relu);
+    return;
+  }
   const int hl = threadIdx.x & 15, sub = threadIdx.x >> 4;
-  const XcdWalk16 w(batch, n_vert);
+  const XcdWalk16 w(batch, n_vert, hub);
   // this lane's bias values stay in registers (c <= 128: one channel pass): loading them per vertex put 8 loads and a
   // full vmcnt wait — which also waits for the previous vertex's stores — behind every gather
   const F8 bs0 = csr16_load_bias(bias, hl * 8, c);
@@ -459,58 +525,6 @@ __global__ __launch_bounds__(256) void csr16_fwd_kernel(const u16 *__restrict__ 
   }
 }
 
-// Hub rows (see gcn_csr.hip): one workgroup per (mesh, row); its 16 lane groups take a sixteenth of the edge list each.
-template <int MODE>  // 0 forward epilogue, 1 backward (A^T gather, channels [c, cpad) pass the own gradient through)
-__global__ __launch_bounds__(256) void csr16_heavy_kernel(const u16 *__restrict__ src, int ld_src,
-                                                          const float *__restrict__ bias, int c, int cpad,
-                                                          const int32_t *__restrict__ rowptr,
-                                                          const int32_t *__restrict__ colidx,
-                                                          const float *__restrict__ val, int n_vert, int batch,
-                                                          const int32_t *__restrict__ heavy, u16 *__restrict__ dst,
-                                                          int ld_dst, uint8_t *__restrict__ maskb, int mld, int relu) {
-  __shared__ F8 red[16][16];
-  const int hl = threadIdx.x & 15, sub = threadIdx.x >> 4;
-  const int count = heavy[0];
-  const int width = MODE == 0 ? c : cpad;
-  for (long long item = blockIdx.x; item < (long long)count * batch; item += gridDim.x) {
-    const int v = heavy[64 + (int)(item % count)];
-    const long long b = item / count, row = b * n_vert + v;
-    const u16 *sb = src + b * n_vert * (long long)ld_src;
-    const int e0 = rowptr[v], e1 = rowptr[v + 1];
-    const int per = ((e1 - e0 + 15) / 16 + 3) & ~3;
-    const int s0 = min(e1, e0 + sub * per), s1 = min(e1, s0 + per);
-    for (int ch0 = 0; ch0 < width; ch0 += 128) {
-      const int ch = ch0 + hl * 8;
-      const bool on = ch < width;
-      red[sub][hl] = gather_row16(sb, ld_src, ch, on, s0, s1, hl, colidx, val);
-      __syncthreads();
-      if (sub == 0 && on) {
-        F8 acc = red[0][hl];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) {
-          acc.lo += red[r][hl].lo;
-          acc.hi += red[r][hl].hi;
-        }
-        u16 *o = dst + row * ld_dst + ch;
-        if (MODE == 0) {
-          csr16_fwd_store(acc, ch, c, csr16_load_bias(bias, ch, c), relu, o, maskb ? maskb + row * mld : nullptr);
-        } else {
-          const F8 own = unpack8(*reinterpret_cast<const u32x4 *>(sb + (long long)v * ld_src + ch));
-          F8 out;
-#pragma unroll
-          for (int t = 0; t < 8; ++t) {
-            const float x = ch + t < c ? f8_get(acc, t) : f8_get(own, t);
-            if (t < 4) out.lo[t] = x;
-            else out.hi[t - 4] = x;
-          }
-          *reinterpret_cast<u32x4 *>(o) = pack8(out);
-        }
-      }
-      __syncthreads();
-    }
-  }
-}
-
 int launch_csr16_fwd(const void *za, int ldza, const float *bias, int c, const int32_t *rowptr, const int32_t *col,
                      const float *val, const int32_t *heavy, int n_vert, int batch, void *y, int ldy, uint8_t *maskb,
                      int mld, int relu, hipStream_t s) {
@@ -520,32 +534,40 @@ int launch_csr16_fwd(const void *za, int ldza, const float *bias, int c, const i
   }
   const long long m = (long long)batch * n_vert;
   const int grid = (int)(cdiv(m, 16) < 4096 ? (cdiv(m, 16) + 7) / 8 * 8 : 4096);
-  A3VT_LAUNCH(csr16_fwd_kernel, dim3(grid), dim3(256), 0, s, static_cast<const u16 *>(za), ldza, bias, c, rowptr, col, val,
-              n_vert, batch, static_cast<u16 *>(y), ldy, maskb, mld, relu, heavy ? csr_heavy_degree() : 0x7fffffff);
+  if (heavy)
+    A3VT_LAUNCH(csr16_fwd_kernel<true>, dim3(grid + kCsr16HubWgs), dim3(256), 0, s, static_cast<const u16 *>(za), ldza, bias, c,
+                rowptr, col, val, n_vert, batch, static_cast<u16 *>(y), ldy, maskb, mld, relu, csr_heavy_degree(), heavy);
+  else
+    A3VT_LAUNCH(csr16_fwd_kernel<false>, dim3(grid), dim3(256), 0, s, static_cast<const u16 *>(za), ldza, bias, c, rowptr, col,
+                val, n_vert, batch, static_cast<u16 *>(y), ldy, maskb, mld, relu, 0x7fffffff, heavy);
   A3VT_CHECK_LAUNCH();
-  if (heavy) {
-    A3VT_LAUNCH(csr16_heavy_kernel<0>, dim3(2048), dim3(256), 0, s, static_cast<const u16 *>(za), ldza, bias, c,
-                (c + 7) & ~7, rowptr, col, val, n_vert, batch, heavy, static_cast<u16 *>(y), ldy, maskb, mld, relu);
-    A3VT_CHECK_LAUNCH();
-  }
   return 0;
 }
 
 // Backward: dZa[m][ch] = sum_e valT[e] G[b][colT[e]][ch] (ch < c), = G[m][ch] (c <= ch < cpad); bias-gradient partials.
+template <bool HUB>
 __global__ __launch_bounds__(256) void csr16_bwd_kernel(const u16 *__restrict__ g, int ldg, int c, int cpad,
                                                         const int32_t *__restrict__ rowptr,
                                                         const int32_t *__restrict__ colidx,
                                                         const float *__restrict__ val, int n_vert, int batch,
                                                         u16 *__restrict__ dza, int lddza,
-                                                        float *__restrict__ db_slab, int heavy_thresh) {
+                                                        float *__restrict__ db_slab, int heavy_thresh,
+                                                        const int32_t *__restrict__ heavy) {
   __shared__ float red[16][128];
+  constexpr int hub = HUB ? kCsr16HubWgs : 0;
+  if (HUB && (int)blockIdx.x < hub) {
+    static_assert(sizeof(F8) * 16 * 16 <= sizeof(red), "hub rows reuse the bias-gradient staging");
+    csr16_hub_rows<1>(reinterpret_cast<F8(*)[16]>(&red[0][0]), g, ldg, nullptr, c, cpad, rowptr, colidx, val, n_vert, batch,
+                      heavy, dza, lddza, nullptr, 0, 0);
+    return;
+  }
   const int hl = threadIdx.x & 15, sub = threadIdx.x >> 4;
   for (int ch0 = 0; ch0 < cpad; ch0 += 128) {
     const int ch = ch0 + hl * 8;
     const bool on = ch < cpad;
     F8 bsum;
     bsum.lo = bsum.hi = f32x4{0.f, 0.f, 0.f, 0.f};
-    const XcdWalk16 w(batch, n_vert);
+    const XcdWalk16 w(batch, n_vert, hub);
     for (long long gi = w.nloc; gi < w.ngroups; gi += w.stride) {
       long long b;
       int v;
@@ -578,7 +600,7 @@ __global__ __launch_bounds__(256) void csr16_bwd_kernel(const u16 *__restrict__ 
       float sm = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) sm += red[r][threadIdx.x];
-      db_slab[(size_t)blockIdx.x * cpad + ch0 + threadIdx.x] = sm;
+      db_slab[(size_t)(blockIdx.x - hub) * cpad + ch0 + threadIdx.x] = sm;
     }
     __syncthreads();
   }
@@ -591,15 +613,14 @@ int launch_csr16_bwd(const void *g, int ldg, int c, int cpad, const int32_t *row
     set_error("csr16_bwd: ldg=%d lddza=%d cpad=%d violate alignment rules", ldg, lddza, cpad);
     return -1;
   }
-  A3VT_LAUNCH(csr16_bwd_kernel, dim3(csr_bwd_num_slabs(batch, n_vert)), dim3(256), 0, s, static_cast<const u16 *>(g), ldg,
-              c, cpad, rowptrT, colT, valT, n_vert, batch, static_cast<u16 *>(dza), lddza, db_slab,
-              heavyT ? csr_heavy_degree() : 0x7fffffff);
+  const int slabs = csr_bwd_num_slabs(batch, n_vert);
+  if (heavyT)
+    A3VT_LAUNCH(csr16_bwd_kernel<true>, dim3(slabs + kCsr16HubWgs), dim3(256), 0, s, static_cast<const u16 *>(g), ldg, c, cpad,
+                rowptrT, colT, valT, n_vert, batch, static_cast<u16 *>(dza), lddza, db_slab, csr_heavy_degree(), heavyT);
+  else
+    A3VT_LAUNCH(csr16_bwd_kernel<false>, dim3(slabs), dim3(256), 0, s, static_cast<const u16 *>(g), ldg, c, cpad, rowptrT, colT,
+                valT, n_vert, batch, static_cast<u16 *>(dza), lddza, db_slab, 0x7fffffff, heavyT);
   A3VT_CHECK_LAUNCH();
-  if (heavyT) {
-    A3VT_LAUNCH(csr16_heavy_kernel<1>, dim3(2048), dim3(256), 0, s, static_cast<const u16 *>(g), ldg, nullptr, c, cpad,
-                rowptrT, colT, valT, n_vert, batch, heavyT, static_cast<u16 *>(dza), lddza, nullptr, 0, 0);
-    A3VT_CHECK_LAUNCH();
-  }
   return 0;
 }
 

@@ -22,10 +22,11 @@ struct XcdWalk {
   int xcd, nloc, stride;       // this workgroup's XCD group, its index inside the group, workgroups per group
   long long ngroups;           // 8-vertex groups owned by the XCD group
   int gps, nmesh;              // groups per mesh, meshes owned
-  __device__ XcdWalk(int batch, int n_vert) {
-    xcd = blockIdx.x & 7;
-    nloc = blockIdx.x >> 3;
-    stride = (gridDim.x + 7 - xcd) >> 3;  // workgroups with this blockIdx % 8
+  __device__ XcdWalk(int batch, int n_vert, int skip = 0) {   // skip: workgroups in front that do other work (% 8 == 0)
+    const int bid = blockIdx.x - skip, grid = gridDim.x - skip;
+    xcd = bid & 7;
+    nloc = bid >> 3;
+    stride = (grid + 7 - xcd) >> 3;  // workgroups with this blockIdx % 8
     gps = (n_vert + 7) >> 3;
     nmesh = batch > xcd ? (batch - xcd + 7) >> 3 : 0;
     ngroups = (long long)nmesh * gps;
@@ -108,20 +109,21 @@ int launch_csr_heavy_list(const int32_t *rowptr, int n_vert, int32_t *heavy, hip
 }
 
 // mode 0: forward epilogue (bias, optional ReLU, sign bytes).  mode 1: backward (A^T gather; channels [c, cpad) pass
-// the row's own gradient through).
+// the row's own gradient through).  Runs in the FIRST kCsrHubWgs workgroups of the aggregation launch (they start first and
+// finish under the row walk of the others; as a launch of its own the hub pass cost 16-18 us per layer and direction).
+constexpr int kCsrHubWgs = 256;   // multiple of 8: the row walk's blockIdx -> XCD mapping is unchanged behind them
+
 template <int MODE>
-__global__ __launch_bounds__(256) void csr_heavy_kernel(const float *__restrict__ src, int ld_src,
-                                                        const float *__restrict__ bias, int c, int cpad,
-                                                        const int32_t *__restrict__ rowptr,
-                                                        const int32_t *__restrict__ colidx,
-                                                        const float *__restrict__ val, int n_vert, int batch,
-                                                        const int32_t *__restrict__ heavy, float *__restrict__ dst,
-                                                        int ld_dst, uint8_t *__restrict__ maskb, int mld, int relu) {
-  __shared__ f32x4 red[8][32];
+__device__ __forceinline__ void csr_hub_rows(f32x4 (*red)[32], const float *__restrict__ src, int ld_src,
+                                             const float *__restrict__ bias, int c, int cpad,
+                                             const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+                                             const float *__restrict__ val, int n_vert, int batch,
+                                             const int32_t *__restrict__ heavy, float *__restrict__ dst, int ld_dst,
+                                             uint8_t *__restrict__ maskb, int mld, int relu) {
   const int hl = threadIdx.x & 31, sub = threadIdx.x >> 5;
   const int count = heavy[0];
   const int width = MODE == 0 ? c : cpad;
-  for (long long item = blockIdx.x; item < (long long)count * batch; item += gridDim.x) {
+  for (long long item = blockIdx.x; item < (long long)count * batch; item += kCsrHubWgs) {
     const int v = heavy[64 + (int)(item % count)];
     const long long b = item / count, row = b * n_vert + v;
     const float *sb = src + b * n_vert * (long long)ld_src;
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256) void csr_heavy_kernel(const float *__restrict_
       __syncthreads();
       if (sub == 0 && on) {
         f32x4 acc = red[0][hl];
-#pragma unroll
+#pragma unroll 2
         for (int r = 1; r < 8; ++r) acc += red[r][hl];
         float *o = dst + row * ld_dst + ch;
         if (MODE == 0) {
@@ -164,6 +166,8 @@ __global__ __launch_bounds__(256) void csr_heavy_kernel(const float *__restrict_
 // A half-wave (32 lanes) owns one vertex; lane l handles channels 4l..4l+3 (16-byte loads of the
 // neighbour row), so up to 128 aggregated channels are covered per pass.
 // ------------------------------------------------------------------------------------------------
+template <bool HUB>   // HUB: the first kCsrHubWgs workgroups take the hub rows (own instantiation: graphs without hubs keep
+                      // the smaller register allocation)
 __global__ __launch_bounds__(256) void csr_fwd_kernel(const float *__restrict__ za, int ldza,
                                                       const float *__restrict__ bias, int c,
                                                       const int32_t *__restrict__ rowptr,
@@ -171,9 +175,16 @@ __global__ __launch_bounds__(256) void csr_fwd_kernel(const float *__restrict__ 
                                                       const float *__restrict__ val, int n_vert, long long m,
                                                       float *__restrict__ y, int ldy,
                                                       uint8_t *__restrict__ maskb, int mld, int relu,
-                                                      int heavy_thresh) {
+                                                      int heavy_thresh, const int32_t *__restrict__ heavy) {
+  constexpr int hub = HUB ? kCsrHubWgs : 0;
+  if (HUB && (int)blockIdx.x < hub) {
+    __shared__ f32x4 red[8][32];
+    csr_hub_rows<0>(red, za, ldza, bias, c, (c + 3) & ~3, rowptr, colidx, val, n_vert, (int)(m / n_vert), heavy, y, ldy, maskb,
+                    mld, relu);
+    return;
+  }
   const int hl = threadIdx.x & 31;
-  const XcdWalk w((int)(m / n_vert), n_vert);
+  const XcdWalk w((int)(m / n_vert), n_vert, hub);
   float bsv[4] = {0.f, 0.f, 0.f, 0.f};  // bias of this lane's 4 channels (c <= 128: one pass)
   if (c <= 128) {
 #pragma unroll
@@ -187,7 +198,7 @@ __global__ __launch_bounds__(256) void csr_fwd_kernel(const float *__restrict__ 
     const long long row = b * n_vert + v;
     const float *zb = za + b * n_vert * (long long)ldza;
     const int e0 = rowptr[v], e1 = rowptr[v + 1];
-    if (e1 - e0 > heavy_thresh) continue;  // hub row: csr_heavy_kernel spreads it over a whole workgroup
+    if (e1 - e0 > heavy_thresh) continue;  // hub row: csr_hub_rows spreads it over a whole workgroup
     for (int ch0 = 0; ch0 < c; ch0 += 128) {
       const int ch = ch0 + hl * 4;
       const bool on = ch < c;
@@ -226,14 +237,13 @@ int launch_csr_fwd(const float *za, int ldza, const float *bias, int c, const in
   }
   const long long m = (long long)batch * n_vert;
   const int grid = (int)(cdiv(m, 8) < 4096 ? (cdiv(m, 8) + 7) / 8 * 8 : 4096);  // multiple of 8: whole XCD groups
-  A3VT_LAUNCH(csr_fwd_kernel, dim3(grid), dim3(256), 0, s, za, ldza, bias, c, rowptr, col, val, n_vert, m, y, ldy,
-              maskb, mld, relu, heavy ? kHeavyDeg : 0x7fffffff);
+  if (heavy)
+    A3VT_LAUNCH(csr_fwd_kernel<true>, dim3(grid + kCsrHubWgs), dim3(256), 0, s, za, ldza, bias, c, rowptr, col, val, n_vert, m,
+                y, ldy, maskb, mld, relu, kHeavyDeg, heavy);
+  else
+    A3VT_LAUNCH(csr_fwd_kernel<false>, dim3(grid), dim3(256), 0, s, za, ldza, bias, c, rowptr, col, val, n_vert, m, y, ldy,
+                maskb, mld, relu, 0x7fffffff, heavy);
   A3VT_CHECK_LAUNCH();
-  if (heavy) {
-    A3VT_LAUNCH(csr_heavy_kernel<0>, dim3(2048), dim3(256), 0, s, za, ldza, bias, c, pad4(c), rowptr, col, val, n_vert,
-                batch, heavy, y, ldy, maskb, mld, relu);
-    A3VT_CHECK_LAUNCH();
-  }
   return 0;
 }
 
@@ -245,19 +255,28 @@ int launch_csr_fwd(const float *za, int ldza, const float *bias, int c, const in
 // ------------------------------------------------------------------------------------------------
 constexpr int kCsrBwdMaxBlocks = 2048;
 
+template <bool HUB>
 __global__ __launch_bounds__(256) void csr_bwd_kernel(const float *__restrict__ g, int ldg, int c, int cpad,
                                                       const int32_t *__restrict__ rowptr,
                                                       const int32_t *__restrict__ colidx,
                                                       const float *__restrict__ val, int n_vert, long long m,
                                                       float *__restrict__ dza, int lddza,
-                                                      float *__restrict__ db_slab, int heavy_thresh) {
+                                                      float *__restrict__ db_slab, int heavy_thresh,
+                                                      const int32_t *__restrict__ heavy) {
   __shared__ float red[8][128];
+  constexpr int hub = HUB ? kCsrHubWgs : 0;
+  if (HUB && (int)blockIdx.x < hub) {
+    static_assert(sizeof(f32x4) * 8 * 32 <= sizeof(red), "hub rows reuse the bias-gradient staging");
+    csr_hub_rows<1>(reinterpret_cast<f32x4(*)[32]>(&red[0][0]), g, ldg, nullptr, c, cpad, rowptr, colidx, val, n_vert,
+                    (int)(m / n_vert), heavy, dza, lddza, nullptr, 0, 0);
+    return;
+  }
   const int hl = threadIdx.x & 31, grp = threadIdx.x >> 5;
   for (int ch0 = 0; ch0 < cpad; ch0 += 128) {
     const int ch = ch0 + hl * 4;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     const bool on = ch < cpad;  // all 32 lanes of the half-wave stay in the loop: gather_row shuffles across them
-    const XcdWalk w((int)(m / n_vert), n_vert);
+    const XcdWalk w((int)(m / n_vert), n_vert, hub);
     for (long long gi = w.nloc; gi < w.ngroups; gi += w.stride) {
       long long b;
       int v;
@@ -268,7 +287,7 @@ __global__ __launch_bounds__(256) void csr_bwd_kernel(const float *__restrict__ 
       if (on) own = *reinterpret_cast<const f32x4 *>(gb + (long long)v * ldg + ch);
       bsum += own;
       const int e0 = rowptr[v], e1 = rowptr[v + 1];
-      if (e1 - e0 > heavy_thresh) continue;  // hub row: gathered and stored by csr_heavy_kernel (its bias share is counted above)
+      if (e1 - e0 > heavy_thresh) continue;  // hub row: gathered and stored by csr_hub_rows (its bias share is counted above)
       const f32x4 acc = gather_row(gb, ldg, ch, on, e0, e1, hl, colidx, val);
       if (on) {
         f32x4 out;
@@ -285,7 +304,7 @@ __global__ __launch_bounds__(256) void csr_bwd_kernel(const float *__restrict__ 
       float s = 0.f;
 #pragma unroll
       for (int r = 0; r < 8; ++r) s += red[r][threadIdx.x];
-      db_slab[(size_t)blockIdx.x * cpad + ch0 + threadIdx.x] = s;
+      db_slab[(size_t)(blockIdx.x - hub) * cpad + ch0 + threadIdx.x] = s;
     }
     __syncthreads();
   }
@@ -304,14 +323,14 @@ int launch_csr_bwd(const float *g, int ldg, int c, const int32_t *rowptrT, const
     return -1;
   }
   const long long m = (long long)batch * n_vert;
-  A3VT_LAUNCH(csr_bwd_kernel, dim3(csr_bwd_num_slabs(batch, n_vert)), dim3(256), 0, s, g, ldg, c, cpad, rowptrT,
-                     colT, valT, n_vert, m, dza, lddza, db_slab, heavyT ? kHeavyDeg : 0x7fffffff);
+  const int slabs = csr_bwd_num_slabs(batch, n_vert);
+  if (heavyT)
+    A3VT_LAUNCH(csr_bwd_kernel<true>, dim3(slabs + kCsrHubWgs), dim3(256), 0, s, g, ldg, c, cpad, rowptrT, colT, valT, n_vert,
+                m, dza, lddza, db_slab, kHeavyDeg, heavyT);
+  else
+    A3VT_LAUNCH(csr_bwd_kernel<false>, dim3(slabs), dim3(256), 0, s, g, ldg, c, cpad, rowptrT, colT, valT, n_vert, m, dza,
+                lddza, db_slab, 0x7fffffff, heavyT);
   A3VT_CHECK_LAUNCH();
-  if (heavyT) {
-    A3VT_LAUNCH(csr_heavy_kernel<1>, dim3(2048), dim3(256), 0, s, g, ldg, nullptr, c, cpad, rowptrT, colT, valT, n_vert,
-                batch, heavyT, dza, lddza, nullptr, 0, 0);
-    A3VT_CHECK_LAUNCH();
-  }
   return 0;
 }
 

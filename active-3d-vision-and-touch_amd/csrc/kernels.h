@@ -232,6 +232,10 @@ struct PoolArgs {
 int launch_pool_fwd(PoolArgs a, hipStream_t s);
 int launch_pool_bwd(PoolArgs a, hipStream_t s);
 
+// bias_grad.hip: column sums of a channels-last gradient map (slab: bias_grad_wgs(rows * c, c) * c floats)
+int bias_grad_wgs(long long n_elem, int c);
+int launch_bias_grad(const void *g, int bf16, long long rows, int c, float *out, float *slab, hipStream_t s);
+
 // chamfer.hip
 size_t chamfer_scratch_bytes(int draws, int batch, int q);
 // algo: 0 = choose (pruned search when the workspace holds it and the clouds are large enough to pay for the sort),

@@ -73,6 +73,7 @@ class FlatGradBucket:
         # parameters there is no fresh tensor for autograd to assign, no add kernel for the second use and nothing to copy
         # in gather().  Only on the GPU (the sinks are consulted by ops.GCNStackFn).
         self._sinks = []
+        self._open = False
         if sinks and self.flat.is_cuda:
             from . import ops as _ops
             for k, (p, v) in enumerate(zip(self.params, self.views)):
@@ -92,6 +93,12 @@ class FlatGradBucket:
             p.grad = v
 
     def zero(self):
+        if self._open and any(k.written for k in self._sinks):
+            # the library wrote gradients into the buffer but nobody re-homed the .grad fields: the optimiser would have
+            # skipped those parameters
+            raise RuntimeError("a3vt: FlatGradBucket.all_reduce_mean() (or gather()) must run between backward() and "
+                               "optimizer.step(); the previous step skipped it")
+        self._open = True
         for p in self.params:
             p.grad = None
         self._early_done = False
@@ -124,6 +131,7 @@ class FlatGradBucket:
         if not self._early_done:
             self._gather(0, self.n_early, self.flat[:self.early_numel])
         self._gather(self.n_early, len(self.params), self.flat[self.early_numel:])
+        self._open = False
 
     @staticmethod
     def _active():

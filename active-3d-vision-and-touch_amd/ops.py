@@ -358,6 +358,49 @@ def image_pool(verts, matrix, maps):
     return ImagePoolFn.apply(verts, matrix, *maps)
 
 
+def bias_grad_nhwc(grad):
+    """Sum of a (B,C,H,W) channels-last gradient over B, H, W -> fp32 (C,) (``a3vt_bias_grad_nhwc``)."""
+    L = _lib.load()
+    if not grad.is_cuda or grad.dim() != 4 or grad.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError("a3vt: bias_grad_nhwc takes a float32 / bfloat16 (B,C,H,W) tensor on the GPU")
+    g = grad.contiguous(memory_format=torch.channels_last)
+    B, C, H, W = g.shape
+    rows = B * H * W
+    need = L.a3vt_bias_grad_scratch_bytes(rows, C)
+    if need == 0:
+        raise RuntimeError(f"a3vt: bias_grad_nhwc does not support {C} channels")
+    scratch = torch.empty(need, dtype=torch.uint8, device=g.device)
+    out = torch.empty(C, dtype=torch.float32, device=g.device)
+    _lib.check(L.a3vt_bias_grad_nhwc(_lib.ptr(g), int(g.dtype == torch.bfloat16), rows, C, _lib.ptr(out), _lib.ptr(scratch),
+                                     need, _stream()), "bias_grad_nhwc")
+    return out
+
+
+class ConvNHWCFn(torch.autograd.Function):
+    """``nn.Conv2d`` of the image pyramid (vision/model.py:15-23) in the channels-last bf16 branch: MIOpen's NHWC bf16
+    kernels for the convolution and its data / weight gradients, the bias gradient from the library (torch's own column
+    reduction of the channels-last output gradient takes 1.3 ms on the 3-channel full-resolution map)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding):
+        xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        wb = weight.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        y = torch.ops.aten.convolution(xb, wb, bias.to(torch.bfloat16), stride, padding, [1, 1], False, [0, 0], 1)
+        ctx.save_for_backward(xb, wb)
+        ctx.conf = (stride, padding, x.dtype, weight.dtype, bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xb, wb = ctx.saved_tensors
+        stride, padding, xdt, wdt, bdt = ctx.conf
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        gx, gw, _ = torch.ops.aten.convolution_backward(gy, xb, wb, None, stride, padding, [1, 1], False, [0, 0], 1,
+                                                        [ctx.needs_input_grad[0], True, False])
+        gb = bias_grad_nhwc(gy)
+        return (gx.to(xdt) if gx is not None else None), gw.to(wdt, memory_format=torch.contiguous_format), gb.to(bdt), None, None
+
+
 class VertexUpdateFn(torch.autograd.Function):
     """vertices[:, :n_vision] += update[:, :n_vision] (vision/model.py:250,270,283), out of place."""
 

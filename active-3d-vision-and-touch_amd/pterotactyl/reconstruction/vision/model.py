@@ -109,21 +109,40 @@ class Image_Encoder(nn.Module):
         prec = getattr(self.args, "cnn_precision", None) or getattr(self.args, "gemm_precision", "fp32")
         return img.is_cuda and prec in ("bf16", "bf16s")
 
+    library_bias_grad = True   # (tools flip it to time torch's own reduction)
+
+    @staticmethod
+    def _block_nhwc(block, x):
+        """One ``CNN_layer`` Sequential in the bf16 channels-last branch: BatchNorm / ReLU as they are (MIOpen under
+        autocast), the convolution through ``ops.ConvNHWCFn`` (same MIOpen kernels, bias gradient from the library)."""
+        for m in block:
+            if isinstance(m, nn.BatchNorm2d) and m.training and x.shape[0] < 4:
+                # MIOpen's training BatchNorm crashes the host on bf16 NHWC input at batch sizes below 4 (seen for 3 x 254^2,
+                # 3 x 64^2 and 64 x 27^2 maps; ROCm 7.2 image, tools/experiments/miopen_bn_nhwc_c3_crash.py): such tiny
+                # batches take the NCHW kernel (which would cost 5 ms per step at batch 64)
+                x = m(x.contiguous()).contiguous(memory_format=torch.channels_last)
+            elif not isinstance(m, nn.Conv2d):
+                x = m(x)
+            elif Image_Encoder.library_bias_grad and m.bias is not None and m.groups == 1 and tuple(m.dilation) == (1, 1):
+                x = _ops.ConvNHWCFn.apply(x, m.weight, m.bias, list(m.stride), list(m.padding))
+            else:   # torch's own autocast convolution on a channels-last view of the weights
+                x = nn.functional.conv2d(x, m.weight.contiguous(memory_format=torch.channels_last), m.bias, m.stride,
+                                         m.padding, m.dilation, m.groups)
+        return x
+
     def forward(self, img):
         """Feature maps of the three layers ``layers_per_block`` apart from the end, plus the last map reached
         before the spatial size drops below the kernel size (:147-164)."""
         n = len(self.layers)
         picks = {n - 1 - (i + 1) * self.args.layers_per_block for i in range(3)}
-        low = self._bf16_branch(img)
-        if low and not getattr(self, "_channels_last", False):
-            self.layers.to(memory_format=torch.channels_last)   # (weights only change their strides: state dict untouched)
-            self._channels_last = True
+        low = self._bf16_branch(img)   # (parameters keep their NCHW strides — the flat gradient bucket and fused Adam see one
+        #                                layout; the convolutions take a channels-last bf16 copy of their weights per call)
         x, maps = (img.contiguous(memory_format=torch.channels_last) if low else img), []
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=low):
             for e, layer in enumerate(self.layers):
                 if x.shape[-1] < self.args.CNN_ker_size:
                     break
-                x = layer(x)
+                x = self._block_nhwc(layer, x) if low else layer(x)
                 if e in picks:
                     maps.append(x)
             maps.append(x)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define A3VT_VERSION 130 /* 0.2.x: bf16 storage mode (gemm_bf16 = 2), a3vt_gcn_stack_stash_bytes / _scratch_bytes_mode, deterministic backward scatters; 120: a3vt_chamfer_fwd_ws (pruned exact search); 130: a3vt_posenc_wide_* (448-wide vertex-feature encoder), larger a3vt_gcn_stack_mask_bytes / _scratch_bytes (channel-sliced aggregation) */
+#define A3VT_VERSION 131 /* 0.2.x: bf16 storage mode (gemm_bf16 = 2), a3vt_gcn_stack_stash_bytes / _scratch_bytes_mode, deterministic backward scatters; 120: a3vt_chamfer_fwd_ws (pruned exact search); 130: a3vt_posenc_wide_* (448-wide vertex-feature encoder), larger a3vt_gcn_stack_mask_bytes / _scratch_bytes (channel-sliced aggregation) */
 
 int a3vt_version(void);
 const char *a3vt_last_error(void);
@@ -195,6 +195,15 @@ int a3vt_image_pool_bwd(const float *verts, int batch, int n_vert, const float *
                         const float *const *maps, const int *chans, const int *heights, const int *widths,
                         const float *grad_feats, int ld_feats, float *const *grad_maps, float *grad_verts,
                         void *stream);
+
+/* Bias gradient of a convolution whose output gradient is stored channels-last (the bias gradients of the nn.Conv2d
+ * layers of the image pyramid, model.py:15-47, in the channels-last bf16 branch):
+ *   out[c] = sum over rows of grad[row][c],  grad = [rows = N*H*W][channels] contiguous, fp32 (bf16 == 0) or bf16 (== 1),
+ * 16-byte aligned; out fp32 [channels], overwritten.  Fixed summation order (repeatable bit for bit).
+ * scratch: a3vt_bias_grad_scratch_bytes(rows, channels) bytes (0 = unsupported channel count). */
+size_t a3vt_bias_grad_scratch_bytes(long long rows, int channels);
+int a3vt_bias_grad_nhwc(const void *grad, int bf16, long long rows, int channels, float *out, void *scratch,
+                        size_t scratch_bytes, void *stream);
 
 /* Vertex update, model.py:250,270,283:  out[b][v] = in[b][v] + (v < n_vision ? update[b][v] : 0). */
 int a3vt_vertex_update(const float *verts_in, const float *update, int batch, int n_vert, int n_vision,

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 def test_library_loads(cuda):
     from a3vt_amd import lib
-    assert lib.load().a3vt_version() == 130
+    assert lib.load().a3vt_version() == 131
 
 
 @pytest.mark.parametrize("m,k,n", [(128, 16, 16), (1000, 52, 300), (4099, 300, 300), (300, 300, 50), (77, 300, 3),
@@ -516,3 +516,47 @@ def test_sample_points_rng_statistics(cuda):
     assert np.abs(hist - prob).max() < 4 * np.sqrt(prob.max() / num) + 1e-3
     assert 0.0 <= uu.min().item() and uu.max().item() < 1.0 and abs(uu.mean().item() - 0.5) < 5e-3
     assert abs(vv.mean().item() - 0.5) < 5e-3
+
+
+@pytest.mark.parametrize("B,C,H,W,dt", [(4, 3, 61, 59, "bf16"), (64, 3, 254, 254, "bf16"), (5, 16, 126, 126, "bf16"),
+                                        (3, 48, 17, 9, "fp32"), (2, 512, 3, 3, "bf16"), (1, 24, 7, 5, "fp32"),
+                                        (2, 7, 11, 13, "bf16")])
+def test_bias_grad_nhwc_is_the_column_sum(cuda, B, C, H, W, dt):
+    """a3vt_bias_grad_nhwc against a float64 sum of the same (bf16 or fp32) values; repeatable bit for bit.
+    Tolerance: fp32 accumulation of B*H*W terms in a fixed tree, 1e-5 of the sum of magnitudes."""
+    from a3vt_amd import ops
+    g = torch.Generator().manual_seed(B * C + H)
+    x = torch.randn(B, C, H, W, generator=g).to(torch.bfloat16 if dt == "bf16" else torch.float32)
+    xd = x.to(cuda).contiguous(memory_format=torch.channels_last)
+    out = ops.bias_grad_nhwc(xd)
+    ref = x.double().sum((0, 2, 3))
+    scale = x.double().abs().sum((0, 2, 3))
+    assert out.dtype == torch.float32 and out.shape == (C,)
+    assert ((out.cpu().double() - ref).abs() / scale).max().item() < 1e-5
+    assert torch.equal(out, ops.bias_grad_nhwc(xd))
+    assert torch.equal(out, ops.bias_grad_nhwc(x.to(cuda)))          # NCHW input: made channels-last by the wrapper
+
+
+def test_conv_nhwc_function_matches_autocast_conv(cuda):
+    """ops.ConvNHWCFn (image pyramid, bf16 channels-last branch) against nn.Conv2d under bf16 autocast: same MIOpen kernels,
+    so outputs and data / weight gradients agree to bf16 rounding; the bias gradient agrees with the float64 sum."""
+    from a3vt_amd import ops
+    torch.manual_seed(3)
+    conv = torch.nn.Conv2d(16, 32, 5, stride=2, padding=1).to(cuda).to(memory_format=torch.channels_last)
+    x = torch.randn(6, 16, 40, 40, device=cuda).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(6, 32, 19, 19, device=cuda).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    xa = x.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        ya = conv(xa)
+    ya.backward(gy)
+    ref = (xa.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone())
+    conv.zero_grad()
+    xb = x.clone().requires_grad_(True)
+    yb = ops.ConvNHWCFn.apply(xb, conv.weight, conv.bias, [2, 2], [1, 1])
+    yb.backward(gy)
+    assert yb.dtype == torch.bfloat16 and rel_err(yb.float(), ya.float()) < 1e-2
+    assert rel_err(xb.grad.float(), ref[0].float()) < 1e-2
+    assert conv.weight.grad.dtype == torch.float32 and rel_err(conv.weight.grad, ref[1]) < 1e-2
+    exact = gy.double().sum((0, 2, 3))
+    assert rel_err(conv.bias.grad.double(), exact) < 1e-5            # fp32 sum; torch's own is rounded to bf16
+    assert rel_err(ref[2].double(), exact) < 1e-2

@@ -50,6 +50,7 @@ def main():
                 v = net(img, charts)[0]
                 loss = args.loss_coeff * utils.chamfer_distance(v, info["faces_i32"], clouds[i % 4], num=a.points).mean()
                 loss.backward()
+                bucket.all_reduce_mean()   # single process: gathers the gradients and re-homes .grad
                 if adam:
                     opt.step()
             for i in range(a.warmup):

@@ -28,6 +28,7 @@ def run(name, net, info, charts, img, gt, args, steps=10, warm=8):
         v = net(img, charts)[0]
         loss = args.loss_coeff * utils.chamfer_distance(v, info["faces_i32"], gt, num=args.number_points).mean()
         loss.backward()
+        bucket.all_reduce_mean()   # single process: gathers the gradients and re-homes .grad
         opt.step()
         return loss
 

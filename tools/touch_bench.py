@@ -39,6 +39,7 @@ def main():
         v = net(img, charts)[0]
         loss = args.loss_coeff * utils.chamfer_distance(v, info["faces_i32"], gt, num=P).mean()
         loss.backward()
+        bucket.all_reduce_mean()   # single process: gathers the gradients and re-homes .grad
         opt.step()
 
     for _ in range(3):
