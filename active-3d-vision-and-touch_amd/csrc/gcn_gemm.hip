@@ -867,6 +867,8 @@ int launch_rowgemm(const RowGemmArgs &a, int epi, hipStream_t s) {
     set_error("rowgemm: k=%d ksplit=%d ldb=%d violate alignment rules", a.k, a.ksplit, a.ldb);
     return -1;
   }
+  static const bool old16 = getenv("A3VT_DBG_ROWGEMM16_OFF") != nullptr;   // developer switch: bf16 storage mode on rowgemm_kernel
+  if (!old16 && rowgemm16_ok(a, epi)) return launch_rowgemm16(a, epi, s);
   switch (epi) {
     case EPI_PLAIN: return launch_rowgemm_epi<EPI_PLAIN>(a, s);
     case EPI_FWD_HIDDEN: return launch_rowgemm_epi<EPI_FWD_HIDDEN>(a, s);

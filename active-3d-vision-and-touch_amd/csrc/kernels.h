@@ -55,6 +55,9 @@ struct RowGemmArgs {
 };
 int rowgemm_bt_rows(int n_store);
 int launch_rowgemm(const RowGemmArgs &a, int epi, hipStream_t s);
+// gcn_gemm16.hip: the hidden layers of the bf16 storage mode with the weight image held in registers
+bool rowgemm16_ok(const RowGemmArgs &a, int epi);
+int launch_rowgemm16(const RowGemmArgs &a, int epi, hipStream_t s);
 int launch_transpose_pad(const float *w, int k, int n, float *wt, int rows, int ld, hipStream_t s);
 int launch_copy_pad(const float *w, int rows_in, int cols_in, float *out, int rows, int ld, hipStream_t s);
 // Weight images of up to kMaxImages layers in one launch.  transpose = 1: dst_l [rows_l][ld_l] = W_l^T (W_l is

@@ -67,6 +67,10 @@ def _stack_case(cuda, tname, use_touch, L, H, B, I=50, cut=0.33, seed=3):
     ("ico3", False, 4, 64, 5, 50, 0.5),         # narrow hidden, another cut
     ("ico3", False, 3, 300, 2, 448, 0.33),      # the image model's 448-wide input: dW in two column windows
     ("ico2", False, 3, 128, 4, 50, 0.0),        # cut 0: nothing aggregated
+    ("ico4", False, 3, 300, 3, 50, 0.33),       # 7686 rows: the register-resident product (gcn_gemm16.hip), one block per workgroup
+    ("atlas", True, 3, 300, 8, 50, 0.33),       # the same on the fused touch graph (15592 rows, ragged last block)
+    ("ico4", False, 3, 296, 4, 50, 0.25),       # 296 columns: 37 store groups, K short of the last k-step, another cut
+    ("ico4", False, 4, 304, 5, 50, 0.0),        # widest hidden size, nothing aggregated (no raw-output stores)
 ])
 def test_gcn_stack_bf16_storage(cuda, tname, use_touch, L, H, B, I, cut):
     e = _stack_case(cuda, tname, use_touch, L, H, B, I, cut)
