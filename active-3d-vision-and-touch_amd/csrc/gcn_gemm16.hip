@@ -149,14 +149,30 @@ __global__ __launch_bounds__(512, 2) void rowgemm16_kernel(RowGemmArgs p) {
     if (nblk > 0) issue_a(0, 0);
     if (nblk > 1) issue_a(1, 1);
   }
+  // Column tiles of this wave: logical tiles wave, wave + 8, wave + 16, rotated by a per-workgroup offset — every
+  // workgroup reads the whole weight image from L2 at launch, and with the same wave -> tile map everywhere all 256 CUs
+  // ask for the same lines at the same moment (the prologue took 8.5 us, 3.6 without these loads).
+  const int rot = blockIdx.x % nt;
+  int tile_of[3];
+#pragma unroll
+  for (int jt = 0; jt < 3; ++jt) {
+    const int t = wave + 8 * jt + rot;
+    tile_of[jt] = wave + 8 * jt < nt ? (t >= nt ? t - nt : t) : nt;   // (absent tile: the zero rows behind the image's last tile)
+  }
   f32x4 bfrag[3][kKS];
 #pragma unroll
   for (int jt = 0; jt < 3; ++jt) {
-    int br = (wave + 8 * jt) * 16 + l16;
+    int br = tile_of[jt] * 16 + l16;
     br = br < p.bt_rows ? br : p.bt_rows - 1;
     const float *brow = p.bt + (size_t)br * p.ldb + q * 4;
 #pragma unroll
-    for (int s = 0; s < kKS; ++s) bfrag[jt][s] = *reinterpret_cast<const f32x4 *>(brow + s * 16);
+    for (int s = 0; s < kKS; ++s) {
+#ifdef A3VT_DBG_R16_NOB   // timing-only: what the weight loads cost the prologue (results are wrong by design)
+      bfrag[jt][s] = f32x4{1.f + s, 2.f + jt, 3.f + lane, 4.f};
+#else
+      bfrag[jt][s] = *reinterpret_cast<const f32x4 *>(brow + s * 16);
+#endif
+    }
   }
   // (the B loads of waves 0-3 are younger than their first two blocks' DMA: the first counted wait below covers them
   // only by waiting for everything — one vmcnt(0) at the top of block 0)
@@ -219,8 +235,8 @@ __global__ __launch_bounds__(512, 2) void rowgemm16_kernel(RowGemmArgs p) {
     // ---- accumulators -> fp32 tile [48][308] (C/D layout: col = lane & 15, row = 4 (lane >> 4) + reg) ---------------
 #pragma unroll
     for (int jt = 0; jt < 3; ++jt) {
-      if (jt == 2 && !third) continue;
-      const int col = (wave + 8 * jt) * 16 + l16;
+      if (wave + 8 * jt >= nt) continue;
+      const int col = tile_of[jt] * 16 + l16;
 #pragma unroll
       for (int rt = 0; rt < kRT; ++rt)
 #pragma unroll

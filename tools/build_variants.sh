@@ -24,6 +24,7 @@ elif [ "$1" = "stamps" ]; then   # rowgemm with s_memrealtime stamps at its phas
   build RG_STAMPS -DA3VT_DBG_RG_STAMPS
 elif [ "$1" = "stamps16" ]; then   # rowgemm16 (bf16 storage mode) with stamps at its phase boundaries (tools/rowgemm16_stamps.py)
   build R16_STAMPS -DA3VT_DBG_R16_STAMPS
+  build R16_STAMPS_NOB -DA3VT_DBG_R16_STAMPS -DA3VT_DBG_R16_NOB   # ... without the weight loads of the prologue
 elif [ "$1" = "prefetch" ]; then   # rowgemm prefetch-depth experiments: tools/rowgemm_bench.py / stack_bench.py with A3VT_LIB=...
   build RG_NOSPREAD -DA3VT_DBG_RG_NOSPREAD
   build RG_NSTAGE4 -DA3VT_DBG_RG_NSTAGE4
