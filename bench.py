@@ -309,6 +309,17 @@ def main():
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "traffic": None, "avg_launch_ms": t_ms, "launches": n_dx, "flop_per_launch": flop,
                 "other_mfma_ms": per, "mfma_ms_per_step": (tot[0] + tot[1] + tot[2]) / a.profile_steps}
+        if a.gemm_precision == "bf16s":
+            # the bf16 storage mode's products are bound by their bytes, not by the matrix pipe (gcn_gemm16.hip): dX reads the
+            # gradient rows (pad8(cut) + pad8(hidden) bf16 columns) and the sign bytes, writes pad8(hidden) bf16 columns
+            m_rows = a.batch * int(vt.shape[0])
+            ldh, cpad = (a.hidden + 7) // 8 * 8, (round(a.hidden * 0.33) + 7) // 8 * 8
+            nbytes = m_rows * ((cpad + ldh) * 2 + ldh * 2 + (cpad // 4 + (a.hidden + 3) // 4 + 1) // 2 * 2)
+            gbs = nbytes / (t_ms * 1e-3) / 1e9
+            roof.update({"bound": "hbm", "kernel": "rowgemm16_kernel<EPI_DX_MASK> (weights in registers, v_mfma_f32_16x16x32_bf16, "
+                                                   "M x 304 x 304 bf16, dX = dZ W^T, fp32 accumulate)",
+                         "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "bytes_per_launch": nbytes,
+                         "mfma_tflops": achieved})
         if rank == 0 and world == 1 and fp32 and not a.no_traffic:
             fence()
             try:
