@@ -276,7 +276,7 @@ def main():
     final_loss = loss.item()
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
     pick = lambda q: per_step[min(len(per_step) - 1, int(round(q * (len(per_step) - 1))))]  # noqa: E731
-    step_ms = {"p10": pick(0.1), "median": pick(0.5), "p90": pick(0.9), "n": len(per_step),
+    step_ms = {"p10": pick(0.1), "median": pick(0.5), "p90": pick(0.9), "max": per_step[-1], "sum": sum(per_step), "n": len(per_step),
                "how": "one HIP event per iteration boundary on the compute stream (rank 0)"}
 
     # roofline leg: per-launch device time of the MFMA kernels, HIP events on the launch stream
