@@ -76,10 +76,13 @@ def test_gcn_stack_bf16_storage(cuda, tname, use_touch, L, H, B, I, cut):
     e = _stack_case(cuda, tname, use_touch, L, H, B, I, cut)
     # forward: same roundings as the emulation (a value within fp32 rounding of a bf16 tie may round the other way: 2^-8
     # of one activation) -> close in L2; bf16 level against the exact network
-    assert e["out_vs_emul_l2"] < 3e-3 and e["out_vs_emul_max"] < 2e-2, e
-    assert e["out_vs_fp32_l2"] < 3e-2, e
+    # Tolerances = 2.5x the worst case measured over these ten configurations (round 3: 2.4e-4 / 6.5e-4 against the emulation,
+    # 3.0e-3 against the exact network, 8.1e-3 on a gradient — the deep touch-graph case); the kernels are deterministic, so the
+    # figures do not move from box to box.  (Round 2 asserted 3e-3 / 2e-2 / 3e-2 / 5e-2.)
+    assert e["out_vs_emul_l2"] < 6e-4 and e["out_vs_emul_max"] < 2e-3, e
+    assert e["out_vs_fp32_l2"] < 7.5e-3, e
     grads = {k: v for k, v in e.items() if k[0] in "gd"}
-    assert max(grads.values()) < 5e-2, e
+    assert max(grads.values()) < 2e-2, e
 
 
 def test_g4_full_size_forward_bf16_storage(cuda):
