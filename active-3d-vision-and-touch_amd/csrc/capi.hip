@@ -1077,21 +1077,23 @@ size_t a3vt_posenc_wide_scratch_bytes(int m, int input_size, int need_backward) 
   return posenc_wide_supported(input_size) && m > 0 ? posenc_wide_scratch_floats(m, input_size, need_backward) * sizeof(float) : 0;
 }
 int a3vt_posenc_wide_fwd(const float *verts, const float *mask, int m, int input_size, const float *pe_params, float *feats,
-                         int ld_feats, float *acts, float *scratch, void *stream) {
+                         int ld_feats, float *acts, float *scratch, int gemm_bf16, void *stream) {
   A3VT_CHECK_ARG(verts && mask && pe_params && feats && acts && scratch && m > 0);
   const float *zeros = zero_page();
   A3VT_CHECK_ARG(zeros != nullptr);
-  return launch_posenc_wide_fwd(verts, mask, m, input_size, pe_params, feats, ld_feats, acts, scratch, zeros,
+  A3VT_CHECK_ARG(gemm_bf16 == 0 || gemm_bf16 == 1);
+  return launch_posenc_wide_fwd(verts, mask, m, input_size, pe_params, feats, ld_feats, acts, scratch, zeros, gemm_bf16,
                                 static_cast<hipStream_t>(stream));
 }
 int a3vt_posenc_wide_bwd(const float *verts, const float *mask, int m, int input_size, const float *pe_params,
                          const float *grad_feats, int ld_feats, const float *acts, float *grad_verts, float *grad_params,
-                         float *scratch, void *stream) {
+                         float *scratch, int gemm_bf16, void *stream) {
   A3VT_CHECK_ARG(verts && mask && pe_params && grad_feats && acts && grad_verts && grad_params && scratch && m > 0);
   const float *zeros = zero_page();
   A3VT_CHECK_ARG(zeros != nullptr);
+  A3VT_CHECK_ARG(gemm_bf16 == 0 || gemm_bf16 == 1);
   return launch_posenc_wide_bwd(verts, mask, m, input_size, pe_params, grad_feats, ld_feats, acts, grad_verts, grad_params,
-                                scratch, zeros, static_cast<hipStream_t>(stream));
+                                scratch, zeros, gemm_bf16, static_cast<hipStream_t>(stream));
 }
 
 int a3vt_vertex_update(const float *verts_in, const float *update, int batch, int n_vert, int n_vision,

@@ -198,15 +198,16 @@ int launch_posenc_bwd(const float *verts, const float *mask, int m, int input_si
 
 // posenc_wide.hip — the same encoder for wide inputs (I = 448 of the image models): three augmented products on rowgemm /
 // dw_kernel; `acts` keeps E', H1', H2' for the backward (posenc_wide_acts_floats), `scratch` the operand images and the
-// backward's intermediates (posenc_wide_scratch_floats).  ld must equal input_size.
+// backward's intermediates (posenc_wide_scratch_floats).  ld must equal input_size.  gemm_bf16 != 0: the products of layers 2
+// and 3 (and every backward product) take bf16-rounded operands (the bf16 configurations); the embedding layer stays exact.
 bool posenc_wide_supported(int input_size);
 size_t posenc_wide_acts_floats(int m, int input_size);
 size_t posenc_wide_scratch_floats(int m, int input_size, int need_backward);
 int launch_posenc_wide_fwd(const float *verts, const float *mask, int m, int input_size, const float *params, float *feats,
-                           int ld, float *acts, float *scratch, const float *zeros, hipStream_t s);
+                           int ld, float *acts, float *scratch, const float *zeros, int gemm_bf16, hipStream_t s);
 int launch_posenc_wide_bwd(const float *verts, const float *mask, int m, int input_size, const float *params,
                            const float *gfeats, int ld, const float *acts, float *gverts, float *gparams, float *scratch,
-                           const float *zeros, hipStream_t s);
+                           const float *zeros, int gemm_bf16, hipStream_t s);
 
 // sample.hip
 int launch_face_cdf(const float *verts, const int32_t *faces, int batch, int n_vert, int n_faces, float *cdf,

@@ -235,8 +235,9 @@ static int build_images(const WideDims &d, const float *params, float *scratch, 
 }
 
 static RowGemmArgs plain_gemm(const float *a, int lda, int k, const float *bt, int n_store, float *c, int ldc, size_t m,
-                              const float *zeros, int relu) {
+                              const float *zeros, int relu, int bf16) {
   RowGemmArgs g{};
+  g.bf16 = bf16 ? 1 : 0;   // bf16 OPERAND mode of the bf16 configurations: fp32 rows in memory, operands rounded into the matrix pipe
   g.a0 = g.a1 = a;
   g.lda0 = g.lda1 = lda;
   g.ksplit = k;
@@ -264,7 +265,7 @@ size_t posenc_wide_scratch_floats(int m, int input_size, int need_backward) {
 }
 
 int launch_posenc_wide_fwd(const float *verts, const float *mask, int m, int input_size, const float *params, float *feats,
-                           int ld, float *acts, float *scratch, const float *zeros, hipStream_t s) {
+                           int ld, float *acts, float *scratch, const float *zeros, int gemm_bf16, hipStream_t s) {
   const WideDims d(input_size);
   if (!posenc_wide_supported(input_size) || ld != input_size) {   // (input_size % 8 == 0: the feature rows have no pad columns)
     set_error("posenc_wide: input_size=%d ld=%d unsupported", input_size, ld);
@@ -275,20 +276,20 @@ int launch_posenc_wide_fwd(const float *verts, const float *mask, int m, int inp
   if (int rc = build_images(d, params, scratch, L, s)) return rc;
   A3VT_LAUNCH(pew_embed_kernel, dim3(cdiv(m, 256)), dim3(256), 0, s, verts, mask, m, acts + A.e);
   A3VT_CHECK_LAUNCH();
-  if (int rc = launch_rowgemm(plain_gemm(acts + A.e, d.LE, d.LE, scratch + L.btf[0], d.LH1, acts + A.h1, d.LH1, m, zeros, 1),
+  if (int rc = launch_rowgemm(plain_gemm(acts + A.e, d.LE, d.LE, scratch + L.btf[0], d.LH1, acts + A.h1, d.LH1, m, zeros, 1, 0),   // the embedding layer stays exact in every mode (positions, sin / cos)
                               EPI_PLAIN, s))
     return rc;
-  if (int rc = launch_rowgemm(plain_gemm(acts + A.h1, d.LH1, d.LH1, scratch + L.btf[1], d.LH2, acts + A.h2, d.LH2, m, zeros, 1),
+  if (int rc = launch_rowgemm(plain_gemm(acts + A.h1, d.LH1, d.LH1, scratch + L.btf[1], d.LH2, acts + A.h2, d.LH2, m, zeros, 1, gemm_bf16),
                               EPI_PLAIN, s))
     return rc;
-  if (int rc = launch_rowgemm(plain_gemm(acts + A.h2, d.LH2, d.LH2, scratch + L.btf[2], d.I, feats, ld, m, zeros, 0), EPI_PLAIN, s))
+  if (int rc = launch_rowgemm(plain_gemm(acts + A.h2, d.LH2, d.LH2, scratch + L.btf[2], d.I, feats, ld, m, zeros, 0, gemm_bf16), EPI_PLAIN, s))
     return rc;
   return 0;
 }
 
 int launch_posenc_wide_bwd(const float *verts, const float *mask, int m, int input_size, const float *params,
                            const float *gfeats, int ld, const float *acts, float *gverts, float *gparams, float *scratch,
-                           const float *zeros, hipStream_t s) {
+                           const float *zeros, int gemm_bf16, hipStream_t s) {
   (void)verts; (void)mask;
   const WideDims d(input_size);
   if (!posenc_wide_supported(input_size) || ld != input_size) {
@@ -322,6 +323,7 @@ int launch_posenc_wide_bwd(const float *verts, const float *mask, int m, int inp
     w.m = m;
     w.k_in = lin;
     w.n_out = nz;
+    w.bf16 = (gemm_bf16 && l > 0) ? 1 : 0;   // layer 0 (its weight gradient and the gradient that goes on to the positions) exact
     if (int rc = launch_dw(w, s)) return rc;
     if (int rc = launch_slab_reduce(scratch + L.slab, dw_num_slabs(nz), (size_t)lin * nz, (size_t)lin * nz, scratch + L.dbp, s))
       return rc;
@@ -332,7 +334,7 @@ int launch_posenc_wide_bwd(const float *verts, const float *mask, int m, int inp
       A3VT_CHECK_LAUNCH();
     }
     // dX' = dZ B'^T, then through the ReLU of the layer below (E' has none)
-    RowGemmArgs g = plain_gemm(dz, ldz, nz, scratch + L.btb[l], lin, dx[l], lin, m, zeros, 0);
+    RowGemmArgs g = plain_gemm(dz, ldz, nz, scratch + L.btb[l], lin, dx[l], lin, m, zeros, 0, l > 0 ? gemm_bf16 : 0);
     g.ldb = pad16(lout);
     if (int rc = launch_rowgemm(g, EPI_PLAIN, s)) return rc;
     if (l > 0) {

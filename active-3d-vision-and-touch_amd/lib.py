@@ -51,8 +51,8 @@ SIGNATURES = {
     "a3vt_posenc_wide_supported": (_i, [_i]),
     "a3vt_posenc_wide_acts_bytes": (_sz, [_i, _i]),
     "a3vt_posenc_wide_scratch_bytes": (_sz, [_i, _i, _i]),
-    "a3vt_posenc_wide_fwd": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp]),
-    "a3vt_posenc_wide_bwd": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "a3vt_posenc_wide_fwd": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp]),
+    "a3vt_posenc_wide_bwd": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "a3vt_image_pool_fwd": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "a3vt_image_pool_bwd": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "a3vt_bias_grad_scratch_bytes": (_sz, [ctypes.c_longlong, _i]),

@@ -263,7 +263,7 @@ class PosEncMaskFn(torch.autograd.Function):
     """Positional_Encoder + Mask_Encoder + add (vision/model.py:229-232 etc.): (B,N,3),(B,N,1) -> (B,N,ld)."""
 
     @staticmethod
-    def forward(ctx, verts, mask, packed, input_size, ld):
+    def forward(ctx, verts, mask, packed, input_size, ld, gemm_bf16=False):
         L = _lib.load()
         verts, mask, packed = _req(verts, "verts"), _req(mask, "mask"), _req(packed, "pe_params")
         if packed.numel() != L.a3vt_posenc_param_count(input_size):
@@ -281,11 +281,12 @@ class PosEncMaskFn(torch.autograd.Function):
             need_bwd = ctx.needs_input_grad[0] or ctx.needs_input_grad[2]   # (grad mode is off inside forward)
             scratch = workspace("posenc", L.a3vt_posenc_wide_scratch_bytes(B * N, input_size, 0), verts.device)
             _lib.check(L.a3vt_posenc_wide_fwd(_lib.ptr(verts), _lib.ptr(mask), B * N, input_size, _lib.ptr(packed),
-                                              _lib.ptr(feats), ld, _lib.ptr(acts), _lib.ptr(scratch), _stream()),
-                       "posenc_wide_fwd")
+                                              _lib.ptr(feats), ld, _lib.ptr(acts), _lib.ptr(scratch), int(bool(gemm_bf16)),
+                                              _stream()), "posenc_wide_fwd")
             ctx.wide_acts = acts if need_bwd else None
         ctx.save_for_backward(verts, mask, packed)
         ctx.dims = (input_size, ld)
+        ctx.gemm_bf16 = int(bool(gemm_bf16))
         return feats
 
     @staticmethod
@@ -308,9 +309,9 @@ class PosEncMaskFn(torch.autograd.Function):
             scratch = workspace("posenc", L.a3vt_posenc_wide_scratch_bytes(B * N, input_size, 1), verts.device)
             _lib.check(L.a3vt_posenc_wide_bwd(_lib.ptr(verts), _lib.ptr(mask), B * N, input_size, _lib.ptr(packed),
                                               _lib.ptr(gfeats), ld, _lib.ptr(ctx.wide_acts), _lib.ptr(gverts),
-                                              _lib.ptr(gparams), _lib.ptr(scratch), _stream()), "posenc_wide_bwd")
+                                              _lib.ptr(gparams), _lib.ptr(scratch), ctx.gemm_bf16, _stream()), "posenc_wide_bwd")
             ctx.wide_acts = None
-        return gverts, None, gparams, None, None
+        return gverts, None, gparams, None, None, None
 
 
 class ImagePoolFn(torch.autograd.Function):

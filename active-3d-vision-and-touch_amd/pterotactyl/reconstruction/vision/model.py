@@ -323,7 +323,8 @@ class Deformation(nn.Module):
         if packed is not None:
             # I = 50: the LDS-resident fused kernel; wide inputs (448 of the image models): three products on the matrix
             # pipe (csrc/posenc_wide.hip) — both behind the same C-ABI pair and autograd function
-            feats = _ops.PosEncMaskFn.apply(vertices, mask, packed, self.input_size, self.ld_feats)
+            feats = _ops.PosEncMaskFn.apply(vertices, mask, packed, self.input_size, self.ld_feats,
+                                            getattr(self.args, "gemm_precision", "fp32") in ("bf16", "bf16s"))
         else:  # input sizes the library does not take (not a multiple of 8): torch ops, padded to the 4-float row granule
             feats = self.positional_encoder(vertices) + self.mask_encoder(mask)
         if img_maps is not None:

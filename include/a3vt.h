@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define A3VT_VERSION 131 /* 0.2.x: bf16 storage mode (gemm_bf16 = 2), a3vt_gcn_stack_stash_bytes / _scratch_bytes_mode, deterministic backward scatters; 120: a3vt_chamfer_fwd_ws (pruned exact search); 130: a3vt_posenc_wide_* (448-wide vertex-feature encoder), larger a3vt_gcn_stack_mask_bytes / _scratch_bytes (channel-sliced aggregation) */
+#define A3VT_VERSION 132 /* 0.2.x: bf16 storage mode (gemm_bf16 = 2), a3vt_gcn_stack_stash_bytes / _scratch_bytes_mode, deterministic backward scatters; 120: a3vt_chamfer_fwd_ws (pruned exact search); 130: a3vt_posenc_wide_* (448-wide vertex-feature encoder), larger a3vt_gcn_stack_mask_bytes / _scratch_bytes (channel-sliced aggregation) */
 
 int a3vt_version(void);
 const char *a3vt_last_error(void);
@@ -169,15 +169,17 @@ int a3vt_posenc_mask_bwd(const float *verts, const float *mask, int m, int input
  * pipe (csrc/posenc_wide.hip).  a3vt_posenc_wide_supported: input_size % 8 == 0, 16 <= input_size <= 630.  ld_feats must
  * equal input_size.  `acts` (a3vt_posenc_wide_acts_bytes) receives the layer activations in the forward and is read by the
  * backward — the caller keeps it between the two calls; `scratch` (a3vt_posenc_wide_scratch_bytes) is free afterwards.
- * pe_params / grad_params: the packing of a3vt_posenc_mask_fwd.  Replaces the same reference lines. */
+ * pe_params / grad_params: the packing of a3vt_posenc_mask_fwd.  Replaces the same reference lines.
+ * gemm_bf16: 0 = exact fp32 products (the default path), 1 = the products after the embedding layer, forward and
+ * backward, take bf16-rounded operands (fp32 storage and accumulation; the bf16 configurations' knob). */
 int a3vt_posenc_wide_supported(int input_size);
 size_t a3vt_posenc_wide_acts_bytes(int m, int input_size);
 size_t a3vt_posenc_wide_scratch_bytes(int m, int input_size, int need_backward);
 int a3vt_posenc_wide_fwd(const float *verts, const float *mask, int m, int input_size, const float *pe_params,
-                         float *feats, int ld_feats, float *acts, float *scratch, void *stream);
+                         float *feats, int ld_feats, float *acts, float *scratch, int gemm_bf16, void *stream);
 int a3vt_posenc_wide_bwd(const float *verts, const float *mask, int m, int input_size, const float *pe_params,
                          const float *grad_feats, int ld_feats, const float *acts, float *grad_verts,
-                         float *grad_params, float *scratch, void *stream);
+                         float *grad_params, float *scratch, int gemm_bf16, void *stream);
 
 /* Per-vertex image features.  Replaces Image_Encoder.pooling (model.py:70-103): project the vertices with the fixed
  * camera matrix `proj` = K.RT (row-major 3 x 4, model.py:50-67; HOST pointer), z == 0 -> 0.1,

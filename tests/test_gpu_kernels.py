@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 def test_library_loads(cuda):
     from a3vt_amd import lib
-    assert lib.load().a3vt_version() == 131
+    assert lib.load().a3vt_version() == 132
 
 
 @pytest.mark.parametrize("m,k,n", [(128, 16, 16), (1000, 52, 300), (4099, 300, 300), (300, 300, 50), (77, 300, 3),
@@ -560,3 +560,33 @@ def test_conv_nhwc_function_matches_autocast_conv(cuda):
     exact = gy.double().sum((0, 2, 3))
     assert rel_err(conv.bias.grad.double(), exact) < 1e-5            # fp32 sum; torch's own is rounded to bf16
     assert rel_err(ref[2].double(), exact) < 1e-2
+
+
+def test_posenc_wide_bf16_operand_mode(cuda):
+    """gemm_bf16 = 1 of a3vt_posenc_wide_fwd/bwd (the bf16 configurations): products after the embedding layer on bf16-rounded
+    operands, fp32 storage and accumulation; the embedding layer and its backward stay exact.  Against the exact path of the
+    same call: features 1.6e-3 (tolerance 5e-3, the bf16 configurations' level on positions); gradients 2.1e-2 (parameters) and
+    3.6e-2 (positions: random upstream gradient, i.e. full cancellation inside every 232- and 448-term sum, then the
+    frequencies up to 18 pi of the embedding's derivative) — tolerance 6e-2; repeatable bit for bit."""
+    from a3vt_amd import ops
+    from a3vt_amd.pterotactyl.reconstruction.vision import model as vmodel
+    I, B, N = 448, 2, 1949
+    torch.manual_seed(5)
+    pe, me = vmodel.Positional_Encoder(I).to(cuda), vmodel.Mask_Encoder(I).to(cuda)
+    packed = torch.cat([p.reshape(-1) for p in pe.packed()] + [me.model[0].weight.reshape(-1)]).detach()
+    g = torch.Generator().manual_seed(9)
+    verts = ((torch.rand(B, N, 3, generator=g) - 0.5) * 0.6).to(cuda)
+    mask = torch.randint(0, 4, (B, N, 1), generator=g).float().to(cuda)
+    gout = torch.randn(B, N, I, generator=g).to(cuda)
+    res = []
+    for mode in (False, True, True):
+        v, pk = verts.clone().requires_grad_(True), packed.clone().requires_grad_(True)
+        f = ops.PosEncMaskFn.apply(v, mask, pk, I, I, mode)
+        (f * gout).sum().backward()
+        res.append((f.detach(), v.grad, pk.grad))
+    exact, a, b = res
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert not torch.equal(a[0], exact[0])                      # the flag does reach the products
+    from helpers import rel_l2
+    errs = [rel_l2(x, y) for x, y in zip(a, exact)]
+    assert errs[0] < 5e-3 and max(errs[1:]) < 6e-2, errs
