@@ -237,7 +237,10 @@ def main():
     adist.broadcast_parameters(eng.encoder)
     adist.seed_rank(1234, rank)                  # per-rank RNG stream (surface samples), SURVEY §8d
     params = list(eng.encoder.parameters())
-    eng.bucket = adist.FlatGradBucket(params)
+    # as Engine.setup(): the chunk that is final once the backward pass has left stage 2 is reduced while stage 1 still runs
+    early = [p for name in ("mesh_deform_2", "img_encoder_local") if hasattr(eng.encoder, name)
+             for p in getattr(eng.encoder, name).parameters()]
+    eng.bucket = adist.FlatGradBucket(params, early=early)
     try:
         eng.optimizer = torch.optim.Adam(params, lr=args.lr, weight_decay=0, fused=True)
     except (RuntimeError, TypeError):
