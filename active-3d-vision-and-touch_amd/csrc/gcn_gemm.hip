@@ -203,7 +203,15 @@ __device__ __forceinline__ void rowtile_unit(const RowGemmArgs &p, int row_base,
 // deeper ring because a handful of MFMAs per chunk cannot cover a DMA round trip.  Known cost: the epilogue is
 // bound by the CU's store path (~7-10 B/clk: 770 KB per CU per launch = 30-45 us) and is not overlapped.
 // ------------------------------------------------------------------------------------------------
-template <int NT, int EPI, int NSTAGE, int WAVES, int MODE>
+template <int V>
+using RgIdx = std::integral_constant<int, V>;
+
+// ADIRECT: the A operand goes from global memory straight into registers — lane (row l16, k-quad q) loads the 16 bytes that
+// ARE its MFMA operand for the chunk (one global_load_dwordx4 in place of one LDS-DMA instruction and one ds_read_b128 per
+// 16-row tile and chunk; same rows, same 64-byte runs per row, same position in the wave's vmcnt sequence), held in one
+// register set per ring stage; only Bt still crosses the LDS.  The chunk loop is then unrolled by NSTAGE so that the sets
+// are indexed statically.
+template <int NT, int EPI, int NSTAGE, int WAVES, int MODE, bool ADIRECT = false>
 __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
   constexpr bool BF16 = MODE == 1;   // bf16 operand mode (fp32 storage, operands rounded on the way into the matrix pipe)
   constexpr bool ST16 = MODE == 2;   // bf16 storage mode
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
     const size_t a0mul = p.a0q_nvert > 0 ? (size_t)p.a0q_nvert : 1;   // quad-major a0: k -> k * N floats past the row's base
 #pragma unroll
     for (int j = 0; j < A_INSTR; ++j) {
-      int r = row0 + j * 16 + (lane >> 2);
+      int r = row0 + j * 16 + (ADIRECT ? l16 : (lane >> 2));
       r = r < p.m ? r : p.m - 1;
       a0row[j] = p.a0 + (size_t)r * p.lda0;
       if (p.a0q_nvert > 0) {
@@ -285,8 +293,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
       for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // One DMA wave-instruction of a chunk: pieces [0, A_INSTR) are this wave's A tiles, the rest its share of Bt.
-    auto issue_piece = [&](int chunk, int buf, int piece) {
-      const int kk = chunk * 16 + kpiece;
+    f32x4 areg[ADIRECT ? NSTAGE : 1][MT];   // ADIRECT: the A fragments of the chunks in flight, one set per ring stage
+    auto issue_piece = [&](int chunk, auto bufc, int piece) {
+      const int buf = bufc;
+      const int kk = chunk * 16 + ((ADIRECT && piece < A_INSTR) ? q * 4 : kpiece);
 #ifdef A3VT_DBG_RG_NOA   // timing-only ablations (tools/build_variants.sh rowgemm): results are wrong by design
       if (piece < A_INSTR) return;
 #endif
@@ -297,7 +307,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
         float *sA = lds + buf * STAGE + wave * (MT * 256);
         const float *src =
             (piece >= nm || kk >= p.k) ? p.zeros : (kk < p.ksplit ? a0row[piece] + (size_t)kk * a0mul : a1row[piece] + kk);
-        glds16(src, sA + piece * 256);
+        if constexpr (ADIRECT) {
+          (void)sA;
+          areg[decltype(bufc)::value][piece] = *reinterpret_cast<const f32x4 *>(src);
+        } else {
+          glds16(src, sA + piece * 256);
+        }
       } else {
         const int j = piece - A_INSTR;
         if (j >= nbp) return;
@@ -305,9 +320,9 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
         glds16(brow[j] + kk, sB + (j * WAVES + wave) * 256);
       }
     };
-    auto issue = [&](int chunk, int buf) {
+    auto issue = [&](int chunk, auto bufc) {
 #pragma unroll
-      for (int pc = 0; pc < PER; ++pc) issue_piece(chunk, buf, pc);
+      for (int pc = 0; pc < PER; ++pc) issue_piece(chunk, bufc, pc);
     };
 
     if (EPI == EPI_DX_MASK) {
@@ -322,11 +337,19 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
         glds16(reinterpret_cast<const float *>(src), ms + o / 4);
       }
     }
+    if constexpr (ADIRECT) {
+      if (0 < DIST && 0 < nchunks) issue(0, RgIdx<0>{});
+      if (1 < DIST && 1 < nchunks) issue(1, RgIdx<1 < NSTAGE ? 1 : 0>{});
+      if (2 < DIST && 2 < nchunks) issue(2, RgIdx<2 < NSTAGE ? 2 : 0>{});
+      if (3 < DIST && 3 < nchunks) issue(3, RgIdx<3 < NSTAGE ? 3 : 0>{});
+      static_assert(DIST <= 4, "prologue of the register-resident A path");
+    } else {
 #pragma unroll
-    for (int d = 0; d < DIST; ++d)
-      if (d < nchunks) issue(d, d);
-    int buf = 0;
-    for (int t = 0; t < nchunks; ++t) {
+      for (int d = 0; d < DIST; ++d)
+        if (d < nchunks) issue(d, d);
+    }
+    auto step = [&](const int t, auto bufc) {
+      const int buf = bufc;
       // chunk t landed; up to DIST-1 younger chunks may still be in flight
       const int younger = nchunks - 1 - t < DIST - 1 ? nchunks - 1 - t : DIST - 1;
       if (full_per) {   // this wave issues PER instructions per chunk ...
@@ -354,14 +377,20 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
       constexpr bool SPREAD = NPAIR >= 2 * PER;
 #endif
       const bool prefetch = t + DIST < nchunks;
-      const int nbuf = buf >= 1 ? buf - 1 : NSTAGE - 1;
+      auto nbuf = [&] {   // stage of chunk t + DIST = the one freed by the barrier above (a constant when buf is)
+        if constexpr (ADIRECT) return RgIdx<(decltype(bufc)::value + NSTAGE - 1) % NSTAGE>{};
+        else return buf >= 1 ? buf - 1 : NSTAGE - 1;
+      }();
       if (prefetch && (!SPREAD || !active)) issue(t + DIST, nbuf);
       if (active) {
         const float *sA = lds + buf * STAGE + wave * (MT * 256);
         const float *sB = lds + buf * STAGE + A_FLOATS;
         f32x4 af[MT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4 *>(sA + (i * 16 + l16) * 16 + qs * 4);
+        for (int i = 0; i < MT; ++i) {
+          if constexpr (ADIRECT) af[i] = areg[decltype(bufc)::value][i];
+          else af[i] = *reinterpret_cast<const f32x4 *>(sA + (i * 16 + l16) * 16 + qs * 4);
+        }
         s16x4 abf[MT];
         if (BF16) {
 #pragma unroll
@@ -440,7 +469,22 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
           bc1 = bn1;
         }
       }
-      buf = buf == NSTAGE - 1 ? 0 : buf + 1;
+    };
+    if constexpr (ADIRECT) {
+      for (int tt = 0; tt < nchunks; tt += NSTAGE) {
+        step(tt, RgIdx<0>{});
+        if (NSTAGE > 1 && tt + 1 < nchunks) step(tt + 1, RgIdx<1 < NSTAGE ? 1 : 0>{});
+        if (NSTAGE > 2 && tt + 2 < nchunks) step(tt + 2, RgIdx<2 < NSTAGE ? 2 : 0>{});
+        if (NSTAGE > 3 && tt + 3 < nchunks) step(tt + 3, RgIdx<3 < NSTAGE ? 3 : 0>{});
+        if (NSTAGE > 4 && tt + 4 < nchunks) step(tt + 4, RgIdx<4 < NSTAGE ? 4 : 0>{});
+        static_assert(NSTAGE <= 5, "chunk loop of the register-resident A path");
+      }
+    } else {
+      int buf = 0;
+      for (int t = 0; t < nchunks; ++t) {
+        step(t, buf);
+        buf = buf == NSTAGE - 1 ? 0 : buf + 1;
+      }
     }
     wait_lgkm0();
     __builtin_amdgcn_s_barrier();  // all waves finished reading the ring -> reuse it for the epilogue
@@ -730,6 +774,9 @@ static int launch_rowgemm_nt(const RowGemmArgs &a, int grid_y, hipStream_t s) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     (void)hipFuncSetAttribute((const void *)rowgemm_kernel<NT, EPI, C::NSTAGE, C::WAVES, 2>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (NT == 19)
+      (void)hipFuncSetAttribute((const void *)rowgemm_kernel<NT, EPI, C::NSTAGE, C::WAVES, 0, NT == 19>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
   });
   const int tiles = cdiv(a.m, 16);
   static const int env_wg = getenv("A3VT_RG_MAXWG") ? atoi(getenv("A3VT_RG_MAXWG")) : 0;  // developer override (experiments)
@@ -740,8 +787,14 @@ static int launch_rowgemm_nt(const RowGemmArgs &a, int grid_y, hipStream_t s) {
     A3VT_LAUNCH((rowgemm_kernel<NT, EPI, C::NSTAGE, C::WAVES, 2>), dim3(grid, grid_y), dim3(64 * C::WAVES), shmem, s, a);
   else if (a.bf16)
     A3VT_LAUNCH((rowgemm_kernel<NT, EPI, C::NSTAGE, C::WAVES, 1>), dim3(grid, grid_y), dim3(64 * C::WAVES), shmem, s, a);
-  else
-    A3VT_LAUNCH((rowgemm_kernel<NT, EPI, C::NSTAGE, C::WAVES, 0>), dim3(grid, grid_y), dim3(64 * C::WAVES), shmem, s, a);
+  else {
+    // the exact fp32 products of the full-width layers take their A operand straight into registers (ADIRECT)
+    static const bool via_lds = getenv("A3VT_DBG_RG_ADIRECT_OFF") != nullptr;   // developer switch: A through the LDS ring
+    if (NT == 19 && !via_lds)
+      A3VT_LAUNCH((rowgemm_kernel<NT, EPI, C::NSTAGE, C::WAVES, 0, NT == 19>), dim3(grid, grid_y), dim3(64 * C::WAVES), shmem, s, a);
+    else
+      A3VT_LAUNCH((rowgemm_kernel<NT, EPI, C::NSTAGE, C::WAVES, 0>), dim3(grid, grid_y), dim3(64 * C::WAVES), shmem, s, a);
+  }
   A3VT_CHECK_LAUNCH();
   return 0;
 }
