@@ -789,7 +789,11 @@ static int launch_rowgemm_nt(const RowGemmArgs &a, int grid_y, hipStream_t s) {
     A3VT_LAUNCH((rowgemm_kernel<NT, EPI, C::NSTAGE, C::WAVES, 1>), dim3(grid, grid_y), dim3(64 * C::WAVES), shmem, s, a);
   else {
     // the exact fp32 products of the full-width layers take their A operand straight into registers (ADIRECT)
-    static const bool via_lds = getenv("A3VT_DBG_RG_ADIRECT_OFF") != nullptr;   // developer switch: A through the LDS ring
+#ifdef A3VT_DBG_RG_ADIRECT_OFF   // variant build (tools/build_variants.sh adirect): A through the LDS ring everywhere
+    constexpr bool via_lds = true;
+#else
+    constexpr bool via_lds = false;
+#endif
     if (NT == 19 && !via_lds)
       A3VT_LAUNCH((rowgemm_kernel<NT, EPI, C::NSTAGE, C::WAVES, 0, NT == 19>), dim3(grid, grid_y), dim3(64 * C::WAVES), shmem, s, a);
     else
@@ -920,8 +924,9 @@ int launch_rowgemm(const RowGemmArgs &a, int epi, hipStream_t s) {
     set_error("rowgemm: k=%d ksplit=%d ldb=%d violate alignment rules", a.k, a.ksplit, a.ldb);
     return -1;
   }
-  static const bool old16 = getenv("A3VT_DBG_ROWGEMM16_OFF") != nullptr;   // developer switch: bf16 storage mode on rowgemm_kernel
-  if (!old16 && rowgemm16_ok(a, epi)) return launch_rowgemm16(a, epi, s);
+#ifndef A3VT_DBG_ROWGEMM16_OFF   // (variant build, tools/build_variants.sh adirect: the bf16 storage mode on rowgemm_kernel)
+  if (rowgemm16_ok(a, epi)) return launch_rowgemm16(a, epi, s);
+#endif
   switch (epi) {
     case EPI_PLAIN: return launch_rowgemm_epi<EPI_PLAIN>(a, s);
     case EPI_FWD_HIDDEN: return launch_rowgemm_epi<EPI_FWD_HIDDEN>(a, s);

@@ -22,6 +22,9 @@ elif [ "$1" = "nn" ]; then   # pruned nearest-neighbour search with its counters
   build NN_STATS -DA3VT_DBG_NN_STATS
 elif [ "$1" = "stamps" ]; then   # rowgemm with s_memrealtime stamps at its phase boundaries (tools/rowgemm_stamps.py)
   build RG_STAMPS -DA3VT_DBG_RG_STAMPS
+elif [ "$1" = "adirect" ]; then   # A/B builds for the round-3 product kernels (A3VT_LIB=$GRAFT_REPO_ROOT/gpurun_variants/...)
+  build RG_ADIRECT_OFF -DA3VT_DBG_RG_ADIRECT_OFF     # fp32 rowgemm with the A operand through the LDS ring
+  build ROWGEMM16_OFF -DA3VT_DBG_ROWGEMM16_OFF       # bf16 storage mode on rowgemm_kernel<..., 2> instead of rowgemm16
 elif [ "$1" = "stamps16" ]; then   # rowgemm16 (bf16 storage mode) with stamps at its phase boundaries (tools/rowgemm16_stamps.py)
   build R16_STAMPS -DA3VT_DBG_R16_STAMPS
   build R16_STAMPS_NOB -DA3VT_DBG_R16_STAMPS -DA3VT_DBG_R16_NOB   # ... without the weight loads of the prologue
