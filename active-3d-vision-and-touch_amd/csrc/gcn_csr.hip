@@ -349,14 +349,23 @@ int thin_num_slabs() { return kThinBlocks; }
 
 // Hybrid rows (the stack's channel-sliced path): columns [0, 4 xq_quads) of X come from the quad-major array xq
 // [m / n_vert][xq_quads][n_vert] float4 (the aggregation kernel's output), the rest from x (pre-offset, row stride ldx).
-__device__ __forceinline__ const float *hybrid_piece(const float *x, int ldx, const float *xq, int xq_quads, int n_vert,
-                                                     long long row, int kk) {
-  if (xq != nullptr && kk < xq_quads * 4) {
-    const long long bq = row / n_vert;
-    return xq + (((size_t)bq * xq_quads + (kk >> 2)) * n_vert + (size_t)(row - bq * n_vert)) * 4;
+// (mesh, vertex) of a row that advances by a fixed step: one 64-bit division at the start, then adds and one compare per step
+// (a 64-bit `row / n_vert` per row cost thin_bwd 10 us of its 167)
+struct MeshWalk {
+  int b, v, sb, sv, n;
+  __device__ MeshWalk(long long row0, long long step, int n_vert) {
+    n = n_vert > 0 ? n_vert : 1;
+    b = (int)(row0 / n);
+    v = (int)(row0 - (long long)b * n);
+    sb = (int)(step / n);
+    sv = (int)(step - (long long)sb * n);
   }
-  return x + row * ldx + kk;
-}
+  __device__ void next() {
+    b += sb;
+    v += sv;
+    if (v >= n) { v -= n; ++b; }
+  }
+};
 
 __global__ __launch_bounds__(256) void thin_fwd_kernel(const float *__restrict__ x, int ldx, int k,
                                                        const float *__restrict__ w, long long m,
@@ -372,13 +381,16 @@ __global__ __launch_bounds__(256) void thin_fwd_kernel(const float *__restrict__
 #pragma unroll
       for (int j = 0; j < 3; ++j) wr[p][t][j] = kk < k ? w[kk * 3 + j] : 0.f;
     }
-  for (long long row = (long long)blockIdx.x * 16 + grp; row < m; row += (long long)gridDim.x * 16) {
+  MeshWalk mw((long long)blockIdx.x * 16 + grp, (long long)gridDim.x * 16, n_vert);
+  for (long long row = (long long)blockIdx.x * 16 + grp; row < m; row += (long long)gridDim.x * 16, mw.next()) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    const float *xqr = xq ? xq + ((size_t)mw.b * xq_quads * n_vert + (size_t)mw.v) * 4 : nullptr;   // this row in quad plane 0
 #pragma unroll
     for (int p = 0; p < kThinPieces; ++p) {
       const int kk = (p * 16 + l16) * 4;
       if (kk < k) {
-        const f32x4 xv = *reinterpret_cast<const f32x4 *>(hybrid_piece(x, ldx, xq, xq_quads, n_vert, row, kk));
+        const float *src = (xq && kk < xq_quads * 4) ? xqr + (size_t)(kk >> 2) * n_vert * 4 : x + row * ldx + kk;
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(src);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           s0 += xv[t] * wr[p][t][0];
@@ -515,7 +527,8 @@ __global__ __launch_bounds__(256) void thin_bwd_kernel(const float *__restrict__
       }
     }
   float db0 = 0.f, db1 = 0.f, db2 = 0.f;
-  for (long long row = (long long)blockIdx.x * 16 + grp; row < m; row += (long long)gridDim.x * 16) {
+  MeshWalk mw((long long)blockIdx.x * 16 + grp, (long long)gridDim.x * 16, n_vert);
+  for (long long row = (long long)blockIdx.x * 16 + grp; row < m; row += (long long)gridDim.x * 16, mw.next()) {
     const f32x4 d = *reinterpret_cast<const f32x4 *>(dz3 + row * 4);
     if (l16 == 0) {
       db0 += du[row * 3 + 0];
@@ -524,13 +537,14 @@ __global__ __launch_bounds__(256) void thin_bwd_kernel(const float *__restrict__
     }
     float *gr = gprev + row * ldg;
     // quad-major copy of the aggregated-channel columns for csrq_kernel<1> (launch_csrq_bwd), when asked for
-    const long long bq = gq ? row / n_vert : 0;
-    float *gqr = gq ? gq + ((size_t)bq * nq * n_vert + (size_t)(row - bq * n_vert)) * 4 : nullptr;
+    float *gqr = gq ? gq + ((size_t)mw.b * nq * n_vert + (size_t)mw.v) * 4 : nullptr;
+    const float *xqr = xq ? xq + ((size_t)mw.b * xq_quads * n_vert + (size_t)mw.v) * 4 : nullptr;
 #pragma unroll
     for (int p = 0; p < kThinPieces; ++p) {
       const int kk = (p * 16 + l16) * 4;
       if (kk < k) {
-        const f32x4 xv = *reinterpret_cast<const f32x4 *>(hybrid_piece(x, ldx, xq, xq_quads, n_vert, row, kk));
+        const float *src = (xq && kk < xq_quads * 4) ? xqr + (size_t)(kk >> 2) * n_vert * 4 : x + row * ldx + kk;
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(src);
         f32x4 o;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
