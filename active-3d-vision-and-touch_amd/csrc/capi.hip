@@ -90,7 +90,7 @@ struct StackLayout {
 // switch back to the half-wave-per-vertex kernels (both paths give the same outputs).
 constexpr int kQuadCols = 160;   // quad-major columns of a hybrid layer output: the first column group of rowgemm's epilogue
 static bool use_csrq(int batch, int n_vert, int hidden, int cut_len, int gemm_bf16, int max_degree) {
-  if (gemm_bf16) return false;   // the bf16 operand / storage modes keep the half-wave kernels
+  if (gemm_bf16 == 1 || gemm_bf16 == 2) return false;   // the bf16 operand / storage modes keep the half-wave kernels (mode 3 stores fp32: as mode 0)
   // Rows longer than the eight index slots a thread keeps in registers fall back to per-lane CSR walks: on the fused
   // vision + touch graphs (mean degree 12-26, hub rows of ~1150) that made the step 108 ms where the half-wave kernels
   // take 64 — those graphs stay on the half-wave kernels.  (The caller passes the larger of the two maximum degrees of
@@ -107,7 +107,7 @@ static bool use_csrq(int batch, int n_vert, int hidden, int cut_len, int gemm_bf
 static inline size_t signq_stride(size_t m, int cut_len) { return align_up(m * (size_t)(pad4(cut_len) / 4), 256); }
 
 static StackLayout stack_layout(int batch, int n_vert, int in_features, int hidden, int num_layers, int cut_len,
-                                int need_backward) {
+                                int need_backward, int gemm_mode = 0) {
   StackLayout L{};
   const size_t m = (size_t)batch * n_vert;
   const int cpad = pad4(cut_len);
@@ -119,6 +119,7 @@ static StackLayout stack_layout(int batch, int n_vert, int in_features, int hidd
   };
   const int kmax = hidden > pad4(in_features) ? hidden : pad4(in_features);
   L.wt_stride = align_up((size_t)rowgemm_bt_rows(kmax) * pad16(kmax), 64);
+  if (gemm_mode == 3 && L.wt_stride < 3 * (size_t)kX3ImageFloats) L.wt_stride = 3 * (size_t)kX3ImageFloats;   // hi / mid / lo images (gcn_gemm3.hip)
   L.wt = take(L.wt_stride * (num_layers > 1 ? num_layers - 1 : 1));
   L.za = take(m * (cpad > 4 ? cpad : 4));
   L.z3 = take(2 * m * 4);
@@ -478,7 +479,7 @@ size_t a3vt_gcn_stack_scratch_bytes_mode(int batch, int n_vert, int in_features,
                                          int cut_len, int need_backward, int gemm_bf16) {
   if (gemm_bf16 == 2)
     return stack16_layout(batch, n_vert, in_features, hidden, num_layers, cut_len, need_backward).total * sizeof(float);
-  return a3vt_gcn_stack_scratch_bytes(batch, n_vert, in_features, hidden, num_layers, cut_len, need_backward);
+  return stack_layout(batch, n_vert, in_features, hidden, num_layers, cut_len, need_backward, gemm_bf16).total * sizeof(float);
 }
 
 int a3vt_gcn_stack_stash_bytes(int batch, int n_vert, int hidden, int num_layers, int cut_len, int gemm_bf16,
@@ -513,7 +514,7 @@ int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const 
                        max_degree, n_vert, batch, acts, masks, scratch, update, s);
   const float *zeros = zero_page();
   A3VT_CHECK_ARG(zeros != nullptr);
-  const StackLayout L = stack_layout(batch, n_vert, in_features, hidden, num_layers, cut_len, 0);
+  const StackLayout L = stack_layout(batch, n_vert, in_features, hidden, num_layers, cut_len, 0, gemm_bf16);
   const size_t m = (size_t)batch * n_vert;
   const int cpad = pad4(cut_len);
   const int mld = mask_ld(hidden, cut_len);
@@ -525,11 +526,31 @@ int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const 
     heavy = reinterpret_cast<int32_t *>(scratch + L.heavy);
     if (int rc = launch_csr_heavy_list(rowptr, n_vert, heavy, s)) return rc;
   }
+  // Gemm mode 3 ("fp32x3", gcn_gemm3.hip): the hidden-layer products whose shape the split-operand kernels take run there;
+  // everything else of the call (the first layer, narrow or short stacks) on the exact fp32 kernels.
+  const bool x3 = gemm_bf16 == 3 && rowgemm3_dims_ok((long long)m, hidden, hidden);
+  const int omode = gemm_bf16 == 1 ? 1 : 0;   // operand mode of the kernels shared with modes 0 / 1
   // transposed, zero-padded weight images of all hidden layers (one launch)
   const bool batched_images = num_layers - 1 <= kMaxImages;
+  if (x3) {   // layers 1 .. L-2 as three bf16 images each; layer 0 (K = in_features) keeps its fp32 image
+    for (int i0 = 1; i0 + 1 < num_layers; i0 += kMaxImages) {
+      WeightImages w3{};
+      const int cnt = num_layers - 1 - i0 < kMaxImages ? num_layers - 1 - i0 : kMaxImages;
+      for (int j = 0; j < cnt; ++j) {
+        w3.w[j] = weights[i0 + j];
+        w3.k[j] = hidden;
+      }
+      w3.dst = scratch + L.wt + L.wt_stride * i0;
+      w3.dst_stride = L.wt_stride;
+      w3.n = hidden;
+      w3.count = cnt;
+      w3.transpose = 1;
+      if (int rc = launch_weight_images3(w3, s)) return rc;
+    }
+  }
   if (batched_images && num_layers > 1) {
     WeightImages wi{};
-    for (int i = 0; i + 1 < num_layers; ++i) {
+    for (int i = 0; i + 1 < (x3 ? 2 : num_layers); ++i) {
       wi.w[i] = weights[i];
       wi.k[i] = i == 0 ? in_features : hidden;
       wi.rows[i] = rowgemm_bt_rows(hidden);
@@ -538,7 +559,7 @@ int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const 
     wi.dst = scratch + L.wt;
     wi.dst_stride = L.wt_stride;
     wi.n = hidden;
-    wi.count = num_layers - 1;
+    wi.count = x3 ? 1 : num_layers - 1;
     wi.transpose = 1;
     if (int rc = launch_weight_images(wi, rowgemm_bt_rows(hidden), pad16(ld_feats > hidden ? ld_feats : hidden), s)) return rc;
   }
@@ -561,7 +582,8 @@ int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const 
     const int k = i == 0 ? ld_feats : hidden;       // K walked by the kernel (pad columns of feats are zero)
     const int kin = i == 0 ? in_features : hidden;  // rows of W_i
     float *wt = scratch + L.wt + L.wt_stride * i;
-    if (!batched_images)
+    const bool l3 = x3 && i > 0;   // this layer's product on the split-operand kernel
+    if (!batched_images && !l3)
       if (int rc = launch_transpose_pad(weights[i], kin, hidden, wt, rowgemm_bt_rows(hidden), pad16(k), s)) return rc;
     float *y = acts ? acts + (size_t)i * m * hidden : scratch + L.ping[i & 1];
     RowGemmArgs g{};
@@ -589,7 +611,7 @@ int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const 
     g.maskb = mk;
     g.mld = mld;
     g.moff = cpad / 4;
-    g.bf16 = gemm_bf16 ? 1 : 0;
+    g.bf16 = l3 ? 3 : omode;
     if (quad) {   // raw columns [0, cpad) leave the product quad-major, for the channel-sliced aggregation;
       g.zq_nvert = n_vert;   // activated columns [cpad, 160) quad-major into the layer's output
       g.zq_quads = cpad / 4;
@@ -651,7 +673,7 @@ int a3vt_gcn_stack_bwd_acc(const float *feats, int ld_feats, int in_features, co
                        scratch, acc, s);
   const float *zeros = zero_page();
   A3VT_CHECK_ARG(zeros != nullptr);
-  const StackLayout L = stack_layout(batch, n_vert, in_features, hidden, num_layers, cut_len, 1);
+  const StackLayout L = stack_layout(batch, n_vert, in_features, hidden, num_layers, cut_len, 1, gemm_bf16);
   const size_t m = (size_t)batch * n_vert;
   const int cpad = pad4(cut_len);
   const int mld = mask_ld(hidden, cut_len);
@@ -691,12 +713,30 @@ int a3vt_gcn_stack_bwd_acc(const float *feats, int ld_feats, int in_features, co
     if (int rc = launch_slab_reduce_za(scratch + L.thin_db_slab, thin_num_slabs(), 3, 3, 3, grad_biases[last], acc, s)) return rc;
   }
 
+  const bool x3 = gemm_bf16 == 3 && rowgemm3_dims_ok((long long)m, hidden, hidden);   // as a3vt_gcn_stack_fwd
+  const int omode = gemm_bf16 == 1 ? 1 : 0;
   // zero-padded weight images (Bt = W_i for dX) of all hidden layers, one launch
   const bool batched_images = num_layers - 1 <= kMaxImages;
+  if (x3) {   // layers 1 .. L-2: three bf16 images each (layer 0's dX has the plain epilogue: exact kernels, fp32 image)
+    for (int i0 = 1; i0 < last; i0 += kMaxImages) {
+      WeightImages w3{};
+      const int cnt = last - i0 < kMaxImages ? last - i0 : kMaxImages;
+      for (int j = 0; j < cnt; ++j) {
+        w3.w[j] = weights[i0 + j];
+        w3.k[j] = hidden;
+      }
+      w3.dst = scratch + L.wt + L.wt_stride * i0;
+      w3.dst_stride = L.wt_stride;
+      w3.n = hidden;
+      w3.count = cnt;
+      w3.transpose = 0;
+      if (int rc = launch_weight_images3(w3, s)) return rc;
+    }
+  }
   if (batched_images && num_layers > 1) {
     WeightImages wi{};
     int max_rows = 0;
-    for (int i = 0; i < last; ++i) {
+    for (int i = 0; i < (x3 ? 1 : last); ++i) {
       wi.w[i] = weights[i];
       wi.k[i] = i == 0 ? in_features : hidden;
       wi.rows[i] = rowgemm_bt_rows(i == 0 ? ld_feats : hidden);
@@ -706,7 +746,7 @@ int a3vt_gcn_stack_bwd_acc(const float *feats, int ld_feats, int in_features, co
     wi.dst = scratch + L.wt;
     wi.dst_stride = L.wt_stride;
     wi.n = hidden;
-    wi.count = last;
+    wi.count = x3 ? 1 : last;
     wi.transpose = 0;
     if (int rc = launch_weight_images(wi, max_rows, pad16(hidden), s)) return rc;
   }
@@ -781,7 +821,7 @@ int a3vt_gcn_stack_bwd_acc(const float *feats, int ld_feats, int in_features, co
       d.m = (int)m;
       d.k_in = w;
       d.n_out = hidden;
-      d.bf16 = gemm_bf16 ? 1 : 0;
+      d.bf16 = omode;
       {
         ProfScope ps(PROF_DW, s);
         if (int rc = launch_dw(d, s)) return rc;
@@ -794,7 +834,8 @@ int a3vt_gcn_stack_bwd_acc(const float *feats, int ld_feats, int in_features, co
     // dX_i = dZ W_i^T  (masked by the ReLU of layer i-1, whose output is X_i)
     const int n_store = i == 0 ? ld_feats : hidden;
     float *wp = scratch + L.wt + L.wt_stride * i;
-    if (!batched_images)
+    const bool l3 = x3 && i > 0;
+    if (!batched_images && !l3)
       if (int rc = launch_copy_pad(weights[i], kin, hidden, wp, rowgemm_bt_rows(n_store), pad16(hidden), s)) return rc;
     RowGemmArgs r{};
     r.a0 = dza;
@@ -812,7 +853,7 @@ int a3vt_gcn_stack_bwd_acc(const float *feats, int ld_feats, int in_features, co
     r.m = (int)m;
     r.k = hidden;
     r.n_store = n_store;
-    r.bf16 = gemm_bf16 ? 1 : 0;
+    r.bf16 = l3 ? 3 : omode;
     if (i == 0) {
       r.c = grad_feats;
       r.ldc = ld_feats;
@@ -924,7 +965,7 @@ int a3vt_gcn_layer_fwd(const float *x, int ld_x, int in_features, const float *w
   g.ldc2 = cpad > 4 ? cpad : 4;
   g.csplit = cut_len;
   g.no_relu = relu ? 0 : 1;
-  g.bf16 = gemm_bf16 ? 1 : 0;
+  g.bf16 = gemm_bf16 == 1 ? 1 : 0;   // (mode 3 is a stack mode: a lone layer runs exact)
   if (int rc = launch_rowgemm(g, EPI_FWD_HIDDEN, s)) return rc;
   if (cut_len > 0) {
     int32_t *heavy = nullptr;
@@ -995,7 +1036,7 @@ int a3vt_gcn_layer_bwd(const float *x, int ld_x, int in_features, const float *w
     d.m = (int)m;
     d.k_in = w;
     d.n_out = out_features;
-    d.bf16 = gemm_bf16 ? 1 : 0;
+    d.bf16 = gemm_bf16 == 1 ? 1 : 0;
     if (int rc = launch_dw(d, s)) return rc;
     if (int rc = launch_slab_reduce(scratch + L.dw_slab, dw_num_slabs(out_features), (size_t)w * out_features,
                                     (size_t)w * out_features, grad_weight + (size_t)c0 * out_features, s))
@@ -1017,7 +1058,7 @@ int a3vt_gcn_layer_bwd(const float *x, int ld_x, int in_features, const float *w
   r.m = (int)m;
   r.k = npad;
   r.n_store = ld_x;
-  r.bf16 = gemm_bf16 ? 1 : 0;
+  r.bf16 = gemm_bf16 == 1 ? 1 : 0;
   r.c = grad_x;
   r.ldc = ld_x;
   return launch_rowgemm(r, EPI_PLAIN, s);
@@ -1047,7 +1088,7 @@ int a3vt_rowgemm(const float *a, int lda, int m, int k, const float *wt, int n_o
   g.n_store = n_out;
   g.c = c;
   g.ldc = ldc;
-  g.bf16 = gemm_bf16 ? 1 : 0;
+  g.bf16 = gemm_bf16 == 1 ? 1 : 0;   // (mode 3 is a stack mode: a lone layer runs exact)
   return launch_rowgemm(g, EPI_PLAIN, static_cast<hipStream_t>(stream));
 }
 
@@ -1240,6 +1281,11 @@ int a3vt_profile_read(double *total_ms, int *count) {
   }
   g_prof.used = 0;
   return 0;
+}
+
+int a3vt_split3_bf16(const float *x, size_t n, uint16_t *hi, uint16_t *mid, uint16_t *lo, void *stream) {
+  A3VT_CHECK_ARG(n == 0 || (x && hi && mid && lo));
+  return launch_split3(x, n, hi, mid, lo, static_cast<hipStream_t>(stream));
 }
 
 int a3vt_check_finite(const float *data, size_t n, int32_t *flag, void *stream) {

@@ -902,6 +902,7 @@ bool rowgemm_quad_major_ok(int m, int n_store, int cpad) {
 }
 
 int launch_rowgemm(const RowGemmArgs &a, int epi, hipStream_t s) {
+  if (a.bf16 == 3) return launch_rowgemm3(a, epi, s);   // split-operand mode: its own kernel and checks (gcn_gemm3.hip)
   if (a.a0q_nvert > 0 && (a.bf16 == 2 || a.m % a.a0q_nvert != 0 || a.ksplit != a.a0q_quads * 4)) {
     set_error("rowgemm: quad-major a0 needs ksplit = 4 * quads (ksplit=%d quads=%d) and whole meshes (m=%d)", a.ksplit, a.a0q_quads, a.m);
     return -1;

@@ -1,0 +1,459 @@
+// gcn_gemm3.hip — gemm mode 3 ("fp32x3"): the fp32 per-vertex products of the hidden layers on the bf16 matrix pipe.
+//
+//   C[M][n] = A[M][K] * Bt[n][K]^T,  A / C fp32 in HBM exactly as in mode 0,  288 < K <= 320, 288 < n <= 304
+//   (torch.matmul(features, W) of GCN_layer.forward, vision/model.py:352, and autograd's dX = dZ W^T)
+//
+// Every fp32 operand x is cut into three bf16 pieces with  x == hi + mid + lo  bit for bit (split3 below), and the
+// product is formed from the six partial products down to 2^-16 of the largest one,
+//     a b ~= ah bh + ah bm + am bh + ah bl + al bh + am bm        (dropped: am bl, al bm, al bl <= 2^-23 |a b|),
+// each a v_mfma_f32_16x16x32_bf16 into the same fp32 accumulator: 6 x 16 cycles per 16 x 16 x 32 block where the exact
+// v_mfma_f32_16x16x4_f32 path takes 8 x 32 — 3/8 of the matrix-pipe cycles, at fp32-level error (the products of bf16
+// pieces are exact in fp32; what remains is the accumulation, rounded once per 32 k instead of once per k; measured
+// against the fp64 oracle in tests/test_gpu_fp32x3.py and tabulated in DESIGN.md).  NOT bit-identical to mode 0, which
+// stays the default and the parity mode.
+//
+// Kernel shape (rowgemm3_kernel): the round structure of rowgemm_kernel<19, EPI, ..., ADIRECT> (gcn_gemm.hip) —
+// persistent 8-wave workgroups, 16-row tiles dealt evenly, two tiles x 19 column tiles of accumulators per wave and round.
+//   A : each lane loads the 32 bytes that are ITS operand elements of a 32-wide k chunk (row l16, k = 8 q .. 8 q + 7)
+//       straight into registers, two global_load_dwordx4 (row-major rows or the quad-major planes of the hybrid layout),
+//       and splits them once (11 VALU per pair of elements): three 16-byte MFMA operands per tile.
+//   Bt: pre-split ONCE per stack call into three bf16 images [320][320] (weight_images3_kernel); a chunk stages
+//       3 x 19 pieces of 16 rows x 64 bytes through a 2-stage LDS ring with LDS-DMA (global_load_lds_dwordx4), bank
+//       swizzled as in rowgemm_kernel; a fragment read is one ds_read_b128 = the operand, three per column tile serve
+//       twelve MFMAs.
+//   one s_barrier per chunk (25 per launch at M = 163,968 where the fp32 kernel has 47.5), the chunk after next is never
+//   needed: a chunk is 228 MFMAs = 3,650 matrix-pipe cycles per wave.
+// Epilogues: those of rowgemm_kernel, value for value (forward: raw aggregated columns / ReLU'd pass-through columns /
+// sign bytes, row-major or the quad-major hybrid layout; backward: ReLU-sign multiply from the bytes DMA'd into LDS).
+#include <type_traits>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace a3vt {
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+constexpr int kNT = 19;                 // column tiles of 16
+constexpr int kWaves = 8;
+constexpr int kMT = 2;                  // row tiles per wave and round
+constexpr int kPieces = 3 * kNT;        // LDS-DMA pieces (1 KiB: 16 Bt rows x 64 B) per chunk: three images x 19 tiles
+constexpr int kStage = kPieces * 256;   // floats per ring stage (58,368 B)
+constexpr int kStages = 2;
+constexpr int kMSlot = 1024;            // floats (4 KiB) of ReLU-sign bytes per wave
+constexpr int kBPer = (kPieces + kWaves - 1) / kWaves;   // Bt pieces per wave and chunk (8; waves 1-7 carry 7)
+constexpr size_t kLdsBytes = (size_t)(kStages * kStage + kWaves * kMSlot) * sizeof(float);   // 149,504 B
+static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
+
+__device__ __forceinline__ void glds16(const float *gsrc, float *lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                   (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma(f32x4 a, f32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ unsigned fbits(float v) { return __builtin_bit_cast(unsigned, v); }
+__device__ __forceinline__ float bfloat(unsigned v) { return __builtin_bit_cast(float, v); }
+__device__ __forceinline__ unsigned cvt_pk(float a, float b) {   // v_cvt_pk_bf16_f32: round to nearest even, a in the low half
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2));
+}
+
+// The exact three-way split of two floats (a -> low halves, b -> high halves of the packed words):
+//   hi  = the upper 16 bits of x (truncation: never overflows, x - hi is exact and has the sign of x),
+//   mid = RNE_bf16(x - hi), lo = (x - hi) - mid  — exact again, and lo has at most 8 significant bits, so it IS a bf16.
+// hi + mid + lo == x for every finite x whose lowest set bit is >= 2^-133 (the bf16 subnormal grid; all normal floats
+// down to 2^-110 qualify); below that the difference is < 2^-133.  11 VALU instructions per pair.
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned &h, unsigned &m, unsigned &l) {
+  const unsigned ua = fbits(a), ub = fbits(b);
+  h = __builtin_amdgcn_perm(ub, ua, 0x07060302u);            // (ua >> 16) | (ub & 0xffff0000)
+  const float ra = a - bfloat(ua & 0xffff0000u), rb = b - bfloat(ub & 0xffff0000u);
+  m = cvt_pk(ra, rb);
+  const float sa = ra - bfloat(m << 16), sb = rb - bfloat(m & 0xffff0000u);
+  l = cvt_pk(sa, sb);
+}
+struct Pieces {
+  f32x4 h, m, l;   // 8 bf16 each, element j = k-offset j of the lane's 8 operand elements
+};
+__device__ __forceinline__ Pieces split3_x8(f32x4 x0, f32x4 x1) {
+  unsigned h[4], m[4], l[4];
+  split3_pair(x0[0], x0[1], h[0], m[0], l[0]);
+  split3_pair(x0[2], x0[3], h[1], m[1], l[1]);
+  split3_pair(x1[0], x1[1], h[2], m[2], l[2]);
+  split3_pair(x1[2], x1[3], h[3], m[3], l[3]);
+  return Pieces{__builtin_bit_cast(f32x4, (u32x4){h[0], h[1], h[2], h[3]}), __builtin_bit_cast(f32x4, (u32x4){m[0], m[1], m[2], m[3]}),
+                __builtin_bit_cast(f32x4, (u32x4){l[0], l[1], l[2], l[3]})};
+}
+
+template <int EPI>
+__global__ __launch_bounds__(64 * kWaves, 2) void rowgemm3_kernel(RowGemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l16 = lane & 15, q = lane >> 4;
+  const int kpiece = ((lane & 3) ^ ((lane >> 3) & 2)) * 4;   // DMA side of the bank swizzle (rowgemm_kernel), 4-byte units
+  const int qs = q ^ ((l16 >> 1) & 2);                       // reader side
+  const int nchunks = (p.k + 31) >> 5;
+
+  // 16-row tiles, dealt evenly to the workgroups
+  const int tiles = (p.m + 15) >> 4;
+  const int tbase = tiles / gridDim.x, trem = tiles % gridDim.x;
+  const int t0 = blockIdx.x * tbase + ((int)blockIdx.x < trem ? blockIdx.x : trem);
+  const int t1 = t0 + tbase + ((int)blockIdx.x < trem ? 1 : 0);
+
+  // Bt pieces of this wave: piece pc = wave + 8 j = (image pc / 19, column tile pc % 19) — a wave-uniform offset — plus the
+  // per-lane part of the source address: row (lane >> 2) of the tile, 16-byte k-quad kpiece of the chunk's 64 bytes.
+  const int blane = (lane >> 2) * kX3ImageLd + kpiece;
+  const int nbp = (kPieces - wave + kWaves - 1) / kWaves;   // wave-uniform: 8 for wave 0, 7 for the others
+
+  for (int tb = t0; tb < t1; tb += kMT * kWaves) {
+    // tiles of this round for this wave: two each when the round is full, an even split otherwise
+    const int cnt = t1 - tb < kMT * kWaves ? t1 - tb : kMT * kWaves;
+    const int base = cnt / kWaves, extra = cnt % kWaves;
+    const int nm = base + (wave < extra ? 1 : 0);   // 0..2, wave-uniform
+    const int first = tb + wave * base + (wave < extra ? wave : extra);
+    const bool active = nm > 0;
+    const int row0 = first * 16;
+
+    // this lane's A rows (ragged tail: duplicate the last row, never stored), as float offsets from a0 / a1
+    unsigned a0off[kMT], a1off[kMT];
+    const unsigned a0mul = p.a0q_nvert > 0 ? (unsigned)p.a0q_nvert : 1u;   // quad-major a0: k -> k * N floats past the row's base
+#pragma unroll
+    for (int i = 0; i < kMT; ++i) {
+      int r = row0 + i * 16 + l16;
+      r = r < p.m ? r : p.m - 1;
+      a0off[i] = (unsigned)r * (unsigned)p.lda0;
+      if (p.a0q_nvert > 0) {
+        const int bq = r / p.a0q_nvert;
+        a0off[i] = ((unsigned)bq * (unsigned)(p.a0q_quads * p.a0q_nvert) + (unsigned)(r - bq * p.a0q_nvert)) * 4u;
+      }
+      a1off[i] = (unsigned)r * (unsigned)p.lda1;
+    }
+
+    f32x4 acc[kMT][kNT];
+#pragma unroll
+    for (int i = 0; i < kMT; ++i)
+#pragma unroll
+      for (int j = 0; j < kNT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // The fp32 operand elements of the chunk in flight.  Past the last k (K = 300 of a 320-wide chunk row) the lane re-reads
+    // the row's last quad: those elements meet zero rows of the weight images.  An absent second tile (partial round) reads
+    // the clamped row and is never multiplied or stored.
+    f32x4 raw[kMT][2];
+    auto issue_a = [&](int chunk) {
+#pragma unroll
+      for (int i = 0; i < kMT; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          int kk = chunk * 32 + q * 8 + h * 4;
+          kk = kk < p.k ? kk : p.k - 4;
+          const float *src = kk < p.ksplit ? p.a0 + (size_t)(a0off[i] + (unsigned)kk * a0mul) : p.a1 + (size_t)(a1off[i] + (unsigned)kk);
+          raw[i][h] = *reinterpret_cast<const f32x4 *>(src);
+        }
+    };
+    auto issue_b = [&](int chunk, int buf, int j) {
+      if (j >= nbp) return;   // wave-uniform
+      const int pc = wave + kWaves * j, img = pc / kNT, tile = pc - img * kNT;   // scalar
+      glds16(p.bt + ((size_t)img * kX3ImageFloats + (size_t)tile * (16 * kX3ImageLd) + chunk * 16) + blane, lds + buf * kStage + pc * 256);
+    };
+
+    if (EPI == EPI_DX_MASK) {
+      // this round's ReLU-sign bytes (16 nm rows x mld contiguous bytes) ride along with the first chunk
+      float *ms = lds + kStages * kStage + wave * kMSlot;
+      const uint8_t *src0 = p.maskb + (size_t)row0 * p.mld;
+      const int nbytes = 16 * nm * p.mld;
+      for (int o = 0; o < 32 * p.mld; o += 1024) {
+        const int b = o + lane * 16;
+        const void *src = b < nbytes ? (const void *)(src0 + b) : (const void *)p.zeros;
+        glds16(reinterpret_cast<const float *>(src), ms + o / 4);
+      }
+    }
+    issue_a(0);
+#pragma unroll
+    for (int j = 0; j < kBPer; ++j) issue_b(0, 0, j);
+
+    // One chunk for a wave that owns NM (1 or 2, compile-time) tiles this round.
+    auto chunk_step = [&](auto nmc, int t) __attribute__((always_inline)) {
+      constexpr int NM = decltype(nmc)::value;
+      const int buf = t & 1;
+      const bool prefetch = t + 1 < nchunks;
+      Pieces ap[NM];
+#pragma unroll
+      for (int i = 0; i < NM; ++i) ap[i] = split3_x8(raw[i][0], raw[i][1]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (prefetch) issue_a(t + 1);     // HBM-streamed: as early as the registers are free
+      __builtin_amdgcn_sched_barrier(0);
+      const float *sB = lds + buf * kStage + l16 * 16 + qs * 4;
+      // Fragments of column tile j: lo first, then mid, then hi; each register set is refilled for tile j + 1 as soon as
+      // its last MFMA of tile j has issued, so the LDS latency hides under the rest of the tile (no second register set).
+      f32x4 bl = *reinterpret_cast<const f32x4 *>(sB + 2 * kNT * 256);
+      f32x4 bm = *reinterpret_cast<const f32x4 *>(sB + kNT * 256);
+      f32x4 bh = *reinterpret_cast<const f32x4 *>(sB);
+#pragma unroll
+      for (int j = 0; j < kNT; ++j) {
+#pragma unroll
+        for (int i = 0; i < NM; ++i) acc[i][j] = mfma(ap[i].h, bl, acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 1 < kNT) bl = *reinterpret_cast<const f32x4 *>(sB + (2 * kNT + j + 1) * 256);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+          acc[i][j] = mfma(ap[i].m, bm, acc[i][j]);
+          acc[i][j] = mfma(ap[i].h, bm, acc[i][j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 1 < kNT) bm = *reinterpret_cast<const f32x4 *>(sB + (kNT + j + 1) * 256);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+          acc[i][j] = mfma(ap[i].l, bh, acc[i][j]);
+          acc[i][j] = mfma(ap[i].m, bh, acc[i][j]);
+          acc[i][j] = mfma(ap[i].h, bh, acc[i][j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 1 < kNT) bh = *reinterpret_cast<const f32x4 *>(sB + (j + 1) * 256);
+        if ((j & 1) && (j >> 1) < kBPer) {   // the next chunk's Bt pieces, one per two column tiles
+          if (prefetch) issue_b(t + 1, buf ^ 1, j >> 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    // (one loop per tile count: with both bodies inside one loop the register allocator spills the accumulators)
+    if (nm == 2) {
+      for (int t = 0; t < nchunks; ++t) {
+        wait_vm0();                       // chunk t (this wave's share) has landed
+        __builtin_amdgcn_s_barrier();     // ... everyone's has; everyone is done with chunk t - 1's stage
+        chunk_step(std::integral_constant<int, 2>{}, t);
+      }
+    } else if (nm == 1) {
+      for (int t = 0; t < nchunks; ++t) {
+        wait_vm0();
+        __builtin_amdgcn_s_barrier();
+        chunk_step(std::integral_constant<int, 1>{}, t);
+      }
+    } else {                              // idle wave of a partial round: it still carries its share of the Bt staging
+      for (int t = 0; t < nchunks; ++t) {
+        wait_vm0();
+        __builtin_amdgcn_s_barrier();
+        if (t + 1 < nchunks) {
+#pragma unroll
+          for (int j = 0; j < kBPer; ++j) issue_b(t + 1, (t & 1) ^ 1, j);
+        }
+      }
+    }
+    wait_lgkm0();
+    __builtin_amdgcn_s_barrier();   // all waves finished reading the ring -> reuse it for the epilogue
+
+    // ---- epilogue (rowgemm_kernel's, fp32 rows; launch_rowgemm3 guarantees ldc % 4 == 0, n_store % 4 == 0 and, for the
+    // forward without the quad-major side output, ldc2 % 4 == 0: every column quad leaves with one 16-byte store)
+    if (active) {
+      float *ep = lds + wave * ((kStages * kStage) / kWaves);
+      constexpr int G0 = (kNT + 1) / 2;
+      static_assert(16 * (G0 * 16 + 4) <= (kStages * kStage) / kWaves, "epilogue slice too small");
+      uint8_t *mslot = reinterpret_cast<uint8_t *>(lds + kStages * kStage + wave * kMSlot);
+      const bool mask_rows = EPI == EPI_FWD_HIDDEN && p.maskb != nullptr && 32 * p.mld <= 4 * kMSlot;
+      const bool zq_mode = p.zq_nvert > 0;
+#pragma unroll
+      for (int i = 0; i < kMT; ++i) {
+        if (i >= nm) continue;
+#pragma unroll
+        for (int grp = 0; grp < 2; ++grp) {
+          const int j0 = grp == 0 ? 0 : G0;
+          const int tiles_g = grp == 0 ? G0 : kNT - G0;
+          const int ncols = tiles_g * 16, stride = ncols + 4, f4row = ncols / 4;
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int jj = 0; jj < G0; ++jj) {
+            if (jj < tiles_g) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) ep[(q * 4 + r) * stride + jj * 16 + l16] = acc[i][j0 + jj][r];
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+          int qlo = 0;
+          if (zq_mode && grp == 0) {
+            // quad-major side output: the first zq_quads column quads leave as 16 consecutive rows x 16 B per quad
+            const int nqz = p.zq_quads;
+            const int rl = lane & 15;
+            const int row = row0 + i * 16 + rl;
+            const int bq = row / p.zq_nvert;
+            float *qbase = p.c2 + ((size_t)bq * nqz * p.zq_nvert + (size_t)(row - bq * p.zq_nvert)) * 4;
+            for (int c4 = lane >> 4; c4 < nqz; c4 += 4) {
+              const f32x4 v = *reinterpret_cast<const f32x4 *>(ep + rl * stride + c4 * 4);
+              if (row < p.m) *reinterpret_cast<f32x4 *>(qbase + (size_t)c4 * p.zq_nvert * 4) = v;
+            }
+            qlo = nqz;
+            if (EPI == EPI_FWD_HIDDEN && p.yq_quads > nqz) {
+              // the pass-through columns [4 Q, 4 yq_quads) of the hybrid activations: ReLU, sign bits, row-fastest stores
+              float *ybase = p.yq + ((size_t)bq * p.yq_quads * p.zq_nvert + (size_t)(row - bq * p.zq_nvert)) * 4;
+              for (int c4 = nqz + (lane >> 4); c4 < p.yq_quads; c4 += 4) {
+                f32x4 v = *reinterpret_cast<const f32x4 *>(ep + rl * stride + c4 * 4);
+                unsigned bits = 0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                  bits |= (v[t] > 0.f ? 1u : 0u) << t;
+                  v[t] = (v[t] > 0.f || p.no_relu) ? v[t] : 0.f;
+                }
+                if (row >= p.m) continue;
+                if (p.maskb) {
+                  if (mask_rows) mslot[(i * 16 + rl) * p.mld + p.moff + c4] = (uint8_t)bits;
+                  else p.maskb[(size_t)row * p.mld + p.moff + c4] = (uint8_t)bits;
+                }
+                *reinterpret_cast<f32x4 *>(ybase + (size_t)c4 * p.zq_nvert * 4) = v;
+              }
+              qlo = p.yq_quads;
+            }
+          }
+          const int wq = f4row - qlo, nf4 = 16 * wq;
+          for (int f = lane; f < nf4; f += 64) {
+            const int rl = f / wq, c4 = qlo + (f - rl * wq);
+            const int row = row0 + i * 16 + rl;
+            const int col = j0 * 16 + c4 * 4;
+            if (row >= p.m || col >= p.n_store) continue;
+            f32x4 v = *reinterpret_cast<const f32x4 *>(ep + rl * stride + c4 * 4);
+            if (EPI == EPI_FWD_HIDDEN) {
+              if (p.maskb && col + 3 >= p.csplit) {   // ReLU sign of the pass-through channels, 1 byte per 4 columns
+                unsigned bits = 0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) bits |= ((col + t >= p.csplit && v[t] > 0.f) ? 1u : 0u) << t;
+                if (mask_rows) mslot[(i * 16 + rl) * p.mld + p.moff + (col >> 2)] = (uint8_t)bits;
+                else p.maskb[(size_t)row * p.mld + p.moff + (col >> 2)] = (uint8_t)bits;
+              }
+              if (!zq_mode && col + 3 < p.csplit) {   // aggregated channels: raw Z for the neighbour gather
+                *reinterpret_cast<f32x4 *>(p.c2 + (size_t)row * p.ldc2 + col) = v;
+              } else {
+                // (the quad that straddles the cut goes to BOTH outputs whole, as in rowgemm_kernel)
+                if (!zq_mode && col < p.csplit) *reinterpret_cast<f32x4 *>(p.c2 + (size_t)row * p.ldc2 + col) = v;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = (v[t] > 0.f || p.no_relu) ? v[t] : 0.f;
+                *reinterpret_cast<f32x4 *>(p.c + (size_t)row * p.ldc + col) = v;
+              }
+            } else {   // EPI_DX_MASK: gradient through the ReLU of the producing layer (sign bytes from LDS)
+              const int ur = i * 16 + rl;
+              const unsigned ba = mslot[ur * p.mld + (col >> 2)];
+              const unsigned bb = mslot[ur * p.mld + p.moff + (col >> 2)];
+#pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                const unsigned bit = ((col + t < p.csplit ? ba : bb) >> t) & 1u;
+                v[t] = bit ? v[t] : 0.f;
+              }
+              *reinterpret_cast<f32x4 *>(p.c + (size_t)row * p.ldc + col) = v;
+            }
+          }
+        }
+      }
+      if (mask_rows) {   // sign bytes of this wave's 16 nm rows: one contiguous block, 16 bytes per lane
+        wait_lgkm0();
+        __builtin_amdgcn_wave_barrier();
+        const int nbytes = 16 * nm * p.mld;
+        uint8_t *dstm = p.maskb + (size_t)row0 * p.mld;
+        for (int o = lane * 16; o < nbytes; o += 1024)
+          *reinterpret_cast<f32x4 *>(dstm + o) = *reinterpret_cast<const f32x4 *>(mslot + o);
+      }
+    }
+    wait_lgkm0();
+    __builtin_amdgcn_s_barrier();   // epilogue slices are free again before the next round's DMA
+  }
+}
+
+// The three bf16 images of up to kMaxImages weight matrices in one launch (blockIdx.z = layer): image p of layer l is
+// [kX3ImageRows][2 kX3ImageLd] bf16 at dst + l * dst_stride + p * kX3ImageFloats (floats), zero padded;
+// transpose = 1: row n, column k = W[k][n] (forward operand Bt = W^T), transpose = 0: row r, column c = W[r][c] (dX).
+__global__ void weight_images3_kernel(WeightImages w) {
+  const int l = blockIdx.z;
+  const float *src = w.w[l];
+  unsigned short *dst = reinterpret_cast<unsigned short *>(w.dst + (size_t)l * w.dst_stride);
+  const int k = w.k[l], n = w.n;
+  const int ld = 2 * kX3ImageLd, total = kX3ImageRows * ld;
+  const int tid = threadIdx.y * 32 + threadIdx.x;
+  const int nblk = gridDim.x * gridDim.y, blk = blockIdx.y * gridDim.x + blockIdx.x;
+  for (int idx = blk * 256 + tid; idx < total; idx += nblk * 256) {
+    const int r = idx / ld, c = idx - r * ld;
+    float v = 0.f;
+    if (w.transpose) {
+      if (c < k && r < n) v = src[(size_t)c * n + r];
+    } else {
+      if (r < k && c < n) v = src[(size_t)r * n + c];
+    }
+    unsigned h, m, lo;
+    split3_pair(v, 0.f, h, m, lo);
+    dst[idx] = (unsigned short)(h & 0xffffu);
+    dst[idx + 2 * kX3ImageFloats] = (unsigned short)(m & 0xffffu);
+    dst[idx + 4 * kX3ImageFloats] = (unsigned short)(lo & 0xffffu);
+  }
+}
+
+__global__ void split3_kernel(const float *__restrict__ x, size_t n, unsigned short *__restrict__ hi,
+                              unsigned short *__restrict__ mid, unsigned short *__restrict__ lo) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned h, m, l;
+  split3_pair(x[i], 0.f, h, m, l);
+  hi[i] = (unsigned short)(h & 0xffffu);
+  mid[i] = (unsigned short)(m & 0xffffu);
+  lo[i] = (unsigned short)(l & 0xffffu);
+}
+
+}  // namespace
+
+int launch_weight_images3(const WeightImages &w, hipStream_t s) {
+  A3VT_LAUNCH(weight_images3_kernel, dim3(10, 10, w.count), dim3(32, 8), 0, s, w);
+  A3VT_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_split3(const float *x, size_t n, unsigned short *hi, unsigned short *mid, unsigned short *lo, hipStream_t s) {
+  if (n == 0) return 0;
+  A3VT_LAUNCH(split3_kernel, dim3(cdiv((long long)n, 256)), dim3(256), 0, s, x, n, hi, mid, lo);
+  A3VT_CHECK_LAUNCH();
+  return 0;
+}
+
+// Shapes the split-operand kernel takes: the hidden layers (K and n in (288, 320] / (288, 304]) with enough rows to fill
+// the chip; everything else of a mode-3 stack runs the exact fp32 kernels.
+bool rowgemm3_dims_ok(long long m, int k, int n_store) {
+  return k > 288 && k <= 320 && k % 4 == 0 && n_store > 288 && n_store <= 304 && n_store % 4 == 0 && m >= 96 * 128 &&
+         m < (1ll << 31) - 64;
+}
+
+bool rowgemm3_ok(const RowGemmArgs &a, int epi) {
+  if (a.bf16 != 3 || (epi != EPI_FWD_HIDDEN && epi != EPI_DX_MASK)) return false;
+  if (!rowgemm3_dims_ok(a.m, a.k, a.n_store)) return false;
+  if (a.lda0 % 4 != 0 || a.lda1 % 4 != 0 || a.ksplit % 4 != 0 || a.ldc % 4 != 0 || a.csplit > a.n_store) return false;
+  if (a.a0q_nvert > 0 && (a.m % a.a0q_nvert != 0 || a.ksplit != a.a0q_quads * 4)) return false;
+  if (a.zq_nvert > 0 && (a.c2 == nullptr || a.m % a.zq_nvert != 0 || a.zq_quads * 4 != pad4(a.csplit) || a.zq_quads * 4 > 160)) return false;
+  if (a.yq_quads > 0 && (a.zq_nvert <= 0 || a.yq == nullptr || epi != EPI_FWD_HIDDEN || a.yq_quads < a.zq_quads || a.yq_quads * 4 > 160)) return false;
+  if (epi == EPI_FWD_HIDDEN && a.zq_nvert == 0 && a.csplit > 0 && (a.c2 == nullptr || a.ldc2 % 4 != 0 || pad4(a.csplit) > a.ldc2)) return false;
+  if (epi == EPI_DX_MASK && (a.maskb == nullptr || 32 * a.mld > 4 * kMSlot)) return false;
+  return true;
+}
+
+int launch_rowgemm3(const RowGemmArgs &a, int epi, hipStream_t s) {
+  if (!rowgemm3_ok(a, epi)) {
+    set_error("rowgemm3: unsupported call (m=%d k=%d n=%d epi=%d mode=%d)", a.m, a.k, a.n_store, epi, a.bf16);
+    return -1;
+  }
+  static OncePerDevice once;
+  once.run([] {
+    (void)hipFuncSetAttribute((const void *)rowgemm3_kernel<EPI_FWD_HIDDEN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+    (void)hipFuncSetAttribute((const void *)rowgemm3_kernel<EPI_DX_MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
+  });
+  const int tiles = cdiv(a.m, 16);
+  const int grid = cdiv(tiles, kWaves) < 256 ? cdiv(tiles, kWaves) : 256;
+  if (epi == EPI_FWD_HIDDEN)
+    A3VT_LAUNCH((rowgemm3_kernel<EPI_FWD_HIDDEN>), dim3(grid), dim3(64 * kWaves), kLdsBytes, s, a);
+  else
+    A3VT_LAUNCH((rowgemm3_kernel<EPI_DX_MASK>), dim3(grid), dim3(64 * kWaves), kLdsBytes, s, a);
+  A3VT_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace a3vt

@@ -31,6 +31,9 @@ struct RowGemmArgs {
   // 2: bf16 STORAGE — a0 / a1 / bt point at bf16 rows (lda*, ldb, k, ksplit still in 4-byte units = pairs of bf16),
   //    v_mfma_f32_16x16x32_bf16; EPI_FWD_HIDDEN / EPI_DX_MASK write bf16 (c, c2 as bf16 with ldc, ldc2 in ELEMENTS, all
   //    columns < ldc written), EPI_PLAIN writes fp32.  fp32 accumulation in every mode.
+  // 3: "fp32x3" (gcn_gemm3.hip) — fp32 storage as mode 0, the product as six bf16 MFMA passes on exactly split operands;
+  //    bt points at the THREE bf16 images of the layer (launch_weight_images3; ldb is ignored).  Hidden-layer shapes only
+  //    (rowgemm3_ok); launch_rowgemm sends everything else of such a call to the exact mode-0 kernels.
   int bf16;
   // rows [rem_row0, rem_row0 + rem_rows) beyond the m rows of the main loop: the few leftover tiles of the load-balanced
   // split, done by the tail of the same launch (set by launch_rowgemm; 0 = none)
@@ -71,6 +74,19 @@ struct WeightImages {
   int n, count, transpose;
 };
 int launch_weight_images(const WeightImages &w, int max_rows, int max_ld, hipStream_t s);
+
+// gcn_gemm3.hip — gemm mode 3 ("fp32x3"): the hidden-layer products as six bf16 MFMA passes on exactly split fp32 operands
+constexpr int kX3ImageRows = 320;                               // Bt rows of a weight image (n <= 304, zero padded)
+constexpr int kX3ImageLd = 160;                                 // 4-byte units per image row (320 bf16: K <= 320, zero padded)
+constexpr int kX3ImageFloats = kX3ImageRows * kX3ImageLd;       // one image; a layer owns three (hi, mid, lo), back to back
+bool rowgemm3_dims_ok(long long m, int k, int n_store);
+bool rowgemm3_ok(const RowGemmArgs &a, int epi);
+int launch_rowgemm3(const RowGemmArgs &a, int epi, hipStream_t s);
+// dst_l + p * kX3ImageFloats (p = 0, 1, 2: hi, mid, lo) = piece p of W_l^T (transpose = 1) or W_l (transpose = 0) as
+// [kX3ImageRows][2 kX3ImageLd] bf16, dst_l = w.dst + l * w.dst_stride (floats); w.rows / w.ld are ignored
+int launch_weight_images3(const WeightImages &w, hipStream_t s);
+// x[i] = hi[i] + mid[i] + lo[i] (bf16 bit patterns): the split every mode-3 operand goes through
+int launch_split3(const float *x, size_t n, unsigned short *hi, unsigned short *mid, unsigned short *lo, hipStream_t s);
 
 // slab[wg][k_in][n_out] = X[rows of wg]^T * dZ[rows of wg];  dZ cols [0,zsplit) from z0, rest from z1.
 struct DwArgs {

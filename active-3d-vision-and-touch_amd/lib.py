@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("A3VT_LIB", os.path.join(_HERE, "liba3vt.so"))  # A3VT_LIB: developer override (variant builds)
-SOURCES = ["capi.hip", "gcn_gemm.hip", "gcn_gemm16.hip", "gcn_csr.hip", "gcn_csrq.hip", "gcn_bf16s.hip", "posenc.hip", "posenc_wide.hip", "bias_grad.hip", "sample.hip", "chamfer.hip", "nn_prune.hip",
+SOURCES = ["capi.hip", "gcn_gemm.hip", "gcn_gemm16.hip", "gcn_gemm3.hip", "gcn_csr.hip", "gcn_csrq.hip", "gcn_bf16s.hip", "posenc.hip", "posenc_wide.hip", "bias_grad.hip", "sample.hip", "chamfer.hip", "nn_prune.hip",
            "pooling.hip"]
 # Per-file extra flags (none at present; sample.hip / gcn_csr.hip rely on IEEE NaN semantics — the reference's NaN
 # scrubs, a3vt_check_finite — so fast-math style flags must never be applied globally).
@@ -67,6 +67,7 @@ SIGNATURES = {
     "a3vt_chamfer_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "a3vt_chamfer_fwd_ws": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     "a3vt_chamfer_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "a3vt_split3_bf16": (_i, [_vp, _sz, _vp, _vp, _vp, _vp]),
     "a3vt_check_finite": (_i, [_vp, _sz, _vp, _vp]),
     "a3vt_profile_enable": (_i, [_i]),
     "a3vt_profile_read": (_i, [_vp, _vp]),

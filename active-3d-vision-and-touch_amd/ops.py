@@ -70,12 +70,14 @@ def _ptr_array(tensors):
     return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
-GEMM_MODES = {"fp32": 0, "bf16": 1, "bf16s": 2}
+GEMM_MODES = {"fp32": 0, "bf16": 1, "bf16s": 2, "fp32x3": 3}
 
 
 def gemm_mode(bf16):
     """0 exact fp32 MFMA; 1 bf16 operands, fp32 storage; 2 bf16 storage (activations / gradients / weight images bf16 in
-    HBM, fp32 accumulation).  Accepts the mode number, a bool (True = 1) or the ``args.gemm_precision`` string."""
+    HBM, fp32 accumulation); 3 "fp32x3": fp32 storage, the hidden-layer products as six bf16 MFMA passes on operands split
+    exactly into three bf16 pieces (fp32-level error, not bit-identical to mode 0; csrc/gcn_gemm3.hip).  Accepts the mode
+    number, a bool (True = 1) or the ``args.gemm_precision`` string."""
     if isinstance(bf16, str):
         return GEMM_MODES[bf16]
     return int(bf16)
@@ -256,7 +258,9 @@ class GCNLayerFn(torch.autograd.Function):
 
 
 def gcn_layer(x, adj, weight, bias, cut_len, relu, bf16=False):
-    return GCNLayerFn.apply(x, adj, weight, bias, cut_len, relu, bf16, _wants_grad(x, weight, bias))
+    """``bf16``: a gemm mode (:func:`gemm_mode`); a lone layer knows the exact products and the bf16 operand mode only
+    (modes 1 and 2 -> operand mode, mode 3 "fp32x3" -> exact)."""
+    return GCNLayerFn.apply(x, adj, weight, bias, cut_len, relu, gemm_mode(bf16) in (1, 2), _wants_grad(x, weight, bias))
 
 
 class PosEncMaskFn(torch.autograd.Function):
@@ -578,6 +582,16 @@ def rowgemm(a, w, bf16=False):
     _lib.check(L.a3vt_rowgemm(_lib.ptr(a), K, M, K, _lib.ptr(wt), N, 1 if bf16 else 0, _lib.ptr(c), N, _stream()),
                "rowgemm")
     return c
+
+
+def split3(x):
+    """The exact operand split of gemm mode 3 (``a3vt_split3_bf16``): three int16 tensors of bf16 bit patterns with
+    ``hi + mid + lo == x``."""
+    L = _lib.load()
+    x = _req(x, "x")
+    hi, mid, lo = (torch.empty(x.shape, dtype=torch.int16, device=x.device) for _ in range(3))
+    _lib.check(L.a3vt_split3_bf16(_lib.ptr(x), x.numel(), _lib.ptr(hi), _lib.ptr(mid), _lib.ptr(lo), _stream()), "split3_bf16")
+    return hi, mid, lo
 
 
 def check_finite(t, flag):

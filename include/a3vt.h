@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define A3VT_VERSION 132 /* 0.2.x: bf16 storage mode (gemm_bf16 = 2), a3vt_gcn_stack_stash_bytes / _scratch_bytes_mode, deterministic backward scatters; 120: a3vt_chamfer_fwd_ws (pruned exact search); 130: a3vt_posenc_wide_* (448-wide vertex-feature encoder), larger a3vt_gcn_stack_mask_bytes / _scratch_bytes (channel-sliced aggregation) */
+#define A3VT_VERSION 140 /* 140: gemm_bf16 = 3 ("fp32x3": fp32 products as six bf16 MFMA passes on exactly split operands), a3vt_split3_bf16; 0.2.x: bf16 storage mode (gemm_bf16 = 2), a3vt_gcn_stack_stash_bytes / _scratch_bytes_mode, deterministic backward scatters; 120: a3vt_chamfer_fwd_ws (pruned exact search); 130: a3vt_posenc_wide_* (448-wide vertex-feature encoder), larger a3vt_gcn_stack_mask_bytes / _scratch_bytes (channel-sliced aggregation) */
 
 int a3vt_version(void);
 const char *a3vt_last_error(void);
@@ -52,6 +52,11 @@ int a3vt_csr_validate(const int32_t *rowptr_host, const int32_t *col_host, int n
  * mode, BASELINE configs[1]/[2]); 1 = "bf16 + MFMA feature MLP" (configs[3]/[4]): the operands of X W, dZ W^T and
  * X^T dZ are rounded to bf16 on their way into the matrix pipe (v_mfma_f32_16x16x16_bf16, fp32 accumulation); every
  * stored tensor stays fp32.  Vertex positions then agree with the fp32 reference to ~2e-3 relative instead of 3e-7.
+ * 3 = "fp32x3" (stack entry points only; csrc/gcn_gemm3.hip): every stored tensor stays fp32 exactly as in mode 0, and
+ * the three products of the hidden layers (K, n in (288, 304], >= 12 288 rows) are formed on the bf16 matrix pipe from
+ * operands split EXACTLY into three bf16 pieces (x == hi + mid + lo, a3vt_split3_bf16), the six partial products down
+ * to 2^-16 of the largest kept, fp32 accumulation: fp32-level error (measured against the fp64 oracle: DESIGN.md), not
+ * bit-identical to mode 0; all other shapes of such a call run the mode-0 kernels.  Mode 0 stays the default.
  * csr_max_degree / csrT_max_degree: the largest number of entries in a row of that matrix, or 0 if unknown.  The
  * fused vision + touch graphs have hub rows (chart centres linked to every seam vertex, ~1150 entries,
  * utility/utils.py:119-128); rows above 64 entries are aggregated by a whole workgroup in a second launch, which a
@@ -264,6 +269,13 @@ int a3vt_chamfer_fwd_ws(const float *x, const float *y, int draws, int batch, in
 int a3vt_chamfer_bwd(const float *x, const float *y, int draws, int batch, int p, int q,
                      const int32_t *idx_xy, const int32_t *idx_yx, const float *grad_cd,
                      float *grad_x, float *grad_y, void *stream);
+
+/* The operand split of gemm mode 3 (replaces nothing in the reference: it is how torch.matmul(features, self.weight),
+ * model.py:352, is fed to the bf16 matrix pipe without losing fp32 bits).  hi / mid / lo receive bf16 bit patterns with
+ * float(hi[i]) + float(mid[i]) + float(lo[i]) == x[i] exactly for every finite x[i] whose lowest set bit is >= 2^-133
+ * (all normal floats down to 2^-110; FLT_MAX included: hi is a truncation and cannot overflow); smaller magnitudes
+ * differ by < 2^-133.  Device pointers, n elements each. */
+int a3vt_split3_bf16(const float *x, size_t n, uint16_t *hi, uint16_t *mid, uint16_t *lo, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Deferred finite check (replaces the blocking NaN trap of model.py:326-329): sets *flag (device
