@@ -822,6 +822,10 @@ int a3vt_gcn_stack_bwd_acc(const float *feats, int ld_feats, int in_features, co
       d.k_in = w;
       d.n_out = hidden;
       d.bf16 = omode;
+      if (x3 && i > 0) {   // hidden layer of a mode-3 stack: the split-operand kernel when it takes the shape
+        d.bf16 = 3;
+        if (!dw3_ok(d)) d.bf16 = omode;
+      }
       {
         ProfScope ps(PROF_DW, s);
         if (int rc = launch_dw(d, s)) return rc;

@@ -1424,6 +1424,7 @@ int dw_num_slabs(int n_out) {
 }
 
 int launch_dw(const DwArgs &a0, hipStream_t s) {
+  if (a0.bf16 == 3) return launch_dw3(a0, s);   // split-operand mode (gcn_gemm3.hip)
   DwArgs a = a0;
 #ifdef A3VT_DBG_DW_NOHYB   // timing-only: the plain kernel on the same buffers (wrong results)
   a.xq = nullptr; a.xq_nvert = a.xq_quads = a.z0q_nvert = a.z0q_quads = 0; a.ldx_src = 0;

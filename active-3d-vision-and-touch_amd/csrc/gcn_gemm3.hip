@@ -56,6 +56,10 @@ __device__ __forceinline__ void glds16(const float *gsrc, float *lds_wave_base) 
                                    (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 __device__ __forceinline__ f32x4 mfma(f32x4 a, f32x4 b, f32x4 c) {
+#ifdef A3VT_DBG_X3_NOMFMA   // timing-only ablations of this file (tools/build_variants.sh x3): results are wrong by design
+  asm volatile("" ::"v"(a), "v"(b));
+  return c;
+#endif
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -74,6 +78,10 @@ __device__ __forceinline__ unsigned cvt_pk(float a, float b) {   // v_cvt_pk_bf1
 // down to 2^-110 qualify); below that the difference is < 2^-133.  11 VALU instructions per pair.
 __device__ __forceinline__ void split3_pair(float a, float b, unsigned &h, unsigned &m, unsigned &l) {
   const unsigned ua = fbits(a), ub = fbits(b);
+#ifdef A3VT_DBG_X3_NOSPLIT
+  h = ua; m = ub; l = ua ^ ub;
+  return;
+#endif
   h = __builtin_amdgcn_perm(ub, ua, 0x07060302u);            // (ua >> 16) | (ub & 0xffff0000)
   const float ra = a - bfloat(ua & 0xffff0000u), rb = b - bfloat(ub & 0xffff0000u);
   m = cvt_pk(ra, rb);
@@ -156,11 +164,18 @@ __global__ __launch_bounds__(64 * kWaves, 2) void rowgemm3_kernel(RowGemmArgs p)
           int kk = chunk * 32 + q * 8 + h * 4;
           kk = kk < p.k ? kk : p.k - 4;
           const float *src = kk < p.ksplit ? p.a0 + (size_t)(a0off[i] + (unsigned)kk * a0mul) : p.a1 + (size_t)(a1off[i] + (unsigned)kk);
+#ifdef A3VT_DBG_RG3_NOA
+          raw[i][h] = f32x4{1.f + kk, 2.f + i, 3.f + lane, (float)(size_t)src};
+#else
           raw[i][h] = *reinterpret_cast<const f32x4 *>(src);
+#endif
         }
     };
     auto issue_b = [&](int chunk, int buf, int j) {
       if (j >= nbp) return;   // wave-uniform
+#ifdef A3VT_DBG_RG3_NOB
+      return;
+#endif
       const int pc = wave + kWaves * j, img = pc / kNT, tile = pc - img * kNT;   // scalar
       glds16(p.bt + ((size_t)img * kX3ImageFloats + (size_t)tile * (16 * kX3ImageLd) + chunk * 16) + blane, lds + buf * kStage + pc * 256);
     };
@@ -254,7 +269,11 @@ __global__ __launch_bounds__(64 * kWaves, 2) void rowgemm3_kernel(RowGemmArgs p)
 
     // ---- epilogue (rowgemm_kernel's, fp32 rows; launch_rowgemm3 guarantees ldc % 4 == 0, n_store % 4 == 0 and, for the
     // forward without the quad-major side output, ldc2 % 4 == 0: every column quad leaves with one 16-byte store)
+#ifdef A3VT_DBG_RG3_NOEPI
+    if (active && acc[0][0][0] == 1.2345e-33f) {   // never true in practice: keeps the accumulators alive, skips the epilogue
+#else
     if (active) {
+#endif
       float *ep = lds + wave * ((kStages * kStage) / kWaves);
       constexpr int G0 = (kNT + 1) / 2;
       static_assert(16 * (G0 * 16 + 4) <= (kStages * kStage) / kWaves, "epilogue slice too small");
@@ -368,23 +387,31 @@ __global__ __launch_bounds__(64 * kWaves, 2) void rowgemm3_kernel(RowGemmArgs p)
 // [kX3ImageRows][2 kX3ImageLd] bf16 at dst + l * dst_stride + p * kX3ImageFloats (floats), zero padded;
 // transpose = 1: row n, column k = W[k][n] (forward operand Bt = W^T), transpose = 0: row r, column c = W[r][c] (dX).
 __global__ void weight_images3_kernel(WeightImages w) {
+  __shared__ float tile[32][33];
   const int l = blockIdx.z;
   const float *src = w.w[l];
   unsigned short *dst = reinterpret_cast<unsigned short *>(w.dst + (size_t)l * w.dst_stride);
   const int k = w.k[l], n = w.n;
-  const int ld = 2 * kX3ImageLd, total = kX3ImageRows * ld;
-  const int tid = threadIdx.y * 32 + threadIdx.x;
-  const int nblk = gridDim.x * gridDim.y, blk = blockIdx.y * gridDim.x + blockIdx.x;
-  for (int idx = blk * 256 + tid; idx < total; idx += nblk * 256) {
-    const int r = idx / ld, c = idx - r * ld;
+  constexpr int ld = 2 * kX3ImageLd;
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;   // bx over image columns, by over image rows (32 x 32 tiles of 320 x 320)
+  for (int i = threadIdx.y; i < 32; i += 8) {
     float v = 0.f;
-    if (w.transpose) {
+    if (w.transpose) {   // image (row r, column c) = W[c][r]: read W rows (c fixed) along r
+      const int c = bx + i, r = by + threadIdx.x;
       if (c < k && r < n) v = src[(size_t)c * n + r];
-    } else {
+      tile[i][threadIdx.x] = v;
+    } else {             // image (row r, column c) = W[r][c]
+      const int r = by + i, c = bx + threadIdx.x;
       if (r < k && c < n) v = src[(size_t)r * n + c];
+      tile[threadIdx.x][i] = v;
     }
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += 8) {
+    const int r = by + i, c = bx + threadIdx.x;   // consecutive threads -> consecutive columns of one image row
     unsigned h, m, lo;
-    split3_pair(v, 0.f, h, m, lo);
+    split3_pair(tile[threadIdx.x][i], 0.f, h, m, lo);
+    const size_t idx = (size_t)r * ld + c;
     dst[idx] = (unsigned short)(h & 0xffffu);
     dst[idx + 2 * kX3ImageFloats] = (unsigned short)(m & 0xffffu);
     dst[idx + 4 * kX3ImageFloats] = (unsigned short)(lo & 0xffffu);
@@ -400,6 +427,282 @@ __global__ void split3_kernel(const float *__restrict__ x, size_t n, unsigned sh
   hi[i] = (unsigned short)(h & 0xffffu);
   mid[i] = (unsigned short)(m & 0xffffu);
   lo[i] = (unsigned short)(l & 0xffffu);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// dW = X^T dZ in mode 3 (autograd's weight gradient of model.py:352).  Same decomposition as dw_kernel / dw16_kernel:
+// grid = (128 row slabs, 2 column groups), a workgroup's partial [k_in][n_out] goes to its slab, slab_reduce sums the
+// slabs in a fixed order.  8 waves: wave (wi = w & 3, wo = w >> 2) owns up to 5 input tiles x 5 output tiles of its
+// column group (100 accumulator registers).
+// A stage is 32 rows.  Both operands are fp32 in HBM and both are needed as three bf16 pieces, column-wise (the MFMA sums
+// over ROWS), by several waves each — so the split is done ONCE per element, through LDS:
+//   1. LDS-DMA of the stage's fp32 quads (X: 76 per row; this column group's window of dZ: 40 per row) into a raw buffer
+//      (59 KB), issued at the top of the previous stage's MFMA phase; quad-major planes (the hybrid layout) are walked
+//      row-fastest, row-major rows quad-fastest, so that every wave-instruction covers whole cache lines;
+//   2. split phase: every thread reads back the quads it requested, splits them (split3_pair) and writes the three piece
+//      images, row-major [32][304] (X) / [32][176] (window) bf16 — row strides of 8 (odd) dwords, so that the transposed
+//      reads below are bank-conflict free;
+//   3. MFMA phase: operands come out of the images with ds_read_b64_tr_b16 exactly as in dw16_kernel (k-group g takes rows
+//      4 g .. 4 g + 3 and 16 + 4 g ..), six passes of 25 MFMAs per stage, the next pass's fragments in flight.
+// Two barriers per stage.  The raw slots are wave-private (a wave splits the quads it requested), so the next stage's DMA is
+// issued as soon as a wave holds its quads in registers and stays in flight through the split, the barriers and the MFMA phase.
+// ------------------------------------------------------------------------------------------------
+using s16x4 = __attribute__((ext_vector_type(4))) short;
+using s16x8 = __attribute__((ext_vector_type(8))) short;
+using u16 = unsigned short;
+
+constexpr int kDwThreads = 512;
+constexpr int kDwXq = 76, kDwZq = 40;                    // fp32 quads per stage row: X (304 columns), dZ window (160)
+constexpr int kDwUnits = 32 * (kDwXq + kDwZq);           // 3712 quads per stage
+constexpr int kDwPer = (kDwUnits + kDwThreads - 1) / kDwThreads;   // 8 per thread (the last wave-instruction is partial)
+constexpr int kDwXld = 304, kDwZld = 176;                // piece image row strides (bf16 elements)
+constexpr int kDwXimg = 32 * kDwXld, kDwZimg = 32 * kDwZld;
+constexpr int kDwPieceElems = 3 * (kDwXimg + kDwZimg);   // 46,080 bf16 = 92,160 B
+constexpr int kDwRawFloats = kDwPer * kDwThreads * 4;    // 16,384 floats = 65,536 B
+constexpr size_t kDwLdsBytes = (size_t)kDwPieceElems * 2 + (size_t)kDwRawFloats * 4 + 1024;   // + tail slack for clamped tiles
+
+__device__ __forceinline__ f32x4 tr_operand(const u16 *lds_row0_col, int row_stride_elems) {
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(lds_row0_col));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4 *)(lds_row0_col + 16 * row_stride_elems));
+  return __builtin_bit_cast(f32x4, (s16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]});
+}
+
+__global__ __launch_bounds__(kDwThreads, 2) void dw3_kernel(DwArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  u16 *pieces = reinterpret_cast<u16 *>(lds);
+  float *raw = lds + kDwPieceElems / 2;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l16 = lane & 15, g = lane >> 4;
+  const int bq = l16 >> 2, bp = l16 & 3;           // transposed-read address role: block row bq, column quad bp
+  const int wi = wave & 3, wo = wave >> 2;
+
+  // tile ownership (as dw16_kernel)
+  const int tin = (p.k_in + 15) >> 4, tout = (p.n_out + 15) >> 4;
+  const int ni = tin / 4 + (wi < tin % 4 ? 1 : 0);
+  const int i0 = wi * (tin / 4) + (wi < tin % 4 ? wi : tin % 4);
+  const int gbase = tout / gridDim.y, grem = tout % gridDim.y;
+  const int gt0 = blockIdx.y * gbase + ((int)blockIdx.y < grem ? blockIdx.y : grem);
+  const int gtn = gbase + ((int)blockIdx.y < grem ? 1 : 0);
+  const int no = gtn / 2 + (wo < gtn % 2 ? 1 : 0);
+  const int o0 = gt0 + wo * (gtn / 2) + (wo < gtn % 2 ? wo : gtn % 2);
+  const int gcol0 = gt0 * 16;                      // first dZ column of this group's window
+
+  // rows of this workgroup in stages of 32
+  const int units = (p.m + 31) >> 5;
+  const int ubase = units / gridDim.x, urem = units % gridDim.x;
+  const int u0 = blockIdx.x * ubase + ((int)blockIdx.x < urem ? blockIdx.x : urem);
+  const int nu = ubase + ((int)blockIdx.x < urem ? 1 : 0);
+
+  // ---- this thread's quads of a stage: e = tid + 512 j.  Blocks of the e range (each a multiple of 32 long):
+  //   [X quad-major quads: row-fastest][X row-major quads: quad-fastest][window quad-major quads][window row-major quads]
+  const int nq0 = p.xq_nvert > 0 ? p.xq_quads : 0, nq1 = kDwXq - nq0;
+  const int zq_quads_win = p.z0q_nvert > 0 ? max(min(p.z0q_quads - gcol0 / 4, kDwZq), 0) : 0;   // window quads served by the quad-major dZa
+  const int nq2 = zq_quads_win, nq3 = kDwZq - nq2;
+  const int e1 = 32 * nq0, e2 = e1 + 32 * nq1, e3 = e2 + 32 * nq2;
+  const int qn = p.xq_nvert > 0 ? p.xq_nvert : p.z0q_nvert;   // vertices per mesh (the same for X and dZa)
+  const float *sp[kDwPer];     // source of the quad for the next stage
+  int adv[kDwPer];             // floats to advance per stage: 128 = a quad-major quad (32 rows x 4 floats), 0 = a zero quad
+  int pdst[kDwPer];            // bf16 element offset of the quad in piece image 0 (X images, then the window images); -1: none
+  const size_t row_first = (size_t)u0 * 32;
+  auto unit_row = [&](int e) {   // stage row of quad e (the block structure above)
+    if (e < e1) return e & 31;
+    if (e < e2) return (e - e1) / nq1;
+    if (e < e3) return (e - e2) & 31;
+    return (e - e3) / nq3;
+  };
+#pragma unroll
+  for (int j = 0; j < kDwPer; ++j) {
+    const int e = tid + kDwThreads * j;
+    const int row = unit_row(e);
+    int quad;
+    bool isx = true, qm = false;
+    if (e < e1) { quad = e >> 5; qm = true; }
+    else if (e < e2) { quad = nq0 + (e - e1 - row * nq1); }
+    else if (e < e3) { quad = (e - e2) >> 5; isx = false; qm = true; }
+    else { quad = nq2 + (e - e3 - row * nq3); isx = false; }
+    const bool on = e < kDwUnits;
+    const size_t grow = row_first + row;
+    const float *src = p.zeros;
+    int a = 0;
+    if (on && isx) {
+      const int col = quad * 4;
+      if (qm) {
+        const int b = (int)(grow / qn), v = (int)(grow - (size_t)b * qn);
+        src = p.xq + (((size_t)b * p.xq_quads + quad) * qn + v) * 4;
+        a = 128;
+      } else if (col < p.k_in) {
+        src = p.x + grow * p.ldx_src + col;
+        a = 32 * p.ldx_src;
+      }
+    } else if (on) {
+      const int col = gcol0 + quad * 4;   // dZ column
+      if (qm) {
+        const int b = (int)(grow / qn), v = (int)(grow - (size_t)b * qn);
+        src = p.z0 + (((size_t)b * p.z0q_quads + (col >> 2)) * qn + v) * 4;
+        a = 128;
+      } else if (col < p.zsplit) {
+        src = p.z0 + grow * p.ldz0 + col;
+        a = 32 * p.ldz0;
+      } else if (col < p.n_out) {
+        src = p.z1 + grow * p.ldz1 + col;
+        a = 32 * p.ldz1;
+      }
+    }
+    sp[j] = src;
+    adv[j] = a;
+    pdst[j] = !on ? -1 : (isx ? row * kDwXld + quad * 4 : 3 * kDwXimg + row * kDwZld + quad * 4);
+  }
+  // vertex index (inside its mesh) of this thread's row of the NEXT stage to be issued: quad-major quads all sit on stage
+  // row tid & 31 (every block of the e range starts at a multiple of 32)
+  int vrow = qn > 0 ? (int)((row_first + (tid & 31)) % (size_t)qn) : 0;
+  const int wrap_x = p.xq_nvert > 0 ? (p.xq_quads - 1) * qn * 4 : 0, wrap_z = p.z0q_nvert > 0 ? (p.z0q_quads - 1) * qn * 4 : 0;
+
+  auto issue = [&](int unit) {   // DMA of stage `unit` (global index) into the raw buffer, then move every pointer 32 rows on
+    const int rows_left = p.m - unit * 32;
+    if (rows_left >= 32) {
+#pragma unroll
+      for (int j = 0; j < kDwPer; ++j) {
+        if (j * kDwThreads + wave * 64 >= kDwUnits) continue;   // wave-uniform: nothing of this instruction exists
+#ifndef A3VT_DBG_DW3_NODMA
+        glds16(sp[j], raw + (j * kDwThreads + wave * 64) * 4);
+#endif
+        sp[j] += adv[j];
+      }
+    } else {   // the ragged last stage of the whole problem: rows >= m contribute zeros
+#pragma unroll
+      for (int j = 0; j < kDwPer; ++j) {
+        if (j * kDwThreads + wave * 64 >= kDwUnits) continue;
+        const int e = tid + kDwThreads * j;
+        glds16(e < kDwUnits && unit_row(e) < rows_left ? sp[j] : p.zeros, raw + (j * kDwThreads + wave * 64) * 4);
+      }
+    }
+    if (qn > 0) {
+      vrow += 32;
+      if (vrow >= qn) {          // per-lane: this row has crossed into the next mesh
+        vrow -= qn;
+#pragma unroll
+        for (int j = 0; j < kDwPer; ++j)
+          if (adv[j] == 128) sp[j] += pdst[j] < 3 * kDwXimg ? wrap_x : wrap_z;
+      }
+    }
+  };
+
+  f32x4 acc[5][5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // per-lane element offsets of the transposed reads inside piece image 0: block row (4 g + bq), column quad 4 bp of the
+  // tile; tiles a wave does not own are clamped in-bounds (read, multiplied, never stored)
+  int xoff[5], zoff[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) xoff[i] = (4 * g + bq) * kDwXld + min((i0 + i) * 16 + 4 * bp, kDwXld - 4);
+#pragma unroll
+  for (int j = 0; j < 5; ++j) zoff[j] = 3 * kDwXimg + (4 * g + bq) * kDwZld + min((o0 - gt0 + j) * 16 + 4 * bp, 160 - 4);
+
+  // A wave reads back exactly the quads it requested (raw slot (j * 512 + tid)), so the raw buffer needs no workgroup
+  // barrier: as soon as a wave has its stage in registers it requests the next one, which then has the split, the barriers
+  // and the whole MFMA phase to land.
+  if (nu > 0) issue(u0);
+  for (int t = 0; t < nu; ++t) {
+    wait_vm0();                     // this wave's quads of stage t have landed
+    f32x4 rv[kDwPer];
+#pragma unroll
+    for (int j = 0; j < kDwPer; ++j) rv[j] = *reinterpret_cast<const f32x4 *>(raw + (j * kDwThreads + tid) * 4);
+    wait_lgkm0();
+    if (t + 1 < nu) issue(u0 + t + 1);
+    // ---- split (registers), then the piece images once everyone is done with those of stage t - 1
+    unsigned hh[kDwPer][2], mm[kDwPer][2], ll[kDwPer][2];
+#pragma unroll
+    for (int j = 0; j < kDwPer; ++j) {
+      split3_pair(rv[j][0], rv[j][1], hh[j][0], mm[j][0], ll[j][0]);
+      split3_pair(rv[j][2], rv[j][3], hh[j][1], mm[j][1], ll[j][1]);
+    }
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int j = 0; j < kDwPer; ++j) {
+#ifdef A3VT_DBG_DW3_NOSPLITPHASE
+      continue;
+#endif
+      if (pdst[j] >= 0) {
+        const bool isx = pdst[j] < 3 * kDwXimg;
+        u16 *d = pieces + pdst[j];
+        const int img = isx ? kDwXimg : kDwZimg;
+        using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+        *reinterpret_cast<u32x2 *>(d) = u32x2{hh[j][0], hh[j][1]};
+        *reinterpret_cast<u32x2 *>(d + img) = u32x2{mm[j][0], mm[j][1]};
+        *reinterpret_cast<u32x2 *>(d + 2 * img) = u32x2{ll[j][0], ll[j][1]};
+      }
+    }
+    wait_lgkm0();
+    __builtin_amdgcn_s_barrier();   // piece images of stage t complete
+    // ---- MFMA phase: passes (a piece, b piece) = (h,h) (h,m) (h,l) (m,h) (m,m) (l,h)
+    const u16 *xp = pieces, *zp = pieces;   // (zoff already carries the window images' base)
+    // Passes (a piece, b piece) in the order (h,l) (h,m) (h,h) (l,h) (m,h) (m,m): one fragment set changes per pass and is
+    // loaded under the previous pass's MFMAs — three sets of five fragments live (60 registers), 35 fragments per stage.
+    f32x4 fa[5], fb[5], fc[5];
+    auto load_a = [&](f32x4 (&dst)[5], int piece) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) dst[i] = tr_operand(xp + piece * kDwXimg + xoff[i], kDwXld);
+    };
+    auto load_b = [&](f32x4 (&dst)[5], int piece) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) dst[j] = tr_operand(zp + piece * kDwZimg + zoff[j], kDwZld);
+    };
+    auto pass = [&](const f32x4 (&av)[5], const f32x4 (&bv)[5]) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[i][j] = mfma(av[i], bv[j], acc[i][j]);
+    };
+    load_a(fa, 0);                  // a_h
+    load_b(fb, 2);                  // b_l
+    __builtin_amdgcn_sched_barrier(0);
+    load_b(fc, 1);                  // b_m
+    __builtin_amdgcn_sched_barrier(0);
+    pass(fa, fb);                   // (h, l)
+    __builtin_amdgcn_sched_barrier(0);
+    load_b(fb, 0);                  // b_h
+    __builtin_amdgcn_sched_barrier(0);
+    pass(fa, fc);                   // (h, m)
+    __builtin_amdgcn_sched_barrier(0);
+    load_a(fc, 2);                  // a_l
+    __builtin_amdgcn_sched_barrier(0);
+    pass(fa, fb);                   // (h, h)
+    __builtin_amdgcn_sched_barrier(0);
+    load_a(fa, 1);                  // a_m
+    __builtin_amdgcn_sched_barrier(0);
+    pass(fc, fb);                   // (l, h)
+    __builtin_amdgcn_sched_barrier(0);
+    load_b(fc, 1);                  // b_m
+    __builtin_amdgcn_sched_barrier(0);
+    pass(fa, fb);                   // (m, h)
+    __builtin_amdgcn_sched_barrier(0);
+    pass(fa, fc);                   // (m, m)
+  }
+
+  // partial -> slab[blockIdx.x][k_in][n_out]; C/D layout: lane holds column (lane & 15) of rows 4 g .. 4 g + 3 of the tile
+  float *slab = p.slab + (size_t)blockIdx.x * p.k_in * p.n_out;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    if (i >= ni) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int kin = (i0 + i) * 16 + g * 4 + r;
+      if (kin >= p.k_in) continue;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        if (j >= no) continue;
+        const int col = (o0 + j) * 16 + l16;
+        if (col < p.n_out) slab[(size_t)kin * p.n_out + col] = acc[i][j][r];
+      }
+    }
+  }
 }
 
 }  // namespace
@@ -452,6 +755,35 @@ int launch_rowgemm3(const RowGemmArgs &a, int epi, hipStream_t s) {
     A3VT_LAUNCH((rowgemm3_kernel<EPI_FWD_HIDDEN>), dim3(grid), dim3(64 * kWaves), kLdsBytes, s, a);
   else
     A3VT_LAUNCH((rowgemm3_kernel<EPI_DX_MASK>), dim3(grid), dim3(64 * kWaves), kLdsBytes, s, a);
+  A3VT_CHECK_LAUNCH();
+  return 0;
+}
+
+
+// dW shapes of mode 3: both dimensions those of a hidden layer, enough rows for 128 slabs of a few stages each.
+bool dw3_ok(const DwArgs &a) {
+  if (a.bf16 != 3) return false;
+  if (a.k_in <= 288 || a.k_in > 304 || a.n_out <= 288 || a.n_out > 304 || a.m < 96 * 128) return false;
+  if (a.ldz0 % 4 != 0 || a.ldz1 % 4 != 0 || a.zsplit % 4 != 0 || a.zsplit > 160 || a.n_out > a.ldz1) return false;
+  const int ldx_src = a.ldx_src > 0 ? a.ldx_src : a.ldx;
+  if (ldx_src % 4 != 0) return false;
+  if (a.xq_nvert > 0 && (a.xq == nullptr || a.xq_quads * 4 > 160 || a.m % a.xq_nvert != 0 || a.xq_nvert < 32)) return false;
+  if (a.z0q_nvert > 0 && (a.z0q_quads * 4 != a.zsplit || a.m % a.z0q_nvert != 0 || a.z0q_nvert < 32)) return false;
+  if (a.xq_nvert > 0 && a.z0q_nvert > 0 && a.xq_nvert != a.z0q_nvert) return false;
+  if (a.z0q_nvert == 0 && a.zsplit > 0 && (a.zsplit > a.ldz0 || a.ldz0 == 4)) return false;   // (a stage step of 128 floats marks a quad-major quad)
+  return true;
+}
+
+int launch_dw3(const DwArgs &a0, hipStream_t s) {
+  DwArgs a = a0;
+  if (a.ldx_src == 0) a.ldx_src = a.ldx;
+  if (!dw3_ok(a)) {
+    set_error("dw3: unsupported call (m=%d k_in=%d n_out=%d zsplit=%d mode=%d)", a.m, a.k_in, a.n_out, a.zsplit, a.bf16);
+    return -1;
+  }
+  static OncePerDevice once;
+  once.run([] { (void)hipFuncSetAttribute((const void *)dw3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDwLdsBytes); });
+  A3VT_LAUNCH(dw3_kernel, dim3(dw_num_slabs(a.n_out), 2), dim3(kDwThreads), kDwLdsBytes, s, a);
   A3VT_CHECK_LAUNCH();
   return 0;
 }

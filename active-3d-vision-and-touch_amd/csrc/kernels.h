@@ -97,7 +97,7 @@ struct DwArgs {
   float *slab;  // [dw_num_slabs(n_out)][k_in][n_out]
   int ldx, ldz0, ldz1, zsplit;
   int m, k_in, n_out;
-  int bf16;  // as RowGemmArgs::bf16
+  int bf16;  // as RowGemmArgs::bf16 (0, 1; 3 = the split-operand kernel dw3_kernel, hidden-layer shapes only: dw3_ok)
   int nstage;  // LDS ring depth (set by launch_dw)
   // Quad-major operands (0 = off; the outputs of the channel-sliced aggregation kernels, gcn_csrq.hip):
   //   xq_nvert > 0 : X columns [0, 4 xq_quads) come from xq [m / xq_nvert][xq_quads][xq_nvert] float4; the other columns
@@ -108,6 +108,9 @@ struct DwArgs {
   int ldx_src, xq_nvert, xq_quads, z0q_nvert, z0q_quads;
 };
 int dw_num_slabs(int n_out);
+// dW = X^T dZ of a hidden layer in mode 3 (DwArgs::bf16 == 3, gcn_gemm3.hip; same slabs as launch_dw); dw3_ok: the shapes it takes
+bool dw3_ok(const DwArgs &a);
+int launch_dw3(const DwArgs &a, hipStream_t s);
 // True when dw_kernel can take the first 4 * quads columns of a k_in-wide X quad-major (they must end where a wave's input tiles end).
 bool dw_quad_major_ok(int k_in, int quads);
 int launch_dw(const DwArgs &a, hipStream_t s);

@@ -20,6 +20,10 @@ Extra objects on the JSON line — everything in them is measured IN THIS RUN (n
   ``traffic`` = HBM bytes per launch of that kernel from the PMC counters FETCH_SIZE (doubled, as the guide prescribes
   for gfx950) + WRITE_SIZE, collected by two child ``rocprofv3 --pmc`` passes over a short run of the same kernel at
   the same shape (``tools/stack_bench.py``); null when rocprofv3 is unavailable, fails, or the mode is not fp32.
+* ``alt_modes`` — after the timed region (default fp32 run only): the SAME trained model switched to gemm mode 3
+  ("fp32x3": the hidden-layer products as six bf16 MFMA passes on exactly split fp32 operands, csrc/gcn_gemm3.hip):
+  its ms/step over ``--alt-steps`` steps, its per-launch MFMA times, and its measured error against the exact mode on
+  identical weights, batch and surface samples (vertex positions, loss, whole-gradient relative L2).  Never ``value``.
 * ``cpu_baseline`` — the CPU oracle (a restatement of the reference path; kind "port") timed on this box's host
   cores, rank 0 at N = 1 only, inside a ~75 s budget: the reference-faithful variant (dense (N,N) adjacency products as
   vision/model.py:356,360 + compiled brute-force nearest neighbour) and the CSR variant, bs 2 and bs 8, median of up to
@@ -62,8 +66,10 @@ def parse():
     p.add_argument("--cpu-budget", type=float, default=100.0, help="seconds of wall time for the cpu_baseline leg")
     p.add_argument("--no-traffic", action="store_true", help="skip the child rocprofv3 --pmc passes")
     p.add_argument("--profile-steps", type=int, default=2)
-    p.add_argument("--gemm-precision", default="fp32", choices=["fp32", "bf16", "bf16s"],
-                   help="bf16 = operand mode, bf16s = bf16 activation storage (BASELINE configs[3]/[4]); NOT the headline")
+    p.add_argument("--gemm-precision", default="fp32", choices=["fp32", "bf16", "bf16s", "fp32x3"],
+                   help="bf16 = operand mode, bf16s = bf16 activation storage (BASELINE configs[3]/[4]), fp32x3 = fp32 products as "
+                        "six bf16 MFMA passes on exactly split operands; NOT the headline")
+    p.add_argument("--alt-steps", type=int, default=10, help="timed steps of the alt_modes leg (0 = skip it)")
     return p.parse_args()
 
 
@@ -160,6 +166,67 @@ def cpu_baseline(level, layers, hidden, points, budget_s, seed=0):
                       f"{head.get('iters_timed')} fwd+bwd iterations, no optimizer; scaled by bs/64). "
                       f"{spent:.0f} s of CPU wall time for all variants",
             "variants": variants}
+
+
+# ---- alt_modes leg: the split-operand products on the model the timed region trained -------------------------------------
+def alt_modes_leg(eng, img, charts, clouds, step, fence, steps, world, modes=("fp32x3",), warm=2):
+    from a3vt_amd import lib, ops
+    from a3vt_amd.pterotactyl.utility import utils
+    stacks = [m for m in eng.encoder.modules() if hasattr(m, "gemm_bf16")]
+
+    def set_mode(mode):
+        for m in stacks:
+            m.gemm_bf16 = ops.gemm_mode(mode)
+
+    def evaluate(mode):
+        """forward + loss + backward on the current weights; the Philox surface samples are seeded from torch's CPU generator,
+        so the same seed gives both modes the same clouds"""
+        set_mode(mode)
+        torch.manual_seed(4242)
+        eng.bucket.zero()
+        verts = eng.encoder(img, charts)[0]
+        cd = utils.chamfer_distance(verts, eng.mesh_info["faces_i32"], clouds[0], num=eng.args.number_points)
+        loss = eng.args.loss_coeff * cd.mean()
+        loss.backward()
+        eng.bucket.gather()
+        return verts.detach().clone(), loss.item(), eng.bucket.flat.clone()
+
+    L = lib.load()
+    out = {}
+    try:
+        v0, l0, g0 = evaluate("fp32")
+        v0b, l0b, g0b = evaluate("fp32")                      # the exact mode against itself: must be 0 (bit-reproducible)
+        for mode in modes:
+            v, l, g = evaluate(mode)
+            err = {"verts_rel_max": ((v - v0).abs().max() / v0.abs().max()).item(), "loss_rel": abs(l - l0) / abs(l0),
+                   "grad_rel_l2": ((g - g0).norm() / g0.norm()).item(),
+                   "exact_vs_itself": {"verts_rel_max": ((v0b - v0).abs().max() / v0.abs().max()).item(),
+                                       "grad_rel_l2": ((g0b - g0).norm() / g0.norm()).item()},
+                   "how": "same weights (after the timed steps), same batch, same surface samples; reference = this run's exact "
+                          "fp32 mode; gradient = the whole flat bucket (kink flips of ReLU arguments within rounding of 0 included)"}
+            set_mode(mode)
+            for i in range(warm):
+                step(i)
+            fence()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(steps):
+                loss = step(warm + i)
+            e1.record()
+            fence()
+            ms = e0.elapsed_time(e1) / steps
+            L.a3vt_profile_enable(1)
+            step(0)
+            torch.cuda.synchronize()
+            tot, cnt = (ctypes.c_double * 3)(), (ctypes.c_int * 3)()
+            lib.check(L.a3vt_profile_read(tot, cnt), "profile_read")
+            L.a3vt_profile_enable(0)
+            out[mode] = {"ms_per_step": ms, "iters_per_s": 1e3 * world / ms, "steps": steps, "final_loss": loss.item(),
+                         "mfma_launch_us": {k: 1e3 * tot[i] / max(cnt[i], 1) for i, k in enumerate(("fwd", "dx", "dw"))},
+                         "error_vs_exact_fp32": err}
+    finally:
+        set_mode("fp32")
+    return out
 
 
 # ---- roofline.traffic: child rocprofv3 --pmc passes over the dominant kernel at the bench shape ------------------------
@@ -305,8 +372,10 @@ def main():
         fp32 = a.gemm_precision == "fp32"
         # dense matrix peaks (MI355X_MICROARCH.md): fp32 157.3; bf16 2500 for v_mfma_f32_16x16x32_bf16 (the bf16s mode), half
         # of that for the K = 16 instruction of the operand mode
-        peak = 157.3 if fp32 else (2500.0 if a.gemm_precision == "bf16s" else 1250.0)
-        instr = {"fp32": "v_mfma_f32_16x16x4_f32", "bf16": "v_mfma_f32_16x16x16_bf16", "bf16s": "v_mfma_f32_16x16x32_bf16"}
+        # (fp32x3: six bf16 passes per product -> 2500 / 6 TFLOP/s of fp32-equivalent work)
+        peak = 157.3 if fp32 else {"bf16s": 2500.0, "fp32x3": 2500.0 / 6.0}.get(a.gemm_precision, 1250.0)
+        instr = {"fp32": "v_mfma_f32_16x16x4_f32", "bf16": "v_mfma_f32_16x16x16_bf16", "bf16s": "v_mfma_f32_16x16x32_bf16",
+                 "fp32x3": "6 x v_mfma_f32_16x16x32_bf16 on split operands"}
         roof = {"bound": "mfma", "kernel": f"rowgemm_kernel<19,EPI_DX_MASK> ({instr.get(a.gemm_precision, '?')}, M x 300 x 300, "
                                            f"dX = dZ W^T{'' if fp32 else ', fp32 accumulate'})",
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
@@ -332,7 +401,9 @@ def main():
 
     dtype = {"fp32": "f32", "bf16": "f32 storage, bf16 GEMM operands (reduced precision, not the headline)",
              "bf16s": "bf16 activation storage + bf16 GEMM operands, fp32 accumulate / weights / optimizer (reduced "
-                      "precision, not the headline)"}[a.gemm_precision]
+                      "precision, not the headline)",
+             "fp32x3": "f32 storage; hidden-layer products as six bf16 MFMA passes on exactly split f32 operands, f32 accumulate "
+                       "(fp32-level error, not bit-identical to the exact mode; not the headline)"}[a.gemm_precision]
     default_cfg = (a.level, a.batch, a.points, a.layers, a.hidden, a.gemm_precision) == (4, 64, 10000, 20, 300, "fp32")
     pts = f"{a.points // 1000}k" if a.points % 1000 == 0 else str(a.points)
     out = {
@@ -348,6 +419,9 @@ def main():
     }
     if roof is not None:
         out["roofline"] = roof
+    if a.gemm_precision == "fp32" and a.alt_steps > 0:   # every rank runs it (the steps hold collectives); rank 0 reports
+        alt = alt_modes_leg(eng, img, charts, clouds, step, fence, a.alt_steps, world)
+        out["alt_modes"] = alt
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.level, a.layers, a.hidden, a.points, a.cpu_budget)
     if rank == 0:

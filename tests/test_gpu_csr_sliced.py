@@ -26,7 +26,8 @@ def _run(cuda, adj, st, feats, gup, L, H, cut_len):
 
 @pytest.mark.parametrize("tname,use_touch,L,B,cut", [("ico3", False, 4, 24, 0.33), ("ico4", False, 3, 6, 0.33),
                                                       ("atlas", False, 3, 8, 0.33), ("atlas", True, 3, 8, 0.33),
-                                                      ("ico3", False, 3, 20, 0.5), ("ico3", False, 3, 20, 0.04)])
+                                                      ("ico3", False, 3, 20, 0.5), ("ico3", False, 3, 20, 0.04),
+                                                      ("ico4", False, 20, 6, 0.33)])   # the benchmark's depth and template
 def test_channel_sliced_aggregation_equals_row_kernels_and_oracle(cuda, tname, use_touch, L, B, cut):
     from a3vt_amd import mesh as amesh, ops
     from oracle import gcn as og

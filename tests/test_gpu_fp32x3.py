@@ -85,7 +85,7 @@ def _oracle(adj_o, st, feats, gup, L, cut):
 @pytest.mark.parametrize("tname,use_touch,L,B,cut", [("ico3", False, 4, 24, 0.33), ("ico4", False, 3, 6, 0.33),
                                                       ("atlas", False, 3, 8, 0.33), ("atlas", True, 3, 8, 0.33),
                                                       ("ico3", False, 3, 20, 0.5), ("ico3", False, 3, 20, 0.04),
-                                                      ("ico4", False, 20, 6, 0.33), ("ico5", False, 4, 2, 0.33)])
+                                                      ("ico4", False, 20, 6, 0.33), ("ico5", False, 4, 4, 0.33)])
 def test_stack_fp32x3_vs_fp64_oracle(cuda, tname, use_touch, L, B, cut):
     """Hidden 300, >= 12 288 rows: the three products of layers 1 .. L-2 run on the split-operand kernels — with the
     hybrid quad-major rows on the plain templates (channel-sliced aggregation), row-major on the touch graph / ico5.
@@ -120,9 +120,12 @@ def test_stack_fp32x3_vs_fp64_oracle(cuda, tname, use_touch, L, B, cut):
     assert e_s < max(3.0 * e_x, 2e-6)                                       # fp32-level, not bf16-level
     assert_grad_close(split[1][..., :50], ref[1], "grad_feats")
     assert split[1][..., 50:].abs().max().item() == 0.0
+    # (ico5: the element tolerance of the exact mode's test at that size, tests/test_gpu_named_sizes.py — sums over 41 k rows
+    # see a few ReLU arguments within rounding of zero take the other branch than in float64)
+    tol = 5e-3 if tname == "ico5" else 1e-3
     for i in range(L):
-        assert_grad_close(split[2][i], ref[2][i], f"dW layer {i}")
-        assert_grad_close(split[3][i], ref[3][i], f"db layer {i}")
+        assert_grad_close(split[2][i], ref[2][i], f"dW layer {i}", tol=tol)
+        assert_grad_close(split[3][i], ref[3][i], f"db layer {i}", tol=tol)
         if i < L - 1 and cut_len < H:
             assert split[3][i][cut_len:].abs().max().item() == 0.0
 

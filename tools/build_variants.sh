@@ -18,6 +18,16 @@ elif [ "$1" = "csrq" ]; then   # channel-sliced aggregation without its LDS gath
   build CSRQ_NOGATHER -DA3VT_DBG_CSRQ_NOGATHER
   build DW_NOWRAP -DA3VT_DBG_DW_NOWRAP   # dw without its mesh-boundary bookkeeping
   build DW_NOHYB -DA3VT_DBG_DW_NOHYB     # the plain dw kernel on the same buffers
+elif [ "$1" = "x3" ]; then   # gemm mode 3 (gcn_gemm3.hip) ablations: python tools/stack_bench.py --precision fp32x3 with A3VT_LIB=...
+  build X3_NOMFMA -DA3VT_DBG_X3_NOMFMA
+  build X3_NOSPLIT -DA3VT_DBG_X3_NOSPLIT
+  build RG3_NOA -DA3VT_DBG_RG3_NOA
+  build RG3_NOB -DA3VT_DBG_RG3_NOB
+  build RG3_NOEPI -DA3VT_DBG_RG3_NOEPI
+  build RG3_NODMA_NOEPI -DA3VT_DBG_RG3_NOA -DA3VT_DBG_RG3_NOB -DA3VT_DBG_RG3_NOEPI
+  build DW3_NODMA -DA3VT_DBG_DW3_NODMA
+  build DW3_NOSPLITPHASE -DA3VT_DBG_DW3_NOSPLITPHASE
+  build DW3_MFMAONLY -DA3VT_DBG_DW3_NODMA -DA3VT_DBG_DW3_NOSPLITPHASE
 elif [ "$1" = "nn" ]; then   # pruned nearest-neighbour search with its counters (tools/nn_stats.py)
   build NN_STATS -DA3VT_DBG_NN_STATS
 elif [ "$1" = "stamps" ]; then   # rowgemm with s_memrealtime stamps at its phase boundaries (tools/rowgemm_stamps.py)

@@ -17,7 +17,7 @@ p.add_argument("--hidden", type=int, default=300)
 p.add_argument("--batch", type=int, default=64)
 p.add_argument("--level", type=int, default=4)
 p.add_argument("--reps", type=int, default=5)
-p.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16s"])
+p.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16s", "fp32x3"])
 p.add_argument("--subdivision-order", action="store_true", help="icosphere vertices in subdivision order (poor locality)")
 a = p.parse_args()
 
