@@ -6,6 +6,9 @@
 #include <string.h>
 
 #include "../../include/a3vt.h"
+#include <mutex>
+#include <unordered_map>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -85,22 +88,37 @@ struct StackLayout {
 };
 
 // Channel-sliced aggregation (gcn_csr.hip "csrq") for the hidden layers of a stack: the mesh slice must fit LDS and the
-// product kernel must run the shape as one column block so that its epilogues can write quad-major.  Forward and backward
-// decide from the same arguments (the backward reads the sign bytes the forward left).  A3VT_CSR_ALGO=rows is a developer
-// switch back to the half-wave-per-vertex kernels (both paths give the same outputs).
+// product kernel must run the shape as one column block so that its epilogues can write quad-major.  The forward decides
+// and records the decision with the stash (stash_layout_*); the backward follows the record.  a3vt_dbg_csr_algo() is the
+// test hook that forces either path (both give the same outputs; the shipped library reads no environment variable).
 constexpr int kQuadCols = 160;   // quad-major columns of a hybrid layer output: the first column group of rowgemm's epilogue
+static int g_csr_algo = 0;       // 0 = by shape, 1 = half-wave ("rows"), 2 = channel-sliced where it fits, long rows included
 static bool use_csrq(int batch, int n_vert, int hidden, int cut_len, int gemm_bf16, int max_degree) {
   if (gemm_bf16 == 1 || gemm_bf16 == 2) return false;   // the bf16 operand / storage modes keep the half-wave kernels (mode 3 stores fp32: as mode 0)
   // Rows longer than the eight index slots a thread keeps in registers fall back to per-lane CSR walks: on the fused
   // vision + touch graphs (mean degree 12-26, hub rows of ~1150) that made the step 108 ms where the half-wave kernels
-  // take 64 — those graphs stay on the half-wave kernels.  (The caller passes the larger of the two maximum degrees of
-  // A and A^T to both calls, so forward and backward decide alike.)
-  const char *force = getenv("A3VT_CSR_ALGO");   // "sliced": developer / test switch, long rows included (they are correct, just slow)
-  if (!(force && strcmp(force, "sliced") == 0) && (max_degree <= 0 || max_degree > csrq_max_degree())) return false;
-  const char *algo = getenv("A3VT_CSR_ALGO");   // read per call: the parity tests run both paths in one process
-  if ((algo && strcmp(algo, "rows") == 0) || cut_len <= 0) return false;
+  // take 64 — those graphs stay on the half-wave kernels unless the test hook forces them (they are correct, just slow).
+  if (g_csr_algo != 2 && (max_degree <= 0 || max_degree > csrq_max_degree())) return false;
+  if (g_csr_algo == 1 || cut_len <= 0) return false;
   return hidden % 4 == 0 && hidden >= kQuadCols + 16 && csrq_fits(n_vert, cut_len) && dw_quad_major_ok(hidden, kQuadCols / 4) &&
          rowgemm_quad_major_ok(batch * n_vert, hidden, pad4(cut_len));
+}
+// Which layout a forward call left in a stash (activations + sign bytes), keyed by the sign-byte pointer: the backward
+// call that receives the same stash adopts it instead of re-deriving it from its own max_degree hint (a C-ABI caller
+// that passes csr_max_degree to the forward and csrT_max_degree to the backward would otherwise read hybrid rows as
+// row-major ones, silently).  Host-side, a few bytes per live stash; cleared when it grows past 4096 entries.
+static std::mutex g_stash_mu;
+static std::unordered_map<const void *, int> g_stash_layout;
+static void stash_layout_record(const void *masks, bool quad) {
+  if (!masks) return;
+  std::lock_guard<std::mutex> lock(g_stash_mu);
+  if (g_stash_layout.size() > 4096) g_stash_layout.clear();
+  g_stash_layout[masks] = quad ? 1 : 0;
+}
+static int stash_layout_lookup(const void *masks) {   // 1 / 0, or -1 when this library did not write that stash
+  std::lock_guard<std::mutex> lock(g_stash_mu);
+  auto it = g_stash_layout.find(masks);
+  return it == g_stash_layout.end() ? -1 : it->second;
 }
 // sign bytes of the aggregated channels, quad-major [batch][Q][n_vert] per hidden layer, kept behind the row-major
 // sign bytes in the caller's `masks` buffer
@@ -565,6 +583,7 @@ int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const 
   }
 
   const bool quad = use_csrq(batch, n_vert, hidden, cut_len, gemm_bf16, max_degree) && num_layers > 1;
+  if (num_layers > 1) stash_layout_record(masks, quad);
   int32_t *ell = reinterpret_cast<int32_t *>(scratch + L.ell);
   if (quad)
     if (int rc = launch_csrq_ell(rowptr, col, val, n_vert, ell, s)) return rc;
@@ -687,7 +706,10 @@ int a3vt_gcn_stack_bwd_acc(const float *feats, int ld_feats, int in_features, co
     if (int rc = launch_csr_heavy_list(rowptrT, n_vert, heavyT, s)) return rc;
   }
 
-  const bool quad = masks != nullptr && num_layers > 1 && use_csrq(batch, n_vert, hidden, cut_len, gemm_bf16, max_degreeT);   // same rule as the forward (which left the quad-major signs in `masks`)
+  // the layout the forward left in this stash (recorded by a3vt_gcn_stack_fwd); a stash this library did not write: by shape
+  const int rec = stash_layout_lookup(masks);
+  const bool quad = masks != nullptr && num_layers > 1 &&
+                    (rec >= 0 ? rec == 1 : use_csrq(batch, n_vert, hidden, cut_len, gemm_bf16, max_degreeT));
   int32_t *ellT = reinterpret_cast<int32_t *>(scratch + L.ell);
   if (quad)
     if (int rc = launch_csrq_ell(rowptrT, colT, valT, n_vert, ellT, s)) return rc;
@@ -1284,6 +1306,12 @@ int a3vt_profile_read(double *total_ms, int *count) {
     count[g_prof.cls[i]] += 1;
   }
   g_prof.used = 0;
+  return 0;
+}
+
+int a3vt_dbg_csr_algo(int algo) {
+  A3VT_CHECK_ARG(algo >= 0 && algo <= 2);
+  g_csr_algo = algo;
   return 0;
 }
 

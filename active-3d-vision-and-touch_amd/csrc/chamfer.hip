@@ -138,7 +138,11 @@ static int launch_nn(const float *q, int nq, int q_mod, const float *c, int nc, 
   // up) x R; among equals the smaller R wins (more waves per SIMD: R = 10 measured 5.5 ms where R = 5 takes 4.85, R = 8 5.2).
   // 10,000-point clouds x 192: R = 8 gives 960 workgroups = 3.75 per CU, so some CUs carry 4 x 8 = 32 units; R = 5
   // gives 1,536 = exactly 6 per CU, 30 units, all resident at once (72 VGPRs) — measured 5.2 -> 4.85 ms per call.
+#ifdef A3VT_DBG_ENV   // variant builds only (tools/build_variants.sh env): the shipped library reads no environment variable
   static const int env_r = getenv("A3VT_NN_R") ? atoi(getenv("A3VT_NN_R")) : 0;  // developer override
+#else
+  constexpr int env_r = 0;
+#endif
   int best_r = 4;
   long long best_cost = -1;
   for (int r : {5, 4, 6, 3}) {  // 8 and 10 can never beat 4 and 5 under this cost (half the R, at most twice the workgroups)
@@ -362,7 +366,11 @@ static int launch_nn2(const float *x, int p, const float *y, int q, int batch, i
     set_error("chamfer_fwd: clearing the column scratch failed");
     return -2;
   }
+#ifdef A3VT_DBG_ENV   // variant builds only (tools/build_variants.sh env): the shipped library reads no environment variable
   static const int env_r = getenv("A3VT_NN_R") ? atoi(getenv("A3VT_NN_R")) : 0;  // developer override
+#else
+  constexpr int env_r = 0;
+#endif
   int best_r = 4;
   long long best_cost = -1;
   // balance rule of launch_nn, plus the column fold: ~28 wave-instructions per 4 candidates whatever R is, i.e. about
@@ -436,7 +444,11 @@ int launch_chamfer_fwd(const float *x, const float *y, int draws, int batch, int
   }
   if (algo == NN_AUTO) {
     // the sort and the per-wave block scan pay for themselves from a couple of thousand points per cloud on
+#ifdef A3VT_DBG_ENV
     static const int env = getenv("A3VT_NN_ALGO") ? atoi(getenv("A3VT_NN_ALGO")) : 0;   // developer override
+#else
+    constexpr int env = 0;
+#endif
     if (env == NN_BRUTE_TWO_PASS || (env == NN_BRUTE_SWEEP && fits_sweep) || (env == NN_PRUNED && fits_pruned)) algo = env;
     else algo = (fits_pruned && p >= 2048 && q >= 2048) ? NN_PRUNED : fits_sweep ? NN_BRUTE_SWEEP : NN_BRUTE_TWO_PASS;
   }

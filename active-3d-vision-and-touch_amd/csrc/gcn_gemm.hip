@@ -779,7 +779,11 @@ static int launch_rowgemm_nt(const RowGemmArgs &a, int grid_y, hipStream_t s) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
   });
   const int tiles = cdiv(a.m, 16);
+#ifdef A3VT_DBG_ENV   // variant builds only (tools/build_variants.sh env): the shipped library reads no environment variable
   static const int env_wg = getenv("A3VT_RG_MAXWG") ? atoi(getenv("A3VT_RG_MAXWG")) : 0;  // developer override (experiments)
+#else
+  constexpr int env_wg = 0;
+#endif
   const int max_wg = env_wg > 0 ? env_wg : 256 * C::WG_PER_CU;
   // one tile per wave until every CU has a workgroup; beyond that the kernel deals tiles evenly (two per wave per round)
   const int grid = cdiv(tiles, C::WAVES) < max_wg ? cdiv(tiles, C::WAVES) : max_wg;
@@ -861,7 +865,11 @@ static int launch_rowgemm_epi(const RowGemmArgs &a0, hipStream_t s) {
   if (full == 0 || rem == 0 || rem * nt > 1024 || nt < 2) return launch_rowgemm_cols<EPI>(a, s);
   RowGemmArgs m = a;
   m.m = full * 16;
+#ifdef A3VT_DBG_ENV
   static const bool separate = getenv("A3VT_ROWTILE_SEPARATE") != nullptr;  // developer switch: remainder as its own launch
+#else
+  constexpr bool separate = false;
+#endif
   if (!separate) {
     m.rem_row0 = full * 16;
     m.rem_rows = a.m - full * 16;

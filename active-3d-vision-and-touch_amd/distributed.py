@@ -45,10 +45,21 @@ class FlatGradBucket:
     ``Deformation`` the modules only stages 2 and 3 use (``mesh_deform_2``; ``img_encoder_local``).  They sit at the front
     of the buffer and carry a post-accumulate hook each: when the last of them has received its gradient, ``reduce_early()``
     starts their all-reduce asynchronously, so it overlaps with the rest of the backward pass (stage 1 and the global image
-    encoder: 95 MB of the 189 MB image model); ``all_reduce_mean()`` reduces the rest and waits for both.  If an early
-    parameter gets no gradient in some step the early reduce simply does not start and everything is reduced at the end."""
+    encoder); ``all_reduce_mean()`` reduces the rest and waits for both.
 
-    def __init__(self, params, early=(), sinks=True):
+    Early parameters that never receive a gradient (``Image_Encoder.forward`` leaves its loop before the last layers of the
+    default 6 x 3 pyramid: 20 tensors of ``img_encoder_local``) would keep the countdown from ever reaching zero, so the
+    countdown only counts the early parameters that HAD a gradient in the previous step (at first all are assumed to; a
+    model with unused early parameters starts nothing early in its first step, learns the count, and overlaps from then on).  Whether the early chunk started during the backward pass or not,
+    the collective SEQUENCE is always [early chunk][rest]: a rank whose countdown did not fire issues the same two calls at
+    the end, so ranks cannot fall out of step over it.
+
+    ``force_collectives=True`` issues the collectives on an initialised process group of ONE rank too (they are no-ops
+    numerically): the RCCL path — ``div_`` → async ``all_reduce`` on the communicator's stream → ``wait`` → optimiser — then
+    runs on a single GPU exactly as it does on eight (tests/test_gpu_trainer.py)."""
+
+    def __init__(self, params, early=(), sinks=True, force_collectives=False):
+        self.force_collectives = bool(force_collectives)
         params = [p for p in params if p.requires_grad]
         early_ids = {id(p) for p in early}
         self.params = [p for p in params if id(p) in early_ids] + [p for p in params if id(p) not in early_ids]
@@ -66,24 +77,52 @@ class FlatGradBucket:
             self.early_numel = off
         self._early_done = False
         self._early_work = None
-        self._pending = self.n_early
+        self._early_live = self.n_early   # early parameters that received a gradient in the previous step (at first: all assumed)
+        self._fired = 0
+        self._late = False
+        self._pending = self.n_early if self.n_early else -1
+        self.early_started_in_backward = 0   # steps whose early all-reduce was launched from inside the backward pass
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_early_grad) for p in self.params[:self.n_early]]
         # Gradients written where they live: the library's GCN backward takes these views as its output pointers (first use
         # of a step overwrites, the second use of the shared mesh_deform_2 accumulates in the kernel), so for those
         # parameters there is no fresh tensor for autograd to assign, no add kernel for the second use and nothing to copy
         # in gather().  Only on the GPU (the sinks are consulted by ops.GCNStackFn).
         self._sinks = []
+        self._sink_by_id = {}
         self._open = False
         if sinks and self.flat.is_cuda:
             from . import ops as _ops
             for k, (p, v) in enumerate(zip(self.params, self.views)):
                 self._sinks.append(_ops.register_grad_sink(p, v, self._on_early_grad_sink if k < self.n_early else None))
+                self._sink_by_id[id(p)] = self._sinks[-1]
         self._rehome()
 
     def _on_early_grad(self, _param):
+        if _param is not None and self._sink_by_id:
+            # torch fires the post-accumulate hook even when the incoming gradient is undefined — which is what the library
+            # returns for a parameter whose gradient it wrote through the sink (counted once, by the sink's on_final)
+            k = self._sink_by_id.get(id(_param))
+            if k is not None and k.written:
+                return
+        self._fired += 1
+        if self._early_done:
+            self._late = True             # arrived after its chunk was gathered (and possibly reduced): see all_reduce_mean()
         self._pending -= 1
         if self._pending == 0:
+            self.early_started_in_backward += 1
             self.reduce_early()
+
+    def close(self):
+        """Detach from the parameters: remove the gradient hooks and the library's gradient sinks (a bucket that is replaced
+        must not keep writing into — or reducing — its old buffer)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        if self._sinks:
+            from . import ops as _ops
+            for p, k in zip(self.params, self._sinks):
+                _ops.unregister_grad_sink(p, k)
+        self._sinks = []
 
     def _on_early_grad_sink(self):
         self._on_early_grad(None)
@@ -103,11 +142,13 @@ class FlatGradBucket:
             p.grad = None
         self._early_done = False
         self._early_work = None
-        self._pending = self.n_early
+        self._fired = 0
+        self._late = False
+        self._pending = self._early_live if self._early_live else -1   # unknown / none live: the countdown cannot fire
         for k in self._sinks:
             k.reset()
 
-    def _gather(self, lo, hi, out):
+    def _gather(self, lo, hi):
         """Bring the gradients of params[lo:hi] into their slice of the flat buffer: nothing to do for those the library wrote
         in place (ops.GradSink) or that already live there, one multi-tensor copy for the ones autograd assigned as fresh
         tensors, zeros for parameters the graph did not use."""
@@ -129,13 +170,13 @@ class FlatGradBucket:
     def gather(self):
         """Collect every gradient into the flat buffer (the early chunk only if ``reduce_early`` has not already)."""
         if not self._early_done:
-            self._gather(0, self.n_early, self.flat[:self.early_numel])
-        self._gather(self.n_early, len(self.params), self.flat[self.early_numel:])
+            self._gather(0, self.n_early)
+        self._gather(self.n_early, len(self.params))
         self._open = False
+        self._early_live = self._fired     # what the next step's countdown waits for
 
-    @staticmethod
-    def _active():
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    def _active(self):
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.force_collectives)
 
     def reduce_early(self):
         """Gather the early chunk and start its all-reduce (asynchronously).  Safe to call when there is no early chunk or no
@@ -143,7 +184,7 @@ class FlatGradBucket:
         if self._early_done or self.n_early == 0:
             return
         chunk = self.flat[:self.early_numel]
-        self._gather(0, self.n_early, chunk)
+        self._gather(0, self.n_early)
         self._early_done = True
         if self._active():
             chunk.div_(dist.get_world_size())
@@ -152,11 +193,25 @@ class FlatGradBucket:
     def all_reduce_mean(self):
         """Average the whole gradient over the ranks: the early chunk's reduce may already be in flight; the rest is reduced
         here; both are complete on return (on the current stream for RCCL)."""
+        started = self._early_done
+        if self._late:
+            # more early parameters received a gradient than in the previous step, so the countdown fired before the last of
+            # them: that gradient is not in the chunk that was reduced.  Never silently: the graph changed between steps.
+            self._early_live = self.n_early
+            raise RuntimeError("a3vt: FlatGradBucket: an early parameter received its gradient after the early chunk had been "
+                               "gathered — the set of parameters that receive gradients changed since the previous step. "
+                               "Nothing was reduced; call gather() to keep this step's local gradients, or repeat the step.")
         self.gather()
         if not self._active():
             return None
         world = dist.get_world_size()
-        rest = self.flat[self.early_numel:] if self._early_done else self.flat
+        if self.n_early and not started:
+            # the countdown did not fire during the backward pass (first step, or an early parameter without a gradient):
+            # same two collectives, in the same order, as on a rank where it did
+            chunk = self.flat[:self.early_numel]
+            chunk.div_(world)
+            dist.all_reduce(chunk, op=dist.ReduceOp.SUM)
+        rest = self.flat[self.early_numel:]
         if rest.numel():
             rest.div_(world)
             dist.all_reduce(rest, op=dist.ReduceOp.SUM)

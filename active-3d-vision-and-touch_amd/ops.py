@@ -4,6 +4,7 @@ memory, the current HIP stream and autograd bookkeeping; every op below is one C
 All tensors must be float32 / int32, contiguous, on a ROCm device.  There is no CPU path.
 """
 import ctypes
+import weakref
 
 import numpy as np
 import torch
@@ -98,16 +99,33 @@ class GradSink:
         self.written, self.expect = False, 0
 
 
-GRAD_SINKS = {}     # id(parameter) -> GradSink; filled by FlatGradBucket, consulted by GCNStackFn
+GRAD_SINKS = {}     # id(parameter) -> (weakref to the parameter, GradSink); filled by FlatGradBucket, consulted by GCNStackFn
 
 
 def register_grad_sink(param, view, on_final=None):
-    GRAD_SINKS[id(param)] = GradSink(view, on_final)
-    return GRAD_SINKS[id(param)]
+    sink = GradSink(view, on_final)
+    key = id(param)
+    # the weak reference both proves identity at lookup time (ids are reused once a Parameter is freed) and drops the
+    # entry — and with it the reference to the owner's flat buffer — when the parameter dies
+    def _gone(ref, key=key):
+        if GRAD_SINKS.get(key, (None,))[0] is ref:
+            del GRAD_SINKS[key]
+
+    GRAD_SINKS[key] = (weakref.ref(param, _gone), sink)
+    return sink
 
 
-def unregister_grad_sink(param):
-    GRAD_SINKS.pop(id(param), None)
+def unregister_grad_sink(param, sink=None):
+    """Remove ``param``'s sink (only if it is ``sink``, when given: a newer bucket may have registered its own since)."""
+    ent = GRAD_SINKS.get(id(param))
+    if ent is not None and ent[0]() is param and (sink is None or ent[1] is sink):
+        del GRAD_SINKS[id(param)]
+
+
+def grad_sink_of(param):
+    """The sink registered for exactly this parameter object, or None."""
+    ent = GRAD_SINKS.get(id(param))
+    return ent[1] if ent is not None and ent[0]() is param else None
 
 
 class GCNStackFn(torch.autograd.Function):
@@ -145,7 +163,7 @@ class GCNStackFn(torch.autograd.Function):
         ctx.adj, ctx.dims, ctx.mode = adj, (in_features, hidden, cut_len, nl), mode
         ctx.acts, ctx.masks = acts, masks
         # gradients written where they live: every parameter of this call has a sink in the trainer's flat bucket
-        sinks = [GRAD_SINKS.get(id(p)) for p in params] if need_bwd else []
+        sinks = [grad_sink_of(p) for p in params] if need_bwd else []
         ctx.sinks = sinks if sinks and all(k is not None and k.view.shape == p.shape and k.view.is_contiguous()
                                            for k, p in zip(sinks, params)) else None
         if ctx.sinks:
@@ -582,6 +600,15 @@ def rowgemm(a, w, bf16=False):
     _lib.check(L.a3vt_rowgemm(_lib.ptr(a), K, M, K, _lib.ptr(wt), N, 1 if bf16 else 0, _lib.ptr(c), N, _stream()),
                "rowgemm")
     return c
+
+
+CSR_ALGOS = {"auto": 0, "rows": 1, "sliced": 2}
+
+
+def dbg_csr_algo(name):
+    """Test hook (``a3vt_dbg_csr_algo``): force the neighbour-aggregation kernels of the fp32 stacks — "auto" (default, by
+    shape), "rows" (half-wave per vertex) or "sliced" (channel-sliced wherever a mesh slice fits LDS).  Same outputs."""
+    _lib.check(_lib.load().a3vt_dbg_csr_algo(CSR_ALGOS[name]), "dbg_csr_algo")
 
 
 def split3(x):

@@ -40,6 +40,26 @@ except Exception:  # tensorboard is optional
             pass
 
 
+def pretrained_location(args):
+    """Directory of the pretrained reconstruction model for ``args`` — the reference's choice (:218-241): one of four
+    sub-directories of the ``pretrained`` package picked by ``(use_img, finger)``,
+    ``<root>/reconstruction/vision/{v_t_p, v_t_g, t_p, t_g}/``.  ``<root>`` = ``args.pretrained_root``, else
+    ``$PTEROTACTYL_PRETRAINED``, else an installed ``pterotactyl.pretrained`` package, else ``pretrained/`` next to this
+    package.  ``args.pretrained_location`` (a directory holding config.json + model) overrides the whole rule."""
+    explicit = getattr(args, "pretrained_location", None)
+    if explicit:
+        return explicit
+    root = getattr(args, "pretrained_root", None) or os.environ.get("PTEROTACTYL_PRETRAINED")
+    if not root:
+        try:
+            from pterotactyl import pretrained as _pre      # the reference's own package, when it is installed
+            root = os.path.dirname(_pre.__file__)
+        except Exception:
+            root = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "pretrained")
+    sub = ("v_t_p" if args.finger else "v_t_g") if args.use_img else ("t_p" if args.finger else "t_g")
+    return os.path.join(root, "reconstruction", "vision", sub) + os.sep
+
+
 class Engine:
     def __init__(self, args, loaders=None, template="vision_charts"):
         np.random.seed(args.seed)
@@ -58,6 +78,7 @@ class Engine:
         if not self.args.eval:
             utils.save_config(self.checkpoint_dir, args)
         self.rank, self.world, self.local_rank = adist.init_from_env()
+        self.bucket = None
 
     def setup(self):
         """Everything ``__call__`` does before touching data (reference :52-64)."""
@@ -68,14 +89,17 @@ class Engine:
         adist.broadcast_buffers(self.encoder)
         if self.world > 1:   # identical weights everywhere; from here on every rank draws its own random numbers
             adist.seed_rank(self.args.seed, self.rank)
-        self.bucket = None
         if not self.args.eval:
             params = list(self.encoder.parameters())
             # gradients that are final once the backward pass has left stage 2: their all-reduce starts as soon as the last of
             # them has arrived (two chunks, FlatGradBucket)
             early = [p for name in ("mesh_deform_2", "img_encoder_local") if hasattr(self.encoder, name)
                      for p in getattr(self.encoder, name).parameters()] if getattr(self.encoder, "num_stages", 3) > 1 else []
-            self.bucket = adist.FlatGradBucket(params, early=early)
+            if getattr(self, "bucket", None) is not None:
+                self.bucket.close()
+            # args.force_collectives (this package's knob, default off): issue the gradient all-reduces on a process group of
+            # one rank as well — the RCCL path on a single GPU (tests)
+            self.bucket = adist.FlatGradBucket(params, early=early, force_collectives=getattr(self.args, "force_collectives", False))
             try:
                 self.optimizer = optim.Adam(params, lr=self.args.lr, weight_decay=0, fused=True)
             except (RuntimeError, TypeError):
@@ -190,10 +214,12 @@ class Engine:
 
     def load(self):
         if self.args.eval and getattr(self.args, "pretrained", False):
-            location = getattr(self.args, "pretrained_location", None)
-            if location is None:
-                raise RuntimeError("a3vt: pretrained weights are not bundled (reference download_models.sh); set "
-                                   "args.pretrained_location to a directory holding config.json + model")
+            location = pretrained_location(self.args)
+            if not os.path.exists(os.path.join(location, "model")):
+                raise FileNotFoundError(
+                    f"a3vt: no pretrained model at {location} (the reference fetches its weights with download_models.sh into "
+                    "pterotactyl/pretrained/; point args.pretrained_root / $PTEROTACTYL_PRETRAINED at that directory, or "
+                    "args.pretrained_location at one holding config.json + model)")
             vision_args, _ = utils.load_model_config(location)
             self.mesh_info, self.initial_mesh = utils.load_mesh_vision(vision_args, self.vision_chart_location)
             self.n_vision_charts = self.initial_mesh.shape[0]

@@ -307,6 +307,8 @@ def main():
     # as Engine.setup(): the chunk that is final once the backward pass has left stage 2 is reduced while stage 1 still runs
     early = [p for name in ("mesh_deform_2", "img_encoder_local") if hasattr(eng.encoder, name)
              for p in getattr(eng.encoder, name).parameters()]
+    if getattr(eng, "bucket", None) is not None:
+        eng.bucket.close()
     eng.bucket = adist.FlatGradBucket(params, early=early)
     try:
         eng.optimizer = torch.optim.Adam(params, lr=args.lr, weight_decay=0, fused=True)
@@ -417,6 +419,13 @@ def main():
                    "global_batch": a.batch * world, "parallelism": f"dp{world}", "final_loss": final_loss},
         "step_ms": step_ms,
     }
+    # what the gradient exchange looked like to RCCL in this run (N = 1: no process group, nothing is exchanged)
+    out["rccl"] = {"world": dist.get_world_size() if dist.is_initialized() else 1,
+                   "backend": dist.get_backend() if dist.is_initialized() else None,
+                   "bucket_bytes": eng.bucket.flat.numel() * 4, "early_chunk_bytes": eng.bucket.early_numel * 4,
+                   "collectives_per_step": 2 if (dist.is_initialized() and world > 1 and eng.bucket.n_early) else (1 if world > 1 else 0),
+                   "overlapped": bool(world > 1 and eng.bucket.early_started_in_backward > 0),
+                   "early_started_in_backward_steps": eng.bucket.early_started_in_backward}
     if roof is not None:
         out["roofline"] = roof
     if a.gemm_precision == "fp32" and a.alt_steps > 0:   # every rank runs it (the steps hold collectives); rank 0 reports

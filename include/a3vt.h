@@ -60,10 +60,10 @@ int a3vt_csr_validate(const int32_t *rowptr_host, const int32_t *col_host, int n
  * csr_max_degree / csrT_max_degree: the largest number of entries in a row of that matrix, or 0 if unknown.  The
  * fused vision + touch graphs have hub rows (chart centres linked to every seam vertex, ~1150 entries,
  * utility/utils.py:119-128); rows above 64 entries are aggregated by a whole workgroup in a second launch, which a
- * known small maximum lets the library skip.  Results do not depend on the value — but pass the SAME value (the larger
- * of the two maxima) to the forward and the backward call of a stack: with every row <= 8 entries (the vision templates),
- * fp32, hidden 273-304, <= 3072 vertices per mesh and >= 12 288 rows, both calls use the channel-sliced aggregation
- * (csrc/gcn_csrq.hip) and the backward reads sign bytes in the layout the forward wrote.
+ * known small maximum lets the library skip.  Results do not depend on the value.  With every row <= 8 entries (the vision
+ * templates), fp32 storage, hidden 273-304, <= 3072 vertices per mesh and >= 12 288 rows the forward uses the channel-sliced
+ * aggregation (csrc/gcn_csrq.hip) and leaves hybrid rows in the stash; the library remembers which layout it wrote into a
+ * stash (keyed by the `masks` pointer) and the backward call that receives that stash follows it, whatever its own hint.
  *
  * feats  : [M][ld_feats] with ld_feats == in_features rounded up to a multiple of 4; pad columns must be zero.
  * acts   : saved inputs of layers 1..L-1, (L-1) * M * hidden floats (needed by the backward pass).  OPAQUE to the caller:
@@ -269,6 +269,12 @@ int a3vt_chamfer_fwd_ws(const float *x, const float *y, int draws, int batch, in
 int a3vt_chamfer_bwd(const float *x, const float *y, int draws, int batch, int p, int q,
                      const int32_t *idx_xy, const int32_t *idx_yx, const float *grad_cd,
                      float *grad_x, float *grad_y, void *stream);
+
+/* Test hook (tests/test_gpu_csr_sliced.py): which neighbour-aggregation kernels the fp32 stacks use — 0 = chosen by shape
+ * (default), 1 = the half-wave-per-vertex kernels everywhere, 2 = the channel-sliced kernels wherever a mesh slice fits
+ * LDS, graphs with long rows included.  Every choice gives the same outputs; process-wide; not a tuning knob.  The
+ * library reads NO environment variable. */
+int a3vt_dbg_csr_algo(int algo);
 
 /* The operand split of gemm mode 3 (replaces nothing in the reference: it is how torch.matmul(features, self.weight),
  * model.py:352, is fed to the bf16 matrix pipe without losing fp32 bits).  hi / mid / lo receive bf16 bit patterns with

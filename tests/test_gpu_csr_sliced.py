@@ -3,8 +3,6 @@ adjacency products of reconstruction/vision/model.py:356,360 for the hidden laye
 half-wave-per-vertex kernels it replaces — bit for bit, the summation order per element is the same — and (ii) the fp64
 oracle, on shapes that take the new path (>= 12 288 rows, hidden 300): plain icospheres, the reference atlas, and the
 fused vision + touch graph whose hub rows (~1150 neighbours) go through ``csrq_heavy_kernel``."""
-import os
-
 import pytest
 import torch
 
@@ -49,25 +47,21 @@ def test_channel_sliced_aggregation_equals_row_kernels_and_oracle(cuda, tname, u
         nn_ = verts.shape[0]
     adj = ops.DeviceCSR(amesh.CSRAdjacency.from_pairs(r, c, nn_), cuda)
     cut_len = og.cut_length(H, cut)
-    old = os.environ.get("A3VT_CSR_ALGO")
     try:
-        os.environ["A3VT_CSR_ALGO"] = "rows"
+        ops.dbg_csr_algo("rows")
         ref = _run(cuda, adj, st, feats, gup, L, H, cut_len)
         # "sliced" forces the channel-sliced path on graphs with rows longer than its eight register slots too (the fused
         # touch graph: CSR continuation of long rows, hub rows through csrq_heavy_kernel) — by default those graphs stay on
         # the half-wave kernels, which are faster for them
-        os.environ["A3VT_CSR_ALGO"] = "sliced"
+        ops.dbg_csr_algo("sliced")
         new = _run(cuda, adj, st, feats, gup, L, H, cut_len)
         again = _run(cuda, adj, st, feats, gup, L, H, cut_len)
         if not use_touch:
-            os.environ.pop("A3VT_CSR_ALGO")
+            ops.dbg_csr_algo("auto")
             default = _run(cuda, adj, st, feats, gup, L, H, cut_len)     # short rows: the default IS the sliced path
             assert torch.equal(default[0], new[0]) and torch.equal(default[1], new[1])
     finally:
-        if old is None:
-            os.environ.pop("A3VT_CSR_ALGO", None)
-        else:
-            os.environ["A3VT_CSR_ALGO"] = old
+        ops.dbg_csr_algo("auto")
     # (i) same bits as the kernels it replaces: outputs, input gradient, every weight gradient
     assert torch.equal(new[0], ref[0])
     assert torch.equal(new[1], ref[1])
@@ -112,3 +106,34 @@ def test_forward_only_call_takes_the_sliced_path_without_a_stash(cuda):
         out_o = og.gcn(feats.double(), {k: v.double() for k, v in st.items()}, "mesh_deform_1",
                        (adj_o[0], adj_o[1], adj_o[2].double()), L, 0.33)
     assert rel_err(out, out_o) < 1e-4
+
+
+def test_backward_follows_the_layout_the_forward_recorded(cuda):
+    """a C-ABI caller may hand different max-degree hints to the forward and the backward call (csr_max_degree /
+    csrT_max_degree, or 0 = unknown).  The forward records the layout it left in the stash; the backward adopts it — here
+    the hook flips the shape rule between the two calls and the gradients must not change."""
+    from a3vt_amd import mesh as amesh, ops
+    from oracle import gcn as og
+    L, H, B = 3, 300, 24
+    verts, faces = template("ico3")
+    st = og.init_state(50, H, L, seed=5)
+    g = torch.Generator().manual_seed(21)
+    feats = torch.randn(B, verts.shape[0], 50, generator=g) * 0.5
+    gup = torch.randn(B, verts.shape[0], 3, generator=g)
+    r, c = amesh.vision_pairs(faces, verts.shape[0])
+    adj = ops.DeviceCSR(amesh.CSRAdjacency.from_pairs(r, c, verts.shape[0]), cuda)
+    ref = _run(cuda, adj, st, feats, gup, L, H, 99)
+
+    ws = [st[f"mesh_deform_1.layers.{i}.weight"].to(cuda).requires_grad_(True) for i in range(L)]
+    bs = [st[f"mesh_deform_1.layers.{i}.bias"].to(cuda).requires_grad_(True) for i in range(L)]
+    fd = torch.nn.functional.pad(feats, (0, 2)).to(cuda).requires_grad_(True)
+    try:
+        out = ops.gcn_stack(fd, adj, 50, H, 99, ws, bs)          # forward: channel-sliced path, hybrid rows in the stash
+        ops.dbg_csr_algo("rows")                                  # the backward's own rule would now say "row-major"
+        (out * gup.to(cuda)).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.dbg_csr_algo("auto")
+    assert torch.equal(fd.grad, ref[1])
+    for i in range(L):
+        assert torch.equal(ws[i].grad, ref[2][i]) and torch.equal(bs[i].grad, ref[3][i])

@@ -368,14 +368,14 @@ def test_gradients_written_into_the_bucket_equal_the_autograd_path(cuda, tmp_pat
         bucket.all_reduce_mean()
         return bucket.flat.clone(), early_started
 
-    assert eng.bucket._sinks and all(id(p) in ops.GRAD_SINKS for p in eng.bucket.params)
+    assert eng.bucket._sinks and all(ops.grad_sink_of(p) is not None for p in eng.bucket.params)
     stash0 = ops.STATS["stack_stash_calls"]
     flat_sink, early = grads_of(eng.bucket)
     assert ops.STATS["stack_stash_calls"] - stash0 == 3
     assert early                                                  # mesh_deform_2's chunk was complete inside the backward
     w = eng.encoder.mesh_deform_2.layers[1].weight
-    assert ops.GRAD_SINKS[id(w)].written and ops.GRAD_SINKS[id(w)].expect == 0
-    assert w.grad.data_ptr() == ops.GRAD_SINKS[id(w)].view.data_ptr()
+    assert ops.grad_sink_of(w).written and ops.grad_sink_of(w).expect == 0
+    assert w.grad.data_ptr() == ops.grad_sink_of(w).view.data_ptr()
     flat_sink2, _ = grads_of(eng.bucket)                          # second step: flags were reset, nothing left over
     assert torch.equal(flat_sink, flat_sink2)
     # a step that skips all_reduce_mean() would leave .grad == None on the sink parameters (the optimiser would skip them):
@@ -384,17 +384,15 @@ def test_gradients_written_into_the_bucket_equal_the_autograd_path(cuda, tmp_pat
     verts = eng.encoder(torch.zeros(3, 1), charts)[0]
     verts.sum().backward()
     w1 = eng.encoder.mesh_deform_1.layers[1].weight               # (not in the early chunk, which re-homes itself)
-    assert w1.grad is None and ops.GRAD_SINKS[id(w1)].written
+    assert w1.grad is None and ops.grad_sink_of(w1).written
     with pytest.raises(RuntimeError, match="all_reduce_mean"):
         eng.bucket.zero()
     eng.bucket.gather()
-    assert w1.grad.data_ptr() == ops.GRAD_SINKS[id(w1)].view.data_ptr()
+    assert w1.grad.data_ptr() == ops.grad_sink_of(w1).view.data_ptr()
     # the autograd path on the same parameters, same order in the buffer
     early = list(eng.encoder.mesh_deform_2.parameters())
-    for p in params:
-        ops.unregister_grad_sink(p)
-    for h in eng.bucket._hooks:
-        h.remove()
+    eng.bucket.close()                                            # hooks and sinks gone (a replaced bucket must let go)
+    assert all(ops.grad_sink_of(p) is None for p in params)
     plain = adist.FlatGradBucket(params, early=early, sinks=False)
     assert [id(p) for p in plain.params] == [id(p) for p in eng.bucket.params] and not plain._sinks
     flat_plain, early_plain = grads_of(plain)
@@ -437,3 +435,75 @@ def test_engine_steps_the_image_model(cuda, tmp_path, precision):
     for name in ("mesh_deform_1.layers.0.weight", "mesh_deform_2.layers.1.bias", "img_encoder_global.layers.0.0.weight",
                  "img_encoder_local.layers.5.2.bias"):
         assert not torch.equal(dict(eng.encoder.named_parameters())[name].detach(), before[name]), name
+
+
+@pytest.mark.parametrize("image_model", [False, True])
+def test_collective_path_on_one_gpu_is_bit_identical(cuda, tmp_path, image_model):
+    """the gradient exchange of vision/train.py:120-157 as it runs on N ranks — ``div_`` -> asynchronous RCCL
+    ``all_reduce`` of the early chunk from inside the backward pass -> all-reduce of the rest -> ``wait`` -> fused Adam — on a
+    process group of ONE rank (``FlatGradBucket(force_collectives=True)``): three ``Engine.train_step``s with and without the
+    collectives give bit-identical weights, on the 20 x 300 model and on the image model (189 MB bucket; its early chunk holds
+    parameters that never get a gradient — ADVICE r03: the countdown learns that in step 1 and overlaps from step 2)."""
+    import torch.distributed as dist
+    from a3vt_amd.pterotactyl.reconstruction.vision import model, train
+    if dist.is_initialized():
+        pytest.skip("a process group is already up in this process")
+    os.chdir(tmp_path)
+    if image_model:
+        kw = dict(number_points=800, num_GCN_layers=3, hidden_GCN_size=64, use_img=True, use_touch=True, finger=False,
+                  num_grasps=1, CNN_ker_size=5, num_CNN_blocks=6, layers_per_block=3, batch_size=2)
+    else:
+        kw = dict(number_points=1000, batch_size=2)
+    g = torch.Generator().manual_seed(2)
+    B = 2
+    tc = torch.zeros(B, 1, 4, 25, 4)
+    tc[..., :3] = (torch.rand(B, 1, 4, 25, 3, generator=g) - 0.5) * 0.3
+    tc[..., 3] = 2
+    img = torch.rand(B, 3, 256, 256, generator=g).to(cuda) if image_model else torch.zeros(B, 1)
+    gt = random_cloud(B, kw["number_points"], 6).to(cuda)
+
+    def three_steps(force, tag=""):
+        args = make_args(exp_type="t", exp_id=f"coll{int(force)}{int(image_model)}{tag}", eval=False, epochs=1, patience=70,
+                         log_interval=0, force_collectives=force, **kw)
+        torch.manual_seed(0)
+        eng = train.Engine(args, loaders=((), ()))
+        eng.setup()
+        batch = {"img": img, "touch_charts": tc} if image_model else {"img": img}
+        charts = model.prepare_mesh(batch, eng.initial_mesh, args)
+        nf = eng.mesh_info["faces"].shape[0]
+        gs = torch.Generator().manual_seed(9)
+        P = kw["number_points"]
+        early_flags = []
+        for _ in range(3):
+            samples = (torch.randint(0, nf, (3, B, P), generator=gs).to(torch.int32).to(cuda),
+                       torch.rand(3, B, P, generator=gs).to(cuda), torch.rand(3, B, P, generator=gs).to(cuda))
+            eng.train_step(img.to(cuda) if image_model else img, charts, gt, samples=samples)
+            early_flags.append(eng.bucket._early_done)
+        torch.cuda.synchronize()
+        flat = torch.cat([p.detach().reshape(-1) for p in eng.encoder.parameters()]).clone()
+        started = eng.bucket.early_started_in_backward
+        eng.bucket.close()
+        return flat, early_flags, started, eng.bucket.early_numel * 4, eng.bucket.flat.numel() * 4
+
+    plain, flags0, started0, _, _ = three_steps(False)
+    plain_again = three_steps(False, "b")[0]
+    dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1)
+    try:
+        forced, flags1, started1, early_bytes, total_bytes = three_steps(True)
+    finally:
+        dist.destroy_process_group()
+    if torch.equal(plain, plain_again):
+        assert torch.equal(plain, forced)
+    else:
+        # the image encoders' convolutions are MIOpen's, whose algorithm choice may differ between two runs in one process
+        # (DESIGN §2 "Determinism"): then two runs WITHOUT collectives already differ, and the forced run must be as close
+        assert image_model
+        spread = (plain - plain_again).abs().max().item()
+        assert (plain - forced).abs().max().item() <= 4.0 * spread + 1e-7, (spread, (plain - forced).abs().max().item())
+    assert early_bytes > 0 and total_bytes > early_bytes
+    # the early chunk's reduce was launched from inside the backward pass: every step on the image-free model; from the
+    # second step on the image model (20 tensors of img_encoder_local never receive a gradient)
+    assert flags1 == ([False, True, True] if image_model else [True, True, True]), flags1
+    assert started1 == (2 if image_model else 3) and started0 == started1
+    if image_model:
+        assert total_bytes > 150e6

@@ -56,7 +56,7 @@ def test_header_symbols_all_bound_and_exported():
     for name in declared:
         assert hasattr(dll, name), name
     L = lib.load()
-    assert L.a3vt_version() == 132
+    assert L.a3vt_version() == 140
     assert L.a3vt_posenc_param_count(50) == 12 * 63 + 12 + 25 * 12 + 25 + 50 * 25 + 50 + 200
     assert L.a3vt_wt_rows(300) >= 304 and L.a3vt_wt_ld(300) == 304
     # host-only entry point: CSR validation
@@ -273,3 +273,69 @@ def test_public_header_is_plain_c(tmp_path):
                 ["g++", "-std=c++17", "-Wall", "-Werror", "-x", "c++", "-I", inc, "-c", str(src), "-o", str(tmp_path / "cc.o")]):
         out = subprocess.run(cmd, capture_output=True, text=True)
         assert out.returncode == 0, out.stderr
+
+
+def test_pretrained_location_follows_the_reference_rule(tmp_path, monkeypatch):
+    """vision/train.py:218-241 — eval + pretrained picks one of four directories by (use_img, finger); here the root comes
+    from args.pretrained_root / $PTEROTACTYL_PRETRAINED, and a missing model is a FileNotFoundError that names the place."""
+    import json
+    from types import SimpleNamespace
+    from a3vt_amd.pterotactyl.reconstruction.vision import train
+    want = {(True, True): "v_t_p", (True, False): "v_t_g", (False, True): "t_p", (False, False): "t_g"}
+    for (use_img, finger), sub in want.items():
+        a = SimpleNamespace(use_img=use_img, finger=finger, pretrained_root=str(tmp_path))
+        assert train.pretrained_location(a) == os.path.join(str(tmp_path), "reconstruction", "vision", sub) + os.sep
+    monkeypatch.setenv("PTEROTACTYL_PRETRAINED", "/somewhere")
+    assert train.pretrained_location(SimpleNamespace(use_img=False, finger=False)) == "/somewhere/reconstruction/vision/t_g/"
+    assert train.pretrained_location(SimpleNamespace(use_img=True, finger=True, pretrained_location="/x/y")) == "/x/y"
+    # Engine.load() on a fake tree: the config is read from the chosen directory, the weights file is looked for there
+    from a3vt_amd.synthetic import make_args
+    os.chdir(tmp_path)
+    loc = tmp_path / "reconstruction" / "vision" / "t_g"
+    loc.mkdir(parents=True)
+    args = make_args(exp_type="t", exp_id="pre", eval=True, pretrained=True, use_img=False, finger=False,
+                     pretrained_root=str(tmp_path), num_GCN_layers=3, hidden_GCN_size=16)
+    eng = train.Engine(args, loaders=((), ()))
+    with pytest.raises(FileNotFoundError, match="t_g"):
+        eng.load()
+    (loc / "config.json").write_text(json.dumps({k: v for k, v in vars(args).items() if isinstance(v, (int, float, str, bool))}
+                                                | {"check_point": str(loc)}))
+    (loc / "model").write_bytes(b"")
+    with pytest.raises(Exception) as e:   # past the location logic: fails only because there is no GPU / the file is not a checkpoint
+        eng.load()
+    assert not isinstance(e.value, FileNotFoundError)
+
+
+def test_flat_bucket_early_countdown_learns_unused_parameters():
+    """an early parameter that never receives a gradient must not keep the early chunk from starting — the
+    countdown counts the early parameters that had a gradient in the previous step; a gradient that arrives AFTER the early
+    chunk was gathered (the set grew between steps) is an error, not a silent loss."""
+    import torch
+    from a3vt_amd import distributed as adist
+    torch.manual_seed(0)
+    used, unused, late, head = (torch.nn.Linear(4, 4) for _ in range(4))
+    params = [*head.parameters(), *used.parameters(), *unused.parameters(), *late.parameters()]
+    bucket = adist.FlatGradBucket(params, early=[*used.parameters(), *unused.parameters(), *late.parameters()], sinks=False)
+    x = torch.randn(3, 4)
+
+    def step(with_late):
+        bucket.zero()
+        y = head(used(x))
+        if with_late:
+            y = y + late(x)
+        y.sum().backward()
+        done = bucket._early_done
+        bucket.all_reduce_mean()
+        return done
+
+    assert step(False) is False and bucket._early_live == 2            # learns: two of the six early tensors are live
+    assert step(False) is True and bucket.early_started_in_backward == 1
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views))
+    assert unused.weight.grad.abs().max().item() == 0.0
+    with pytest.raises(RuntimeError, match="changed since the previous step"):
+        step(True)                                                      # `late` fires after the countdown reached zero
+    bucket.gather()                                                     # (the caller's way out: gather, or repeat the step)
+    assert bucket._early_live == 4                                      # relearned from the step that failed
+    assert step(True) is True and step(True) is True
+    bucket.close()
+    assert not bucket._hooks

@@ -24,9 +24,9 @@ for tname, L, B in [("ico3", 2, 24), ("ico3", 4, 24), ("ico4", 3, 6)]:
     gup = torch.randn(B, n, 3, generator=g)
     r, c = amesh.vision_pairs(faces, n)
     adj = ops.DeviceCSR(amesh.CSRAdjacency.from_pairs(r, c, n), cuda)
-    os.environ["A3VT_CSR_ALGO"] = "rows"
+    ops.dbg_csr_algo("rows")
     ref = run(adj, st, feats, gup, L, H, 99)
-    os.environ.pop("A3VT_CSR_ALGO")
+    ops.dbg_csr_algo("auto")
     new = run(adj, st, feats, gup, L, H, 99)
     st64 = {k: v.double() for k, v in st.items()}
     out_o = og.gcn(feats.double(), st64, "mesh_deform_1", (adj_o[0], adj_o[1], adj_o[2].double()), L, 0.33)
