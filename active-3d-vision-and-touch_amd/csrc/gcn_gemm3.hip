@@ -101,6 +101,20 @@ __device__ __forceinline__ Pieces split3_x8(f32x4 x0, f32x4 x1) {
                 __builtin_bit_cast(f32x4, (u32x4){l[0], l[1], l[2], l[3]})};
 }
 
+#ifdef A3VT_DBG_RG3_STAMPS   // diagnostic build (tools/build_variants.sh stamps3): s_memrealtime (100 MHz) + s_memtime at the phase boundaries
+__device__ unsigned long long g_rg3_stamps[2 * 2 * 256 * 4 * 8];   // [real time | shader cycles][epilogue][workgroup][round (< 4)][8]
+#define RG3_STAMP(round, k)                                                                                                  \
+  do {                                                                                                                       \
+    if (threadIdx.x == 0 && blockIdx.x < 256 && (round) < 4) {                                                               \
+      const int i_ = (((EPI == EPI_DX_MASK ? 1 : 0) * 256 + blockIdx.x) * 4 + (round)) * 8 + (k);                            \
+      g_rg3_stamps[i_] = __builtin_amdgcn_s_memrealtime();                                                                   \
+      g_rg3_stamps[2 * 256 * 4 * 8 + i_] = __builtin_amdgcn_s_memtime();                                                     \
+    }                                                                                                                        \
+  } while (0)
+#else
+#define RG3_STAMP(round, k) do { } while (0)
+#endif
+
 template <int EPI>
 __global__ __launch_bounds__(64 * kWaves, 2) void rowgemm3_kernel(RowGemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -122,18 +136,20 @@ __global__ __launch_bounds__(64 * kWaves, 2) void rowgemm3_kernel(RowGemmArgs p)
   const int blane = (lane >> 2) * kX3ImageLd + kpiece;
   const int nbp = (kPieces - wave + kWaves - 1) / kWaves;   // wave-uniform: 8 for wave 0, 7 for the others
 
-  for (int tb = t0; tb < t1; tb += kMT * kWaves) {
-    // tiles of this round for this wave: two each when the round is full, an even split otherwise
+  // This lane's A rows of a round (ragged tail: duplicate the last row, never stored), as float offsets from a0 / a1, and the
+  // fp32 operand elements of the chunk in flight.  Past the last k (K = 300 of a 320-wide chunk row) the lane re-reads the
+  // row's last quad: those elements meet zero rows of the weight images.  An absent second tile (partial round) reads the
+  // clamped row and is never multiplied or stored.
+  unsigned a0off[kMT], a1off[kMT];
+  const unsigned a0mul = p.a0q_nvert > 0 ? (unsigned)p.a0q_nvert : 1u;   // quad-major a0: k -> k * N floats past the row's base
+  f32x4 raw[kMT][2];
+  auto round_first_tile = [&](int tb) {   // first tile of this wave in the round that starts at tile tb
     const int cnt = t1 - tb < kMT * kWaves ? t1 - tb : kMT * kWaves;
     const int base = cnt / kWaves, extra = cnt % kWaves;
-    const int nm = base + (wave < extra ? 1 : 0);   // 0..2, wave-uniform
-    const int first = tb + wave * base + (wave < extra ? wave : extra);
-    const bool active = nm > 0;
-    const int row0 = first * 16;
-
-    // this lane's A rows (ragged tail: duplicate the last row, never stored), as float offsets from a0 / a1
-    unsigned a0off[kMT], a1off[kMT];
-    const unsigned a0mul = p.a0q_nvert > 0 ? (unsigned)p.a0q_nvert : 1u;   // quad-major a0: k -> k * N floats past the row's base
+    return tb + wave * base + (wave < extra ? wave : extra);
+  };
+  auto set_rows = [&](int tb) {
+    const int row0 = round_first_tile(tb) * 16;
 #pragma unroll
     for (int i = 0; i < kMT; ++i) {
       int r = row0 + i * 16 + l16;
@@ -145,6 +161,34 @@ __global__ __launch_bounds__(64 * kWaves, 2) void rowgemm3_kernel(RowGemmArgs p)
       }
       a1off[i] = (unsigned)r * (unsigned)p.lda1;
     }
+  };
+  auto issue_a = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < kMT; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int kk = chunk * 32 + q * 8 + h * 4;
+        kk = kk < p.k ? kk : p.k - 4;
+        const float *src = kk < p.ksplit ? p.a0 + (size_t)(a0off[i] + (unsigned)kk * a0mul) : p.a1 + (size_t)(a1off[i] + (unsigned)kk);
+#ifdef A3VT_DBG_RG3_NOA
+        raw[i][h] = f32x4{1.f + kk, 2.f + i, 3.f + lane, (float)(size_t)src};
+#else
+        raw[i][h] = *reinterpret_cast<const f32x4 *>(src);
+#endif
+      }
+  };
+
+  int rnd_ = 0;
+  bool a_ahead = false;   // the first A elements of this round were requested before the previous round's epilogue
+  for (int tb = t0; tb < t1; tb += kMT * kWaves, ++rnd_) {
+    RG3_STAMP(rnd_, 0);
+    // tiles of this round for this wave: two each when the round is full, an even split otherwise
+    const int cnt = t1 - tb < kMT * kWaves ? t1 - tb : kMT * kWaves;
+    const int base = cnt / kWaves, extra = cnt % kWaves;
+    const int nm = base + (wave < extra ? 1 : 0);   // 0..2, wave-uniform
+    const int first = tb + wave * base + (wave < extra ? wave : extra);
+    const bool active = nm > 0;
+    const int row0 = first * 16;
 
     f32x4 acc[kMT][kNT];
 #pragma unroll
@@ -152,25 +196,6 @@ __global__ __launch_bounds__(64 * kWaves, 2) void rowgemm3_kernel(RowGemmArgs p)
 #pragma unroll
       for (int j = 0; j < kNT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // The fp32 operand elements of the chunk in flight.  Past the last k (K = 300 of a 320-wide chunk row) the lane re-reads
-    // the row's last quad: those elements meet zero rows of the weight images.  An absent second tile (partial round) reads
-    // the clamped row and is never multiplied or stored.
-    f32x4 raw[kMT][2];
-    auto issue_a = [&](int chunk) {
-#pragma unroll
-      for (int i = 0; i < kMT; ++i)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          int kk = chunk * 32 + q * 8 + h * 4;
-          kk = kk < p.k ? kk : p.k - 4;
-          const float *src = kk < p.ksplit ? p.a0 + (size_t)(a0off[i] + (unsigned)kk * a0mul) : p.a1 + (size_t)(a1off[i] + (unsigned)kk);
-#ifdef A3VT_DBG_RG3_NOA
-          raw[i][h] = f32x4{1.f + kk, 2.f + i, 3.f + lane, (float)(size_t)src};
-#else
-          raw[i][h] = *reinterpret_cast<const f32x4 *>(src);
-#endif
-        }
-    };
     auto issue_b = [&](int chunk, int buf, int j) {
       if (j >= nbp) return;   // wave-uniform
 #ifdef A3VT_DBG_RG3_NOB
@@ -191,7 +216,10 @@ __global__ __launch_bounds__(64 * kWaves, 2) void rowgemm3_kernel(RowGemmArgs p)
         glds16(reinterpret_cast<const float *>(src), ms + o / 4);
       }
     }
-    issue_a(0);
+    if (!a_ahead) {
+      set_rows(tb);
+      issue_a(0);
+    }
 #pragma unroll
     for (int j = 0; j < kBPer; ++j) issue_b(0, 0, j);
 
@@ -246,6 +274,8 @@ __global__ __launch_bounds__(64 * kWaves, 2) void rowgemm3_kernel(RowGemmArgs p)
       for (int t = 0; t < nchunks; ++t) {
         wait_vm0();                       // chunk t (this wave's share) has landed
         __builtin_amdgcn_s_barrier();     // ... everyone's has; everyone is done with chunk t - 1's stage
+        if (t == 0) RG3_STAMP(rnd_, 1);
+        if (t == 1) RG3_STAMP(rnd_, 5);
         chunk_step(std::integral_constant<int, 2>{}, t);
       }
     } else if (nm == 1) {
@@ -266,6 +296,17 @@ __global__ __launch_bounds__(64 * kWaves, 2) void rowgemm3_kernel(RowGemmArgs p)
     }
     wait_lgkm0();
     __builtin_amdgcn_s_barrier();   // all waves finished reading the ring -> reuse it for the epilogue
+    RG3_STAMP(rnd_, 2);
+#ifdef A3VT_DBG_RG3_AHEAD
+    // Measured, not shipped: the next round's first A elements (HBM-streamed) requested here, into the
+    // free operand registers, land under the epilogue — the first-chunk wait of the next round falls from 6 to 1.2 us and
+    // its K loop grows by the same 5 us (the loads share the CU's memory path with the epilogue's stores).
+    a_ahead = tb + kMT * kWaves < t1;
+    if (a_ahead) {
+      set_rows(tb + kMT * kWaves);
+      issue_a(0);
+    }
+#endif
 
     // ---- epilogue (rowgemm_kernel's, fp32 rows; launch_rowgemm3 guarantees ldc % 4 == 0, n_store % 4 == 0 and, for the
     // forward without the quad-major side output, ldc2 % 4 == 0: every column quad leaves with one 16-byte store)
@@ -378,8 +419,10 @@ __global__ __launch_bounds__(64 * kWaves, 2) void rowgemm3_kernel(RowGemmArgs p)
           *reinterpret_cast<f32x4 *>(dstm + o) = *reinterpret_cast<const f32x4 *>(mslot + o);
       }
     }
+    RG3_STAMP(rnd_, 3);
     wait_lgkm0();
     __builtin_amdgcn_s_barrier();   // epilogue slices are free again before the next round's DMA
+    RG3_STAMP(rnd_, 4);
   }
 }
 
@@ -706,6 +749,12 @@ __global__ __launch_bounds__(kDwThreads, 2) void dw3_kernel(DwArgs p) {
 }
 
 }  // namespace
+
+#ifdef A3VT_DBG_RG3_STAMPS
+extern "C" int a3vt_dbg_rg3_stamps(unsigned long long *host_dst) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_rg3_stamps), sizeof(unsigned long long) * 2 * 2 * 256 * 4 * 8);
+}
+#endif
 
 int launch_weight_images3(const WeightImages &w, hipStream_t s) {
   A3VT_LAUNCH(weight_images3_kernel, dim3(10, 10, w.count), dim3(32, 8), 0, s, w);

@@ -110,16 +110,26 @@ class Image_Encoder(nn.Module):
         return img.is_cuda and prec in ("bf16", "bf16s")
 
     library_bias_grad = True   # (tools flip it to time torch's own reduction)
+    # MIOpen's training BatchNorm crashes the HOST on bf16 NHWC input at batch sizes below 4 (seen for 3 x 254^2, 3 x 64^2 and
+    # 64 x 27^2 maps on the ROCm 7.2 image this was built on: tools/experiments/miopen_bn_nhwc_c3_crash.py).  Batches
+    # smaller than this take the NCHW kernel instead (a last partial batch of an epoch, or a small per-rank shard: same
+    # values to bf16 rounding, ~5 ms slower per step at batch 64).  A MIOpen build without the defect: set it to 0
+    # (``Image_Encoder.bn_nhwc_min_batch = 0``); the fallback is reported once per process.
+    bn_nhwc_min_batch = 4
+    _bn_fallback_reported = False
 
     @staticmethod
     def _block_nhwc(block, x):
         """One ``CNN_layer`` Sequential in the bf16 channels-last branch: BatchNorm / ReLU as they are (MIOpen under
         autocast), the convolution through ``ops.ConvNHWCFn`` (same MIOpen kernels, bias gradient from the library)."""
         for m in block:
-            if isinstance(m, nn.BatchNorm2d) and m.training and x.shape[0] < 4:
-                # MIOpen's training BatchNorm crashes the host on bf16 NHWC input at batch sizes below 4 (seen for 3 x 254^2,
-                # 3 x 64^2 and 64 x 27^2 maps; ROCm 7.2 image, tools/experiments/miopen_bn_nhwc_c3_crash.py): such tiny
-                # batches take the NCHW kernel (which would cost 5 ms per step at batch 64)
+            if isinstance(m, nn.BatchNorm2d) and m.training and x.shape[0] < Image_Encoder.bn_nhwc_min_batch:
+                if not Image_Encoder._bn_fallback_reported:
+                    Image_Encoder._bn_fallback_reported = True
+                    import warnings
+                    warnings.warn(f"a3vt: batch of {x.shape[0]} < {Image_Encoder.bn_nhwc_min_batch}: training BatchNorm of the bf16 "
+                                  "channels-last image encoder takes the NCHW kernel (MIOpen bf16 NHWC BatchNorm defect at "
+                                  "tiny batches; Image_Encoder.bn_nhwc_min_batch = 0 disables the workaround)", stacklevel=2)
                 x = m(x.contiguous()).contiguous(memory_format=torch.channels_last)
             elif not isinstance(m, nn.Conv2d):
                 x = m(x)

@@ -590,3 +590,34 @@ def test_posenc_wide_bf16_operand_mode(cuda):
     from helpers import rel_l2
     errs = [rel_l2(x, y) for x, y in zip(a, exact)]
     assert errs[0] < 5e-3 and max(errs[1:]) < 6e-2, errs
+
+
+def test_image_encoder_bf16_branch_batches_1_to_4(cuda):
+    """the bf16 channels-last image encoder at the batch sizes around the BatchNorm workaround's threshold
+    (``Image_Encoder.bn_nhwc_min_batch``: MIOpen's bf16 NHWC training BatchNorm takes the host down below 4 samples, so those
+    batches use the NCHW kernel).  Every batch size trains, and the maps agree with the fp32 branch to bf16 rounding."""
+    import warnings
+    from a3vt_amd.pterotactyl.reconstruction.vision import model
+    args16 = make_args(use_img=True, CNN_ker_size=5, num_CNN_blocks=6, layers_per_block=3, gemm_precision="bf16s")
+    args32 = make_args(use_img=True, CNN_ker_size=5, num_CNN_blocks=6, layers_per_block=3)
+    torch.manual_seed(0)
+    enc16 = model.Image_Encoder(args16).to(cuda)
+    enc32 = model.Image_Encoder(args32).to(cuda)
+    enc32.load_state_dict(enc16.state_dict())
+    g = torch.Generator().manual_seed(1)
+    model.Image_Encoder._bn_fallback_reported = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        for B in (1, 2, 3, 4):
+            img = torch.rand(B, 3, 256, 256, generator=g).to(cuda)
+            enc16.train(), enc32.train()
+            maps16 = enc16(img)
+            maps32 = enc32(img)
+            assert len(maps16) == len(maps32)
+            for a, b in zip(maps16, maps32):
+                assert a.shape == b.shape and torch.isfinite(a.float()).all()
+                assert ((a.float() - b).norm() / b.norm()).item() < 0.1, B    # 16 bf16 convolutions + tiny-batch BatchNorm deep
+            sum(m.float().square().mean() for m in maps16).backward()
+            assert all(torch.isfinite(p.grad).all() for p in enc16.parameters() if p.grad is not None)
+            enc16.zero_grad()
+    assert sum("bn_nhwc_min_batch" in str(x.message) for x in w) == 1      # reported once
