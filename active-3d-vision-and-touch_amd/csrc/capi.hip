@@ -1218,6 +1218,14 @@ int a3vt_chamfer_fwd_ws(const float *x, const float *y, int draws, int batch, in
                             workspace ? workspace_bytes : 0, algo, static_cast<hipStream_t>(stream));
 }
 
+int a3vt_chamfer_fwd_shared(const float *x, const float *y, int draws, int batch, int y_batch, int p, int q, float *dist_xy,
+                            int32_t *idx_xy, float *dist_yx, int32_t *idx_yx, float *cd, void *workspace,
+                            size_t workspace_bytes, int algo, void *stream) {
+  A3VT_CHECK_ARG(x && y && dist_xy && idx_xy && dist_yx && idx_yx && cd && y_batch > 0);
+  return launch_chamfer_fwd(x, y, draws, batch, p, q, dist_xy, idx_xy, dist_yx, idx_yx, cd, workspace,
+                            workspace ? workspace_bytes : 0, algo, static_cast<hipStream_t>(stream), y_batch);
+}
+
 int a3vt_chamfer_bwd(const float *x, const float *y, int draws, int batch, int p, int q, const int32_t *idx_xy,
                      const int32_t *idx_yx, const float *grad_cd, float *grad_x, float *grad_y, void *stream) {
   A3VT_CHECK_ARG(x && y && idx_xy && idx_yx && grad_cd && grad_x && draws > 0 && batch > 0 && p > 0 && q > 0);

@@ -426,9 +426,17 @@ size_t chamfer_workspace_bytes(int draws, int batch, int p, int q) {
 }
 
 int launch_chamfer_fwd(const float *x, const float *y, int draws, int batch, int p, int q, float *dxy, int32_t *ixy,
-                       float *dyx, int32_t *iyx, float *cd, void *scratch, size_t scratch_bytes, int algo, hipStream_t s) {
+                       float *dyx, int32_t *iyx, float *cd, void *scratch, size_t scratch_bytes, int algo, hipStream_t s,
+                       int y_batch) {
   if (p <= 0 || q <= 0 || draws <= 0 || batch <= 0) {
     set_error("chamfer_fwd: empty input (draws=%d batch=%d p=%d q=%d)", draws, batch, p, q);
+    return -1;
+  }
+  // y may hold fewer clouds than x has meshes: mesh b is compared with y[b % y_batch] (the candidate-major batches of the
+  // scoring loop: K candidates x E elements share the E ground-truth clouds — they are sorted / boxed once, not K times)
+  if (y_batch <= 0) y_batch = batch;
+  if (batch % y_batch != 0) {
+    set_error("chamfer_fwd: batch=%d is not a multiple of y_batch=%d", batch, y_batch);
     return -1;
   }
   if (algo < NN_AUTO || algo > NN_PRUNED) {
@@ -453,15 +461,15 @@ int launch_chamfer_fwd(const float *x, const float *y, int draws, int batch, int
     else algo = (fits_pruned && p >= 2048 && q >= 2048) ? NN_PRUNED : fits_sweep ? NN_BRUTE_SWEEP : NN_BRUTE_TWO_PASS;
   }
   if (algo == NN_PRUNED) {
-    if (int rc = launch_nn_pruned(x, y, draws, batch, p, q, dxy, ixy, dyx, iyx, scratch, s)) return rc;
+    if (int rc = launch_nn_pruned(x, y, draws, batch, p, q, dxy, ixy, dyx, iyx, scratch, s, y_batch)) return rc;
   } else if (algo == NN_BRUTE_SWEEP) {
     // one pass over the distance matrix for both directions (rows = predicted clouds, columns = ground truth)
-    if (int rc = launch_nn2(x, p, y, q, batch, draws * batch, dxy, ixy, dyx, iyx, scratch, s)) return rc;
+    if (int rc = launch_nn2(x, p, y, q, y_batch, draws * batch, dxy, ixy, dyx, iyx, scratch, s)) return rc;
   } else {
     // x -> y: queries = x clouds (draws*batch distinct), candidates = y[b]
-    if (int rc = launch_nn(x, p, draws * batch, y, q, batch, draws * batch, dxy, ixy, s)) return rc;
+    if (int rc = launch_nn(x, p, draws * batch, y, q, y_batch, draws * batch, dxy, ixy, s)) return rc;
     // y -> x: queries = y[b], candidates = x[r][b]
-    if (int rc = launch_nn(y, q, batch, x, p, draws * batch, draws * batch, dyx, iyx, s)) return rc;
+    if (int rc = launch_nn(y, q, y_batch, x, p, draws * batch, draws * batch, dyx, iyx, s)) return rc;
   }
   A3VT_LAUNCH(chamfer_reduce_kernel, dim3(batch), dim3(1024), 0, s, dxy, dyx, draws, batch, p, q, cd);
   A3VT_CHECK_LAUNCH();

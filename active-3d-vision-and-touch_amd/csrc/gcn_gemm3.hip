@@ -47,7 +47,12 @@ constexpr int kPieces = 3 * kNT;        // LDS-DMA pieces (1 KiB: 16 Bt rows x 6
 constexpr int kStage = kPieces * 256;   // floats per ring stage (58,368 B)
 constexpr int kStages = 2;
 constexpr int kMSlot = 1024;            // floats (4 KiB) of ReLU-sign bytes per wave
-constexpr int kBPer = (kPieces + kWaves - 1) / kWaves;   // Bt pieces per wave and chunk (8; waves 1-7 carry 7)
+#ifdef A3VT_DBG_RG3_DMA4   // variant (measured 5-8 % slower): waves 0-3, one per SIMD, carry all of the Bt staging
+constexpr int kDmaWaves = 4;
+#else
+constexpr int kDmaWaves = 8;            // the Bt pieces are dealt to all eight waves (8 / 7 per wave and chunk)
+#endif
+constexpr int kBPer = (kPieces + kDmaWaves - 1) / kDmaWaves;   // Bt pieces per DMA wave and chunk
 constexpr size_t kLdsBytes = (size_t)(kStages * kStage + kWaves * kMSlot) * sizeof(float);   // 149,504 B
 static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
 
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void rowgemm3_kernel(RowGemmArgs p)
   // Bt pieces of this wave: piece pc = wave + 8 j = (image pc / 19, column tile pc % 19) — a wave-uniform offset — plus the
   // per-lane part of the source address: row (lane >> 2) of the tile, 16-byte k-quad kpiece of the chunk's 64 bytes.
   const int blane = (lane >> 2) * kX3ImageLd + kpiece;
-  const int nbp = (kPieces - wave + kWaves - 1) / kWaves;   // wave-uniform: 8 for wave 0, 7 for the others
+  const int nbp = wave < kDmaWaves ? (kPieces - wave + kDmaWaves - 1) / kDmaWaves : 0;   // wave-uniform
 
   // This lane's A rows of a round (ragged tail: duplicate the last row, never stored), as float offsets from a0 / a1, and the
   // fp32 operand elements of the chunk in flight.  Past the last k (K = 300 of a 320-wide chunk row) the lane re-reads the
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void rowgemm3_kernel(RowGemmArgs p)
 #ifdef A3VT_DBG_RG3_NOB
       return;
 #endif
-      const int pc = wave + kWaves * j, img = pc / kNT, tile = pc - img * kNT;   // scalar
+      const int pc = wave + kDmaWaves * j, img = pc / kNT, tile = pc - img * kNT;   // scalar
       glds16(p.bt + ((size_t)img * kX3ImageFloats + (size_t)tile * (16 * kX3ImageLd) + chunk * 16) + blane, lds + buf * kStage + pc * 256);
     };
 
@@ -263,8 +268,8 @@ __global__ __launch_bounds__(64 * kWaves, 2) void rowgemm3_kernel(RowGemmArgs p)
         }
         __builtin_amdgcn_sched_barrier(0);
         if (j + 1 < kNT) bh = *reinterpret_cast<const f32x4 *>(sB + (j + 1) * 256);
-        if ((j & 1) && (j >> 1) < kBPer) {   // the next chunk's Bt pieces, one per two column tiles
-          if (prefetch) issue_b(t + 1, buf ^ 1, j >> 1);
+        if (kDmaWaves == 8 ? ((j & 1) && (j >> 1) < kBPer) : j < kBPer) {   // the next chunk's Bt pieces, spread over the column tiles
+          if (prefetch) issue_b(t + 1, buf ^ 1, kDmaWaves == 8 ? j >> 1 : j);
         }
         __builtin_amdgcn_sched_barrier(0);
       }

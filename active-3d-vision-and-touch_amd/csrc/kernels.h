@@ -266,11 +266,12 @@ size_t chamfer_scratch_bytes(int draws, int batch, int q);
 enum { NN_AUTO = 0, NN_BRUTE_TWO_PASS = 1, NN_BRUTE_SWEEP = 2, NN_PRUNED = 3 };
 size_t chamfer_workspace_bytes(int draws, int batch, int p, int q);
 int launch_chamfer_fwd(const float *x, const float *y, int draws, int batch, int p, int q, float *dxy, int32_t *ixy,
-                       float *dyx, int32_t *iyx, float *cd, void *scratch, size_t scratch_bytes, int algo, hipStream_t s);
+                       float *dyx, int32_t *iyx, float *cd, void *scratch, size_t scratch_bytes, int algo, hipStream_t s,
+                       int y_batch = 0 /* clouds in y (mesh b asks y[b % y_batch]); 0 = batch */);
 // nn_prune.hip
 size_t nn_pruned_workspace_bytes(int draws, int batch, int p, int q);
 int launch_nn_pruned(const float *x, const float *y, int draws, int batch, int p, int q, float *dxy, int32_t *ixy,
-                     float *dyx, int32_t *iyx, void *ws, hipStream_t s);
+                     float *dyx, int32_t *iyx, void *ws, hipStream_t s, int y_batch = 0);
 int launch_chamfer_bwd(const float *x, const float *y, int draws, int batch, int p, int q, const int32_t *ixy,
                        const int32_t *iyx, const float *gcd, float *gx, float *gy, hipStream_t s);
 

@@ -454,9 +454,9 @@ __global__ __launch_bounds__(1024) void nn_query_kernel(NNQuery a, int wgs_per_p
   nn_query_wave(a, y, bx * (blockDim.x >> 6) + wave, lane);
 }
 
-static NNClouds nn_layout(const float *x, const float *y, int draws, int batch, int p, int q, void *ws) {
+static NNClouds nn_layout(const float *x, const float *y, int draws, int batch, int y_batch, int p, int q, void *ws) {
   NNClouds c{};
-  c.x = x, c.y = y, c.p = p, c.q = q, c.nx = draws * batch, c.ny = batch;
+  c.x = x, c.y = y, c.p = p, c.q = q, c.nx = draws * batch, c.ny = y_batch;
   c.npx = cdiv(p, kPB) * kPB, c.npy = cdiv(q, kPB) * kPB;
   char *w = static_cast<char *>(ws);
   c.sx = reinterpret_cast<f32x4 *>(w);
@@ -481,12 +481,13 @@ size_t nn_pruned_workspace_bytes(int draws, int batch, int p, int q) {
 }
 
 int launch_nn_pruned(const float *x, const float *y, int draws, int batch, int p, int q, float *dxy, int32_t *ixy,
-                     float *dyx, int32_t *iyx, void *ws, hipStream_t s) {
+                     float *dyx, int32_t *iyx, void *ws, hipStream_t s, int y_batch) {
+  if (y_batch <= 0) y_batch = batch;   // clouds in y: pair (draw, mesh b) asks y[b % y_batch]
   if (reinterpret_cast<uintptr_t>(ws) & 15) {
     set_error("chamfer_fwd: the workspace of the pruned search must be 16-byte aligned");
     return -1;
   }
-  const NNClouds c = nn_layout(x, y, draws, batch, p, q, ws);
+  const NNClouds c = nn_layout(x, y, draws, batch, y_batch, p, q, ws);
   const int bits = nn_grid_bits(p > q ? p : q);
   const size_t shmem = (size_t)(1 << (3 * bits)) * sizeof(unsigned);
   static OncePerDevice once;
@@ -512,7 +513,7 @@ int launch_nn_pruned(const float *x, const float *y, int draws, int batch, int p
   A3VT_LAUNCH(nn_boxes_kernel, dim3((unsigned)box_wgs), dim3(1024), 0, s, c, cdiv(nbmax, 16));
   A3VT_CHECK_LAUNCH();
   if (stages < 3) return 0;
-  NNQuery a{c.sx, c.sy, c.bx, c.by, c.ux, c.uy, p, q, c.npx, c.npy, c.nx, batch, dxy, dyx, ixy, iyx};
+  NNQuery a{c.sx, c.sy, c.bx, c.by, c.ux, c.uy, p, q, c.npx, c.npy, c.nx, y_batch, dxy, dyx, ixy, iyx};
   A3VT_LAUNCH(nn_query_kernel, dim3((unsigned)query_wgs), dim3(64 * wg_waves_q), 0, s, a, cdiv(nbmax, wg_waves_q));
   A3VT_CHECK_LAUNCH();
   return 0;

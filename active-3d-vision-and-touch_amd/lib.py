@@ -66,6 +66,7 @@ SIGNATURES = {
     "a3vt_chamfer_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "a3vt_chamfer_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "a3vt_chamfer_fwd_ws": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
+    "a3vt_chamfer_fwd_shared": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     "a3vt_chamfer_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "a3vt_dbg_csr_algo": (_i, [_i]),
     "a3vt_split3_bf16": (_i, [_vp, _sz, _vp, _vp, _vp, _vp]),

@@ -522,7 +522,8 @@ CHAMFER_ALGO = 0
 
 class ChamferFn(torch.autograd.Function):
     """pytorch3d chamfer_distance(x, y, batch_reduction=None) averaged over draws (utility/utils.py:204-217).
-    x (draws,B,P,3), y (B,Q,3) -> cd (B,)."""
+    x (draws,B,P,3), y (B,Q,3) -> cd (B,).  Forward-only callers may pass y (E,Q,3) with B a multiple of E: mesh b is compared
+    with y[b % E] (the candidate-major batches of ``policies/scoring.py``: the ground truth is sorted once, not per candidate)."""
 
     @staticmethod
     def forward(ctx, x, y):
@@ -530,8 +531,9 @@ class ChamferFn(torch.autograd.Function):
         x, y = _req(x, "x"), _req(y, "y")
         draws, B, P, _ = x.shape
         Q = y.shape[1]
-        if y.shape[0] != B:
-            raise RuntimeError("a3vt: chamfer batch mismatch")
+        E = y.shape[0]
+        if E != B and (E <= 0 or B % E != 0):
+            raise RuntimeError("a3vt: chamfer batch mismatch (a shared ground truth needs B % E == 0)")
         dev = x.device
         dxy = torch.empty((draws, B, P), dtype=torch.float32, device=dev)
         ixy = torch.empty((draws, B, P), dtype=torch.int32, device=dev)
@@ -540,9 +542,9 @@ class ChamferFn(torch.autograd.Function):
         cd = torch.empty((B,), dtype=torch.float32, device=dev)
         nbytes = L.a3vt_chamfer_workspace_bytes(draws, B, P, Q)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
-        _lib.check(L.a3vt_chamfer_fwd_ws(_lib.ptr(x), _lib.ptr(y), draws, B, P, Q, _lib.ptr(dxy), _lib.ptr(ixy),
-                                         _lib.ptr(dyx), _lib.ptr(iyx), _lib.ptr(cd), _lib.ptr(ws), nbytes, CHAMFER_ALGO,
-                                         _stream()), "chamfer_fwd")
+        _lib.check(L.a3vt_chamfer_fwd_shared(_lib.ptr(x), _lib.ptr(y), draws, B, E, P, Q, _lib.ptr(dxy), _lib.ptr(ixy),
+                                             _lib.ptr(dyx), _lib.ptr(iyx), _lib.ptr(cd), _lib.ptr(ws), nbytes, CHAMFER_ALGO,
+                                             _stream()), "chamfer_fwd")
         ctx.save_for_backward(x, y, ixy, iyx)
         ctx.aux = (dxy, dyx)
         return cd
@@ -553,6 +555,9 @@ class ChamferFn(torch.autograd.Function):
         x, y, ixy, iyx = ctx.saved_tensors
         draws, B, P, _ = x.shape
         Q = y.shape[1]
+        if y.shape[0] != B:
+            raise RuntimeError("a3vt: the shared-ground-truth Chamfer (y with fewer clouds than x has meshes) is forward-only "
+                               "(scoring under no_grad); repeat y for a differentiable call")
         gcd = _req(gcd, "grad_cd")
         gx = torch.empty_like(x)
         gy = torch.empty_like(y) if ctx.needs_input_grad[1] else None
@@ -572,6 +577,7 @@ def chamfer_nn(x, y, single_pass=True, algo=None):
     x, y = _req(x, "x"), _req(y, "y")
     draws, B, P, _ = x.shape
     Q = y.shape[1]
+    E = y.shape[0]                     # E < B: shared ground truth, mesh b against y[b % E] (a3vt_chamfer_fwd_shared)
     dev = x.device
     dxy = torch.empty((draws, B, P), dtype=torch.float32, device=dev)
     ixy = torch.empty((draws, B, P), dtype=torch.int32, device=dev)
@@ -582,9 +588,9 @@ def chamfer_nn(x, y, single_pass=True, algo=None):
         algo = "sweep" if single_pass else "two_pass"
     nbytes = L.a3vt_chamfer_workspace_bytes(draws, B, P, Q) if algo != "two_pass" else 0
     ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev) if nbytes else None
-    _lib.check(L.a3vt_chamfer_fwd_ws(_lib.ptr(x), _lib.ptr(y), draws, B, P, Q, _lib.ptr(dxy), _lib.ptr(ixy),
-                                     _lib.ptr(dyx), _lib.ptr(iyx), _lib.ptr(cd), _lib.ptr(ws), nbytes, NN_ALGOS[algo],
-                                     _stream()), "chamfer_fwd")
+    _lib.check(L.a3vt_chamfer_fwd_shared(_lib.ptr(x), _lib.ptr(y), draws, B, E, P, Q, _lib.ptr(dxy), _lib.ptr(ixy),
+                                         _lib.ptr(dyx), _lib.ptr(iyx), _lib.ptr(cd), _lib.ptr(ws), nbytes, NN_ALGOS[algo],
+                                         _stream()), "chamfer_fwd")
     return dxy, ixy, dyx, iyx, cd
 
 

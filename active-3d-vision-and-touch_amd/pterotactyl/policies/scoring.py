@@ -44,7 +44,9 @@ def score_actions(deform, img, charts_list, gt_points, faces, number_points, los
         else:
             gmaps, lmaps = [], []
         verts, mask = deform.deform_with_maps(charts, gmaps, lmaps)
-        gt = gt_points.to(dev).to(torch.float32).repeat(K, 1, 1)
+        # the E ground-truth clouds are shared by the K candidates of each element (candidate-major batch: mesh k*E + e is
+        # compared with gt[e]): uploaded, sorted and boxed once, not K times (a3vt_chamfer_fwd_shared)
+        gt = gt_points.to(dev).to(torch.float32)
         if samples is not None:
             samples = tuple(s.repeat(1, K, 1) for s in samples)
         cd = utils.chamfer_distance(verts, faces, gt, num=number_points, repeat=repeat, samples=samples)

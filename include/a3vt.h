@@ -264,6 +264,13 @@ size_t a3vt_chamfer_workspace_bytes(int draws, int batch, int p, int q);
 int a3vt_chamfer_fwd_ws(const float *x, const float *y, int draws, int batch, int p, int q,
                         float *dist_xy, int32_t *idx_xy, float *dist_yx, int32_t *idx_yx, float *cd,
                         void *workspace, size_t workspace_bytes, int algo, void *stream);
+/* Forward-only callers that score K candidate meshes per ground-truth cloud (policies/environment.py:174-180,252-257: the
+ * greedy search evaluates up to 50 candidate touches against the same object): y holds y_batch clouds, batch is a multiple
+ * of y_batch and mesh b is compared with y[b % y_batch] — the ground truth is uploaded, sorted and boxed once instead of
+ * once per candidate.  Outputs as a3vt_chamfer_fwd_ws (dist_yx / idx_yx per mesh: [draws][batch][q]). */
+int a3vt_chamfer_fwd_shared(const float *x, const float *y, int draws, int batch, int y_batch, int p, int q,
+                            float *dist_xy, int32_t *idx_xy, float *dist_yx, int32_t *idx_yx, float *cd,
+                            void *workspace, size_t workspace_bytes, int algo, void *stream);
 /* grad_cd [batch].  grad_x [draws][batch][p][3] overwritten; grad_y [batch][q][3] overwritten, may be
  * NULL (the trainer's ground truth needs no gradient, vision/train.py:141-143). */
 int a3vt_chamfer_bwd(const float *x, const float *y, int draws, int batch, int p, int q,

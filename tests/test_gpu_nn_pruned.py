@@ -232,3 +232,23 @@ def test_pruned_repeats_bit_for_bit(cuda):
     first = ops.chamfer_nn(x, y, algo="pruned")
     for _ in range(3):
         _assert_same(first, ops.chamfer_nn(x, y, algo="pruned"))
+
+
+@pytest.mark.parametrize("algo", ["two_pass", "sweep", "pruned"])
+def test_shared_ground_truth_equals_repeated(cuda, algo):
+    """a3vt_chamfer_fwd_shared (policies/environment.py:174-180,252-257: K candidates of an element share its ground truth):
+    y with E clouds for a candidate-major batch of K * E meshes gives, bit for bit, what the K-times repeated y gives —
+    distances, indices and the per-mesh Chamfer value, in every search algorithm."""
+    from a3vt_amd import ops
+    K, E, P, Q, draws = 5, 3, 2300, 2600, 2
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(draws, K * E, P, 3, generator=g) * 0.1).to(cuda)
+    y = (torch.randn(E, Q, 3, generator=g) * 0.1).to(cuda)
+    shared = ops.chamfer_nn(x, y, algo=algo)
+    repeated = ops.chamfer_nn(x, y.repeat(K, 1, 1), algo=algo)
+    for a, b in zip(shared, repeated):
+        assert torch.equal(a, b)
+    with torch.no_grad():
+        assert torch.equal(ops.ChamferFn.apply(x, y), ops.ChamferFn.apply(x, y.repeat(K, 1, 1)))
+    with pytest.raises(RuntimeError, match="forward-only"):
+        ops.ChamferFn.apply(x.clone().requires_grad_(True), y).sum().backward()
