@@ -499,6 +499,16 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
 #else
     if (active) {
 #endif
+      // The epilogue's per-lane address arithmetic depends on the lane alone, so the compiler hoists it in front of the round
+      // loop and spills it across the K loop (the forward instantiation sat at 256 registers with 9 spilled): the reloads
+      // then sit between the epilogue's global stores, and a scratch reload waits — on the one vmcnt counter — for every
+      // store issued before it (round 4: that, not the instruction mix, made the forward launch slower than dX).  An opaque
+      // copy of the lane index keeps the arithmetic here, where the operand registers are free again.  Same values.
+      int le = lane;
+#ifndef A3VT_DBG_RG_HOISTED_EPI   // variant build (tools/build_variants.sh epi): the round-3 code generation, for A/B timing
+      asm volatile("" : "+v"(le));
+#endif
+      const int l16 = le & 15, q = le >> 4;
       float *ep = lds + wave * ((NSTAGE * STAGE) / WAVES);
       constexpr int G0 = (NT + 1) / 2;  // n-tiles in the first column group (second gets NT - G0)
       static_assert(16 * (G0 * 16 + 4) <= (NSTAGE * STAGE) / WAVES, "epilogue slice too small");
@@ -528,10 +538,10 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
           }
           __builtin_amdgcn_wave_barrier();
           if (ST16 && EPI != EPI_PLAIN) {
-            // bf16 rows out: a lane packs 8 consecutive columns into one 16-byte store.  Columns up to the padded row
+            // bf16 rows out: a le packs 8 consecutive columns into one 16-byte store.  Columns up to the padded row
             // length ldc are written (the pad columns hold exact zeros: their Bt rows are zero).
             const int f8row = ncols / 8, nf8 = 16 * f8row;
-            for (int f = lane; f < nf8; f += 64) {
+            for (int f = le; f < nf8; f += 64) {
               const int rl = f / f8row, c8 = f - rl * f8row;
               const int row = row0 + i * 16 + rl;
               const int col = col0 + j0 * 16 + c8 * 8;
@@ -596,17 +606,17 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
             continue;
           }
           // Quad-major side output (RowGemmArgs::zq_nvert; one column block, so col0 == 0): the first zq_quads column
-          // quads of this tile leave as 16 consecutive rows x 16 B per quad (lane & 15 = row: 256 contiguous bytes of one
+          // quads of this tile leave as 16 consecutive rows x 16 B per quad (le & 15 = row: 256 contiguous bytes of one
           // quad plane per 16 lanes) instead of as pieces of row-major rows.
           const bool zq_mode = EPI != EPI_PLAIN && p.zq_nvert > 0;
           int qlo = 0;
           if (zq_mode && grp == 0) {
             const int nqz = p.zq_quads;
-            const int rl = lane & 15;
+            const int rl = le & 15;
             const int row = row0 + i * 16 + rl;
             const int bq = row / p.zq_nvert;
             float *qbase = p.c2 + ((size_t)bq * nqz * p.zq_nvert + (size_t)(row - bq * p.zq_nvert)) * 4;
-            for (int c4 = lane >> 4; c4 < nqz; c4 += 4) {
+            for (int c4 = le >> 4; c4 < nqz; c4 += 4) {
               const f32x4 v = *reinterpret_cast<const f32x4 *>(ep + rl * stride + c4 * 4);
 #ifdef A3VT_DBG_RG_NOSTORE
               if (v[0] != 1.2345e-33f) continue;
@@ -618,7 +628,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
               // forward: the pass-through columns [4 Q, 4 yq_quads) — the rest of this column group — are part of the
               // quad-major region of the activations too (RowGemmArgs::yq): ReLU, sign bits, same row-fastest stores
               float *ybase = p.yq + ((size_t)bq * p.yq_quads * p.zq_nvert + (size_t)(row - bq * p.zq_nvert)) * 4;
-              for (int c4 = nqz + (lane >> 4); c4 < p.yq_quads; c4 += 4) {
+              for (int c4 = nqz + (le >> 4); c4 < p.yq_quads; c4 += 4) {
                 f32x4 v = *reinterpret_cast<const f32x4 *>(ep + rl * stride + c4 * 4);
                 unsigned bits = 0;
 #pragma unroll
@@ -640,7 +650,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
             }
           }
           const int wq = f4row - qlo, nf4 = 16 * wq;
-          for (int f = lane; f < nf4; f += 64) {
+          for (int f = le; f < nf4; f += 64) {
             const int rl = f / wq, c4 = qlo + (f - rl * wq);
             const int row = row0 + i * 16 + rl;
             const int col = col0 + j0 * 16 + c4 * 4;
@@ -715,12 +725,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void rowgemm_kernel(RowGemmArgs p) {
           }
         }
       }
-      if (mask_rows) {  // sign bytes of this wave's 16 nm rows: one contiguous block, 16 bytes per lane
+      if (mask_rows) {  // sign bytes of this wave's 16 nm rows: one contiguous block, 16 bytes per le
         wait_lgkm0();
         __builtin_amdgcn_wave_barrier();
         const int nbytes = 16 * nm * p.mld;
         uint8_t *dstm = p.maskb + (size_t)row0 * p.mld;
-        for (int o = lane * 16; o < nbytes; o += 1024)
+        for (int o = le * 16; o < nbytes; o += 1024)
           *reinterpret_cast<f32x4 *>(dstm + o) = *reinterpret_cast<const f32x4 *>(mslot + o);
       }
     }

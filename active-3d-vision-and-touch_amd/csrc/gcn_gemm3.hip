@@ -320,6 +320,15 @@ __global__ __launch_bounds__(64 * kWaves, 2) void rowgemm3_kernel(RowGemmArgs p)
 #else
     if (active) {
 #endif
+      // The epilogue's per-lane address arithmetic depends on the lane alone, so the compiler hoists it in front of the round
+      // loop and then spills it across the K loop (where all 256 registers are taken): the reloads sat between the
+      // epilogue's global stores, and a scratch reload waits — on the one vmcnt counter — for every store issued before it.
+      // An opaque copy of the lane index keeps that arithmetic here, where registers are free again.
+      int le = lane;
+#ifndef A3VT_DBG_RG_HOISTED_EPI   // variant build (tools/build_variants.sh epi): without the fix, for A/B timing
+      asm volatile("" : "+v"(le));
+#endif
+      const int l16 = le & 15, q = le >> 4;
       float *ep = lds + wave * ((kStages * kStage) / kWaves);
       constexpr int G0 = (kNT + 1) / 2;
       static_assert(16 * (G0 * 16 + 4) <= (kStages * kStage) / kWaves, "epilogue slice too small");
@@ -347,11 +356,11 @@ __global__ __launch_bounds__(64 * kWaves, 2) void rowgemm3_kernel(RowGemmArgs p)
           if (zq_mode && grp == 0) {
             // quad-major side output: the first zq_quads column quads leave as 16 consecutive rows x 16 B per quad
             const int nqz = p.zq_quads;
-            const int rl = lane & 15;
+            const int rl = le & 15;
             const int row = row0 + i * 16 + rl;
             const int bq = row / p.zq_nvert;
             float *qbase = p.c2 + ((size_t)bq * nqz * p.zq_nvert + (size_t)(row - bq * p.zq_nvert)) * 4;
-            for (int c4 = lane >> 4; c4 < nqz; c4 += 4) {
+            for (int c4 = le >> 4; c4 < nqz; c4 += 4) {
               const f32x4 v = *reinterpret_cast<const f32x4 *>(ep + rl * stride + c4 * 4);
               if (row < p.m) *reinterpret_cast<f32x4 *>(qbase + (size_t)c4 * p.zq_nvert * 4) = v;
             }
@@ -359,7 +368,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void rowgemm3_kernel(RowGemmArgs p)
             if (EPI == EPI_FWD_HIDDEN && p.yq_quads > nqz) {
               // the pass-through columns [4 Q, 4 yq_quads) of the hybrid activations: ReLU, sign bits, row-fastest stores
               float *ybase = p.yq + ((size_t)bq * p.yq_quads * p.zq_nvert + (size_t)(row - bq * p.zq_nvert)) * 4;
-              for (int c4 = nqz + (lane >> 4); c4 < p.yq_quads; c4 += 4) {
+              for (int c4 = nqz + (le >> 4); c4 < p.yq_quads; c4 += 4) {
                 f32x4 v = *reinterpret_cast<const f32x4 *>(ep + rl * stride + c4 * 4);
                 unsigned bits = 0;
 #pragma unroll
@@ -378,7 +387,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void rowgemm3_kernel(RowGemmArgs p)
             }
           }
           const int wq = f4row - qlo, nf4 = 16 * wq;
-          for (int f = lane; f < nf4; f += 64) {
+          for (int f = le; f < nf4; f += 64) {
             const int rl = f / wq, c4 = qlo + (f - rl * wq);
             const int row = row0 + i * 16 + rl;
             const int col = j0 * 16 + c4 * 4;
@@ -420,7 +429,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void rowgemm3_kernel(RowGemmArgs p)
         __builtin_amdgcn_wave_barrier();
         const int nbytes = 16 * nm * p.mld;
         uint8_t *dstm = p.maskb + (size_t)row0 * p.mld;
-        for (int o = lane * 16; o < nbytes; o += 1024)
+        for (int o = le * 16; o < nbytes; o += 1024)
           *reinterpret_cast<f32x4 *>(dstm + o) = *reinterpret_cast<const f32x4 *>(mslot + o);
       }
     }
@@ -553,8 +562,12 @@ __global__ __launch_bounds__(kDwThreads, 2) void dw3_kernel(DwArgs p) {
   const int e1 = 32 * nq0, e2 = e1 + 32 * nq1, e3 = e2 + 32 * nq2;
   const int qn = p.xq_nvert > 0 ? p.xq_nvert : p.z0q_nvert;   // vertices per mesh (the same for X and dZa)
   const float *sp[kDwPer];     // source of the quad for the next stage
-  int adv[kDwPer];             // floats to advance per stage: 128 = a quad-major quad (32 rows x 4 floats), 0 = a zero quad
   int pdst[kDwPer];            // bf16 element offset of the quad in piece image 0 (X images, then the window images); -1: none
+  // What a quad's pointer advances by per stage, as a 3-bit code per quad packed into one register (the advances themselves
+  // are five wave-uniform values; kept per quad as 64-bit pointer increments they cost 32 registers and spilled into the
+  // stage loop, where a scratch reload waits on the one vmcnt counter behind the LDS-DMA issued a moment earlier):
+  // 0 zero quad, 1 quad-major X, 2 row-major X, 3 row-major dZa, 4 row-major G, 5 quad-major dZa
+  unsigned kinds = 0;
   const size_t row_first = (size_t)u0 * 32;
   auto unit_row = [&](int e) {   // stage row of quad e (the block structure above)
     if (e < e1) return e & 31;
@@ -575,39 +588,40 @@ __global__ __launch_bounds__(kDwThreads, 2) void dw3_kernel(DwArgs p) {
     const bool on = e < kDwUnits;
     const size_t grow = row_first + row;
     const float *src = p.zeros;
-    int a = 0;
+    unsigned kd = 0;
     if (on && isx) {
       const int col = quad * 4;
       if (qm) {
         const int b = (int)(grow / qn), v = (int)(grow - (size_t)b * qn);
         src = p.xq + (((size_t)b * p.xq_quads + quad) * qn + v) * 4;
-        a = 128;
+        kd = 1;
       } else if (col < p.k_in) {
         src = p.x + grow * p.ldx_src + col;
-        a = 32 * p.ldx_src;
+        kd = 2;
       }
     } else if (on) {
       const int col = gcol0 + quad * 4;   // dZ column
       if (qm) {
         const int b = (int)(grow / qn), v = (int)(grow - (size_t)b * qn);
         src = p.z0 + (((size_t)b * p.z0q_quads + (col >> 2)) * qn + v) * 4;
-        a = 128;
+        kd = 5;
       } else if (col < p.zsplit) {
         src = p.z0 + grow * p.ldz0 + col;
-        a = 32 * p.ldz0;
+        kd = 3;
       } else if (col < p.n_out) {
         src = p.z1 + grow * p.ldz1 + col;
-        a = 32 * p.ldz1;
+        kd = 4;
       }
     }
     sp[j] = src;
-    adv[j] = a;
+    kinds |= kd << (3 * j);
     pdst[j] = !on ? -1 : (isx ? row * kDwXld + quad * 4 : 3 * kDwXimg + row * kDwZld + quad * 4);
   }
   // vertex index (inside its mesh) of this thread's row of the NEXT stage to be issued: quad-major quads all sit on stage
   // row tid & 31 (every block of the e range starts at a multiple of 32)
   int vrow = qn > 0 ? (int)((row_first + (tid & 31)) % (size_t)qn) : 0;
   const int wrap_x = p.xq_nvert > 0 ? (p.xq_quads - 1) * qn * 4 : 0, wrap_z = p.z0q_nvert > 0 ? (p.z0q_quads - 1) * qn * 4 : 0;
+  const int adv_x = 32 * p.ldx_src, adv_z0 = 32 * p.ldz0, adv_z1 = 32 * p.ldz1;
 
   auto issue = [&](int unit) {   // DMA of stage `unit` (global index) into the raw buffer, then move every pointer 32 rows on
     const int rows_left = p.m - unit * 32;
@@ -618,7 +632,6 @@ __global__ __launch_bounds__(kDwThreads, 2) void dw3_kernel(DwArgs p) {
 #ifndef A3VT_DBG_DW3_NODMA
         glds16(sp[j], raw + (j * kDwThreads + wave * 64) * 4);
 #endif
-        sp[j] += adv[j];
       }
     } else {   // the ragged last stage of the whole problem: rows >= m contribute zeros
 #pragma unroll
@@ -628,14 +641,14 @@ __global__ __launch_bounds__(kDwThreads, 2) void dw3_kernel(DwArgs p) {
         glds16(e < kDwUnits && unit_row(e) < rows_left ? sp[j] : p.zeros, raw + (j * kDwThreads + wave * 64) * 4);
       }
     }
-    if (qn > 0) {
-      vrow += 32;
-      if (vrow >= qn) {          // per-lane: this row has crossed into the next mesh
-        vrow -= qn;
+    const bool wrap = qn > 0 && vrow + 32 >= qn;   // per-lane: this row crosses into the next mesh
+    if (qn > 0) vrow = wrap ? vrow + 32 - qn : vrow + 32;
 #pragma unroll
-        for (int j = 0; j < kDwPer; ++j)
-          if (adv[j] == 128) sp[j] += pdst[j] < 3 * kDwXimg ? wrap_x : wrap_z;
-      }
+    for (int j = 0; j < kDwPer; ++j) {
+      const unsigned kd = (kinds >> (3 * j)) & 7u;
+      int a = kd == 2 ? adv_x : kd == 3 ? adv_z0 : kd == 4 ? adv_z1 : (kd == 1 || kd == 5) ? 128 : 0;
+      if (wrap) a += kd == 1 ? wrap_x : kd == 5 ? wrap_z : 0;
+      sp[j] += a;
     }
   };
 

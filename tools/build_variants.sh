@@ -18,6 +18,8 @@ elif [ "$1" = "csrq" ]; then   # channel-sliced aggregation without its LDS gath
   build CSRQ_NOGATHER -DA3VT_DBG_CSRQ_NOGATHER
   build DW_NOWRAP -DA3VT_DBG_DW_NOWRAP   # dw without its mesh-boundary bookkeeping
   build DW_NOHYB -DA3VT_DBG_DW_NOHYB     # the plain dw kernel on the same buffers
+elif [ "$1" = "epi" ]; then   # rowgemm / rowgemm3 epilogues with their lane arithmetic hoisted (and spilled) as before round 4: A/B timing
+  build RG_HOISTED_EPI -DA3VT_DBG_RG_HOISTED_EPI
 elif [ "$1" = "stamps3" ]; then   # rowgemm3 (gemm mode 3) with stamps at its phase boundaries (tools/rowgemm3_stamps.py)
   build RG3_STAMPS -DA3VT_DBG_RG3_STAMPS
 elif [ "$1" = "x3" ]; then   # gemm mode 3 (gcn_gemm3.hip) ablations: python tools/stack_bench.py --precision fp32x3 with A3VT_LIB=...
