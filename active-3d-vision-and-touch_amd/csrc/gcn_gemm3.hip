@@ -106,6 +106,97 @@ __device__ __forceinline__ Pieces split3_x8(f32x4 x0, f32x4 x1) {
                 __builtin_bit_cast(f32x4, (u32x4){l[0], l[1], l[2], l[3]})};
 }
 
+
+// One 16 x 16 output tile with its operands pulled straight from global memory — the few rows the load-balanced split
+// leaves over (launch_rowgemm3; rowtile_unit of gcn_gemm.hip in this mode).  Same split, same six products in the same
+// order per 32-wide k chunk as rowgemm3_kernel's main loop, so a row gives the same bits wherever it lands.
+template <int EPI>
+__device__ __forceinline__ void rowtile3_unit(const RowGemmArgs &p, int row_base, int row_end, int mt, int n0, int lane) {
+  constexpr int KB = 5;   // k chunks per register block
+  const int l16 = lane & 15, q = lane >> 4;
+  const int ar = min(row_base + mt * 16 + l16, row_end - 1);   // A row of this lane (ragged tail: duplicate, never stored)
+  unsigned a0off = (unsigned)ar * (unsigned)p.lda0;
+  const unsigned a0mul = p.a0q_nvert > 0 ? (unsigned)p.a0q_nvert : 1u;
+  if (p.a0q_nvert > 0) {
+    const int bq = ar / p.a0q_nvert;
+    a0off = ((unsigned)bq * (unsigned)(p.a0q_quads * p.a0q_nvert) + (unsigned)(ar - bq * p.a0q_nvert)) * 4u;
+  }
+  const unsigned a1off = (unsigned)ar * (unsigned)p.lda1;
+  const float *brow = p.bt + (size_t)(n0 + l16) * kX3ImageLd + q * 4;   // hi image; mid / lo one / two images further
+  const int nch = (p.k + 31) >> 5;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int c0 = 0; c0 < nch; c0 += KB) {
+    f32x4 ra[KB][2], rb[KB][3];
+#pragma unroll
+    for (int c = 0; c < KB; ++c) {
+      const int ch = c0 + c < nch ? c0 + c : nch - 1;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int kk = ch * 32 + q * 8 + h * 4;
+        kk = kk < p.k ? kk : p.k - 4;
+        const float *src = kk < p.ksplit ? p.a0 + (size_t)(a0off + (unsigned)kk * a0mul) : p.a1 + (size_t)(a1off + (unsigned)kk);
+        ra[c][h] = *reinterpret_cast<const f32x4 *>(src);
+      }
+#pragma unroll
+      for (int im = 0; im < 3; ++im) rb[c][im] = *reinterpret_cast<const f32x4 *>(brow + (size_t)im * kX3ImageFloats + ch * 16);
+    }
+#pragma unroll
+    for (int c = 0; c < KB; ++c) {
+      if (c0 + c >= nch) break;
+      const Pieces ap = split3_x8(ra[c][0], ra[c][1]);
+      acc = mfma(ap.h, rb[c][2], acc);
+      acc = mfma(ap.m, rb[c][1], acc);
+      acc = mfma(ap.h, rb[c][1], acc);
+      acc = mfma(ap.l, rb[c][0], acc);
+      acc = mfma(ap.m, rb[c][0], acc);
+      acc = mfma(ap.h, rb[c][0], acc);
+    }
+  }
+  // C/D layout: this lane holds column n0 + l16 of rows 4 q .. 4 q + 3 of the tile
+  const int col = n0 + l16;
+  const bool col_ok = col < p.n_store;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = row_base + mt * 16 + q * 4 + r;
+    const bool row_ok = row < row_end;
+    const float v = acc[r];
+    if (EPI == EPI_FWD_HIDDEN) {
+      // ReLU-sign byte of 4 consecutive pass-through columns: gathered from the 4 lanes that hold them
+      const unsigned mybit = (col_ok && col >= p.csplit && v > 0.f) ? 1u << (l16 & 3) : 0u;
+      unsigned bits = mybit;
+      bits |= __shfl_xor(bits, 1, 64);
+      bits |= __shfl_xor(bits, 2, 64);
+      if (row_ok && p.maskb && (l16 & 3) == 0 && (col | 3) >= p.csplit && col < p.n_store)
+        p.maskb[(size_t)row * p.mld + p.moff + (col >> 2)] = (uint8_t)bits;
+      if (row_ok && col_ok) {
+        if (p.zq_nvert > 0 && col < p.zq_quads * 4) {   // quad-major raw columns
+          const int bq = row / p.zq_nvert;
+          p.c2[(((size_t)bq * p.zq_quads + (col >> 2)) * p.zq_nvert + (row - bq * p.zq_nvert)) * 4 + (col & 3)] = v;
+        } else if (p.zq_nvert > 0 && col < p.yq_quads * 4) {   // quad-major pass-through columns of the activations
+          const int bq = row / p.zq_nvert;
+          p.yq[(((size_t)bq * p.yq_quads + (col >> 2)) * p.zq_nvert + (row - bq * p.zq_nvert)) * 4 + (col & 3)] =
+              (v > 0.f || p.no_relu) ? v : 0.f;
+        } else {
+          // (the quad that straddles the cut: raw to c2 AND activated to c, as the main epilogue does — the raw copy's
+          // columns >= csplit are never gathered, the activation's columns < csplit are overwritten by the aggregation)
+          if (p.zq_nvert == 0 && col < ((p.csplit + 3) & ~3) && col < p.ldc2) p.c2[(size_t)row * p.ldc2 + col] = v;
+          if (col >= (p.csplit & ~3)) p.c[(size_t)row * p.ldc + col] = (v > 0.f || p.no_relu) ? v : 0.f;
+        }
+      }
+    } else {   // EPI_DX_MASK
+      if (row_ok && col_ok) {
+        if (p.zq_nvert > 0 && col < p.zq_quads * 4) {   // quad-major gradient columns: unmasked
+          const int bq = row / p.zq_nvert;
+          p.c2[(((size_t)bq * p.zq_quads + (col >> 2)) * p.zq_nvert + (row - bq * p.zq_nvert)) * 4 + (col & 3)] = v;
+        } else {
+          const unsigned byte = p.maskb[(size_t)row * p.mld + (col < p.csplit ? 0 : p.moff) + (col >> 2)];
+          p.c[(size_t)row * p.ldc + col] = ((byte >> (col & 3)) & 1u) ? v : 0.f;
+        }
+      }
+    }
+  }
+}
+
 #ifdef A3VT_DBG_RG3_STAMPS   // diagnostic build (tools/build_variants.sh stamps3): s_memrealtime (100 MHz) + s_memtime at the phase boundaries
 __device__ unsigned long long g_rg3_stamps[2 * 2 * 256 * 4 * 8];   // [real time | shader cycles][epilogue][workgroup][round (< 4)][8]
 #define RG3_STAMP(round, k)                                                                                                  \
@@ -437,6 +528,14 @@ __global__ __launch_bounds__(64 * kWaves, 2) void rowgemm3_kernel(RowGemmArgs p)
     wait_lgkm0();
     __builtin_amdgcn_s_barrier();   // epilogue slices are free again before the next round's DMA
     RG3_STAMP(rnd_, 4);
+  }
+  // Leftover rows of the load-balanced split (launch_rowgemm3): one 16 x 16 output tile per wave, dealt across the
+  // workgroups, operands straight from global memory — a few microseconds at the end of this launch instead of a lone
+  // extra tile that would make eight workgroups run a longer last round.
+  if (p.rem_rows > 0) {
+    const int units = ((p.rem_rows + 15) >> 4) * kNT;
+    for (int u = wave * gridDim.x + blockIdx.x; u < units; u += kWaves * gridDim.x)
+      rowtile3_unit<EPI>(p, p.rem_row0, p.rem_row0 + p.rem_rows, u / kNT, (u % kNT) * 16, lane);
   }
 }
 
@@ -806,7 +905,9 @@ bool rowgemm3_ok(const RowGemmArgs &a, int epi) {
   return true;
 }
 
-int launch_rowgemm3(const RowGemmArgs &a, int epi, hipStream_t s) {
+int launch_rowgemm3(const RowGemmArgs &a0, int epi, hipStream_t s) {
+  RowGemmArgs a = a0;
+  a.rem_row0 = a.rem_rows = 0;
   if (!rowgemm3_ok(a, epi)) {
     set_error("rowgemm3: unsupported call (m=%d k=%d n=%d epi=%d mode=%d)", a.m, a.k, a.n_store, epi, a.bf16);
     return -1;
@@ -816,7 +917,16 @@ int launch_rowgemm3(const RowGemmArgs &a, int epi, hipStream_t s) {
     (void)hipFuncSetAttribute((const void *)rowgemm3_kernel<EPI_FWD_HIDDEN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
     (void)hipFuncSetAttribute((const void *)rowgemm3_kernel<EPI_DX_MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes);
   });
-  const int tiles = cdiv(a.m, 16);
+  // Load balance as launch_rowgemm_epi (gcn_gemm.hip): the chip runs 2048 waves of this kernel, each owning tiles in pairs;
+  // the tiles that fill whole rounds go to the round loop, a small remainder (8 tiles = 128 rows at bs 64) to the tail.
+  int tiles = cdiv(a.m, 16);
+  const int full = tiles / 2048 * 2048, rem = tiles - full;
+  if (full > 0 && rem > 0 && rem * kNT <= 1024) {
+    a.rem_row0 = full * 16;
+    a.rem_rows = a.m - full * 16;
+    a.m = full * 16;
+    tiles = full;
+  }
   const int grid = cdiv(tiles, kWaves) < 256 ? cdiv(tiles, kWaves) : 256;
   if (epi == EPI_FWD_HIDDEN)
     A3VT_LAUNCH((rowgemm3_kernel<EPI_FWD_HIDDEN>), dim3(grid), dim3(64 * kWaves), kLdsBytes, s, a);
