@@ -85,7 +85,10 @@ def _oracle(adj_o, st, feats, gup, L, cut):
 @pytest.mark.parametrize("tname,use_touch,L,B,cut", [("ico3", False, 4, 24, 0.33), ("ico4", False, 3, 6, 0.33),
                                                       ("atlas", False, 3, 8, 0.33), ("atlas", True, 3, 8, 0.33),
                                                       ("ico3", False, 3, 20, 0.5), ("ico3", False, 3, 20, 0.04),
-                                                      ("ico4", False, 20, 6, 0.33), ("ico5", False, 4, 4, 0.33)])
+                                                      ("ico4", False, 20, 6, 0.33), ("ico5", False, 4, 4, 0.33),
+                                                      # 2071 / 2082 tiles: 23 / 34 leftover tiles go to the launches' tails
+                                                      # (row-major and hybrid layouts)
+                                                      ("atlas", True, 3, 17, 0.33), ("ico4", False, 3, 13, 0.33)])
 def test_stack_fp32x3_vs_fp64_oracle(cuda, tname, use_touch, L, B, cut):
     """Hidden 300, >= 12 288 rows: the three products of layers 1 .. L-2 run on the split-operand kernels — with the
     hybrid quad-major rows on the plain templates (channel-sliced aggregation), row-major on the touch graph / ico5.

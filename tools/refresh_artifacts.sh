@@ -1,8 +1,8 @@
 #!/bin/bash
 # One pass over everything under profiles/ that a kernel change can move (run on the GPU box from the repo root; ~6 min):
-#   tools/refresh_artifacts.sh r03      -> gpurun_out/refresh/r03_*   (copy what should be kept into profiles/)
+#   tools/refresh_artifacts.sh r04      -> gpurun_out/refresh/r04_*   (copy what should be kept into profiles/)
 set -x
-R=${1:-r03}
+R=${1:-r04}
 cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/refresh
 mkdir -p $O
@@ -10,12 +10,19 @@ python bench.py > $O/${R}_bench_default.json 2> $O/bench.err
 tail -c 700 $O/${R}_bench_default.json
 python bench.py --gemm-precision bf16s --no-cpu-baseline > $O/${R}_bench_bf16s.json 2>/dev/null; tail -c 400 $O/${R}_bench_bf16s.json
 python bench.py --gemm-precision bf16 --no-cpu-baseline > $O/${R}_bench_bf16_operand_mode.json 2>/dev/null; tail -c 400 $O/${R}_bench_bf16_operand_mode.json
+python bench.py --gemm-precision fp32x3 --no-cpu-baseline > $O/${R}_bench_fp32x3.json 2>/dev/null; tail -c 400 $O/${R}_bench_fp32x3.json
 python tools/measure_protocol.py > $O/${R}_timing_protocol.json 2> $O/protocol.err; tail -c 400 $O/${R}_timing_protocol.json
 python tools/named_configs.py > $O/${R}_named_configs.jsonl 2> $O/named.err; cut -c 1-300 $O/${R}_named_configs.jsonl
 python tools/named_configs.py --precision bf16 >> $O/${R}_named_configs.jsonl 2>> $O/named.err
 python tools/touch_bench.py > $O/${R}_touch_topology_step.log 2>&1; tail -3 $O/${R}_touch_topology_step.log
-(cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/bstats && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bstats -- python $GRAFT_REPO_ROOT/bench.py --steps 15 --warmup 5 --no-cpu-baseline --no-traffic > /tmp/bstats.log 2>&1; cp $(find /tmp/bstats -name '*kernel_stats.csv' | head -1) $O/${R}_bench_kernel_stats.csv; tail -c 300 /tmp/bstats.log)
+(cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/bstats && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bstats -- python $GRAFT_REPO_ROOT/bench.py --steps 15 --warmup 5 --no-cpu-baseline --no-traffic --alt-steps 0 > /tmp/bstats.log 2>&1; cp $(find /tmp/bstats -name '*kernel_stats.csv' | head -1) $O/${R}_bench_kernel_stats.csv; tail -c 300 /tmp/bstats.log)
 (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/bstats2 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bstats2 -- python $GRAFT_REPO_ROOT/bench.py --steps 15 --warmup 5 --no-cpu-baseline --no-traffic --gemm-precision bf16s > /tmp/bstats2.log 2>&1; cp $(find /tmp/bstats2 -name '*kernel_stats.csv' | head -1) $O/${R}_bench_bf16s_kernel_stats.csv)
+(cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/bstats3 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bstats3 -- python $GRAFT_REPO_ROOT/bench.py --steps 15 --warmup 5 --no-cpu-baseline --no-traffic --alt-steps 0 --gemm-precision fp32x3 > /tmp/bstats3.log 2>&1; cp $(find /tmp/bstats3 -name '*kernel_stats.csv' | head -1) $O/${R}_bench_fp32x3_kernel_stats.csv)
+# gemm mode 3: ablation builds (tools/build_variants.sh x3), phase stamps (stamps3), error table against the fp64 oracle
+[ -f gpurun_variants/liba3vt_X3_NOMFMA.so ] && bash tools/x3_ablate.sh > $O/${R}_x3_ablation.txt 2>&1
+[ -f gpurun_variants/liba3vt_RG3_STAMPS.so ] && A3VT_LIB=$GRAFT_REPO_ROOT/gpurun_variants/liba3vt_RG3_STAMPS.so python tools/rowgemm3_stamps.py > $O/${R}_rowgemm3_phase_stamps.txt 2>/dev/null
+python -m pytest tests/test_gpu_fullsize.py -q -s -k benchmark_configuration 2>&1 | grep "^\[configs\|passed\|failed" > $O/${R}_mode_error_table.txt; cat $O/${R}_mode_error_table.txt
+python -m pytest tests/test_gpu_fp32x3.py -q -s -k vs_fp64 2>&1 | grep "^\[\|passed\|failed" >> $O/${R}_mode_error_table.txt
 # configs[3]: the first steps run MIOpen's find mode, so the table is cut from the kernel TRACE after 5 steps (tools/trace_steady.py)
 (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/c3 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/c3 -- python $GRAFT_REPO_ROOT/tools/named_configs.py --only 3 --steps 10 > /tmp/c3.log 2>&1; python $GRAFT_REPO_ROOT/tools/trace_steady.py $(find /tmp/c3 -name '*kernel_trace.csv' | head -1) --skip 5 --top 60 > $O/${R}_config3_bf16s_steady_kernels.txt; head -8 $O/${R}_config3_bf16s_steady_kernels.txt)
 python tools/chamfer_bench.py > $O/${R}_chamfer_search.txt 2>/dev/null; cat $O/${R}_chamfer_search.txt
@@ -27,3 +34,4 @@ bash tools/collect_sq.sh --precision bf16s > $O/sq16.log 2>&1; cp gpurun_out/sq/
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-traffic 2>/dev/null | tail -c 400
 python tools/kstats_summary.py $O/${R}_bench_kernel_stats.csv 22 16
 python tools/kstats_summary.py $O/${R}_bench_bf16s_kernel_stats.csv 22 12
+python tools/kstats_summary.py $O/${R}_bench_fp32x3_kernel_stats.csv 22 14
