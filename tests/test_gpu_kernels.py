@@ -592,14 +592,15 @@ def test_posenc_wide_bf16_operand_mode(cuda):
     assert errs[0] < 5e-3 and max(errs[1:]) < 6e-2, errs
 
 
-def test_image_encoder_bf16_branch_batches_1_to_4(cuda):
+def test_image_encoder_bf16_branch_batches_1_to_4(cuda):   # (batches 1, 3 and 4: both sides of the threshold)
     """the bf16 channels-last image encoder at the batch sizes around the BatchNorm workaround's threshold
     (``Image_Encoder.bn_nhwc_min_batch``: MIOpen's bf16 NHWC training BatchNorm takes the host down below 4 samples, so those
     batches use the NCHW kernel).  Every batch size trains, and the maps agree with the fp32 branch to bf16 rounding."""
     import warnings
     from a3vt_amd.pterotactyl.reconstruction.vision import model
-    args16 = make_args(use_img=True, CNN_ker_size=5, num_CNN_blocks=6, layers_per_block=3, gemm_precision="bf16s")
-    args32 = make_args(use_img=True, CNN_ker_size=5, num_CNN_blocks=6, layers_per_block=3)
+    # (a three-block pyramid: every new convolution shape costs a MIOpen search)
+    args16 = make_args(use_img=True, CNN_ker_size=5, num_CNN_blocks=3, layers_per_block=2, gemm_precision="bf16s")
+    args32 = make_args(use_img=True, CNN_ker_size=5, num_CNN_blocks=3, layers_per_block=2)
     torch.manual_seed(0)
     enc16 = model.Image_Encoder(args16).to(cuda)
     enc32 = model.Image_Encoder(args32).to(cuda)
@@ -608,7 +609,7 @@ def test_image_encoder_bf16_branch_batches_1_to_4(cuda):
     model.Image_Encoder._bn_fallback_reported = False
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
-        for B in (1, 2, 3, 4):
+        for B in (1, 3, 4):
             img = torch.rand(B, 3, 256, 256, generator=g).to(cuda)
             enc16.train(), enc32.train()
             maps16 = enc16(img)
