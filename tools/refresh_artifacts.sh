@@ -31,6 +31,8 @@ bash tools/collect_nn.sh > $O/nn.log 2>&1; cp gpurun_out/nn/summary.json $O/${R}
 bash tools/collect_traffic.sh > $O/traffic.log 2>&1; cp gpurun_out/traffic/summary.json $O/${R}_pmc_traffic_summary.json
 bash tools/collect_sq.sh > $O/sq.log 2>&1; cp gpurun_out/sq/summary.json $O/${R}_pmc_sq_summary.json
 bash tools/collect_sq.sh --precision bf16s > $O/sq16.log 2>&1; cp gpurun_out/sq/summary.json $O/${R}_pmc_sq_summary_bf16s.json
+bash tools/collect_traffic.sh --precision fp32x3 > $O/traffic3.log 2>&1; cp gpurun_out/traffic/summary.json $O/${R}_pmc_traffic_summary_fp32x3.json
+bash tools/collect_sq.sh --precision fp32x3 > $O/sq3.log 2>&1; cp gpurun_out/sq/summary.json $O/${R}_pmc_sq_summary_fp32x3.json
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-traffic 2>/dev/null | tail -c 400
 python tools/kstats_summary.py $O/${R}_bench_kernel_stats.csv 22 16
 python tools/kstats_summary.py $O/${R}_bench_bf16s_kernel_stats.csv 22 12
