@@ -890,13 +890,16 @@ int launch_split3(const float *x, size_t n, unsigned short *hi, unsigned short *
 // the chip; everything else of a mode-3 stack runs the exact fp32 kernels.
 bool rowgemm3_dims_ok(long long m, int k, int n_store) {
   return k > 288 && k <= 320 && k % 4 == 0 && n_store > 288 && n_store <= 304 && n_store % 4 == 0 && m >= 96 * 128 &&
-         m < (1ll << 31) - 64;
+         m * 320 < (1ll << 32);   // (the kernel addresses A rows with 32-bit float offsets: 13.4 M rows)
 }
 
 bool rowgemm3_ok(const RowGemmArgs &a, int epi) {
   if (a.bf16 != 3 || (epi != EPI_FWD_HIDDEN && epi != EPI_DX_MASK)) return false;
   if (!rowgemm3_dims_ok(a.m, a.k, a.n_store)) return false;
   if (a.lda0 % 4 != 0 || a.lda1 % 4 != 0 || a.ksplit % 4 != 0 || a.ldc % 4 != 0 || a.csplit > a.n_store) return false;
+  // the kernel addresses A rows with 32-bit float offsets from a0 / a1
+  const long long ldmax = a.lda0 > a.lda1 ? a.lda0 : a.lda1;
+  if ((long long)a.m * (ldmax > 320 ? ldmax : 320) >= (1ll << 32)) return false;
   if (a.a0q_nvert > 0 && (a.m % a.a0q_nvert != 0 || a.ksplit != a.a0q_quads * 4)) return false;
   if (a.zq_nvert > 0 && (a.c2 == nullptr || a.m % a.zq_nvert != 0 || a.zq_quads * 4 != pad4(a.csplit) || a.zq_quads * 4 > 160)) return false;
   if (a.yq_quads > 0 && (a.zq_nvert <= 0 || a.yq == nullptr || epi != EPI_FWD_HIDDEN || a.yq_quads < a.zq_quads || a.yq_quads * 4 > 160)) return false;
