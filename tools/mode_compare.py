@@ -14,7 +14,7 @@ p.add_argument("--steps", type=int, default=12)
 p.add_argument("--batch", type=int, default=16)
 p.add_argument("--points", type=int, default=4000)
 p.add_argument("--level", type=int, default=4)
-p.add_argument("--modes", default="fp32,bf16,bf16s")
+p.add_argument("--modes", default="fp32,fp32x3,bf16,bf16s")
 a = p.parse_args()
 
 from a3vt_amd import mesh as amesh  # noqa: E402
@@ -48,7 +48,7 @@ for mode in a.modes.split(","):
             first[mode] = {n: q.grad.detach().clone() for n, q in net.named_parameters()}
         opt.step()
         losses.append(loss.item())
-    print(f"{mode:6s} losses: " + " ".join(f"{x:8.1f}" for x in losses))
+    print(f"{mode:6s} losses: " + " ".join(f"{x:10.3f}" for x in losses))
 ref = first.get("fp32")
 if ref:
     for mode, gr in first.items():
