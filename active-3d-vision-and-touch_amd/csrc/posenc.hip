@@ -174,252 +174,364 @@ int launch_posenc_fwd(const float *verts, const float *mask, int m, int input_si
 }
 
 // ------------------------------------------------------------------------------------------------
-// Backward.  Workgroup = 128 vertices (256 threads).  The per-vertex work is a chain of small dense products over the
-// block's vertices — the forward recompute (63 -> 12 -> 25), the back-propagation (50 -> 25 -> 12 -> 63) — and the
-// parameter gradients are outer-product sums over the same vertices, so everything runs as 16 x 16 tiles of
-// v_mfma_f32_16x16x4_f32 (exact fp32) on vertex rows parked in LDS; threads only compute sin / cos, the ReLU masks and
-// the 63-term position gradient.  (The first version did all of it with per-thread scalar FMAs fed by LDS reads at
-// two waves per CU: 445 us per call against ~70 us here.)
-// LDS: weight images as B operands [k][n] with the bias as an extra k row against a 1 in the vertex row, zero rows
-// where K is padded to a multiple of 4; vertex rows E|1, G, H1|1, H2|1, D2, D1, DE, one-hot token.
+// Backward (round 4 form).  The per-vertex work is a chain of small dense products — the forward recompute (63 -> 12 -> 25),
+// the back-propagation (50 -> 25 -> 12 -> 63) — and the parameter gradients are outer-product sums over vertices, so
+// everything runs as 16 x 16 tiles of v_mfma_f32_16x16x4_f32 (exact fp32); threads only compute sin / cos, the ReLU masks
+// and the 63-term position gradient.
+// A WAVE owns 16 vertices at a time and walks the whole chain on them alone, in its own 15 KB of LDS: no workgroup barrier
+// inside the loop.  An MFMA of this shape fed by two ds_read_b32 is bound by the LDS port (512 B per 32 matrix cycles and
+// SIMD = half the port before any bank conflict), so
+//   * the WEIGHT operands of the five chain products (69 k-steps) live in the wave's registers for the whole launch, read
+//     once from the packed parameters: those MFMAs take one LDS read each;
+//   * the parameter-gradient tiles (14 accumulators) stay in registers over all the wave's vertex tiles; their products run
+//     over the tile's vertices in the order (lane group kq, step st) -> vertex 4 kq + st, which is how an MFMA result lies
+//     in registers: dh2 / dh1 enter them without touching LDS and the other operand rows sit 4 rows (= 16 banks) apart;
+//   * the next tile's inputs are requested before the current tile's chain.
+// Persistent grid, at most 512 workgroups of 4 waves (two per CU); a workgroup's four partials are summed through LDS in a
+// fixed order into its slab.  (Round 3: one 128-vertex workgroup per CU with a barrier between phases, 154 KB of LDS, a slab
+// per 128 vertices — 1281 workgroups on 256 CUs ran as six rounds of ~30 us: 182 us per call.  First version: per-thread
+// scalar FMAs, 445 us.)
+// grad_verts is the same fma chain per element as before (identical bits); the parameter gradients are summed in a different
+// (still fixed) order.
+// Per wave in LDS: the vertex rows E|1, G (later dE), H1|1, H2|1|one-hot token, D2, D1.  Row strides are = 4 mod 16 floats:
+// the A-operand read of a chain tile (lane = row l16, k = kq) touches 64 different banks, and so do the row reads of the
+// outer products.
 // ------------------------------------------------------------------------------------------------
-constexpr int kPEBwdVerts = 128;
 constexpr int kPEBwdThreads = 256;
+constexpr int kPEBwdWaves = kPEBwdThreads / 64;
+constexpr int kPEBwdMaxWgs = 512;
 
-int posenc_num_slabs(int m) { return cdiv(m, kPEBwdVerts); }
+int posenc_num_slabs(int m) {
+  const int wgs = cdiv(cdiv(m, 16), kPEBwdWaves);
+  return wgs < 1 ? 1 : wgs > kPEBwdMaxWgs ? kPEBwdMaxWgs : wgs;
+}
 
 template <int I>
 struct PEB {
   using P = PE<I>;
-  static constexpr int T = kPEBwdVerts, H1 = P::H1, H2 = P::H2;
-  // B-operand weight images
-  static constexpr int oB1 = 0;                      // [64][H1]   rows 0..62 = W1^T, row 63 = b1          (E|1 -> h1)
-  static constexpr int oB2 = oB1 + 64 * H1;          // [16][H2]   rows 0..11 = W2^T, row 12 = b2, rest 0  (H1|1 -> h2)
-  static constexpr int oB3 = oB2 + 16 * H2;          // [52][H2]   = W3 (o, k), rows 50, 51 = 0            (G -> dh2)
-  static constexpr int oB4 = oB3 + 52 * H2;          // [28][H1]   = W2 (j, k), rows 25..27 = 0            (D2 -> dh1)
-  static constexpr int oB5 = oB4 + 28 * H1;          // [12][63]   = W1 (j, k)                             (D1 -> de)
-  static constexpr int NW = oB5 + H1 * 63 + 16;      // + slack for the 16-wide reads of the last row
-  // vertex rows
-  static constexpr int LE = 64, LG = 52, LH1 = 16, LH2 = 28, LD2 = 28, LD1 = 16, LDE = 64, LOH = 4;
-  static constexpr int oE = NW, oG = oE + T * LE, oH1 = oG + T * LG, oH2 = oH1 + T * LH1, oD2 = oH2 + T * LH2,
-                       oD1 = oD2 + T * LD2, oDE = oD1 + T * LD1, oOH = oDE + T * LDE, N = oOH + T * LOH + 64;
+  static constexpr int H1 = P::H1, H2 = P::H2;
+  // a wave's vertex rows (16 vertices)
+  static constexpr int LE = 68, LG = 68, LH1 = 20, LH2 = 36, LD2 = 36, LD1 = 20;
+  static constexpr int oE = 0, oG = oE + 16 * LE, oH1 = oG + 16 * LG, oH2 = oH1 + 16 * LH1, oD2 = oH2 + 16 * LH2,
+                       oD1 = oD2 + 16 * LD2, WAVE = oD1 + 16 * LD1;
+  static constexpr int N = kPEBwdWaves * WAVE;
   static_assert(I == 50, "layout written for I = 50 (H1 = 12, H2 = 25)");
+  static_assert(WAVE >= P::N && WAVE % 4 == 0, "a wave's partial parameter gradients are parked in its own rows at the end");
 };
 
-// 16 x 16 tile of A[rows m0.., K] * B[K, cols n0..]: A rows in LDS (stride lda), B rows in LDS (stride ldb), K % 4 == 0.
-// The lane ends up with column n0 + l16 of rows m0 + 4 kq .. + 3.
-__device__ __forceinline__ f32x4 pe_tile(const float *A, int lda, int m0, const float *B, int ldb, int n0, int K, int l16,
-                                         int kq) {
+// LDS operations of one wave execute in order; this only keeps the COMPILER from moving a phase's reads above the
+// previous phase's writes of other lanes
+__device__ __forceinline__ void pe_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// 16 x 16 tile of A[16 rows, 4 KS] * W: A rows in LDS (stride lda; lane = row l16, k = kq + 4 j), W's k-steps in registers.
+// The lane ends up with its column of rows 4 kq .. + 3.
+template <int KS>
+__device__ __forceinline__ f32x4 pe_chain(const float *A, int lda, const float (&w)[KS], int l16, int kq) {
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const float *pa = A + (m0 + l16) * lda + kq, *pb = B + kq * ldb + n0 + l16;
-#pragma unroll 4
-  for (int k = 0; k < K; k += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[k], pb[k * ldb], acc, 0, 0, 0);
+  const float *pa = A + l16 * lda + kq;
+#pragma unroll
+  for (int j = 0; j < KS; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[4 * j], w[j], acc, 0, 0, 0);
   return acc;
 }
 
 template <int I>
-__global__ __launch_bounds__(kPEBwdThreads) void posenc_bwd_kernel(const float *__restrict__ verts,
-                                                                   const float *__restrict__ mask, int m,
-                                                                   const float *__restrict__ params,
-                                                                   const float *__restrict__ gfeats, int ld,
-                                                                   float *__restrict__ gverts,
-                                                                   float *__restrict__ slab) {
+__global__ __launch_bounds__(kPEBwdThreads, 2) void posenc_bwd_kernel(const float *__restrict__ verts,
+                                                                      const float *__restrict__ mask, int m,
+                                                                      const float *__restrict__ params,
+                                                                      const float *__restrict__ gfeats, int ld,
+                                                                      float *__restrict__ gverts,
+                                                                      float *__restrict__ slab) {
   using P = PE<I>;
   using B = PEB<I>;
-  constexpr int T = B::T, H1 = B::H1, H2 = B::H2;
-  extern __shared__ float smem[];
-  float *sE = smem + B::oE, *sG = smem + B::oG, *sH1 = smem + B::oH1, *sH2 = smem + B::oH2, *sD2 = smem + B::oD2,
-        *sD1 = smem + B::oD1, *sDE = smem + B::oDE, *sOH = smem + B::oOH;
+  constexpr int H1 = B::H1, H2 = B::H2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6, l16 = lane & 15, kq = lane >> 4;
-  float *out = slab + (size_t)blockIdx.x * P::N;
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l16 = lane & 15, kq = lane >> 4;
+  float *wv = smem + wave * B::WAVE;
+  float *sE = wv + B::oE, *sG = wv + B::oG, *sH1 = wv + B::oH1, *sH2 = wv + B::oH2, *sD2 = wv + B::oD2, *sD1 = wv + B::oD1;
+  float *sDE = sG;   // the position-embedding gradient takes G's rows once the products on G are done
 
-  // ---- phase 0: weight images (all threads) and the vertex rows E|1, G, one-hot, constant columns (threads < T)
-  for (int i = t; i < B::NW; i += kPEBwdThreads) smem[i] = 0.f;
-  __syncthreads();
-  for (int i = t; i < H1 * 63; i += kPEBwdThreads) {  // W1 (j, k): transposed into B1, as is into B5
-    const int j = i / 63, k = i - j * 63;
-    const float w = params[P::oW1 + i];
-    smem[B::oB1 + k * H1 + j] = w;
-    smem[B::oB5 + i] = w;
-  }
-  for (int i = t; i < H1; i += kPEBwdThreads) smem[B::oB1 + 63 * H1 + i] = params[P::ob1 + i];
-  for (int i = t; i < H2 * H1; i += kPEBwdThreads) {  // W2 (j, k)
-    const int j = i / H1, k = i - j * H1;
-    const float w = params[P::oW2 + i];
-    smem[B::oB2 + k * H2 + j] = w;
-    smem[B::oB4 + i] = w;
-  }
-  for (int i = t; i < H2; i += kPEBwdThreads) smem[B::oB2 + H1 * H2 + i] = params[P::ob2 + i];
-  for (int i = t; i < I * H2; i += kPEBwdThreads) smem[B::oB3 + i] = params[P::oW3 + i];  // W3 (o, k)
-  {  // embedding: two threads per vertex, five frequencies each
-    const int tv = t >> 1, half = t & 1;
-    const int v = blockIdx.x * T + tv;
-    float p[3] = {0.f, 0.f, 0.f};
-    if (v < m) {
-      p[0] = verts[3 * (long long)v];
-      p[1] = verts[3 * (long long)v + 1];
-      p[2] = verts[3 * (long long)v + 2];
-    }
-    float *myE = sE + tv * B::LE;
-#pragma unroll 1
-    for (int i = half * 5; i < half * 5 + 5; ++i) {
-      const float f = pe_freq(i);
+  // ---- weight operands, B[k = kq + 4 j][n = n0 + l16] of each chain product; rows / columns of padding are zeros
+  float w1[16];       // [W1^T; b1]  (E|1 -> h1)      k < 63: W1[n][k], k = 63: b1[n]
+  float w2[2][4];     // [W2^T; b2]  (H1|1 -> h2)     k < 12: W2[n][k], k = 12: b2[n]
+  float w3[2][13];    // W3 (o, k)   (G -> dh2)       B[o][n] = W3[o][n], o < 50
+  float w4[7];        // W2 (j, k)   (D2 -> dh1)      B[j][n] = W2[j][n], j < 25
+  float w5[4][3];     // W1 (j, k)   (D1 -> de)       B[j][n] = W1[j][n], j < 12, n < 63
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        myE[6 * i + c] = sinf(f * p[c]);
-        myE[6 * i + 3 + c] = cosf(f * p[c]);
-      }
+  for (int j = 0; j < 16; ++j) {
+    const int k = kq + 4 * j;
+    w1[j] = l16 < H1 ? (k < 63 ? params[P::oW1 + l16 * 63 + k] : params[P::ob1 + l16]) : 0.f;
+  }
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int col = n * 16 + l16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = kq + 4 * j;
+      w2[n][j] = col < H2 && k <= H1 ? (k < H1 ? params[P::oW2 + col * H1 + k] : params[P::ob2 + col]) : 0.f;
     }
-    if (half == 0) {
-      myE[60] = p[0];
-      myE[61] = p[1];
-      myE[62] = p[2];
-      myE[63] = 1.f;
+#pragma unroll
+    for (int j = 0; j < 13; ++j) {
+      const int o = kq + 4 * j;
+      w3[n][j] = col < H2 && o < I ? params[P::oW3 + o * H2 + col] : 0.f;
     }
   }
-  // upstream gradient rows: coalesced 16-byte pieces of the [T][ld] tile (columns >= I are zero by contract when ld >= 52)
-  for (int i = t; i < T * (B::LG / 4); i += kPEBwdThreads) {
-    const int r = i / (B::LG / 4), c4 = i - r * (B::LG / 4);
-    const int v = blockIdx.x * T + r;
-    f32x4 g = {0.f, 0.f, 0.f, 0.f};
-    if (v < m) {
-      if (c4 * 4 + 3 < ld) {
-        g = *reinterpret_cast<const f32x4 *>(gfeats + (long long)v * ld + c4 * 4);
-      } else {
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int r = kq + 4 * j;
+    w4[j] = l16 < H1 && r < H2 ? params[P::oW2 + r * H1 + l16] : 0.f;
+  }
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    const int col = n * 16 + l16;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) w5[n][j] = col < 63 ? params[P::oW1 + (kq + 4 * j) * 63 + col] : 0.f;
+  }
+  // this wave's rows zeroed (pad columns stay zero: nothing below writes them), then the bias columns
+  for (int i = lane; i < B::WAVE / 4; i += 64) reinterpret_cast<f32x4 *>(wv)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  pe_wave_sync();
+  if (kq == 0) {
+    sE[l16 * B::LE + 63] = 1.f;
+    sH1[l16 * B::LH1 + H1] = 1.f;
+    sH2[l16 * B::LH2 + H2] = 1.f;
+  }
+
+  // parameter-gradient tiles of this wave, summed over all its vertex tiles
+  f32x4 aW3[4][2], aW2[2], aW1[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) aW3[a][0] = aW3[a][1] = aW1[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+  aW2[0] = aW2[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int ntile = (m + 15) >> 4, nwave = gridDim.x * kPEBwdWaves;
+  // a tile's inputs: the 16 x 52 gradient rows as 208 16-byte pieces (four per lane; columns >= I are zeroed), the
+  // lane's vertex l16 (its position and token)
+  struct Inputs { f32x4 g[4]; float p[3]; int tok; bool live; };
+  auto fetch = [&](int tile) {
+    Inputs in;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = lane + 64 * j, r = i / 13, c4 = i - r * 13;
+      const long long v = (long long)tile * 16 + r;
+      f32x4 g = {0.f, 0.f, 0.f, 0.f};
+      if (i < 208 && v < m) {
+        if (c4 * 4 + 3 < ld) {
+          g = *reinterpret_cast<const f32x4 *>(gfeats + v * ld + c4 * 4);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (c4 * 4 + k < ld) g[k] = gfeats[v * ld + c4 * 4 + k];
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-          if (c4 * 4 + k < ld) g[k] = gfeats[(long long)v * ld + c4 * 4 + k];
+          if (c4 * 4 + k >= I) g[k] = 0.f;
       }
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (c4 * 4 + k >= I) g[k] = 0.f;
+      in.g[j] = g;
     }
-    *reinterpret_cast<f32x4 *>(sG + r * B::LG + c4 * 4) = g;
-  }
-  if (t < T) {
-    const int v = blockIdx.x * T + t;
-    const bool live = v < m;
-    int tok = live ? (int)mask[v] : 0;
-    tok = tok < 0 ? 0 : (tok > 3 ? 3 : tok);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) sOH[t * B::LOH + k] = (live && tok == k) ? 1.f : 0.f;
-    sH1[t * B::LH1 + H1] = 1.f;   // bias column; the other pad columns stay finite zeros
-#pragma unroll
-    for (int k = H1 + 1; k < B::LH1; ++k) sH1[t * B::LH1 + k] = 0.f;
-    sH2[t * B::LH2 + H2] = 1.f;
-#pragma unroll
-    for (int k = H2 + 1; k < B::LH2; ++k) sH2[t * B::LH2 + k] = 0.f;
-#pragma unroll
-    for (int k = H2; k < B::LD2; ++k) sD2[t * B::LD2 + k] = 0.f;
-#pragma unroll
-    for (int k = H1; k < B::LD1; ++k) sD1[t * B::LD1 + k] = 0.f;
-  }
-  __syncthreads();
+    const long long v = (long long)tile * 16 + l16;
+    in.live = v < m;
+    in.p[0] = in.live ? verts[3 * v] : 0.f;
+    in.p[1] = in.live ? verts[3 * v + 1] : 0.f;
+    in.p[2] = in.live ? verts[3 * v + 2] : 0.f;
+    int tok = in.live ? (int)mask[v] : 0;
+    in.tok = tok < 0 ? 0 : (tok > 3 ? 3 : tok);
+    return in;
+  };
 
-  constexpr int NW_ = kPEBwdThreads / 64, MT = T / 16;
-  // ---- phase 1: h1 = relu(E|1 . [W1^T; b1])
-  for (int tile = wave; tile < MT; tile += NW_) {
-    const f32x4 acc = pe_tile(sE, B::LE, tile * 16, smem + B::oB1, H1, 0, 64, l16, kq);
-    if (l16 < H1)
+  int tile = blockIdx.x * kPEBwdWaves + wave;
+  Inputs in;
+  if (tile < ntile) in = fetch(tile);
+#ifdef A3VT_DBG_PE_NOLOOP   // timing-only: set-up and the final reduction alone
+  tile = ntile;
+#endif
+  for (; tile < ntile; tile += nwave) {
+    // ---- park the inputs: G rows, the embedding E (lane = vertex l16, a quarter of the 30 (frequency, axis) pairs), token
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sH1[(tile * 16 + kq * 4 + r) * B::LH1 + l16] = acc[r] > 0.f ? acc[r] : 0.f;
-  }
-  __syncthreads();
-  // ---- phase 2: h2 = relu(H1|1 . [W2^T; b2])
-  for (int tile = wave; tile < MT * 2; tile += NW_) {
-    const int mt = tile >> 1, n0 = (tile & 1) * 16;
-    const f32x4 acc = pe_tile(sH1, B::LH1, mt * 16, smem + B::oB2, H2, n0, 16, l16, kq);
-    if (n0 + l16 < H2)
+    for (int j = 0; j < 4; ++j) {
+      const int i = lane + 64 * j, r = i / 13, c4 = i - r * 13;
+      if (i < 208) *reinterpret_cast<f32x4 *>(sG + r * B::LG + c4 * 4) = in.g[j];
+    }
+    {
+      float *myE = sE + l16 * B::LE;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sH2[(mt * 16 + kq * 4 + r) * B::LH2 + n0 + l16] = acc[r] > 0.f ? acc[r] : 0.f;
-  }
-  __syncthreads();
-  // ---- phase 3: dh2 = (G . W3) * (h2 > 0)
-  for (int tile = wave; tile < MT * 2; tile += NW_) {
-    const int mt = tile >> 1, n0 = (tile & 1) * 16;
-    const f32x4 acc = pe_tile(sG, B::LG, mt * 16, smem + B::oB3, H2, n0, 52, l16, kq);
-    if (n0 + l16 < H2)
+      for (int u = 0; u < 8; ++u) {
+        const int idx = kq + 4 * u;
+        if (idx < 30) {
+          const int i = idx / 3, c = idx - 3 * i;
+          // pe_freq(i) for a runtime i: the same double product, rounded once
+          const float f = i == 0 ? (float)3.141592653589793 : (float)(3.141592653589793 * 2.0 * (double)i);
+          const float pc = c == 0 ? in.p[0] : c == 1 ? in.p[1] : in.p[2];
+#ifdef A3VT_DBG_PE_NOSINCOS   // timing-only
+          myE[6 * i + c] = f * pc;
+          myE[6 * i + 3 + c] = f + pc;
+#else
+          myE[6 * i + c] = sinf(f * pc);
+          myE[6 * i + 3 + c] = cosf(f * pc);
+#endif
+        }
+      }
+      if (kq < 3) myE[60 + kq] = kq == 0 ? in.p[0] : kq == 1 ? in.p[1] : in.p[2];
+      sH2[l16 * B::LH2 + H2 + 1 + kq] = (in.live && in.tok == kq) ? 1.f : 0.f;   // one-hot token behind the bias column
+    }
+    const int vtile = tile;
+    if (tile + nwave < ntile) in = fetch(tile + nwave);   // the next tile's inputs travel during this tile's chain
+    pe_wave_sync();
+
+    // ---- h1 = relu(E|1 . [W1^T; b1])
+    bool h1pos[4];
+    {
+      const f32x4 acc = pe_chain<16>(sE, B::LE, w1, l16, kq);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = mt * 16 + kq * 4 + r;
-        sD2[row * B::LD2 + n0 + l16] = sH2[row * B::LH2 + n0 + l16] > 0.f ? acc[r] : 0.f;
+        h1pos[r] = acc[r] > 0.f;
+        if (l16 < H1) sH1[(kq * 4 + r) * B::LH1 + l16] = h1pos[r] ? acc[r] : 0.f;
       }
-  }
-  __syncthreads();
-  // ---- phase 4: dh1 = (D2 . W2) * (h1 > 0)
-  for (int tile = wave; tile < MT; tile += NW_) {
-    const f32x4 acc = pe_tile(sD2, B::LD2, tile * 16, smem + B::oB4, H1, 0, 28, l16, kq);
-    if (l16 < H1)
+    }
+    pe_wave_sync();
+    // ---- h2 = relu(H1|1 . [W2^T; b2])
+    bool h2pos[2][4];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const f32x4 acc = pe_chain<4>(sH1, B::LH1, w2[n], l16, kq);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = tile * 16 + kq * 4 + r;
-        sD1[row * B::LD1 + l16] = sH1[row * B::LH1 + l16] > 0.f ? acc[r] : 0.f;
+        h2pos[n][r] = acc[r] > 0.f;
+        if (n * 16 + l16 < H2) sH2[(kq * 4 + r) * B::LH2 + n * 16 + l16] = h2pos[n][r] ? acc[r] : 0.f;
       }
-  }
-  __syncthreads();
-  // ---- phase 5: de = D1 . W1
-  for (int tile = wave; tile < MT * 4; tile += NW_) {
-    const int mt = tile >> 2, n0 = (tile & 3) * 16;
-    const f32x4 acc = pe_tile(sD1, B::LD1, mt * 16, smem + B::oB5, 63, n0, H1, l16, kq);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) sDE[(mt * 16 + kq * 4 + r) * B::LDE + n0 + l16] = acc[r];
-  }
-  __syncthreads();
-  // ---- phase 6: gradient w.r.t. the position.  d sin(f p)/dp = f cos(f p) = f e[6i+3+c], d cos(f p)/dp = -f e[6i+c]
-  if (t < T) {
-    const int v = blockIdx.x * T + t;
-    const float *e = sE + t * B::LE, *de = sDE + t * B::LDE;
-    float gp[3] = {de[60], de[61], de[62]};
-#pragma unroll 1
-    for (int i = 0; i < 10; ++i) {
-      const float f = pe_freq(i);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) gp[c] += f * (e[6 * i + 3 + c] * de[6 * i + c] - e[6 * i + c] * de[6 * i + 3 + c]);
     }
-    if (v < m) {
-      gverts[3 * (long long)v + 0] = gp[0];
-      gverts[3 * (long long)v + 1] = gp[1];
-      gverts[3 * (long long)v + 2] = gp[2];
+    // ---- dh2 = (G . W3) * (h2 > 0): kept in registers (columns >= 25 are exact zeros: zero weights), rows for the next product
+    f32x4 d2[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const f32x4 acc = pe_chain<13>(sG, B::LG, w3[n], l16, kq);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        d2[n][r] = h2pos[n][r] ? acc[r] : 0.f;
+        sD2[(kq * 4 + r) * B::LD2 + n * 16 + l16] = d2[n][r];
+      }
     }
+    pe_wave_sync();
+    // The outer products run over the tile's vertices as (kq, st) -> vertex 4 kq + st: operand rows 4 kq + st of G / H2 /
+    // H1 / E from LDS, dh2 / dh1 straight from the registers above.
+    // ---- dW3 | db3 | dE += G^T . [H2 | 1 | one-hot]
+#ifndef A3VT_DBG_PE_NOOUTER
+    {
+      float hb[2][4];
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int st = 0; st < 4; ++st) hb[n][st] = sH2[(kq * 4 + st) * B::LH2 + n * 16 + l16];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        float ga[4];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) ga[st] = sG[(kq * 4 + st) * B::LG + a * 16 + l16];
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int st = 0; st < 4; ++st) aW3[a][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[st], hb[n][st], aW3[a][n], 0, 0, 0);
+      }
+    }
+#endif
+    // ---- dh1 = (D2 . W2) * (h1 > 0)
+    f32x4 d1;
+    {
+      const f32x4 acc = pe_chain<7>(sD2, B::LD2, w4, l16, kq);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        d1[r] = h1pos[r] ? acc[r] : 0.f;
+        sD1[(kq * 4 + r) * B::LD1 + l16] = d1[r];
+      }
+    }
+    // ---- dW2 | db2 += D2^T . [H1 | 1]
+#ifndef A3VT_DBG_PE_NOOUTER
+    {
+      float hb[4];
+#pragma unroll
+      for (int st = 0; st < 4; ++st) hb[st] = sH1[(kq * 4 + st) * B::LH1 + l16];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int st = 0; st < 4; ++st) aW2[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(d2[a][st], hb[st], aW2[a], 0, 0, 0);
+    }
+#endif
+    pe_wave_sync();
+    // ---- de = D1 . W1 (into G's rows: every product on G has been issued, LDS runs in order)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const f32x4 acc = pe_chain<3>(sD1, B::LD1, w5[n], l16, kq);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sDE[(kq * 4 + r) * B::LG + n * 16 + l16] = acc[r];
+    }
+    // ---- dW1 | db1 += D1^T . [E | 1]
+#ifndef A3VT_DBG_PE_NOOUTER
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      float eb[4];
+#pragma unroll
+      for (int st = 0; st < 4; ++st) eb[st] = sE[(kq * 4 + st) * B::LE + n * 16 + l16];
+#pragma unroll
+      for (int st = 0; st < 4; ++st) aW1[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(d1[st], eb[st], aW1[n], 0, 0, 0);
+    }
+#endif
+    pe_wave_sync();
+    // ---- gradient w.r.t. the position (lane = vertex l16, axis kq).  d sin(f p)/dp = f cos(f p) = f e[6i+3+c],
+    // d cos(f p)/dp = -f e[6i+c]
+    if (kq < 3) {
+      const long long v = (long long)vtile * 16 + l16;
+      const float *e = sE + l16 * B::LE, *de = sDE + l16 * B::LG;
+      float gp = de[60 + kq];
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+        const float f = pe_freq(i);
+        gp += f * (e[6 * i + 3 + kq] * de[6 * i + kq] - e[6 * i + kq] * de[6 * i + 3 + kq]);
+      }
+      if (v < m) gverts[3 * v + kq] = gp;
+    }
+    pe_wave_sync();
   }
 
-  // ---- phase 7: parameter gradients of the block, out[a][b] = sum_r A[r][a] B[r][b] over its T vertex rows: each
-  // 16 x 16 tile of each product is one chain of T/4 MFMAs (fixed order).  Rows of padding vertices are zero in
-  // G / D2 / D1 / OH; columns past an array's width read the neighbouring row and only reach discarded outputs.
-  struct Job { const float *A; int lda, a0, na; const float *Bm; int ldb, b0; int kind; };
-  constexpr int NA3 = (I + 15) / 16, NB3 = (H2 + 1 + 15) / 16, NA2 = (H2 + 15) / 16, NB1 = 4;
-  constexpr int J3 = NA3 * NB3, JE = NA3, J2 = NA2, J1 = NB1, NJOBS = J3 + JE + J2 + J1;
-  for (int job = wave; job < NJOBS; job += NW_) {
-    Job jb;
-    if (job < J3) jb = Job{sG, B::LG, (job / NB3) * 16, I, sH2, B::LH2, (job % NB3) * 16, 0};              // dW3 | db3
-    else if (job < J3 + JE) jb = Job{sG, B::LG, (job - J3) * 16, I, sOH, B::LOH, 0, 1};                    // dE
-    else if (job < J3 + JE + J2) jb = Job{sD2, B::LD2, (job - J3 - JE) * 16, H2, sH1, B::LH1, 0, 2};       // dW2 | db2
-    else jb = Job{sD1, B::LD1, 0, H1, sE, B::LE, (job - J3 - JE - J2) * 16, 3};                            // dW1 | db1
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const float *pa = jb.A + kq * jb.lda + jb.a0 + l16, *pb = jb.Bm + kq * jb.ldb + jb.b0 + l16;
-#pragma unroll 8
-    for (int st = 0; st < T / 4; ++st)
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[st * 4 * jb.lda], pb[st * 4 * jb.ldb], acc, 0, 0, 0);
-    const int col = jb.b0 + l16;
+  // ---- the wave's partials into its own rows in the packed parameter order, then the workgroup's four in a fixed order
+  pe_wave_sync();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = jb.a0 + kq * 4 + r;
-      if (row >= jb.na) continue;
-      const float val = acc[r];
-      if (jb.kind == 0) {          // row = o, col = k | bias column
-        if (col < H2) out[P::oW3 + row * H2 + col] = val;
-        else if (col == H2) out[P::ob3 + row] = val;
-      } else if (jb.kind == 1) {   // row = o, col = token
-        if (col < 4) out[P::oE + col * I + row] = val;
-      } else if (jb.kind == 2) {   // row = j, col = k | bias column
-        if (col < H1) out[P::oW2 + row * H1 + col] = val;
-        else if (col == H1) out[P::ob2 + row] = val;
-      } else {                     // row = j, col = k (63 = bias column)
-        if (col < 63) out[P::oW1 + row * 63 + col] = val;
-        else if (col == 63) out[P::ob1 + row] = val;
+  for (int r = 0; r < 4; ++r) {
+    const int row = kq * 4 + r;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {          // row = output channel o, column = k | bias | token
+      const int o = a * 16 + row;
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const int col = n * 16 + l16;
+        if (o >= I) continue;
+        if (col < H2) wv[P::oW3 + o * H2 + col] = aW3[a][n][r];
+        else if (col == H2) wv[P::ob3 + o] = aW3[a][n][r];
+        else if (col < H2 + 5) wv[P::oE + (col - H2 - 1) * I + o] = aW3[a][n][r];
       }
     }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {          // row = j of W2 (j, k), column = k | bias
+      const int j = a * 16 + row;
+      if (j >= H2) continue;
+      if (l16 < H1) wv[P::oW2 + j * H1 + l16] = aW2[a][r];
+      else if (l16 == H1) wv[P::ob2 + j] = aW2[a][r];
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {          // row = j of W1 (j, k), column = k | bias (63)
+      const int col = n * 16 + l16;
+      if (row >= H1) continue;
+      if (col < 63) wv[P::oW1 + row * 63 + col] = aW1[n][r];
+      else wv[P::ob1 + row] = aW1[n][r];
+    }
+  }
+  __syncthreads();
+  float *out = slab + (size_t)blockIdx.x * P::N;
+  for (int i = t; i < P::N; i += kPEBwdThreads) {
+    float s = smem[i];
+#pragma unroll
+    for (int w = 1; w < kPEBwdWaves; ++w) s += smem[w * B::WAVE + i];
+    out[i] = s;
   }
 }
 
@@ -432,6 +544,10 @@ int launch_posenc_bwd(const float *verts, const float *mask, int m, int input_si
                       const float *gfeats, int ld, float *gverts, float *gparams, float *scratch, hipStream_t s) {
   if (input_size != 50) {
     set_error("posenc: fused kernel supports input_size == 50 only (got %d)", input_size);
+    return -1;
+  }
+  if (m <= 0) {
+    set_error("posenc: m=%d", m);
     return -1;
   }
   const int nslab = posenc_num_slabs(m);

@@ -32,6 +32,10 @@ elif [ "$1" = "x3" ]; then   # gemm mode 3 (gcn_gemm3.hip) ablations: python too
   build DW3_NODMA -DA3VT_DBG_DW3_NODMA
   build DW3_NOSPLITPHASE -DA3VT_DBG_DW3_NOSPLITPHASE
   build DW3_MFMAONLY -DA3VT_DBG_DW3_NODMA -DA3VT_DBG_DW3_NOSPLITPHASE
+elif [ "$1" = "posenc" ]; then   # posenc_bwd ablations: python tools/posenc_bench.py with A3VT_LIB=...
+  build PE_NOSINCOS -DA3VT_DBG_PE_NOSINCOS
+  build PE_NOOUTER -DA3VT_DBG_PE_NOOUTER
+  build PE_NOLOOP -DA3VT_DBG_PE_NOLOOP
 elif [ "$1" = "env" ]; then   # the developer environment overrides (A3VT_RG_MAXWG, A3VT_ROWTILE_SEPARATE, A3VT_NN_R, A3VT_NN_ALGO): compiled out of the shipped library
   build ENV -DA3VT_DBG_ENV
 elif [ "$1" = "nn" ]; then   # pruned nearest-neighbour search with its counters (tools/nn_stats.py)
