@@ -343,8 +343,9 @@ constexpr int kThinPieces = 5;  // 16 lanes * 5 pieces * 4 floats = 320 channels
 // Both kernels are grid-stride loops with a per-block preamble (60 weight registers per lane): the grids are what is
 // resident at once — 3 workgroups per CU for thin_bwd (155 VGPRs), 5 for thin_fwd (88) — so no block waits for a slot
 // and then runs alone (thin_bwd: 1024 blocks at 768 resident took two rounds, 128 us per call; 768 take 99.  thin_fwd: 73 -> 52 us).
-constexpr int kThinBlocks = 768;
-constexpr int kThinFwdBlocks = 1280;
+constexpr int kThinBlocks = 512;
+constexpr int kThinFwdBlocks = 768;
+constexpr int kThinFwdRows = 3;
 int thin_num_slabs() { return kThinBlocks; }
 
 // Hybrid rows (the stack's channel-sliced path): columns [0, 4 xq_quads) of X come from the quad-major array xq
@@ -381,31 +382,53 @@ __global__ __launch_bounds__(256) void thin_fwd_kernel(const float *__restrict__
 #pragma unroll
       for (int j = 0; j < 3; ++j) wr[p][t][j] = kk < k ? w[kk * 3 + j] : 0.f;
     }
-  MeshWalk mw((long long)blockIdx.x * 16 + grp, (long long)gridDim.x * 16, n_vert);
-  for (long long row = (long long)blockIdx.x * 16 + grp; row < m; row += (long long)gridDim.x * 16, mw.next()) {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    const float *xqr = xq ? xq + ((size_t)mw.b * xq_quads * n_vert + (size_t)mw.v) * 4 : nullptr;   // this row in quad plane 0
+  // kThinFwdRows rows per trip: that many times five 16-byte loads in flight per lane (one row per trip left the memory
+  // path at 2.6 TB/s: 75 us per call; two 47)
+  const long long step = (long long)gridDim.x * 16;
+  MeshWalk mw((long long)blockIdx.x * 16 + grp, step, n_vert);
+  for (long long row0 = (long long)blockIdx.x * 16 + grp; row0 < m; row0 += kThinFwdRows * step) {
+    long long rows[kThinFwdRows];
+    f32x4 xv[kThinFwdRows][kThinPieces];
 #pragma unroll
-    for (int p = 0; p < kThinPieces; ++p) {
-      const int kk = (p * 16 + l16) * 4;
-      if (kk < k) {
-        const float *src = (xq && kk < xq_quads * 4) ? xqr + (size_t)(kk >> 2) * n_vert * 4 : x + row * ldx + kk;
-        const f32x4 xv = *reinterpret_cast<const f32x4 *>(src);
+    for (int u = 0; u < kThinFwdRows; ++u) {
+      const long long row = row0 + u * step;
+      rows[u] = row;
+      const bool live = row < m;
+      const float *xqr = xq ? xq + ((size_t)mw.b * xq_quads * n_vert + (size_t)mw.v) * 4 : nullptr;   // this row in quad plane 0
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          s0 += xv[t] * wr[p][t][0];
-          s1 += xv[t] * wr[p][t][1];
-          s2 += xv[t] * wr[p][t][2];
+      for (int p = 0; p < kThinPieces; ++p) {
+        const int kk = (p * 16 + l16) * 4;
+        xv[u][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (kk < k && live) {
+          const float *src = (xq && kk < xq_quads * 4) ? xqr + (size_t)(kk >> 2) * n_vert * 4 : x + row * ldx + kk;
+          xv[u][p] = *reinterpret_cast<const f32x4 *>(src);
         }
       }
+      mw.next();
     }
 #pragma unroll
-    for (int off = 8; off > 0; off >>= 1) {
-      s0 += __shfl_xor(s0, off, 16);
-      s1 += __shfl_xor(s1, off, 16);
-      s2 += __shfl_xor(s2, off, 16);
+    for (int u = 0; u < kThinFwdRows; ++u) {
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int p = 0; p < kThinPieces; ++p) {
+        const int kk = (p * 16 + l16) * 4;
+        if (kk < k) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            s0 += xv[u][p][t] * wr[p][t][0];
+            s1 += xv[u][p][t] * wr[p][t][1];
+            s2 += xv[u][p][t] * wr[p][t][2];
+          }
+        }
+      }
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) {
+        s0 += __shfl_xor(s0, off, 16);
+        s1 += __shfl_xor(s1, off, 16);
+        s2 += __shfl_xor(s2, off, 16);
+      }
+      if (l16 == 0 && rows[u] < m) *reinterpret_cast<f32x4 *>(z3 + rows[u] * 4) = f32x4{s0, s1, s2, 0.f};
     }
-    if (l16 == 0) *reinterpret_cast<f32x4 *>(z3 + row * 4) = f32x4{s0, s1, s2, 0.f};
   }
 }
 
@@ -527,41 +550,66 @@ __global__ __launch_bounds__(256) void thin_bwd_kernel(const float *__restrict__
       }
     }
   float db0 = 0.f, db1 = 0.f, db2 = 0.f;
-  MeshWalk mw((long long)blockIdx.x * 16 + grp, (long long)gridDim.x * 16, n_vert);
-  for (long long row = (long long)blockIdx.x * 16 + grp; row < m; row += (long long)gridDim.x * 16, mw.next()) {
-    const f32x4 d = *reinterpret_cast<const f32x4 *>(dz3 + row * 4);
-    if (l16 == 0) {
-      db0 += du[row * 3 + 0];
-      db1 += du[row * 3 + 1];
-      db2 += du[row * 3 + 2];
-    }
-    float *gr = gprev + row * ldg;
-    // quad-major copy of the aggregated-channel columns for csrq_kernel<1> (launch_csrq_bwd), when asked for
-    float *gqr = gq ? gq + ((size_t)mw.b * nq * n_vert + (size_t)mw.v) * 4 : nullptr;
-    const float *xqr = xq ? xq + ((size_t)mw.b * xq_quads * n_vert + (size_t)mw.v) * 4 : nullptr;
+  // two rows per trip (ten 16-byte loads of X in flight per lane), as in thin_fwd
+  const long long step = (long long)gridDim.x * 16;
+  MeshWalk mw((long long)blockIdx.x * 16 + grp, step, n_vert);
+  for (long long row0 = (long long)blockIdx.x * 16 + grp; row0 < m; row0 += 2 * step) {
+    f32x4 xv[2][kThinPieces], d[2];
+    float *gr[2], *gqr[2];
+    bool live[2];
 #pragma unroll
-    for (int p = 0; p < kThinPieces; ++p) {
-      const int kk = (p * 16 + l16) * 4;
-      if (kk < k) {
-        const float *src = (xq && kk < xq_quads * 4) ? xqr + (size_t)(kk >> 2) * n_vert * 4 : x + row * ldx + kk;
-        const f32x4 xv = *reinterpret_cast<const f32x4 *>(src);
-        f32x4 o;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const float gk = d[0] * wr[p][t][0] + d[1] * wr[p][t][1] + d[2] * wr[p][t][2];
-          o[t] = (!apply_mask || xv[t] > 0.f) ? gk : 0.f;
-          dwp[p][t][0] += xv[t] * d[0];
-          dwp[p][t][1] += xv[t] * d[1];
-          dwp[p][t][2] += xv[t] * d[2];
+    for (int u = 0; u < 2; ++u) {
+      const long long row = row0 + u * step;
+      live[u] = row < m;
+      d[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (live[u]) {
+        d[u] = *reinterpret_cast<const f32x4 *>(dz3 + row * 4);
+        if (l16 == 0) {
+          db0 += du[row * 3 + 0];
+          db1 += du[row * 3 + 1];
+          db2 += du[row * 3 + 2];
         }
-        if (gq && kk < nq * 4) {
-          *reinterpret_cast<f32x4 *>(gqr + (size_t)(kk >> 2) * n_vert * 4) = o;
-        } else if (kk + 3 < n_store) {
-          *reinterpret_cast<f32x4 *>(gr + kk) = o;
-        } else {
+      }
+      gr[u] = gprev + row * ldg;
+      // quad-major copy of the aggregated-channel columns for csrq_kernel<1> (launch_csrq_bwd), when asked for
+      gqr[u] = gq ? gq + ((size_t)mw.b * nq * n_vert + (size_t)mw.v) * 4 : nullptr;
+      const float *xqr = xq ? xq + ((size_t)mw.b * xq_quads * n_vert + (size_t)mw.v) * 4 : nullptr;
 #pragma unroll
-          for (int t = 0; t < 4; ++t)
-            if (kk + t < n_store) gr[kk + t] = o[t];
+      for (int p = 0; p < kThinPieces; ++p) {
+        const int kk = (p * 16 + l16) * 4;
+        xv[u][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (kk < k && live[u]) {
+          const float *src = (xq && kk < xq_quads * 4) ? xqr + (size_t)(kk >> 2) * n_vert * 4 : x + row * ldx + kk;
+          xv[u][p] = *reinterpret_cast<const f32x4 *>(src);
+        }
+      }
+      mw.next();
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (!live[u]) continue;   // (uniform per 16-lane group; a dead row would only add zeros)
+#pragma unroll
+      for (int p = 0; p < kThinPieces; ++p) {
+        const int kk = (p * 16 + l16) * 4;
+        if (kk < k) {
+          f32x4 o;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float gk = d[u][0] * wr[p][t][0] + d[u][1] * wr[p][t][1] + d[u][2] * wr[p][t][2];
+            o[t] = (!apply_mask || xv[u][p][t] > 0.f) ? gk : 0.f;
+            dwp[p][t][0] += xv[u][p][t] * d[u][0];
+            dwp[p][t][1] += xv[u][p][t] * d[u][1];
+            dwp[p][t][2] += xv[u][p][t] * d[u][2];
+          }
+          if (gq && kk < nq * 4) {
+            *reinterpret_cast<f32x4 *>(gqr[u] + (size_t)(kk >> 2) * n_vert * 4) = o;
+          } else if (kk + 3 < n_store) {
+            *reinterpret_cast<f32x4 *>(gr[u] + kk) = o;
+          } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              if (kk + t < n_store) gr[u][kk + t] = o[t];
+          }
         }
       }
     }

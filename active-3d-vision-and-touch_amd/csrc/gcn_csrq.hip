@@ -69,6 +69,20 @@ int launch_csrq_ell(const int32_t *rowptr, const int32_t *col, const float *val,
   return 0;
 }
 
+#ifdef A3VT_DBG_CSRQ_STAMPS   // diagnostic build (tools/build_variants.sh stampsq): s_memrealtime (100 MHz) + s_memtime per quad
+__device__ unsigned long long g_csrq_stamps[2 * 2 * 256 * 8 * 4];   // [real time | shader cycles][MODE][workgroup][quad (< 8)][4]
+#define CSRQ_STAMP(qi, k)                                                                                     \
+  do {                                                                                                        \
+    if (threadIdx.x == 0 && blockIdx.x < 256 && (qi) < 8) {                                                   \
+      const int i_ = ((MODE * 256 + blockIdx.x) * 8 + (qi)) * 4 + (k);                                        \
+      g_csrq_stamps[i_] = __builtin_amdgcn_s_memrealtime();                                                   \
+      g_csrq_stamps[2 * 256 * 8 * 4 + i_] = __builtin_amdgcn_s_memtime();                                     \
+    }                                                                                                         \
+  } while (0)
+#else
+#define CSRQ_STAMP(qi, k) do { } while (0)
+#endif
+
 // One persistent workgroup per (mesh, part of the mesh's quads): a thread owns VPT vertices and keeps THEIR index entries
 // (column, weight) in registers for the whole launch — the index image is read once per workgroup, not once per quad (read
 // per quad it was twice the bytes of the data itself: 174 KB against 41 + 41 KB per slice, 46 us per launch even with
@@ -96,6 +110,7 @@ __global__ __launch_bounds__(kCsrqThreads) void csrq_kernel(const float *__restr
   if (b >= batch) return;   // uniform per workgroup
   const int q_lo = part * nq / parts, q_hi = (part + 1) * nq / parts;
   if (q_lo >= q_hi) return;
+  CSRQ_STAMP(7, 0);   // kernel entry (slot 7 is never a quad: a workgroup walks at most seven)
 
   // this thread's vertices: index entries and edge counts, held for all quads.  Threads past the mesh's end work on a
   // copy of the last vertex and skip only the stores: branch-free loads (per-element `v < n_vert ?` guards became 280
@@ -146,6 +161,7 @@ __global__ __launch_bounds__(kCsrqThreads) void csrq_kernel(const float *__restr
   __syncthreads();
 
   for (int q = q_lo; q < q_hi; ++q) {
+    CSRQ_STAMP(q - q_lo, 0);
     const int par = (q - q_lo) & 1;
     const f32x4 *tile = tile0 + (size_t)par * (n_vert + 1);
     f32x4 *tnext = tile0 + (size_t)(par ^ 1) * (n_vert + 1);
@@ -220,6 +236,7 @@ __global__ __launch_bounds__(kCsrqThreads) void csrq_kernel(const float *__restr
       *reinterpret_cast<f32x4 *>(dst + ((((size_t)b * nq_dst + q) * n_vert) + v) * 4) = o;
     }
     __builtin_amdgcn_sched_barrier(0);
+    CSRQ_STAMP(q - q_lo, 1);
     if (MODE == 1) {   // bias-gradient partial of this (mesh, quad), fixed order; red[par] is read behind the barrier below
 #pragma unroll
       for (int t = 0; t < 4; ++t) bsum[t] = wave_sum(bsum[t]);
@@ -232,6 +249,7 @@ __global__ __launch_bounds__(kCsrqThreads) void csrq_kernel(const float *__restr
 #pragma unroll
       for (int k = 0; k < VPT; ++k) park(tnext, q + 1, k, nv4[k], nbits[k]);
     }
+    CSRQ_STAMP(q - q_lo, 2);
     __syncthreads();   // next slice visible; everyone is done with this one (and with red[par ^ 1] of the previous quad)
     if (MODE == 1 && threadIdx.x < 4) {
       float sacc = 0.f;
@@ -239,6 +257,7 @@ __global__ __launch_bounds__(kCsrqThreads) void csrq_kernel(const float *__restr
       for (int w = 0; w < kCsrqThreads / 64; ++w) sacc += red[par][w][threadIdx.x];
       db_slab[(size_t)b * (nq * 4) + ch + threadIdx.x] = sacc;
     }
+    CSRQ_STAMP(q - q_lo, 3);
   }
 }
 
@@ -311,6 +330,13 @@ __global__ __launch_bounds__(256) void csrq_heavy_kernel(const float *__restrict
 }
 
 int csrq_max_degree() { return kEllW; }
+#ifdef A3VT_DBG_CSRQ_STAMPS
+}  // namespace a3vt
+extern "C" int a3vt_dbg_csrq_stamps(unsigned long long *host_dst) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(a3vt::g_csrq_stamps), sizeof(unsigned long long) * 2 * 2 * 256 * 8 * 4);
+}
+namespace a3vt {
+#endif
 bool csrq_fits(int n_vert, int cut_len) {
   // two slices of one mesh in LDS; a thread owns at most 6 vertices (their index entries stay in registers); hub lanes
   // cover up to 32 quads

@@ -399,6 +399,28 @@ def bias_grad_nhwc(grad):
     return out
 
 
+_BF16_COPIES = {}   # id(tensor) -> (weakref, version, data_ptr, bf16 copy)
+
+
+def _bf16_copy(t, channels_last):
+    """bf16 (channels-last) copy of a convolution weight / bias, kept until the tensor changes: every in-place update
+    (optimizer step, load_state_dict) moves ``t._version``, so a training loop casts once per step as before and the
+    forward-only loops (validation, the K-candidate scoring of policies/environment.py:174-180) stop re-casting the 32
+    weights of the image pyramid on every call (64 copy launches per forward)."""
+    key = id(t)
+    hit = _BF16_COPIES.get(key)
+    if hit is not None and hit[0]() is t and hit[1] == t._version and hit[2] == t.data_ptr():
+        return hit[3]
+    c = t.detach().to(torch.bfloat16)
+    if channels_last:
+        c = c.contiguous(memory_format=torch.channels_last)
+    if len(_BF16_COPIES) > 4096:   # tensors that died without being looked up again
+        for k in [k for k, v in _BF16_COPIES.items() if v[0]() is None]:
+            del _BF16_COPIES[k]
+    _BF16_COPIES[key] = (weakref.ref(t), t._version, t.data_ptr(), c)
+    return c
+
+
 class ConvNHWCFn(torch.autograd.Function):
     """``nn.Conv2d`` of the image pyramid (vision/model.py:15-23) in the channels-last bf16 branch: MIOpen's NHWC bf16
     kernels for the convolution and its data / weight gradients, the bias gradient from the library (torch's own column
@@ -407,8 +429,8 @@ class ConvNHWCFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding):
         xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        wb = weight.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        y = torch.ops.aten.convolution(xb, wb, bias.to(torch.bfloat16), stride, padding, [1, 1], False, [0, 0], 1)
+        wb = _bf16_copy(weight, True)
+        y = torch.ops.aten.convolution(xb, wb, _bf16_copy(bias, False), stride, padding, [1, 1], False, [0, 0], 1)
         ctx.save_for_backward(xb, wb)
         ctx.conf = (stride, padding, x.dtype, weight.dtype, bias.dtype)
         return y

@@ -339,3 +339,23 @@ def test_flat_bucket_early_countdown_learns_unused_parameters():
     assert step(True) is True and step(True) is True
     bucket.close()
     assert not bucket._hooks
+
+
+def test_bf16_weight_copies_are_reused_until_the_weight_changes():
+    """ops._bf16_copy (the convolution weights of the channels-last bf16 image branch): one cast per weight VERSION — the
+    forward-only loops reuse it, an optimizer step / load_state_dict (in-place update) invalidates it."""
+    from a3vt_amd import ops
+    w = torch.nn.Parameter(torch.randn(8, 3, 5, 5))
+    a = ops._bf16_copy(w, True)
+    assert a.dtype == torch.bfloat16 and a.is_contiguous(memory_format=torch.channels_last)
+    assert ops._bf16_copy(w, True) is a                                   # unchanged weight: the same copy
+    opt = torch.optim.SGD([w], lr=0.5)
+    w.grad = torch.ones_like(w)
+    opt.step()
+    b = ops._bf16_copy(w, True)
+    assert b is not a and torch.equal(b.float(), w.detach().to(torch.bfloat16).float())
+    with torch.no_grad():
+        w.copy_(torch.zeros_like(w))                                      # load_state_dict path
+    assert ops._bf16_copy(w, True).abs().max().item() == 0.0
+    w2 = torch.nn.Parameter(w.detach().clone())                           # another tensor never aliases the entry
+    assert ops._bf16_copy(w2, True) is not ops._bf16_copy(w, True)

@@ -32,6 +32,9 @@ elif [ "$1" = "x3" ]; then   # gemm mode 3 (gcn_gemm3.hip) ablations: python too
   build DW3_NODMA -DA3VT_DBG_DW3_NODMA
   build DW3_NOSPLITPHASE -DA3VT_DBG_DW3_NOSPLITPHASE
   build DW3_MFMAONLY -DA3VT_DBG_DW3_NODMA -DA3VT_DBG_DW3_NOSPLITPHASE
+elif [ "$1" = "stampsq" ]; then   # csrq_kernel with stamps per quad (tools/csrq_stamps.py)
+  build CSRQ_STAMPS -DA3VT_DBG_CSRQ_STAMPS
+  build CSRQ_NOINDEX -DA3VT_DBG_CSRQ_NOINDEX   # timing-only: conflict-free gathers (fixed offsets instead of the index image)
 elif [ "$1" = "posenc" ]; then   # posenc_bwd ablations: python tools/posenc_bench.py with A3VT_LIB=...
   build PE_NOSINCOS -DA3VT_DBG_PE_NOSINCOS
   build PE_NOOUTER -DA3VT_DBG_PE_NOOUTER
