@@ -377,13 +377,27 @@ __device__ __forceinline__ F8 gather_row16(const u16 *__restrict__ base, long lo
         }
       }
     }
-    for (; j < n; ++j) {
-      const int c0 = __shfl(myc, j, 16);
-      const float w0 = __shfl(myw, j, 16);
+    if (j < n) {  // one to three rows left: requested together as well (gcn_csr.hip gather_row); same order of accumulation
+      const bool p[3] = {true, j + 1 < n, j + 2 < n};
+      int c[3];
+      float w[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        c[t] = __shfl(myc, j + t, 16);
+        w[t] = __shfl(myw, j + t, 16);
+      }
       if (lane_on) {
-        const F8 v = unpack8(*reinterpret_cast<const u32x4 *>(base + c0 * ld + ch));
-        acc.lo += w0 * v.lo;
-        acc.hi += w0 * v.hi;
+        u32x4 r[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) r[t] = p[t] ? *reinterpret_cast<const u32x4 *>(base + c[t] * ld + ch) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          if (p[t]) {
+            const F8 v = unpack8(r[t]);
+            acc.lo += w[t] * v.lo;
+            acc.hi += w[t] * v.hi;
+          }
+        }
       }
     }
   }

@@ -67,10 +67,20 @@ __device__ __forceinline__ f32x4 gather_row(const float *__restrict__ base, long
         acc += w3 * r3;
       }
     }
-    for (; j < n; ++j) {
-      const int c0 = __shfl(myc, j, 32);
-      const float w0 = __shfl(myw, j, 32);
-      if (lane_on) acc += w0 * *reinterpret_cast<const f32x4 *>(base + c0 * ld + ch);
+    if (j < n) {  // one to three rows left: requested together as well (one at a time, a 6- or 7-edge row — every row of
+      // an icosphere — paid two or three more dependent round trips); same order of accumulation
+      const bool p1 = j + 1 < n, p2 = j + 2 < n;
+      const int c0 = __shfl(myc, j, 32), c1 = __shfl(myc, j + 1, 32), c2 = __shfl(myc, j + 2, 32);
+      const float w0 = __shfl(myw, j, 32), w1 = __shfl(myw, j + 1, 32), w2 = __shfl(myw, j + 2, 32);
+      if (lane_on) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 r0 = *reinterpret_cast<const f32x4 *>(base + c0 * ld + ch);
+        const f32x4 r1 = p1 ? *reinterpret_cast<const f32x4 *>(base + c1 * ld + ch) : z;
+        const f32x4 r2 = p2 ? *reinterpret_cast<const f32x4 *>(base + c2 * ld + ch) : z;
+        acc += w0 * r0;
+        if (p1) acc += w1 * r1;
+        if (p2) acc += w2 * r2;
+      }
     }
   }
   return acc;
