@@ -643,6 +643,7 @@ int launch_csr16_bwd(const void *g, int ldg, int c, int cpad, const int32_t *row
 // the fp32 3-channel aggregation of gcn_csr.hip; backward fuses G_prev (bf16, ReLU-masked by X > 0), dW and db partials.
 // ------------------------------------------------------------------------------------------------
 constexpr int kThin16Pieces = 3;
+constexpr int kThin16FwdRows = 4, kThin16FwdBlocks = 768;
 
 __global__ __launch_bounds__(256) void thin16_fwd_kernel(const u16 *__restrict__ x, int ldx, int k,
                                                          const float *__restrict__ w, long long m,
@@ -657,30 +658,46 @@ __global__ __launch_bounds__(256) void thin16_fwd_kernel(const u16 *__restrict__
 #pragma unroll
       for (int j = 0; j < 3; ++j) wr[p][t][j] = kk < k ? w[kk * 3 + j] : 0.f;
     }
-  for (long long row = (long long)blockIdx.x * 16 + grp; row < m; row += (long long)gridDim.x * 16) {
-    const u16 *xr = x + row * ldx;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  // kThin16FwdRows rows per trip: that many times three 16-byte loads in flight per lane (gcn_csr.hip thin_fwd_kernel)
+  const long long step = (long long)gridDim.x * 16;
+  for (long long row0 = (long long)blockIdx.x * 16 + grp; row0 < m; row0 += kThin16FwdRows * step) {
+    u32x4 xr[kThin16FwdRows][kThin16Pieces];
 #pragma unroll
-    for (int p = 0; p < kThin16Pieces; ++p) {
-      const int kk = (p * 16 + l16) * 8;
-      if (kk < k) {
-        const F8 xv = unpack8(*reinterpret_cast<const u32x4 *>(xr + kk));
+    for (int u = 0; u < kThin16FwdRows; ++u) {
+      const long long row = row0 + u * step;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const float xe = f8_get(xv, t);
-          s0 += xe * wr[p][t][0];
-          s1 += xe * wr[p][t][1];
-          s2 += xe * wr[p][t][2];
-        }
+      for (int p = 0; p < kThin16Pieces; ++p) {
+        const int kk = (p * 16 + l16) * 8;
+        xr[u][p] = u32x4{0u, 0u, 0u, 0u};
+        if (kk < k && row < m) xr[u][p] = *reinterpret_cast<const u32x4 *>(x + row * ldx + kk);
       }
     }
 #pragma unroll
-    for (int off = 8; off > 0; off >>= 1) {
-      s0 += __shfl_xor(s0, off, 16);
-      s1 += __shfl_xor(s1, off, 16);
-      s2 += __shfl_xor(s2, off, 16);
+    for (int u = 0; u < kThin16FwdRows; ++u) {
+      const long long row = row0 + u * step;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int p = 0; p < kThin16Pieces; ++p) {
+        const int kk = (p * 16 + l16) * 8;
+        if (kk < k) {
+          const F8 xv = unpack8(xr[u][p]);
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            const float xe = f8_get(xv, t);
+            s0 += xe * wr[p][t][0];
+            s1 += xe * wr[p][t][1];
+            s2 += xe * wr[p][t][2];
+          }
+        }
+      }
+#pragma unroll
+      for (int off = 8; off > 0; off >>= 1) {
+        s0 += __shfl_xor(s0, off, 16);
+        s1 += __shfl_xor(s1, off, 16);
+        s2 += __shfl_xor(s2, off, 16);
+      }
+      if (l16 == 0 && row < m) *reinterpret_cast<f32x4 *>(z3 + row * 4) = f32x4{s0, s1, s2, 0.f};
     }
-    if (l16 == 0) *reinterpret_cast<f32x4 *>(z3 + row * 4) = f32x4{s0, s1, s2, 0.f};
   }
 }
 
@@ -689,7 +706,7 @@ int launch_thin16_fwd_product(const void *x, int ldx, int k, const float *w, lon
     set_error("thin16_fwd: k=%d (max %d) ldx=%d unsupported", k, kThin16Pieces * 128, ldx);
     return -1;
   }
-  const int grid = (int)(cdiv(m, 16) < 1280 ? cdiv(m, 16) : 1280);
+  const int grid = (int)(cdiv(m, 16) < kThin16FwdBlocks ? cdiv(m, 16) : kThin16FwdBlocks);
   A3VT_LAUNCH(thin16_fwd_kernel, dim3(grid), dim3(256), 0, s, static_cast<const u16 *>(x), ldx, k, w, m, z3);
   A3VT_CHECK_LAUNCH();
   return 0;
@@ -716,33 +733,54 @@ __global__ __launch_bounds__(256) void thin16_bwd_kernel(const u16 *__restrict__
       }
     }
   float db0 = 0.f, db1 = 0.f, db2 = 0.f;
-  for (long long row = (long long)blockIdx.x * 16 + grp; row < m; row += (long long)gridDim.x * 16) {
-    const f32x4 d = *reinterpret_cast<const f32x4 *>(dz3 + row * 4);
-    if (l16 == 0) {
-      db0 += du[row * 3 + 0];
-      db1 += du[row * 3 + 1];
-      db2 += du[row * 3 + 2];
-    }
-    const u16 *xr = x + row * ldx;
-    u16 *gr = gprev + row * ldg;
+  // two rows per trip (six 16-byte loads of X in flight per lane), same order of accumulation
+  const long long step = (long long)gridDim.x * 16;
+  for (long long row0 = (long long)blockIdx.x * 16 + grp; row0 < m; row0 += 2 * step) {
+    u32x4 xr[2][kThin16Pieces];
+    f32x4 d[2];
 #pragma unroll
-    for (int p = 0; p < kThin16Pieces; ++p) {
-      const int kk = (p * 16 + l16) * 8;
-      if (kk < ldg) {  // pad columns [k, ldg) are written as zeros (wr = 0 there)
-        const F8 xv = unpack8(*reinterpret_cast<const u32x4 *>(xr + kk));
-        F8 o;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          const float xe = f8_get(xv, t);
-          const float gk = d[0] * wr[p][t][0] + d[1] * wr[p][t][1] + d[2] * wr[p][t][2];
-          const float ov = (!apply_mask || xe > 0.f) ? gk : 0.f;
-          if (t < 4) o.lo[t] = ov;
-          else o.hi[t - 4] = ov;
-          dwp[p][t][0] += xe * d[0];
-          dwp[p][t][1] += xe * d[1];
-          dwp[p][t][2] += xe * d[2];
+    for (int u = 0; u < 2; ++u) {
+      const long long row = row0 + u * step;
+      d[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (row < m) {
+        d[u] = *reinterpret_cast<const f32x4 *>(dz3 + row * 4);
+        if (l16 == 0) {
+          db0 += du[row * 3 + 0];
+          db1 += du[row * 3 + 1];
+          db2 += du[row * 3 + 2];
         }
-        *reinterpret_cast<u32x4 *>(gr + kk) = pack8(o);
+      }
+#pragma unroll
+      for (int p = 0; p < kThin16Pieces; ++p) {
+        const int kk = (p * 16 + l16) * 8;
+        xr[u][p] = u32x4{0u, 0u, 0u, 0u};
+        if (kk < ldg && row < m) xr[u][p] = *reinterpret_cast<const u32x4 *>(x + row * ldx + kk);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const long long row = row0 + u * step;
+      if (row >= m) continue;   // (uniform per 16-lane group)
+      u16 *gr = gprev + row * ldg;
+#pragma unroll
+      for (int p = 0; p < kThin16Pieces; ++p) {
+        const int kk = (p * 16 + l16) * 8;
+        if (kk < ldg) {  // pad columns [k, ldg) are written as zeros (wr = 0 there)
+          const F8 xv = unpack8(xr[u][p]);
+          F8 o;
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            const float xe = f8_get(xv, t);
+            const float gk = d[u][0] * wr[p][t][0] + d[u][1] * wr[p][t][1] + d[u][2] * wr[p][t][2];
+            const float ov = (!apply_mask || xe > 0.f) ? gk : 0.f;
+            if (t < 4) o.lo[t] = ov;
+            else o.hi[t - 4] = ov;
+            dwp[p][t][0] += xe * d[u][0];
+            dwp[p][t][1] += xe * d[u][1];
+            dwp[p][t][2] += xe * d[u][2];
+          }
+          *reinterpret_cast<u32x4 *>(gr + kk) = pack8(o);
+        }
       }
     }
   }
