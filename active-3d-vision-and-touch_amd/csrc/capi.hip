@@ -151,7 +151,9 @@ static StackLayout stack_layout(int batch, int n_vert, int in_features, int hidd
     L.panel = take(pad4(in_features) > 304 ? m * 300 : 0);
     L.dw_slab = take((size_t)dw_num_slabs(hidden) * kin * hidden);
     const size_t nslab = (size_t)csr_bwd_num_slabs(batch, n_vert) > (size_t)batch ? csr_bwd_num_slabs(batch, n_vert) : batch;
-    L.db_slab = take(nslab * cpad);
+    // channel-sliced path: one [batch][cpad] block of partial rows PER LAYER, reduced by one launch at the end of the backward
+    const size_t per_layer = align_up((size_t)batch * cpad, 64) * (num_layers > 1 ? num_layers - 1 : 1);
+    L.db_slab = take(nslab * cpad > per_layer ? nslab * cpad : per_layer);
     L.gq = take(m * (cpad > 4 ? cpad : 4));
     L.thin_dw_slab = take((size_t)thin_num_slabs() * kin * 3);
     L.thin_db_slab = take((size_t)thin_num_slabs() * 3);
@@ -774,6 +776,7 @@ int a3vt_gcn_stack_bwd_acc(const float *feats, int ld_feats, int in_features, co
   }
 
   // ---- hidden layers, last to first.  g = dL/dY_i already multiplied by the ReLU mask of layer i.
+  const size_t db_layer_stride = align_up((size_t)batch * cpad, 64);
   int cur = 0;
   for (int i = last - 1; i >= 0; --i) {
     float *g = scratch + L.ping[cur];
@@ -787,10 +790,10 @@ int a3vt_gcn_stack_bwd_acc(const float *feats, int ld_feats, int in_features, co
     // bias gradient + A^T gather on the aggregated channels
     if (cut_len > 0 && quad) {
       const uint8_t *sq = masks + (size_t)(num_layers - 1) * mpad * mld + (size_t)i * signq_stride(m, cut_len);
+      // the (mesh, channel) partials of this layer: summed over the meshes by ONE launch for all layers behind the loop
       if (int rc = launch_csrq_bwd(scratch + L.gq, cut_len, rowptrT, colT, valT, heavyT, ellT, n_vert, batch, dza, sq,
-                                   scratch + L.db_slab, s))
+                                   scratch + L.db_slab + (size_t)i * db_layer_stride, s))
         return rc;
-      if (int rc = launch_slab_reduce_za(scratch + L.db_slab, batch, cpad, cut_len, hidden, grad_biases[i], acc, s)) return rc;
     } else if (cut_len > 0) {
       if (int rc = launch_csr_bwd(g, hidden, cut_len, rowptrT, colT, valT, heavyT, n_vert, batch, dza, cpad,
                                   scratch + L.db_slab, s))
@@ -902,6 +905,21 @@ int a3vt_gcn_stack_bwd_acc(const float *feats, int ld_feats, int in_features, co
         if (int rc = launch_rowgemm(r, EPI_DX_MASK, s)) return rc;
       }
       cur ^= 1;
+    }
+  }
+  if (cut_len > 0 && quad) {   // bias gradients of all hidden layers from their per-mesh partial rows: one launch
+    for (int i0 = 0; i0 < last; i0 += kMaxImages) {
+      SlabReduceBatch b{};
+      b.count = last - i0 < kMaxImages ? last - i0 : kMaxImages;
+      b.slab = scratch + L.db_slab + (size_t)i0 * db_layer_stride;
+      for (int j = 0; j < b.count; ++j) b.out[j] = grad_biases[i0 + j];
+      b.layer_stride = db_layer_stride;
+      b.stride = cpad;
+      b.n = cut_len;
+      b.n_out = hidden;
+      b.nslab = batch;
+      b.accumulate = acc;
+      if (int rc = launch_slab_reduce_batch(b, s)) return rc;
     }
   }
   return 0;

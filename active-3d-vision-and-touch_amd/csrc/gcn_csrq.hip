@@ -124,6 +124,11 @@ __global__ __launch_bounds__(kCsrqThreads) void csrq_kernel(const float *__restr
     const int v = threadIdx.x + k * kCsrqThreads;
     on[k] = v < n_vert;
     vv[k] = on[k] ? v : n_vert - 1;
+#ifdef A3VT_DBG_CSRQ_NOINDEX   // timing-only: no index image; every lane gathers rows at fixed offsets from its own, so the
+    dg[k] = 6;                 // 16 lanes of a ds_read_b128 group hit 16 different 16-byte slots: conflict-free gathers
+#pragma unroll
+    for (int j = 0; j < kEllW; ++j) cj[k][j] = (vv[k] + j * 37) % n_vert, wj[k][j] = 0.125f;
+#else
     dg[k] = degs[vv[k]];
 #pragma unroll
     for (int j = 0; j < kEllW; ++j) {
@@ -132,6 +137,7 @@ __global__ __launch_bounds__(kCsrqThreads) void csrq_kernel(const float *__restr
       cj[k][j] = e0;
       wj[k][j] = bits_to_f32(e1);
     }
+#endif
   }
 
   // a slice element on its way to LDS: the gradient passes the ReLU of the aggregated channels here (MODE 1)

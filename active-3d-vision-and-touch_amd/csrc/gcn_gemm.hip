@@ -1583,6 +1583,41 @@ __global__ __launch_bounds__(1024) void slab_reduce_tall_kernel(const float *__r
   }
 }
 
+// one launch for the (few, short) partial rows of many layers: blockIdx.y = layer; same summation order as slab_reduce_kernel
+__global__ __launch_bounds__(1024) void slab_reduce_batch_kernel(SlabReduceBatch b) {
+  __shared__ float part[16][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const size_t i = (size_t)blockIdx.x * 64 + lane;
+  const float *__restrict__ slab = b.slab + (size_t)blockIdx.y * b.layer_stride;
+  const int per = (b.nslab + 15) / 16;
+  const int s0 = grp * per, s1 = min(s0 + per, b.nslab);
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (i < b.n) {
+    int s = s0;
+    for (; s + 7 < s1; s += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += slab[(size_t)(s + u) * b.stride + i];
+    }
+    for (; s < s1; ++s) a[0] += slab[(size_t)s * b.stride + i];
+  }
+  part[grp][lane] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  if (grp == 0 && i < b.n_out) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += part[g][lane];
+    t = i < b.n ? t : 0.f;
+    float *out = b.out[blockIdx.y];
+    out[i] = b.accumulate ? out[i] + t : t;
+  }
+}
+int launch_slab_reduce_batch(const SlabReduceBatch &b, hipStream_t s) {
+  if (b.count <= 0) return 0;
+  A3VT_LAUNCH(slab_reduce_batch_kernel, dim3(cdiv((long long)b.n_out, 64), b.count), dim3(1024), 0, s, b);
+  A3VT_CHECK_LAUNCH();
+  return 0;
+}
+
 int launch_slab_reduce_za(const float *slab, int nslab, size_t stride, size_t n, size_t n_out, float *out, int accumulate,
                           hipStream_t s) {
   if (nslab >= 512 && n_out <= 1024)

@@ -75,6 +75,18 @@ struct WeightImages {
 };
 int launch_weight_images(const WeightImages &w, int max_rows, int max_ld, hipStream_t s);
 
+// Bias gradients of up to kMaxImages layers in one launch: out_l[i] = sum over the nslab partial rows of layer l
+// (slab + l * layer_stride + s * stride + i), i < n; entries [n, n_out) are written as zeros; accumulate as slab_reduce.
+// The channel-sliced backward leaves one partial row per (layer, mesh); reduced layer by layer these were 19 launches of
+// 3.8 us per stack call for 25 KB each.
+struct SlabReduceBatch {
+  const float *slab;
+  float *out[kMaxImages];
+  size_t layer_stride, stride, n, n_out;
+  int count, nslab, accumulate;
+};
+int launch_slab_reduce_batch(const SlabReduceBatch &b, hipStream_t s);
+
 // gcn_gemm3.hip — gemm mode 3 ("fp32x3"): the hidden-layer products as six bf16 MFMA passes on exactly split fp32 operands
 constexpr int kX3ImageRows = 320;                               // Bt rows of a weight image (n <= 304, zero padded)
 constexpr int kX3ImageLd = 160;                                 // 4-byte units per image row (320 bf16: K <= 320, zero padded)

@@ -21,6 +21,9 @@ python tools/touch_bench.py > $O/${R}_touch_topology_step.log 2>&1; tail -3 $O/$
 # gemm mode 3: ablation builds (tools/build_variants.sh x3), phase stamps (stamps3), error table against the fp64 oracle
 [ -f gpurun_variants/liba3vt_X3_NOMFMA.so ] && bash tools/x3_ablate.sh > $O/${R}_x3_ablation.txt 2>&1
 [ -f gpurun_variants/liba3vt_RG3_STAMPS.so ] && A3VT_LIB=$GRAFT_REPO_ROOT/gpurun_variants/liba3vt_RG3_STAMPS.so python tools/rowgemm3_stamps.py > $O/${R}_rowgemm3_phase_stamps.txt 2>/dev/null
+# channel-sliced aggregation: phase stamps per quad (tools/build_variants.sh stampsq) and the gather ablations (csrq)
+[ -f gpurun_variants/liba3vt_CSRQ_STAMPS.so ] && A3VT_LIB=$GRAFT_REPO_ROOT/gpurun_variants/liba3vt_CSRQ_STAMPS.so python tools/csrq_stamps.py > $O/${R}_csrq_stamps.txt 2>/dev/null
+[ -f gpurun_variants/liba3vt_CSRQ_NOINDEX.so ] && bash tools/csrq_ablate.sh > /dev/null 2>&1
 python -m pytest tests/test_gpu_fullsize.py -q -s -k benchmark_configuration 2>&1 | grep "^\[configs\|passed\|failed" > $O/${R}_mode_error_table.txt; cat $O/${R}_mode_error_table.txt
 python -m pytest tests/test_gpu_fp32x3.py -q -s -k vs_fp64 2>&1 | grep "^\[\|passed\|failed" >> $O/${R}_mode_error_table.txt
 # configs[3]: the first steps run MIOpen's find mode, so the table is cut from the kernel TRACE after 5 steps (tools/trace_steady.py)
