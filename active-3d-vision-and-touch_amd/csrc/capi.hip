@@ -124,6 +124,25 @@ static int stash_layout_lookup(const void *masks) {   // 1 / 0, or -1 when this 
 // sign bytes in the caller's `masks` buffer
 static inline size_t signq_stride(size_t m, int cut_len) { return align_up(m * (size_t)(pad4(cut_len) / 4), 256); }
 
+// bias gradients of the hidden layers [0, last) from per-layer blocks of partial rows (layer i at slab + i * layer_stride)
+static int reduce_bias_partials(const float *slab, size_t layer_stride, int nslab, int cpad, int cut_len, int hidden, int last,
+                                float *const *grad_biases, int acc, hipStream_t s) {
+  for (int i0 = 0; i0 < last; i0 += kMaxImages) {
+    SlabReduceBatch b{};
+    b.count = last - i0 < kMaxImages ? last - i0 : kMaxImages;
+    b.slab = slab + (size_t)i0 * layer_stride;
+    for (int j = 0; j < b.count; ++j) b.out[j] = grad_biases[i0 + j];
+    b.layer_stride = layer_stride;
+    b.stride = cpad;
+    b.n = cut_len;
+    b.n_out = hidden;
+    b.nslab = nslab;
+    b.accumulate = acc;
+    if (int rc = launch_slab_reduce_batch(b, s)) return rc;
+  }
+  return 0;
+}
+
 static StackLayout stack_layout(int batch, int n_vert, int in_features, int hidden, int num_layers, int cut_len,
                                 int need_backward, int gemm_mode = 0) {
   StackLayout L{};
@@ -151,9 +170,9 @@ static StackLayout stack_layout(int batch, int n_vert, int in_features, int hidd
     L.panel = take(pad4(in_features) > 304 ? m * 300 : 0);
     L.dw_slab = take((size_t)dw_num_slabs(hidden) * kin * hidden);
     const size_t nslab = (size_t)csr_bwd_num_slabs(batch, n_vert) > (size_t)batch ? csr_bwd_num_slabs(batch, n_vert) : batch;
-    // channel-sliced path: one [batch][cpad] block of partial rows PER LAYER, reduced by one launch at the end of the backward
-    const size_t per_layer = align_up((size_t)batch * cpad, 64) * (num_layers > 1 ? num_layers - 1 : 1);
-    L.db_slab = take(nslab * cpad > per_layer ? nslab * cpad : per_layer);
+    // one block of partial rows PER LAYER ([batch][cpad] on the channel-sliced path, [row-walk workgroups][cpad] otherwise),
+    // reduced by one launch at the end of the backward
+    L.db_slab = take(align_up(nslab * cpad, 64) * (num_layers > 1 ? num_layers - 1 : 1));
     L.gq = take(m * (cpad > 4 ? cpad : 4));
     L.thin_dw_slab = take((size_t)thin_num_slabs() * kin * 3);
     L.thin_db_slab = take((size_t)thin_num_slabs() * 3);
@@ -225,7 +244,7 @@ static Stack16Layout stack16_layout(int batch, int n_vert, int in_features, int 
   if (need_backward) {
     const size_t kin = in_features > hidden ? in_features : hidden;
     L.dw_slab = take((size_t)dw16_num_slabs(hidden) * (kin > 304 ? 304 : kin) * hidden);
-    L.db_slab = take((size_t)csr_bwd_num_slabs(batch, n_vert) * (L.cpad > 8 ? L.cpad : 8));
+    L.db_slab = take(align_up((size_t)csr_bwd_num_slabs(batch, n_vert) * (L.cpad > 8 ? L.cpad : 8), 64) * (num_layers > 1 ? num_layers - 1 : 1));
     L.thin_dw_slab = take((size_t)thin_num_slabs() * hidden * 3);
     L.thin_db_slab = take((size_t)thin_num_slabs() * 3);
   }
@@ -380,6 +399,7 @@ static int stack_bwd16(const float *feats, int ld_feats, int in_features, const 
   }
   u16 *dza = reinterpret_cast<u16 *>(scratch + L.za);
   const int cpad = L.cpad, ldza = cpad > 8 ? cpad : 8;
+  const size_t db_layer_stride = align_up((size_t)csr_bwd_num_slabs(batch, n_vert) * (cpad > 8 ? cpad : 8), 64);
   int cur = 0;
   for (int i = last - 1; i >= 0; --i) {
     u16 *g = ping[cur];
@@ -388,10 +408,7 @@ static int stack_bwd16(const float *feats, int ld_feats, int in_features, const 
     const int kin = i == 0 ? in_features : hidden;
     if (cut_len > 0) {
       if (int rc = launch_csr16_bwd(g, L.ldh, cut_len, cpad, rowptrT, colT, valT, heavyT, n_vert, batch, dza, ldza,
-                                    scratch + L.db_slab, s))
-        return rc;
-      if (int rc = launch_slab_reduce_za(scratch + L.db_slab, csr_bwd_num_slabs(batch, n_vert), cpad, cut_len, hidden,
-                                         grad_biases[i], acc, s))
+                                    scratch + L.db_slab + (size_t)i * db_layer_stride, s))
         return rc;
     } else if (!acc) {
       if (int rc = launch_fill_zero(grad_biases[i], hidden, s)) return rc;
@@ -455,6 +472,10 @@ static int stack_bwd16(const float *feats, int ld_feats, int in_features, const 
       cur ^= 1;
     }
   }
+  if (cut_len > 0)   // bias gradients of all hidden layers: one launch (as the fp32 stack)
+    if (int rc = reduce_bias_partials(scratch + L.db_slab, db_layer_stride, csr_bwd_num_slabs(batch, n_vert), cpad, cut_len, hidden,
+                                      last, grad_biases, acc, s))
+      return rc;
   return 0;
 }
 
@@ -776,7 +797,8 @@ int a3vt_gcn_stack_bwd_acc(const float *feats, int ld_feats, int in_features, co
   }
 
   // ---- hidden layers, last to first.  g = dL/dY_i already multiplied by the ReLU mask of layer i.
-  const size_t db_layer_stride = align_up((size_t)batch * cpad, 64);
+  const int db_rows = quad ? batch : csr_bwd_num_slabs(batch, n_vert);
+  const size_t db_layer_stride = align_up((size_t)(csr_bwd_num_slabs(batch, n_vert) > batch ? csr_bwd_num_slabs(batch, n_vert) : batch) * cpad, 64);
   int cur = 0;
   for (int i = last - 1; i >= 0; --i) {
     float *g = scratch + L.ping[cur];
@@ -796,14 +818,9 @@ int a3vt_gcn_stack_bwd_acc(const float *feats, int ld_feats, int in_features, co
         return rc;
     } else if (cut_len > 0) {
       if (int rc = launch_csr_bwd(g, hidden, cut_len, rowptrT, colT, valT, heavyT, n_vert, batch, dza, cpad,
-                                  scratch + L.db_slab, s))
+                                  scratch + L.db_slab + (size_t)i * db_layer_stride, s))
         return rc;
-      // channels >= cut_len are dead bias parameters (model.py:358): written as exact zeros by the same launch.
-      // (Folding this reduce into the weight-gradient reduce below made that launch wait for the two long-running
-      // blocks that walk the 2048 bias slabs: 19.9 us per fused launch against 9.5 + 9.5 for two.)
-      if (int rc = launch_slab_reduce_za(scratch + L.db_slab, csr_bwd_num_slabs(batch, n_vert), cpad, cut_len, hidden,
-                                         grad_biases[i], acc, s))
-        return rc;
+      // (channels >= cut_len are dead bias parameters (model.py:358): written as exact zeros by the reduce behind the loop)
     } else if (!acc) {
       if (int rc = launch_fill_zero(grad_biases[i], hidden, s)) return rc;
     }
@@ -907,21 +924,11 @@ int a3vt_gcn_stack_bwd_acc(const float *feats, int ld_feats, int in_features, co
       cur ^= 1;
     }
   }
-  if (cut_len > 0 && quad) {   // bias gradients of all hidden layers from their per-mesh partial rows: one launch
-    for (int i0 = 0; i0 < last; i0 += kMaxImages) {
-      SlabReduceBatch b{};
-      b.count = last - i0 < kMaxImages ? last - i0 : kMaxImages;
-      b.slab = scratch + L.db_slab + (size_t)i0 * db_layer_stride;
-      for (int j = 0; j < b.count; ++j) b.out[j] = grad_biases[i0 + j];
-      b.layer_stride = db_layer_stride;
-      b.stride = cpad;
-      b.n = cut_len;
-      b.n_out = hidden;
-      b.nslab = batch;
-      b.accumulate = acc;
-      if (int rc = launch_slab_reduce_batch(b, s)) return rc;
-    }
-  }
+  // bias gradients of all hidden layers from their partial rows (one per mesh on the channel-sliced path, one per row-walk
+  // workgroup otherwise): one launch instead of one per layer (19 x 3.8-5.5 us per stack call)
+  if (cut_len > 0)
+    if (int rc = reduce_bias_partials(scratch + L.db_slab, db_layer_stride, db_rows, cpad, cut_len, hidden, last, grad_biases, acc, s))
+      return rc;
   return 0;
 }
 

@@ -1611,9 +1611,38 @@ __global__ __launch_bounds__(1024) void slab_reduce_batch_kernel(SlabReduceBatch
     out[i] = b.accumulate ? out[i] + t : t;
   }
 }
+// the same for many partial rows per layer (the row-walk backward leaves 2048 of them): slab_reduce_tall_kernel's order
+__global__ __launch_bounds__(1024) void slab_reduce_tall_batch_kernel(SlabReduceBatch b) {
+  __shared__ float part[64][17];
+  const int o = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const size_t i = (size_t)blockIdx.x * 16 + o;
+  const float *__restrict__ slab = b.slab + (size_t)blockIdx.y * b.layer_stride;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (i < b.n) {
+    int sl = grp;
+    for (; sl + 7 * 64 < b.nslab; sl += 8 * 64) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += slab[(size_t)(sl + u * 64) * b.stride + i];
+    }
+    for (; sl < b.nslab; sl += 64) a[0] += slab[(size_t)sl * b.stride + i];
+  }
+  part[grp][o] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  if (grp == 0 && i < b.n_out) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 64; ++g) t += part[g][o];
+    t = i < b.n ? t : 0.f;
+    float *out = b.out[blockIdx.y];
+    out[i] = b.accumulate ? out[i] + t : t;
+  }
+}
 int launch_slab_reduce_batch(const SlabReduceBatch &b, hipStream_t s) {
   if (b.count <= 0) return 0;
-  A3VT_LAUNCH(slab_reduce_batch_kernel, dim3(cdiv((long long)b.n_out, 64), b.count), dim3(1024), 0, s, b);
+  if (b.nslab >= 512 && b.n_out <= 1024)   // as launch_slab_reduce_za chooses
+    A3VT_LAUNCH(slab_reduce_tall_batch_kernel, dim3(cdiv((long long)b.n_out, 16), b.count), dim3(1024), 0, s, b);
+  else
+    A3VT_LAUNCH(slab_reduce_batch_kernel, dim3(cdiv((long long)b.n_out, 64), b.count), dim3(1024), 0, s, b);
   A3VT_CHECK_LAUNCH();
   return 0;
 }
