@@ -52,7 +52,7 @@ def main():
     p = argparse.ArgumentParser()
     p.add_argument("--batch3", type=int, default=64)
     p.add_argument("--batch4", type=int, default=8)
-    p.add_argument("--precision", default="bf16s", choices=["fp32", "bf16", "bf16s"])
+    p.add_argument("--precision", default="bf16s", choices=["fp32", "bf16", "bf16s", "fp32x3"])
     p.add_argument("--only", type=int, default=0, choices=[0, 3, 4])
     p.add_argument("--steps", type=int, default=10)
     a = p.parse_args()

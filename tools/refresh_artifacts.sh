@@ -14,7 +14,10 @@ python bench.py --gemm-precision fp32x3 --no-cpu-baseline > $O/${R}_bench_fp32x3
 python tools/measure_protocol.py > $O/${R}_timing_protocol.json 2> $O/protocol.err; tail -c 400 $O/${R}_timing_protocol.json
 python tools/named_configs.py > $O/${R}_named_configs.jsonl 2> $O/named.err; cut -c 1-300 $O/${R}_named_configs.jsonl
 python tools/named_configs.py --precision bf16 >> $O/${R}_named_configs.jsonl 2>> $O/named.err
+python tools/named_configs.py --precision fp32 >> $O/${R}_named_configs.jsonl 2>> $O/named.err
+python tools/named_configs.py --precision fp32x3 >> $O/${R}_named_configs.jsonl 2>> $O/named.err
 python tools/touch_bench.py > $O/${R}_touch_topology_step.log 2>&1; tail -3 $O/${R}_touch_topology_step.log
+python tools/touch_bench.py --precision fp32x3 2>/dev/null | tail -1 >> $O/${R}_touch_topology_step.log
 (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/bstats && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bstats -- python $GRAFT_REPO_ROOT/bench.py --steps 15 --warmup 5 --no-cpu-baseline --no-traffic --alt-steps 0 > /tmp/bstats.log 2>&1; cp $(find /tmp/bstats -name '*kernel_stats.csv' | head -1) $O/${R}_bench_kernel_stats.csv; tail -c 300 /tmp/bstats.log)
 (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/bstats2 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bstats2 -- python $GRAFT_REPO_ROOT/bench.py --steps 15 --warmup 5 --no-cpu-baseline --no-traffic --gemm-precision bf16s > /tmp/bstats2.log 2>&1; cp $(find /tmp/bstats2 -name '*kernel_stats.csv' | head -1) $O/${R}_bench_bf16s_kernel_stats.csv)
 (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/bstats3 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/bstats3 -- python $GRAFT_REPO_ROOT/bench.py --steps 15 --warmup 5 --no-cpu-baseline --no-traffic --alt-steps 0 --gemm-precision fp32x3 > /tmp/bstats3.log 2>&1; cp $(find /tmp/bstats3 -name '*kernel_stats.csv' | head -1) $O/${R}_bench_fp32x3_kernel_stats.csv)

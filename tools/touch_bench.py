@@ -19,7 +19,8 @@ def main():
     from a3vt_amd.synthetic import gt_cloud
     dev = torch.device("cuda", 0)
     B, P = 64, 10000
-    args = make_args(use_touch=True, finger=False, num_grasps=5, number_points=P)
+    prec = sys.argv[sys.argv.index("--precision") + 1] if "--precision" in sys.argv else "fp32"   # fp32 | fp32x3 | bf16 | bf16s
+    args = make_args(use_touch=True, finger=False, num_grasps=5, number_points=P, gemm_precision=prec)
     info, verts = utils.load_mesh_vision(args, "vision_charts")
     torch.manual_seed(0)
     net = model.Deformation(info, verts, args).to(dev)
@@ -51,7 +52,7 @@ def main():
         step()
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / n
-    print(json.dumps({"topology": "atlas + 20 touch charts (N=2324, nnz=60726, max degree 1153)", "batch": B,
+    print(json.dumps({"topology": "atlas + 20 touch charts (N=2324, nnz=60726, max degree 1153)", "batch": B, "gemm_precision": prec,
                       "ms_per_step": ms, "iters_per_s": 1e3 / ms}))
 
 
