@@ -297,12 +297,12 @@ def test_gcn_stack_bf16_mode(cuda, tname, use_touch, L, B):
     assert rel_err(out32, out_fp32) < 1e-4
 
 
-def test_posenc_mask_fwd_bwd(cuda):
+@pytest.mark.parametrize("B,N", [(3, 517), (16, 2563)])   # one tile per wave; several tiles per wave and a ragged last tile
+def test_posenc_mask_fwd_bwd(cuda, B, N):
     from a3vt_amd import ops
     from oracle import gcn as og
     st = og.init_state(50, 8, 1, seed=5)
     g = torch.Generator().manual_seed(2)
-    B, N = 3, 517
     verts = (torch.rand(B, N, 3, generator=g) - 0.5) * 0.6
     mask = torch.randint(0, 4, (B, N, 1), generator=g).float()
     gout = torch.randn(B, N, 52, generator=g)
