@@ -1207,6 +1207,37 @@ __device__ __forceinline__ void dw_stage_bf16(const float *__restrict__ sb, int 
   }
 }
 
+// Narrow inputs (k_in <= 64: the stack's first layer, 53 features): every wave row owns ONE input tile, so a stage is 1 x 2-3
+// tiles per wave — straight-line, operands of k-step ks + 1 read before the MFMAs of k-step ks, three accumulator tiles
+// instead of fifteen.  (The guarded, rolled dw_stage<-1,-1> took 135 us for the first layer's 234 MB; inside the general
+// instantiation a straight-line 1 x 3 stage spilled 65 registers next to the fifteen tiles: DESIGN.md section 8, round 4.)
+template <bool HYB>
+__device__ __forceinline__ void dw_stage_narrow(const float *__restrict__ sb, int ldx, int ldz0, int ldz1, int offG, int xoff,
+                                                const int (&zoff)[DW_MAXO], int q, bool col3, bool z0q, int rot,
+                                                f32x4 (&acc)[1][DW_MAXO]) {
+  float a, b[DW_MAXO], an = 0.f, bn[DW_MAXO] = {0.f, 0.f, 0.f};
+  auto load = [&](int ks, float &av, float (&bv)[DW_MAXO]) {
+    const int r = q * 4 + ks;   // rows {ks, 4 + ks, 8 + ks, 12 + ks}: see dw_stage_fast
+    av = sb[r * ldx + xoff];
+    const int ra = HYB && z0q ? ((r + rot) & 15) * 4 : r * ldz0, rg = r * ldz1;
+#pragma unroll
+    for (int j = 0; j < DW_MAXO; ++j) bv[j] = sb[zoff[j] + (zoff[j] < offG ? ra : rg)];   // unconditional: see dw_stage
+  };
+  load(0, a, b);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    if (ks < 3) load(ks + 1, an, bn);
+    __builtin_amdgcn_sched_barrier(0);
+    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[0], acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[1], acc[0][1], 0, 0, 0);
+    if (col3) acc[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[2], acc[0][2], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    a = an;
+#pragma unroll
+    for (int j = 0; j < DW_MAXO; ++j) b[j] = bn[j];
+  }
+}
+
 // Input tiles of X staged as blocks when its first 4 * quads columns are quad-major: up to the end of the wave (wi) that
 // holds the last of them — waves own tin / 4 (+1) consecutive tiles each, as in dw_kernel.
 __host__ __device__ static inline int dw_blocked_tiles(int k_in, int quads) {
@@ -1216,8 +1247,9 @@ __host__ __device__ static inline int dw_blocked_tiles(int k_in, int quads) {
   return end < tin ? end : tin;
 }
 
-template <bool FAST, bool BF16, bool HYB>
+template <bool FAST, bool BF16, bool HYB, bool NARROW = false>
 __global__ __launch_bounds__(1024, 1) void dw_kernel(DwArgs p) {
+  constexpr int MAXI = NARROW ? 1 : DW_MAXI;   // input tiles a wave can own
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform (SGPR)
@@ -1354,9 +1386,9 @@ __global__ __launch_bounds__(1024, 1) void dw_kernel(DwArgs p) {
     advance(unit);
   };
 
-  f32x4 acc[DW_MAXI][DW_MAXO];
+  f32x4 acc[MAXI][DW_MAXO];
 #pragma unroll
-  for (int i = 0; i < DW_MAXI; ++i)
+  for (int i = 0; i < MAXI; ++i)
 #pragma unroll
     for (int j = 0; j < DW_MAXO; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -1392,6 +1424,9 @@ __global__ __launch_bounds__(1024, 1) void dw_kernel(DwArgs p) {
     if (t + nst - 1 < nu) issue(u0 + t + nst - 1, buf >= 1 ? buf - 1 : nst - 1);
 #endif
     const float *sb = lds + buf * stage;
+    if constexpr (NARROW) {
+      dw_stage_narrow<HYB>(sb, p.ldx, wa, wg, offG, xoff, zoff, q, no == 3, z0q, rot, acc);
+    } else {
     if (BF16) dw_stage_bf16(sb, p.ldx, wa, wg, offG, xoff, zoff, q, ni, no, acc);
     // every wave runs five row tiles: the one SIMD whose waves own four (19 = 5+5+5+4) would otherwise idle for that
     // fifth of the time anyway, its extra tile reads finite neighbouring data and is dropped at the slab write, and the
@@ -1410,6 +1445,7 @@ __global__ __launch_bounds__(1024, 1) void dw_kernel(DwArgs p) {
 #endif
     } else if (FAST) dw_stage_fast<false, false>(sb, p.ldx, wa, wg, offG, xoff, zoff, q, true, no == 3, xo, z0q, rot, acc);
     else dw_stage<-1, -1>(sb, p.ldx, wa, wg, offG, xoff, zoff, q, ni, no, z0q, rot, acc);
+    }
     buf = buf == nst - 1 ? 0 : buf + 1;
   }
   wait_lgkm0();
@@ -1417,7 +1453,7 @@ __global__ __launch_bounds__(1024, 1) void dw_kernel(DwArgs p) {
   // Partial -> slab[blockIdx][k_in][n_out]  (row = input channel, col = output channel)
   float *slab = p.slab + (size_t)blockIdx.x * p.k_in * p.n_out;
 #pragma unroll
-  for (int i = 0; i < DW_MAXI; ++i) {
+  for (int i = 0; i < MAXI; ++i) {
     if (i >= ni) continue;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -1504,6 +1540,8 @@ int launch_dw(const DwArgs &a0, hipStream_t s) {
     (void)hipFuncSetAttribute((const void *)dw_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)dw_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)dw_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)dw_kernel<false, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)dw_kernel<false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   // fast path: every wave owns 4-5 input tiles and 2-3 output tiles (true for 300 x 300)
   const int tin = cdiv(a.k_in, 16), tout = cdiv(a.n_out, 16), groups = dw_col_groups(a.n_out);
@@ -1514,7 +1552,11 @@ int launch_dw(const DwArgs &a0, hipStream_t s) {
     return -1;
   }
   const dim3 grid(dw_num_slabs(a.n_out), groups);
-  if (a.bf16) A3VT_LAUNCH((dw_kernel<false, true, false>), grid, dim3(1024), shmem, s, args);
+  // narrow inputs: at most one input tile per wave row, 2-3 output tiles per wave column; row-major X (the first layer's)
+  const bool narrow = !a.bf16 && tin <= 4 && a.xq_nvert == 0 && (tout / groups) / 4 >= 2 && cdiv(tout, groups) <= 12;
+  if (narrow && hyb) A3VT_LAUNCH((dw_kernel<false, false, true, true>), grid, dim3(1024), shmem, s, args);
+  else if (narrow) A3VT_LAUNCH((dw_kernel<false, false, false, true>), grid, dim3(1024), shmem, s, args);
+  else if (a.bf16) A3VT_LAUNCH((dw_kernel<false, true, false>), grid, dim3(1024), shmem, s, args);
   else if (fast && hyb) A3VT_LAUNCH((dw_kernel<true, false, true>), grid, dim3(1024), shmem, s, args);
   else if (fast) A3VT_LAUNCH((dw_kernel<true, false, false>), grid, dim3(1024), shmem, s, args);
   else if (hyb) A3VT_LAUNCH((dw_kernel<false, false, true>), grid, dim3(1024), shmem, s, args);

@@ -191,8 +191,9 @@ int launch_posenc_fwd(const float *verts, const float *mask, int m, int input_si
 // fixed order into its slab.  (Round 3: one 128-vertex workgroup per CU with a barrier between phases, 154 KB of LDS, a slab
 // per 128 vertices — 1281 workgroups on 256 CUs ran as six rounds of ~30 us: 182 us per call.  First version: per-thread
 // scalar FMAs, 445 us.)
-// grad_verts is the same fma chain per element as before (identical bits); the parameter gradients are summed in a different
-// (still fixed) order.
+// Against the round-3 kernel (tools/experiments/posenc_bwd_bits.py): the forward is untouched; grad_verts agrees to 2e-6 of
+// its largest element (same products and chains, but the compiler contracts the 63-term position sum differently in the
+// unrolled loop), the parameter gradients — summed in a different, still fixed order — to 3e-7.
 // Per wave in LDS: the vertex rows E|1, G (later dE), H1|1, H2|1|one-hot token, D2, D1.  Row strides are = 4 mod 16 floats:
 // the A-operand read of a chain tile (lane = row l16, k = kq) touches 64 different banks, and so do the row reads of the
 // outer products.
