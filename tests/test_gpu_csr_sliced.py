@@ -24,13 +24,16 @@ def _run(cuda, adj, st, feats, gup, L, H, cut_len):
 
 @pytest.mark.parametrize("tname,use_touch,L,B,cut", [("ico3", False, 4, 24, 0.33), ("ico4", False, 3, 6, 0.33),
                                                       ("atlas", False, 3, 8, 0.33), ("atlas", True, 3, 8, 0.33),
+                                                      ("atlas", 5, 3, 8, 0.33),     # 20 touch charts: regular rows of 26-30 entries
                                                       ("ico3", False, 3, 20, 0.5), ("ico3", False, 3, 20, 0.04),
                                                       ("ico4", False, 20, 6, 0.33)])   # the benchmark's depth and template
 def test_channel_sliced_aggregation_equals_row_kernels_and_oracle(cuda, tname, use_touch, L, B, cut):
     from a3vt_amd import mesh as amesh, ops
     from oracle import gcn as og
     H = 300
-    args = make_args(use_touch=use_touch, num_GCN_layers=L, hidden_GCN_size=H, num_grasps=1, cut=cut)
+    grasps = 1 if use_touch in (True, False) else int(use_touch)   # use_touch = 5: the production topology's five grasps
+    use_touch = bool(use_touch)
+    args = make_args(use_touch=use_touch, num_GCN_layers=L, hidden_GCN_size=H, num_grasps=grasps, cut=cut)
     verts, faces = template(tname)
     adj_o, _ = oracle_adj(verts, faces, args)
     n = adj_o[0].numel() - 1
@@ -41,7 +44,7 @@ def test_channel_sliced_aggregation_equals_row_kernels_and_oracle(cuda, tname, u
     gup = torch.randn(B, n, 3, generator=g)
     if use_touch:
         sv, sf = amesh.load_asset("touch_chart")
-        r, c, nn_, _ = amesh.fused_pairs(verts, faces, sf, 1, False)
+        r, c, nn_, _ = amesh.fused_pairs(verts, faces, sf, grasps, False)
     else:
         r, c = amesh.vision_pairs(faces, verts.shape[0])
         nn_ = verts.shape[0]

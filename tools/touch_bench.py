@@ -21,6 +21,9 @@ def main():
     B, P = 64, 10000
     prec = sys.argv[sys.argv.index("--precision") + 1] if "--precision" in sys.argv else "fp32"   # fp32 | fp32x3 | bf16 | bf16s
     args = make_args(use_touch=True, finger=False, num_grasps=5, number_points=P, gemm_precision=prec)
+    if "--csr-algo" in sys.argv:   # auto | rows | sliced (ops.dbg_csr_algo: A/B of the aggregation kernels)
+        from a3vt_amd import ops
+        ops.dbg_csr_algo(sys.argv[sys.argv.index("--csr-algo") + 1])
     info, verts = utils.load_mesh_vision(args, "vision_charts")
     torch.manual_seed(0)
     net = model.Deformation(info, verts, args).to(dev)
