@@ -629,3 +629,18 @@ def test_image_encoder_bf16_branch_batches_1_to_4(cuda):   # (batches 1, 3 and 4
             assert all(torch.isfinite(p.grad).all() for p in enc16.parameters() if p.grad is not None)
             enc16.zero_grad()
     assert sum("bn_nhwc_min_batch" in str(x.message) for x in w) == 1      # reported once
+
+
+def test_bf16_weight_copies_follow_the_fused_optimizer(cuda):
+    """ops._bf16_copy caches the bf16 channels-last copy of a convolution weight per weight VERSION; the trainer's optimizer is
+    torch's fused Adam (vision/train.py mirror), an in-place multi-tensor kernel — the cache must see its updates."""
+    from a3vt_amd import ops
+    w = torch.nn.Parameter(torch.randn(16, 8, 5, 5, device=cuda))
+    opt = torch.optim.Adam([w], lr=0.1, fused=True)
+    a = ops._bf16_copy(w, True)
+    assert ops._bf16_copy(w, True) is a
+    w.grad = torch.ones_like(w)
+    opt.step()
+    b = ops._bf16_copy(w, True)
+    assert b is not a
+    assert torch.equal(b.float(), w.detach().to(torch.bfloat16).float()) and not torch.equal(a.float(), b.float())
