@@ -399,25 +399,41 @@ def bias_grad_nhwc(grad):
     return out
 
 
-_BF16_COPIES = {}   # id(tensor) -> (weakref, version, data_ptr, bf16 copy)
+_BF16_COPIES = {}   # id(tensor) -> (weakref, version, data_ptr, optimizer epoch, bf16 copy)
+_OPT_EPOCH = [0]    # moved by EVERY torch optimizer step of the process
+
+
+def _optimizer_stepped(*_args, **_kwargs):
+    _OPT_EPOCH[0] += 1
+
+
+try:   # torch's fused Adam (the trainer's optimizer) updates the weights in place WITHOUT moving their ``_version``
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook
+    _register_step_hook(_optimizer_stepped)
+    _BF16_CACHE_ON = True
+except ImportError:   # no global step hook: nothing tells a stale copy from a fresh one — cast on every call
+    _BF16_CACHE_ON = False
 
 
 def _bf16_copy(t, channels_last):
-    """bf16 (channels-last) copy of a convolution weight / bias, kept until the tensor changes: every in-place update
-    (optimizer step, load_state_dict) moves ``t._version``, so a training loop casts once per step as before and the
-    forward-only loops (validation, the K-candidate scoring of policies/environment.py:174-180) stop re-casting the 32
-    weights of the image pyramid on every call (64 copy launches per forward)."""
+    """bf16 (channels-last) copy of a convolution weight / bias, kept until the tensor can have changed: an in-place torch
+    op (load_state_dict, copy_) moves ``t._version``; an optimizer step — torch's fused Adam does NOT move it — moves the
+    process-wide optimizer epoch (a global step post-hook).  A training loop casts once per step as before; the forward-only
+    loops (validation, the K-candidate scoring of policies/environment.py:174-180) stop re-casting the 32 weights of the
+    image pyramid on every call (64 copy launches per forward)."""
     key = id(t)
-    hit = _BF16_COPIES.get(key)
-    if hit is not None and hit[0]() is t and hit[1] == t._version and hit[2] == t.data_ptr():
-        return hit[3]
+    hit = _BF16_COPIES.get(key) if _BF16_CACHE_ON else None
+    if (hit is not None and hit[0]() is t and hit[1] == t._version and hit[2] == t.data_ptr()
+            and hit[3] == _OPT_EPOCH[0]):
+        return hit[4]
     c = t.detach().to(torch.bfloat16)
     if channels_last:
         c = c.contiguous(memory_format=torch.channels_last)
     if len(_BF16_COPIES) > 4096:   # tensors that died without being looked up again
         for k in [k for k, v in _BF16_COPIES.items() if v[0]() is None]:
             del _BF16_COPIES[k]
-    _BF16_COPIES[key] = (weakref.ref(t), t._version, t.data_ptr(), c)
+    if _BF16_CACHE_ON:
+        _BF16_COPIES[key] = (weakref.ref(t), t._version, t.data_ptr(), _OPT_EPOCH[0], c)
     return c
 
 

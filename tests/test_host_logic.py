@@ -342,8 +342,9 @@ def test_flat_bucket_early_countdown_learns_unused_parameters():
 
 
 def test_bf16_weight_copies_are_reused_until_the_weight_changes():
-    """ops._bf16_copy (the convolution weights of the channels-last bf16 image branch): one cast per weight VERSION — the
-    forward-only loops reuse it, an optimizer step / load_state_dict (in-place update) invalidates it."""
+    """ops._bf16_copy (the convolution weights of the channels-last bf16 image branch): one cast per weight VERSION and
+    optimizer epoch — the forward-only loops reuse it; an optimizer step (any torch optimizer of the process: a global step
+    hook, because the fused kernels do not move ``_version``) or an in-place update (load_state_dict) invalidates it."""
     from a3vt_amd import ops
     w = torch.nn.Parameter(torch.randn(8, 3, 5, 5))
     a = ops._bf16_copy(w, True)
