@@ -143,6 +143,8 @@ static int reduce_bias_partials(const float *slab, size_t layer_stride, int nsla
   return 0;
 }
 
+static inline int mask_ld(int hidden, int cut_len) { return pad4(cut_len) / 4 + (hidden + 3) / 4; }
+
 static StackLayout stack_layout(int batch, int n_vert, int in_features, int hidden, int num_layers, int cut_len,
                                 int need_backward, int gemm_mode = 0) {
   StackLayout L{};
@@ -502,8 +504,7 @@ int a3vt_csr_validate(const int32_t *rowptr, const int32_t *col, int n_vert, int
 }
 
 // ReLU-sign bytes saved by the forward pass for the backward pass: [num_layers-1][pad32(M)][mld],
-// mld = pad4(cut_len)/4 + ceil(hidden/4).
-static inline int mask_ld(int hidden, int cut_len) { return pad4(cut_len) / 4 + (hidden + 3) / 4; }
+// mld = pad4(cut_len)/4 + ceil(hidden/4).  (mask_ld: defined with stack_x3 above)
 size_t a3vt_gcn_stack_mask_bytes(int batch, int n_vert, int hidden, int num_layers, int cut_len) {
   if (num_layers < 2) return 0;
   const size_t mpad = ((size_t)batch * n_vert + 31) / 32 * 32;
@@ -513,7 +514,15 @@ size_t a3vt_gcn_stack_mask_bytes(int batch, int n_vert, int hidden, int num_laye
 
 size_t a3vt_gcn_stack_scratch_bytes(int batch, int n_vert, int in_features, int hidden, int num_layers, int cut_len,
                                     int need_backward) {
-  return stack_layout(batch, n_vert, in_features, hidden, num_layers, cut_len, need_backward).total * sizeof(float);
+  // enough for EVERY gemm mode (mode 3 keeps three bf16 images per hidden layer: a larger weight slot than mode 0's;
+  // mode 2 has a layout of its own): a caller that sizes its scratch here may pass any gemm_bf16
+  size_t most = 0;
+  for (int mode = 0; mode <= 3; ++mode) {
+    if (mode == 2 && num_layers < 2) continue;
+    const size_t b = a3vt_gcn_stack_scratch_bytes_mode(batch, n_vert, in_features, hidden, num_layers, cut_len, need_backward, mode);
+    most = b > most ? b : most;
+  }
+  return most;
 }
 
 size_t a3vt_gcn_stack_scratch_bytes_mode(int batch, int n_vert, int in_features, int hidden, int num_layers,
@@ -548,6 +557,7 @@ int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const 
   A3VT_CHECK_ARG(feats && weights && biases && rowptr && col && val && scratch && update);
   A3VT_CHECK_ARG((acts == nullptr) == (masks == nullptr) || num_layers < 2);
   A3VT_CHECK_ARG(n_vert > 0 && batch > 0);
+  A3VT_CHECK_ARG(gemm_bf16 >= 0 && gemm_bf16 <= 3);
   if (int rc = check_stack_dims(ld_feats, in_features, num_layers, hidden, cut_len)) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (gemm_bf16 == 2)  // bf16 storage: `acts` holds bf16 rows (a3vt_gcn_stack_stash_bytes)
@@ -569,7 +579,7 @@ int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const 
   }
   // Gemm mode 3 ("fp32x3", gcn_gemm3.hip): the hidden-layer products whose shape the split-operand kernels take run there;
   // everything else of the call (the first layer, narrow or short stacks) on the exact fp32 kernels.
-  const bool x3 = gemm_bf16 == 3 && rowgemm3_dims_ok((long long)m, hidden, hidden);
+  const bool x3 = gemm_bf16 == 3 && rowgemm3_stack_ok((long long)m, hidden, mask_ld(hidden, cut_len));
   const int omode = gemm_bf16 == 1 ? 1 : 0;   // operand mode of the kernels shared with modes 0 / 1
   // transposed, zero-padded weight images of all hidden layers (one launch)
   const bool batched_images = num_layers - 1 <= kMaxImages;
@@ -705,6 +715,7 @@ int a3vt_gcn_stack_bwd_acc(const float *feats, int ld_feats, int in_features, co
   (void)biases; (void)rowptr; (void)col; (void)val;
   A3VT_CHECK_ARG(feats && weights && rowptrT && colT && valT && grad_update && grad_weights && grad_biases);
   A3VT_CHECK_ARG(grad_feats && scratch && n_vert > 0 && batch > 0);
+  A3VT_CHECK_ARG(gemm_bf16 >= 0 && gemm_bf16 <= 3);
   A3VT_CHECK_ARG(num_layers == 1 || acts != nullptr);
   A3VT_CHECK_ARG(num_layers <= 2 || masks != nullptr);
   if (int rc = check_stack_dims(ld_feats, in_features, num_layers, hidden, cut_len)) return rc;
@@ -758,7 +769,7 @@ int a3vt_gcn_stack_bwd_acc(const float *feats, int ld_feats, int in_features, co
     if (int rc = launch_slab_reduce_za(scratch + L.thin_db_slab, thin_num_slabs(), 3, 3, 3, grad_biases[last], acc, s)) return rc;
   }
 
-  const bool x3 = gemm_bf16 == 3 && rowgemm3_dims_ok((long long)m, hidden, hidden);   // as a3vt_gcn_stack_fwd
+  const bool x3 = gemm_bf16 == 3 && rowgemm3_stack_ok((long long)m, hidden, mask_ld(hidden, cut_len));   // as a3vt_gcn_stack_fwd
   const int omode = gemm_bf16 == 1 ? 1 : 0;
   // zero-padded weight images (Bt = W_i for dX) of all hidden layers, one launch
   const bool batched_images = num_layers - 1 <= kMaxImages;

@@ -893,6 +893,14 @@ bool rowgemm3_dims_ok(long long m, int k, int n_store) {
          m * 320 < (1ll << 32);   // (the kernel addresses A rows with 32-bit float offsets: 13.4 M rows)
 }
 
+// A whole mode-3 STACK takes the split-operand kernels for its hidden layers only if both of their products do: the dX
+// epilogue parks 32 rows of ReLU-sign bytes (mld bytes each) in a wave's 4 KiB slot, so a cut that makes the sign rows
+// longer than 128 bytes (hidden 300: cut_len > 212) sends the WHOLE stack to the exact mode-0 kernels — never a forward on
+// one kernel family and a backward that cannot follow it.
+bool rowgemm3_stack_ok(long long m, int hidden, int mld) {
+  return rowgemm3_dims_ok(m, hidden, hidden) && 32 * mld <= 4 * kMSlot;
+}
+
 bool rowgemm3_ok(const RowGemmArgs &a, int epi) {
   if (a.bf16 != 3 || (epi != EPI_FWD_HIDDEN && epi != EPI_DX_MASK)) return false;
   if (!rowgemm3_dims_ok(a.m, a.k, a.n_store)) return false;

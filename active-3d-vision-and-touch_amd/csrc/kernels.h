@@ -33,7 +33,9 @@ struct RowGemmArgs {
   //    columns < ldc written), EPI_PLAIN writes fp32.  fp32 accumulation in every mode.
   // 3: "fp32x3" (gcn_gemm3.hip) — fp32 storage as mode 0, the product as six bf16 MFMA passes on exactly split operands;
   //    bt points at the THREE bf16 images of the layer (launch_weight_images3; ldb is ignored).  Hidden-layer shapes only
-  //    (rowgemm3_ok); launch_rowgemm sends everything else of such a call to the exact mode-0 kernels.
+  //    (rowgemm3_ok): the CALLER decides per stack (rowgemm3_stack_ok) and passes bf16 = 3 with the three images only for
+  //    the layers the kernel takes; every other product of a mode-3 stack is issued as a mode-0 call with an fp32 image.
+  //    A bf16 = 3 call the kernel does not take is an error (launch_rowgemm3 does not fall back: it has no fp32 image).
   int bf16;
   // rows [rem_row0, rem_row0 + rem_rows) beyond the m rows of the main loop: the few leftover tiles of the load-balanced
   // split, done by the tail of the same launch (set by launch_rowgemm; 0 = none)
@@ -92,6 +94,7 @@ constexpr int kX3ImageRows = 320;                               // Bt rows of a 
 constexpr int kX3ImageLd = 160;                                 // 4-byte units per image row (320 bf16: K <= 320, zero padded)
 constexpr int kX3ImageFloats = kX3ImageRows * kX3ImageLd;       // one image; a layer owns three (hi, mid, lo), back to back
 bool rowgemm3_dims_ok(long long m, int k, int n_store);
+bool rowgemm3_stack_ok(long long m, int hidden, int mld);   // what a3vt_gcn_stack_fwd / _bwd decide mode 3 with
 bool rowgemm3_ok(const RowGemmArgs &a, int epi);
 int launch_rowgemm3(const RowGemmArgs &a, int epi, hipStream_t s);
 // dst_l + p * kX3ImageFloats (p = 0, 1, 2: hi, mid, lo) = piece p of W_l^T (transpose = 1) or W_l (transpose = 0) as

@@ -141,7 +141,7 @@ class FlatGradBucket:
         for p in self.params:
             p.grad = None
         self._early_done = False
-        self._early_work = None
+        self.wait_early()                       # a reduce nobody waited for must not still be writing `flat`
         self._fired = 0
         self._late = False
         self._pending = self._early_live if self._early_live else -1   # unknown / none live: the countdown cannot fire
@@ -172,6 +172,7 @@ class FlatGradBucket:
         if not self._early_done:
             self._gather(0, self.n_early)
         self._gather(self.n_early, len(self.params))
+        self.wait_early()                       # callers that read `flat` without all_reduce_mean()
         self._open = False
         self._early_live = self._fired     # what the next step's countdown waits for
 
@@ -194,31 +195,42 @@ class FlatGradBucket:
         """Average the whole gradient over the ranks: the early chunk's reduce may already be in flight; the rest is reduced
         here; both are complete on return (on the current stream for RCCL)."""
         started = self._early_done
-        if self._late:
-            # more early parameters received a gradient than in the previous step, so the countdown fired before the last of
-            # them: that gradient is not in the chunk that was reduced.  Never silently: the graph changed between steps.
-            self._early_live = self.n_early
+        # `_late`: more early parameters received a gradient than in the previous step, so the countdown fired before the last
+        # of them: that gradient is not in the chunk whose reduce is in flight.  Never silently — but the collective sequence
+        # [early][rest] is still completed first, so that a rank where this happens (a per-rank, data-dependent graph change)
+        # does not leave its peers blocked in the [rest] collective.
+        late = self._late
+        self.gather()
+        if late:
+            self._early_live = self.n_early     # (gather() set it to what fired this step)
+        if self._active():
+            world = dist.get_world_size()
+            if self.n_early and not started:
+                # the countdown did not fire during the backward pass (first step, or an early parameter without a gradient):
+                # same two collectives, in the same order, as on a rank where it did
+                chunk = self.flat[:self.early_numel]
+                chunk.div_(world)
+                dist.all_reduce(chunk, op=dist.ReduceOp.SUM)
+            rest = self.flat[self.early_numel:]
+            if rest.numel():
+                rest.div_(world)
+                dist.all_reduce(rest, op=dist.ReduceOp.SUM)
+            if self._early_work is not None:
+                self._early_work.wait()
+                self._early_work = None
+        if late:
             raise RuntimeError("a3vt: FlatGradBucket: an early parameter received its gradient after the early chunk had been "
                                "gathered — the set of parameters that receive gradients changed since the previous step. "
-                               "Nothing was reduced; call gather() to keep this step's local gradients, or repeat the step.")
-        self.gather()
-        if not self._active():
-            return None
-        world = dist.get_world_size()
-        if self.n_early and not started:
-            # the countdown did not fire during the backward pass (first step, or an early parameter without a gradient):
-            # same two collectives, in the same order, as on a rank where it did
-            chunk = self.flat[:self.early_numel]
-            chunk.div_(world)
-            dist.all_reduce(chunk, op=dist.ReduceOp.SUM)
-        rest = self.flat[self.early_numel:]
-        if rest.numel():
-            rest.div_(world)
-            dist.all_reduce(rest, op=dist.ReduceOp.SUM)
+                               "Both collectives of this step have completed (the ranks stay in lock-step), but the early "
+                               "chunk was averaged WITHOUT that late gradient: do not apply this step's gradients; repeat the "
+                               "step (the countdown now expects every early parameter).")
+        return None
+
+    def wait_early(self):
+        """Wait for an early-chunk reduce that is still in flight (callers that read ``flat`` without ``all_reduce_mean``)."""
         if self._early_work is not None:
             self._early_work.wait()
             self._early_work = None
-        return None
 
 
 def broadcast_parameters(module, src=0):
@@ -232,6 +244,8 @@ def broadcast_parameters(module, src=0):
     for p in ps:
         p.copy_(flat[off:off + p.numel()].view_as(p))
         off += p.numel()
+    from . import ops
+    ops.invalidate_bf16_copies()                # writes through .data move no version counter
 
 
 def broadcast_buffers(module, src=0):

@@ -400,40 +400,63 @@ def bias_grad_nhwc(grad):
 
 
 _BF16_COPIES = {}   # id(tensor) -> (weakref, version, data_ptr, optimizer epoch, bf16 copy)
-_OPT_EPOCH = [0]    # moved by EVERY torch optimizer step of the process
+_OPT_EPOCH = [0]    # moved by every torch optimizer step of the process once the cache is in use, and by invalidate_bf16_copies()
+_BF16_HOOK = [None]  # None: not tried yet; True: the global step hook is registered; False: this torch has none (no caching)
 
 
 def _optimizer_stepped(*_args, **_kwargs):
     _OPT_EPOCH[0] += 1
 
 
-try:   # torch's fused Adam (the trainer's optimizer) updates the weights in place WITHOUT moving their ``_version``
-    from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook
-    _register_step_hook(_optimizer_stepped)
-    _BF16_CACHE_ON = True
-except ImportError:   # no global step hook: nothing tells a stale copy from a fresh one — cast on every call
-    _BF16_CACHE_ON = False
+def invalidate_bf16_copies():
+    """Forget every cached bf16 weight copy.  The cache notices in-place torch ops (``_version``), re-allocations
+    (``data_ptr``) and optimizer steps (the step hook); writes through ``.data`` (``p.data.copy_``, ``.data.uniform_``) or a
+    hand-written update move none of these and MUST be followed by this call — ``distributed.broadcast_parameters``,
+    ``GCN_layer.reset_parameters`` and the checkpoint loaders of this package do it themselves."""
+    _OPT_EPOCH[0] += 1
+    _BF16_COPIES.clear()
+
+
+def _bf16_cache_on():
+    """The process-wide optimizer post-step hook is registered on the FIRST use of the bf16 convolution branch, not at import
+    (a host process that imports this module for the fp32 path gets no hook).  torch's fused Adam — the trainer's optimizer —
+    updates the weights in place WITHOUT moving their ``_version``; without a global step hook (older torch) nothing tells a
+    stale copy from a fresh one, and every call casts."""
+    if _BF16_HOOK[0] is None:
+        try:
+            from torch.optim.optimizer import register_optimizer_step_post_hook
+            register_optimizer_step_post_hook(_optimizer_stepped)
+            _BF16_HOOK[0] = True
+        except ImportError:
+            _BF16_HOOK[0] = False
+    return _BF16_HOOK[0]
+
+
+def _bf16_forget(key, ref):
+    hit = _BF16_COPIES.get(key)
+    if hit is not None and hit[0] is ref:       # the id can already belong to a new tensor with its own entry
+        del _BF16_COPIES[key]
 
 
 def _bf16_copy(t, channels_last):
     """bf16 (channels-last) copy of a convolution weight / bias, kept until the tensor can have changed: an in-place torch
     op (load_state_dict, copy_) moves ``t._version``; an optimizer step — torch's fused Adam does NOT move it — moves the
-    process-wide optimizer epoch (a global step post-hook).  A training loop casts once per step as before; the forward-only
-    loops (validation, the K-candidate scoring of policies/environment.py:174-180) stop re-casting the 32 weights of the
-    image pyramid on every call (64 copy launches per forward)."""
+    process-wide optimizer epoch (a global step post-hook); ``.data`` writers call :func:`invalidate_bf16_copies`.  A training
+    loop casts once per step as before; the forward-only loops (validation, the K-candidate scoring of
+    policies/environment.py:174-180) stop re-casting the 32 weights of the image pyramid on every call (64 copy launches per
+    forward).  An entry dies with its tensor (weak-reference callback), so rebuilt models do not pin their copies."""
+    on = _bf16_cache_on()
     key = id(t)
-    hit = _BF16_COPIES.get(key) if _BF16_CACHE_ON else None
+    hit = _BF16_COPIES.get(key) if on else None
     if (hit is not None and hit[0]() is t and hit[1] == t._version and hit[2] == t.data_ptr()
             and hit[3] == _OPT_EPOCH[0]):
         return hit[4]
     c = t.detach().to(torch.bfloat16)
     if channels_last:
         c = c.contiguous(memory_format=torch.channels_last)
-    if len(_BF16_COPIES) > 4096:   # tensors that died without being looked up again
-        for k in [k for k, v in _BF16_COPIES.items() if v[0]() is None]:
-            del _BF16_COPIES[k]
-    if _BF16_CACHE_ON:
-        _BF16_COPIES[key] = (weakref.ref(t), t._version, t.data_ptr(), _OPT_EPOCH[0], c)
+    if on:
+        ref = weakref.ref(t, lambda r, key=key: _bf16_forget(key, r))
+        _BF16_COPIES[key] = (ref, t._version, t.data_ptr(), _OPT_EPOCH[0], c)
     return c
 
 

@@ -195,6 +195,7 @@ class GCN_layer(nn.Module):
         stdv *= 0.3
         self.weight.data.uniform_(-stdv, stdv)
         self.bias.data.uniform_(-0.1, 0.1)
+        _ops.invalidate_bf16_copies()               # .data writes move no version counter
 
     def forward(self, features, adj, activation):
         """The reference's layer call (:351-363) for callers with their own layer loop (the auto-encoder encoder,

@@ -56,7 +56,11 @@ int a3vt_csr_validate(const int32_t *rowptr_host, const int32_t *col_host, int n
  * the three products of the hidden layers (K, n in (288, 304], >= 12 288 rows) are formed on the bf16 matrix pipe from
  * operands split EXACTLY into three bf16 pieces (x == hi + mid + lo, a3vt_split3_bf16), the six partial products down
  * to 2^-16 of the largest kept, fp32 accumulation: fp32-level error (measured against the fp64 oracle: DESIGN.md), not
- * bit-identical to mode 0; all other shapes of such a call run the mode-0 kernels.  Mode 0 stays the default.
+ * bit-identical to mode 0; all other shapes of such a call run the mode-0 kernels — and so does the WHOLE stack when its
+ * ReLU-sign rows are longer than 128 bytes (pad4(cut_len)/4 + ceil(hidden/4) > 128, i.e. cut_len > 212 at hidden 300): a
+ * shape that works in mode 0 works in mode 3.  Mode 3 keeps three bf16 weight images per hidden layer in `scratch`, a
+ * larger slot than mode 0's: size the scratch with a3vt_gcn_stack_scratch_bytes (enough for every mode) or with
+ * a3vt_gcn_stack_scratch_bytes_mode(..., 3).  Values outside 0..3 are refused (A3VT error).  Mode 0 stays the default.
  * csr_max_degree / csrT_max_degree: the largest number of entries in a row of that matrix, or 0 if unknown.  The
  * fused vision + touch graphs have hub rows (chart centres linked to every seam vertex, ~1150 entries,
  * utility/utils.py:119-128); rows above 64 entries are aggregated by a whole workgroup in a second launch, which a
@@ -73,14 +77,18 @@ int a3vt_csr_validate(const int32_t *rowptr_host, const int32_t *col_host, int n
  *          the backward pass reads these 16 MB per layer instead of re-reading the 197 MB activation
  * update : [M][3]
  * Forward-only callers (policy scoring, environment.py:221-257) may pass acts = masks = NULL: the
- * layer outputs then ping-pong inside `scratch`. */
+ * layer outputs then ping-pong inside `scratch`.
+ * a3vt_gcn_stack_scratch_bytes: enough for ANY gemm_bf16 (the maximum over the modes); a3vt_gcn_stack_scratch_bytes_mode
+ * (below) is the exact figure of one mode.  The stack entry points take no scratch size: an undersized scratch is
+ * undefined behaviour, so size it with one of the two. */
 size_t a3vt_gcn_stack_scratch_bytes(int batch, int n_vert, int in_features, int hidden, int num_layers,
                                     int cut_len, int need_backward);
 size_t a3vt_gcn_stack_mask_bytes(int batch, int n_vert, int hidden, int num_layers, int cut_len);
 /* gemm_bf16 == 2, "bf16 storage" (BASELINE configs[3]/[4]): activations, their gradients and the weight images are kept
  * as bf16 in HBM (fp32 accumulation; fp32 weights, gradients of the weights, features and update at this boundary).
  * `acts` then holds bf16 rows of pad8(hidden) elements and the sign bytes use another row length: query both sizes
- * with a3vt_gcn_stack_stash_bytes, and the scratch size with a3vt_gcn_stack_scratch_bytes_mode.  Needs >= 2 layers. */
+ * with a3vt_gcn_stack_stash_bytes, and the scratch size with a3vt_gcn_stack_scratch_bytes_mode (or the all-modes
+ * maximum a3vt_gcn_stack_scratch_bytes).  Needs >= 2 layers. */
 size_t a3vt_gcn_stack_scratch_bytes_mode(int batch, int n_vert, int in_features, int hidden, int num_layers,
                                          int cut_len, int need_backward, int gemm_bf16);
 int a3vt_gcn_stack_stash_bytes(int batch, int n_vert, int hidden, int num_layers, int cut_len, int gemm_bf16,

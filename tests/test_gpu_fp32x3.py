@@ -167,3 +167,39 @@ def test_forward_only_fp32x3(cuda):
         out_o = og.gcn(feats.double(), {k: v.double() for k, v in st.items()}, "mesh_deform_1",
                        (adj_o[0], adj_o[1], adj_o[2].double()), L, 0.33)
     assert rel_err(out, out_o) < 1e-4
+
+
+def test_wide_cut_runs_exact_in_mode3_and_scratch_covers_every_mode(cuda):
+    """(i) hidden 300 with cut_len > 212 makes the ReLU-sign rows longer than the 128 bytes the split-operand dX
+    epilogue parks per row — the forward used to run on those kernels and every hidden dX then failed ('rowgemm3: unsupported
+    call'); the whole stack now runs the exact kernels (bit-equal to mode 0).  (ii) a3vt_gcn_stack_scratch_bytes (no mode
+    argument) is enough for every mode (mode 3's three bf16 images per layer are a larger weight slot than mode 0's).
+    (iii) gemm modes outside 0..3 are refused."""
+    import ctypes
+    from a3vt_amd import lib, ops
+    from oracle import gcn as og
+    L, H, B = 3, 300, 24
+    adj, verts, faces = _adjacency(cuda, "ico3", False)
+    n = verts.shape[0]
+    st = og.init_state(50, H, L, seed=4)
+    g = torch.Generator().manual_seed(8)
+    feats = torch.randn(B, n, 50, generator=g) * 0.5
+    gup = torch.randn(B, n, 3, generator=g)
+    for cut_len in (216, 300):
+        a = _run(cuda, adj, st, feats, gup, L, H, cut_len, "fp32")
+        b = _run(cuda, adj, st, feats, gup, L, H, cut_len, "fp32x3")
+        for u, v in zip([a[0], a[1], *a[2], *a[3]], [b[0], b[1], *b[2], *b[3]]):
+            assert torch.equal(u, v)
+    Lb = lib.load()
+    for (b_, n_, nl) in ((64, 2562, 20), (B, n, L), (2, 162, 3), (8, 10242, 20)):
+        for bwd in (0, 1):
+            every = Lb.a3vt_gcn_stack_scratch_bytes(b_, n_, 50, H, nl, 99, bwd)
+            for mode in range(4):
+                assert every >= Lb.a3vt_gcn_stack_scratch_bytes_mode(b_, n_, 50, H, nl, 99, bwd, mode)
+    assert Lb.a3vt_gcn_stack_scratch_bytes(64, 2562, 50, H, 20, 99, 1) == \
+        max(Lb.a3vt_gcn_stack_scratch_bytes_mode(64, 2562, 50, H, 20, 99, 1, m) for m in range(4))
+    with pytest.raises(RuntimeError):
+        ws = [st[f"mesh_deform_1.layers.{i}.weight"].to(cuda) for i in range(L)]
+        bs = [st[f"mesh_deform_1.layers.{i}.bias"].to(cuda) for i in range(L)]
+        with torch.no_grad():
+            ops.gcn_stack(torch.nn.functional.pad(feats, (0, 2)).to(cuda), adj, 50, H, 99, ws, bs, bf16=7)

@@ -331,9 +331,24 @@ def test_bench_under_torchrun_single_rank(cuda):
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["config"]["parallelism"] == "dp1"
     assert d["roofline"]["traffic"] is None and "step_ms" in d and "cpu_baseline" not in d
     assert d["metric"].startswith("mesh-recon iters/sec (fwd+bwd, 2562-vert GCN + 1k-pt Chamfer) at bs=8")
-    # a wrong --gpus is refused instead of silently measuring something else
+    keys = set(d)
+    # the launcher-less command line (what a driver that does not use torch.distributed.run would type): bench.py starts the
+    # same launch line itself as a child process, at N = 1 through --launcher spawn, and the JSON line has the same keys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    plain = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--launcher", "spawn"] + cmd[cmd.index("--steps"):],
+                           capture_output=True, text=True, timeout=600, env=env)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    assert "torch.distributed.run" in plain.stderr
+    d2 = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])
+    assert set(d2) == keys and d2["n_gpus"] == 1 and d2["value"] > 0 and d2["rccl"]["rank_ms_per_step"]["n"] == 1
+    # more GPUs than the node has: refused by the parent before anything is launched (no hang, no half-started group)
+    ndev = torch.cuda.device_count()
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ndev + 1), "--steps", "1"], capture_output=True,
+                         text=True, timeout=300, env=env)
+    assert bad.returncode != 0 and f"{ndev} device" in bad.stderr and "visible" in bad.stderr
+    # a --gpus that contradicts an existing WORLD_SIZE is refused instead of silently measuring something else
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True,
-                         text=True, timeout=300)
+                         text=True, timeout=300, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
     assert bad.returncode != 0 and "WORLD_SIZE" in (bad.stderr + bad.stdout)
 
 
