@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include "../../include/a3vt.h"
+#include <atomic>
 #include <mutex>
 #include <unordered_map>
 
@@ -92,6 +93,8 @@ struct StackLayout {
 // and records the decision with the stash (stash_layout_*); the backward follows the record.  a3vt_dbg_csr_algo() is the
 // test hook that forces either path (both give the same outputs; the shipped library reads no environment variable).
 constexpr int kQuadCols = 160;   // quad-major columns of a hybrid layer output: the first column group of rowgemm's epilogue
+static std::atomic<long long> g_path_counts[PATH_COUNT];
+void path_count(int which) { g_path_counts[which].fetch_add(1, std::memory_order_relaxed); }
 static int g_csr_algo = 0;       // 0 = by shape, 1 = half-wave ("rows"), 2 = channel-sliced where it fits, long rows included
 static bool use_csrq(int batch, int n_vert, int hidden, int cut_len, int gemm_bf16, int max_degree) {
   if (gemm_bf16 == 1 || gemm_bf16 == 2) return false;   // the bf16 operand / storage modes keep the half-wave kernels (mode 3 stores fp32: as mode 0)
@@ -616,6 +619,7 @@ int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const 
   }
 
   const bool quad = use_csrq(batch, n_vert, hidden, cut_len, gemm_bf16, max_degree) && num_layers > 1;
+  if (num_layers > 1) path_count(quad ? PATH_STACK_QUAD : PATH_STACK_ROWS);
   if (num_layers > 1) stash_layout_record(masks, quad);
   int32_t *ell = reinterpret_cast<int32_t *>(scratch + L.ell);
   if (quad)
@@ -1351,6 +1355,14 @@ int a3vt_profile_read(double *total_ms, int *count) {
   }
   g_prof.used = 0;
   return 0;
+}
+
+int a3vt_dbg_path_counts(long long *counts, int n, int reset) {
+  A3VT_CHECK_ARG(n >= 0 && (counts != nullptr || n == 0));
+  for (int i = 0; i < n; ++i) counts[i] = i < PATH_COUNT ? g_path_counts[i].load(std::memory_order_relaxed) : 0;
+  if (reset)
+    for (auto &c : g_path_counts) c.store(0, std::memory_order_relaxed);
+  return PATH_COUNT;
 }
 
 int a3vt_dbg_csr_algo(int algo) {

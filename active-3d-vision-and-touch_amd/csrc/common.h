@@ -54,6 +54,21 @@ struct OncePerDevice {
   }
 };
 
+// Which kernel families the calls of this process took (a3vt_dbg_path_counts; tests assert that a fixture REACHES the kernels it
+// claims to pin).  Host-side counters, one relaxed increment per launch decision.
+enum PathCount {
+  PATH_STACK_QUAD = 0,   // a3vt_gcn_stack_fwd calls whose hidden layers ran the channel-sliced aggregation on hybrid rows
+  PATH_STACK_ROWS,       // ... the half-wave row-walk aggregation on row-major rows
+  PATH_RG_ADIRECT,       // rowgemm_kernel<19, ..., ADIRECT> launches (exact fp32, A operand straight into registers)
+  PATH_RG3,              // rowgemm3_kernel launches (gemm mode 3, split operands)
+  PATH_DW3,              // dw3_kernel launches
+  PATH_DW_HYBRID,        // dw_kernel launches on quad-major operands
+  PATH_RG16,             // rowgemm16_kernel launches (bf16 storage, weights in registers)
+  PATH_STACK16_QUAD,     // bf16-storage stack forward calls on the channel-sliced aggregation
+  PATH_COUNT
+};
+void path_count(int which);
+
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline int pad4(int n) { return (n + 3) & ~3; }
 static inline int pad16(int n) { return (n + 15) & ~15; }

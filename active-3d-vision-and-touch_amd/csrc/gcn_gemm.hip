@@ -808,6 +808,7 @@ static int launch_rowgemm_nt(const RowGemmArgs &a, int grid_y, hipStream_t s) {
 #else
     constexpr bool via_lds = false;
 #endif
+    if (NT == 19 && !via_lds) path_count(PATH_RG_ADIRECT);
     if (NT == 19 && !via_lds)
       A3VT_LAUNCH((rowgemm_kernel<NT, EPI, C::NSTAGE, C::WAVES, 0, NT == 19>), dim3(grid, grid_y), dim3(64 * C::WAVES), shmem, s, a);
     else
@@ -1500,6 +1501,7 @@ int launch_dw(const DwArgs &a0, hipStream_t s) {
     return -1;
   }
   const bool hyb = a.xq_nvert > 0 || a.z0q_nvert > 0;
+  if (hyb) path_count(PATH_DW_HYBRID);
   const int nbq = a.xq_nvert > 0 ? a.xq_quads / 4 : 0, wrm = a.ldx - nbq * 16;   // as dw_kernel
   if (a.xq_nvert > 0 && (a.xq_quads % 4 != 0 || dw_blocked_tiles(a.k_in, a.xq_quads) != nbq)) {
     set_error("dw: quad-major X columns (%d) must end where a wave's input tiles end (k_in=%d)", a.xq_quads * 4, a.k_in);

@@ -347,6 +347,7 @@ int launch_rowgemm16(const RowGemmArgs &a0, int epi, hipStream_t s) {
   });
   const int nblk = cdiv(a.m, kRows);
   const int grid = nblk < 256 ? nblk : 256;
+  path_count(PATH_RG16);
   if (epi == EPI_FWD_HIDDEN)
     A3VT_LAUNCH((rowgemm16_kernel<EPI_FWD_HIDDEN>), dim3(grid), dim3(512), kLdsFloats * 4, s, a);
   else

@@ -939,6 +939,7 @@ int launch_rowgemm3(const RowGemmArgs &a0, int epi, hipStream_t s) {
     tiles = full;
   }
   const int grid = cdiv(tiles, kWaves) < 256 ? cdiv(tiles, kWaves) : 256;
+  path_count(PATH_RG3);
   if (epi == EPI_FWD_HIDDEN)
     A3VT_LAUNCH((rowgemm3_kernel<EPI_FWD_HIDDEN>), dim3(grid), dim3(64 * kWaves), kLdsBytes, s, a);
   else
@@ -971,6 +972,7 @@ int launch_dw3(const DwArgs &a0, hipStream_t s) {
   }
   static OncePerDevice once;
   once.run([] { (void)hipFuncSetAttribute((const void *)dw3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDwLdsBytes); });
+  path_count(PATH_DW3);
   A3VT_LAUNCH(dw3_kernel, dim3(dw_num_slabs(a.n_out), 2), dim3(kDwThreads), kDwLdsBytes, s, a);
   A3VT_CHECK_LAUNCH();
   return 0;

@@ -74,6 +74,18 @@ def _ptr_array(tensors):
 GEMM_MODES = {"fp32": 0, "bf16": 1, "bf16s": 2, "fp32x3": 3}
 
 
+PATH_NAMES = ("stack_quad", "stack_rows", "rowgemm_adirect", "rowgemm3", "dw3", "dw_hybrid", "rowgemm16", "stack16_quad")
+
+
+def path_counts(reset=False):
+    """Launch decisions per kernel family since the last reset (``a3vt_dbg_path_counts``): a test hook — parity tests assert
+    that their fixture reaches the kernels it claims to pin."""
+    import ctypes
+    buf = (ctypes.c_longlong * len(PATH_NAMES))()
+    _lib.load().a3vt_dbg_path_counts(buf, len(PATH_NAMES), 1 if reset else 0)
+    return dict(zip(PATH_NAMES, (int(x) for x in buf)))
+
+
 def gemm_mode(bf16):
     """0 exact fp32 MFMA; 1 bf16 operands, fp32 storage; 2 bf16 storage (activations / gradients / weight images bf16 in
     HBM, fp32 accumulation); 3 "fp32x3": fp32 storage, the hidden-layer products as six bf16 MFMA passes on operands split

@@ -61,3 +61,136 @@ class SyntheticLoader:
             b["touch_charts"] = touch_charts(self.batch_size, self.args, self.seed * 7 + s) \
                 if self.args.use_touch else torch.ones(self.batch_size, 1)
             yield b
+
+
+# ---- BASELINE.json configs[3] / configs[4] on one GPU (bench.py `named_configs`, tools/named_configs.py) ----------------
+def gcn_activation_bytes(batch, n_vert, in_features, hidden, layers, stages=3, elem=4):
+    """SURVEY §8d ``Bytes_act`` for a whole batch: ``S * 3 * sum_i elem * N * (d_i + d_{i+1})`` with the layer widths
+    ``[in_features, hidden x (L-1), 3]`` — forward reads X and writes Y, backward reads dY and X and writes dX (about twice the
+    forward).  ``elem`` = 4 (fp32) or 2 (bf16 storage).  This is the ALGORITHMIC traffic the HBM roofline of the bf16
+    configurations is priced with (35.1 GB for cfg-4 without image, 135 GB for cfg-5 at bs 64)."""
+    dims = [in_features] + [hidden] * (layers - 1) + [3]
+    return batch * stages * 3 * sum(elem * n_vert * (a + b) for a, b in zip(dims[:-1], dims[1:]))
+
+
+def named_config(which, dev, precision="bf16s", batch=None):
+    """Model and synthetic inputs of BASELINE.json configs[3] (vision + touch: image model with the default CNNs + chart
+    atlas with 4 touch charts, N = 1924, 25 000-point Chamfer, bs 64) or configs[4]'s per-GPU shard (10 242-vertex
+    icosphere-5, 50 000-point Chamfer, bs 8 of the global 64).  Returns a dict; ``NamedStep`` runs training steps on it."""
+    from . import mesh as amesh
+    from .pterotactyl.reconstruction.vision import model
+    from .pterotactyl.utility import utils
+    if which == 3:
+        B = batch or 64
+        g = torch.Generator().manual_seed(0)
+        args = make_args(use_img=True, use_touch=True, finger=False, num_grasps=1, number_points=25000,
+                         gemm_precision=precision, CNN_ker_size=5, num_CNN_blocks=6, layers_per_block=3)
+        info, verts = utils.load_mesh_vision(args, "vision_charts")
+        torch.manual_seed(0)
+        net = model.Deformation(info, verts, args).to(dev)
+        tc = torch.zeros(B, 1, 4, 25, 4)
+        tc[..., :3] = (torch.rand(B, 1, 4, 25, 3, generator=g) - 0.5) * 0.3
+        tc[..., 3] = 2
+        img = torch.rand(B, 3, 256, 256, generator=g).to(dev)
+        charts = model.prepare_mesh({"img": img, "touch_charts": tc}, verts, args)
+        n_vert = int(verts.shape[0]) + 100
+        name = f"configs[3]: image + 4 touch charts (N={n_vert}), 25k-pt Chamfer, {precision}, bs={B}"
+        in_features = 448
+    elif which == 4:
+        B = batch or 8
+        args = make_args(number_points=50000, gemm_precision=precision)
+        v, f = amesh.icosphere(5)
+        verts, ft = torch.from_numpy(v).to(dev), torch.from_numpy(f).to(dev)
+        info = utils.adj_init(verts, ft, args)
+        torch.manual_seed(0)
+        net = model.Deformation(info, verts, args).to(dev)
+        img = torch.zeros(B, 1, device=dev)
+        charts = model.prepare_mesh({"img": img}, verts, args)
+        n_vert = int(verts.shape[0])
+        name = f"configs[4] shard: icosphere-5 (N={n_vert}), 50k-pt Chamfer, {precision}, bs={B}"
+        in_features = 50
+    else:
+        raise ValueError(which)
+    gt = gt_cloud(B, args.number_points, 0).to(dev)
+    elem = 2 if precision == "bf16s" else 4
+    return {"name": name, "net": net, "info": info, "charts": charts, "img": img, "gt": gt, "args": args, "batch": B,
+            "n_vert": n_vert, "in_features": in_features,
+            "activation_bytes": gcn_activation_bytes(B, n_vert, in_features, args.hidden_GCN_size, args.num_GCN_layers, 3, elem)}
+
+
+class NamedStep:
+    """The trainer's step (``Engine.train_step``: flat bucket, fused Adam) on a ``named_config``."""
+
+    def __init__(self, cfg):
+        from . import distributed as adist
+        self.cfg = cfg
+        self.params = list(cfg["net"].parameters())
+        self.bucket = adist.FlatGradBucket(self.params)
+        self.opt = torch.optim.Adam(self.params, lr=cfg["args"].lr, fused=True)
+
+    def __call__(self):
+        from .pterotactyl.utility import utils
+        c = self.cfg
+        self.bucket.zero()
+        v = c["net"](c["img"], c["charts"])[0]
+        loss = c["args"].loss_coeff * utils.chamfer_distance(v, c["info"]["faces_i32"], c["gt"], num=c["args"].number_points).mean()
+        loss.backward()
+        self.bucket.all_reduce_mean()   # single process: gathers the gradients and re-homes .grad
+        self.opt.step()
+        self.verts = v.detach()
+        return loss.detach()
+
+    def chamfer_forward_ms(self, reps=3):
+        """Device time of the loss forward alone (3 surface draws + the exact pruned search both ways + reduce) on the
+        step's last predicted vertices: the search's share of a step."""
+        from .pterotactyl.utility import utils
+        c = self.cfg
+        with torch.no_grad():
+            utils.chamfer_distance(self.verts, c["info"]["faces_i32"], c["gt"], num=c["args"].number_points)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                utils.chamfer_distance(self.verts, c["info"]["faces_i32"], c["gt"], num=c["args"].number_points)
+            e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    def close(self):
+        self.bucket.close()
+
+
+def time_named_config(which, dev, precision="bf16s", batch=None, steps=10, warm=8):
+    """Build, warm up (MIOpen's find mode and the allocator's growth take several steps to settle in the image mode), time
+    ``steps`` training steps; returns the JSON-able record ``bench.py`` prints under ``named_configs``."""
+    import time
+    t_build = time.perf_counter()
+    cfg = named_config(which, dev, precision, batch)
+    step = NamedStep(cfg)
+    for _ in range(warm):
+        loss = step()
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_build
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    marks[0].record()
+    for i in range(steps):
+        loss = step()
+        marks[i + 1].record()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    dev_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    search = step.chamfer_forward_ms()
+    nbytes = cfg["activation_bytes"]
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    rec = {"config": cfg["name"], "ms_per_step": ms, "device_ms_median": dev_ms[len(dev_ms) // 2], "iters_per_s": 1e3 / ms,
+           "steps": steps, "warmup": warm, "setup_s": t_build, "loss": float(loss), "finite": bool(torch.isfinite(loss)),
+           "roofline": {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+                        "bytes_per_step": nbytes,
+                        "bytes_how": f"SURVEY 8d Bytes_act = B*S*3*sum_i e*N*(d_i+d_{{i+1}}), e={2 if precision == 'bf16s' else 4} B, "
+                                     f"N={cfg['n_vert']}, d=[{cfg['in_features']},{cfg['args'].hidden_GCN_size}x"
+                                     f"{cfg['args'].num_GCN_layers - 1},3], B={cfg['batch']}, S=3 (GCN activations only: no CNN, "
+                                     f"no Chamfer bytes)",
+                        "hbm_ms_at_peak": nbytes / 8e12 * 1e3,
+                        "chamfer_forward_ms": search, "chamfer_share": search / ms}}
+    step.close()
+    return rec

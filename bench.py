@@ -71,6 +71,8 @@ def parse():
                    help="bf16 = operand mode, bf16s = bf16 activation storage (BASELINE configs[3]/[4]), fp32x3 = fp32 products as "
                         "six bf16 MFMA passes on exactly split operands; NOT the headline")
     p.add_argument("--alt-steps", type=int, default=10, help="timed steps of the alt_modes leg (0 = skip it)")
+    p.add_argument("--no-named-configs", action="store_true", help="skip the configs[3] / configs[4] leg")
+    p.add_argument("--named-steps", type=int, default=10, help="timed steps of each named configuration")
     p.add_argument("--launcher", default="auto", choices=["auto", "spawn", "none"],
                    help="auto: with --gpus N > 1 and no WORLD_SIZE in the environment, start torch.distributed.run as a CHILD "
                         "process (one rank per GPU) and relay its output; spawn: do that at any N (the N = 1 test of the same "
@@ -264,11 +266,47 @@ def alt_modes_leg(eng, img, charts, clouds, step, fence, steps, world, modes=("f
             tot, cnt = (ctypes.c_double * 3)(), (ctypes.c_int * 3)()
             lib.check(L.a3vt_profile_read(tot, cnt), "profile_read")
             L.a3vt_profile_enable(0)
+            us = {k: 1e3 * tot[i] / max(cnt[i], 1) for i, k in enumerate(("fwd", "dx", "dw"))}
             out[mode] = {"ms_per_step": ms, "iters_per_s": 1e3 * world / ms, "steps": steps, "final_loss": loss.item(),
-                         "mfma_launch_us": {k: 1e3 * tot[i] / max(cnt[i], 1) for i, k in enumerate(("fwd", "dx", "dw"))},
-                         "error_vs_exact_fp32": err}
+                         "mfma_launch_us": us, "error_vs_exact_fp32": err}
+            if mode == "fp32x3" and us["dx"] > 0:
+                # the mode's own roofline, dominant kernel rowgemm3_kernel<EPI_DX_MASK> (dX = dZ W^T of a hidden layer): against
+                # the six-pass bf16 matrix peak (2500 / 6 TFLOP/s of fp32-equivalent work) AND against HBM (it moves the same
+                # fp32 rows as mode 0: M x hidden x 4 B read + written, + the ReLU-sign bytes)
+                args, m = eng.args, v0.shape[0] * v0.shape[1]
+                h, c = args.hidden_GCN_size, round(args.hidden_GCN_size * args.cut)
+                flop = 2.0 * m * h * h
+                nbytes = m * (2 * h * 4 + ((c + 3) // 4 + (h + 3) // 4))
+                tf = flop / (us["dx"] * 1e-6) / 1e12
+                out[mode]["roofline"] = {"bound": "mfma", "kernel": "rowgemm3_kernel<EPI_DX_MASK> (6 x v_mfma_f32_16x16x32_bf16 on "
+                                                                     "exactly split f32 operands, M x 300 x 300)",
+                                         "achieved": tf, "peak": 2500.0 / 6.0, "unit": "TFLOP/s (fp32-equivalent)",
+                                         "frac": tf / (2500.0 / 6.0), "avg_launch_ms": us["dx"] * 1e-3, "flop_per_launch": flop,
+                                         "hbm": {"bytes_per_launch": nbytes, "achieved_GBps": nbytes / (us["dx"] * 1e-6) / 1e9,
+                                                 "frac_of_8TBps": nbytes / (us["dx"] * 1e-6) / 8e12}}
     finally:
         set_mode("fp32")
+    return out
+
+
+# ---- named_configs leg: the two other single-GPU configurations BASELINE.json names, under the same clock ------------------
+def named_configs_leg(eng, dev, steps):
+    """BASELINE.json configs[3] (image model + 4 touch charts, 25 000-point Chamfer, bf16 storage, bs 64) and the per-GPU shard
+    of configs[4] (10 242-vertex template, 50 000-point Chamfer, bf16 storage, bs 8): ``steps`` timed training steps each
+    after the warm-up (MIOpen's find mode has settled), each with its own HBM roofline — SURVEY 8d's algorithmic activation
+    bytes per step / time against 8 TB/s — and the share of the step the Chamfer forward (the exact search) takes.  Never
+    ``value``; a failure here is reported in place and does not cost the bench line."""
+    from a3vt_amd.synthetic import time_named_config
+    out = {}
+    eng.bucket.close()
+    eng.encoder = eng.optimizer = None           # the headline model's weights / Adam state / stash are not needed any more
+    torch.cuda.empty_cache()
+    for key, which in (("configs[3]", 3), ("configs[4]_shard", 4)):
+        try:
+            out[key] = time_named_config(which, dev, "bf16s", None, steps)
+        except Exception as e:  # noqa: BLE001
+            out[key] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
     return out
 
 
@@ -484,6 +522,8 @@ def main():
     if a.gemm_precision == "fp32" and a.alt_steps > 0:   # every rank runs it (the steps hold collectives); rank 0 reports
         alt = alt_modes_leg(eng, img, charts, clouds, step, fence, a.alt_steps, world)
         out["alt_modes"] = alt
+    if rank == 0 and world == 1 and default_cfg and not a.no_named_configs:
+        out["named_configs"] = named_configs_leg(eng, dev, a.named_steps)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.level, a.layers, a.hidden, a.points, a.cpu_budget)
     if rank == 0:

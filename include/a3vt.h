@@ -291,6 +291,15 @@ int a3vt_chamfer_bwd(const float *x, const float *y, int draws, int batch, int p
  * library reads NO environment variable. */
 int a3vt_dbg_csr_algo(int algo);
 
+/* Test hook: how many launch decisions of this process took each kernel family since the last reset — so that a parity test
+ * can assert that its fixture REACHES the kernels it claims to pin (tests/test_gpu_golden.py::test_g12_*).  counts[0..n):
+ *   [0] stack forward calls on the channel-sliced aggregation (hybrid rows)   [1] ... on the half-wave row-walk kernels
+ *   [2] rowgemm_kernel<19,...,ADIRECT> launches (exact fp32 hidden-layer products: the headline kernel)
+ *   [3] rowgemm3_kernel launches (gemm mode 3)   [4] dw3_kernel launches   [5] dw_kernel launches on quad-major operands
+ *   [6] rowgemm16_kernel launches (bf16 storage)  [7] bf16-storage stack forward calls on the channel-sliced aggregation
+ * Returns the number of counters the library keeps (entries beyond it are written as 0); reset != 0 clears them. */
+int a3vt_dbg_path_counts(long long *counts, int n, int reset);
+
 /* The operand split of gemm mode 3 (replaces nothing in the reference: it is how torch.matmul(features, self.weight),
  * model.py:352, is fed to the bf16 matrix pipe without losing fp32 bits).  hi / mid / lo receive bf16 bit patterns with
  * float(hi[i]) + float(mid[i]) + float(lo[i]) == x[i] exactly for every finite x[i] whose lowest set bit is >= 2^-133

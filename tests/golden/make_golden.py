@@ -19,6 +19,11 @@ Fixtures (names follow SURVEY §8c):
   g9_autoencoder.npz   reconstruction/autoencoder AutoEncoder (L=3, H=300): latent, folded points, Chamfer loss with
                        the gradient on the SECOND cloud (autoencoder/train.py:145-150), selected grads
   g10_graph_model.npz  policies/DDQN Graph_Model (3 layers, 300 -> 200 -> 200 -> 50): Q values + selected grads
+  g12_atlas_b8.npz     full-size Deformation (L=20, H=300, seed-0 init) on EIGHT differently perturbed atlases (14 592 rows:
+                       enough for the product kernels bench.py times — the hybrid-row channel-sliced aggregation, the
+                       19-tile products with the A operand in registers, the split-operand kernels of gemm mode 3):
+                       forward verts, Chamfer with injected samples, the gradient norm of every parameter tensor and a few
+                       whole gradients
   g11_loader_batch.npz the reference's ``mesh_loader_vision`` (utility/data_loaders.py:132-258) on the miniature dataset
                        ``golden_util.write_mini_dataset`` writes: instance list, seeded validation grasp choices, seeded
                        training draws, one collated batch (touch_charts, gt_points, image samples), finger variant
@@ -156,6 +161,48 @@ def g4():
          weight_sha256=state_checksum(net.state_dict()),
          w_first=net.mesh_deform_1.layers[0].weight.detach().numpy()[0, :4, :8],
          w_last=net.mesh_deform_2.layers[19].weight.detach().numpy()[0, :8])
+
+
+def g12():
+    a = args_of()
+    torch.manual_seed(0)
+    info, verts = ref.utils.load_mesh_vision(a, OBJ)
+    net = ref.model.Deformation(info, verts, a)
+    B, P, Q = 8, 1000, 1500
+    batch = {"img": torch.zeros(B, 1)}
+    charts = ref.model.prepare_mesh(batch, verts, a)
+    g = torch.Generator().manual_seed(12)
+    # every sample perturbed differently (and by a different amount), so rows of different meshes differ
+    amp = torch.linspace(0.004, 0.02, B).view(B, 1, 1)
+    charts["vision_charts"] = charts["vision_charts"] + amp * torch.randn(B, verts.shape[0], 3, generator=g)
+    verts_in = charts["vision_charts"].clone()
+    out, _ = net(batch["img"], charts)
+    d = torch.randn(B, Q, 3, generator=g)
+    gt = d / d.norm(dim=-1, keepdim=True) * (0.05 + 0.11 * torch.rand(B, 1, 3, generator=g))
+    samples = injected(B, info["faces"].shape[0], P, 112)
+    cd = ref_chamfer_injected(out, info["faces"], gt, samples)
+    loss = 9000.0 * cd.mean()
+    loss.backward()
+    arrs = {"verts_in": verts_in.numpy(), "verts_out": out.detach().numpy(), "cd": cd.detach().numpy(),
+            "loss": np.float32(loss.item()), "gt": gt.numpy(),
+            "face_idx": torch.stack([s_[0] for s_ in samples]).numpy().astype(np.int16),
+            "u": torch.stack([s_[1] for s_ in samples]).numpy(), "v": torch.stack([s_[2] for s_ in samples]).numpy(),
+            "weight_sha256": state_checksum(net.state_dict()), "pytorch3d_restated": np.bool_(True)}
+    names, norms = [], []
+    for k, p in net.named_parameters():
+        names.append(k)
+        norms.append(0.0 if p.grad is None else float(p.grad.double().norm()))
+    arrs["grad_names"] = np.array(names)
+    arrs["grad_norms"] = np.array(norms, dtype=np.float64)
+    keep = ["mesh_deform_1.layers.0.weight", "mesh_deform_1.layers.10.bias", "mesh_deform_2.layers.7.bias",
+            "mesh_deform_2.layers.19.weight", "mesh_deform_2.layers.19.bias", "mesh_deform_1.layers.19.weight",
+            "positional_encoder.model.0.weight", "mask_encoder.model.0.weight"]
+    sd = dict(net.named_parameters())
+    for k in keep:
+        arrs["g:" + k] = sd[k].grad.numpy()
+    # one hidden-layer weight gradient, subsampled (300 x 300 floats would be 360 KB): every 7th row, every 5th column
+    arrs["g:mesh_deform_2.layers.9.weight[::7,::5]"] = sd["mesh_deform_2.layers.9.weight"].grad.numpy()[0, ::7, ::5]
+    save("g12_atlas_b8.npz", **arrs)
 
 
 def g5():
@@ -466,6 +513,6 @@ def g11():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     for w in which:
         globals()[w]()

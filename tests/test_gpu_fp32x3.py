@@ -185,11 +185,20 @@ def test_wide_cut_runs_exact_in_mode3_and_scratch_covers_every_mode(cuda):
     g = torch.Generator().manual_seed(8)
     feats = torch.randn(B, n, 50, generator=g) * 0.5
     gup = torch.randn(B, n, 3, generator=g)
+    ws = [st[f"mesh_deform_1.layers.{i}.weight"].to(cuda) for i in range(L)]
+    bs = [st[f"mesh_deform_1.layers.{i}.bias"].to(cuda) for i in range(L)]
+    fd = torch.nn.functional.pad(feats, (0, 2)).to(cuda)
     for cut_len in (216, 300):
-        a = _run(cuda, adj, st, feats, gup, L, H, cut_len, "fp32")
-        b = _run(cuda, adj, st, feats, gup, L, H, cut_len, "fp32x3")
-        for u, v in zip([a[0], a[1], *a[2], *a[3]], [b[0], b[1], *b[2], *b[3]]):
-            assert torch.equal(u, v)
+        # (forward: the exact mode's own backward does not take cuts this wide at hidden 300 — "dw: rows too wide" — so the
+        # forward-only callers are the ones that can meet the shape)
+        with torch.no_grad():
+            a = ops.gcn_stack(fd, adj, 50, H, cut_len, ws, bs, bf16="fp32")
+            b = ops.gcn_stack(fd, adj, 50, H, cut_len, ws, bs, bf16="fp32x3")
+        assert torch.equal(a, b)
+    # the widest cut whose sign rows still fit: trains in both modes (the split-operand kernels run: other low bits)
+    a = _run(cuda, adj, st, feats, gup, L, H, 132, "fp32")
+    b = _run(cuda, adj, st, feats, gup, L, H, 132, "fp32x3")
+    assert not torch.equal(a[0], b[0]) and rel_err(b[0], a[0]) < 1e-5
     Lb = lib.load()
     for (b_, n_, nl) in ((64, 2562, 20), (B, n, L), (2, 162, 3), (8, 10242, 20)):
         for bwd in (0, 1):
@@ -199,7 +208,5 @@ def test_wide_cut_runs_exact_in_mode3_and_scratch_covers_every_mode(cuda):
     assert Lb.a3vt_gcn_stack_scratch_bytes(64, 2562, 50, H, 20, 99, 1) == \
         max(Lb.a3vt_gcn_stack_scratch_bytes_mode(64, 2562, 50, H, 20, 99, 1, m) for m in range(4))
     with pytest.raises(RuntimeError):
-        ws = [st[f"mesh_deform_1.layers.{i}.weight"].to(cuda) for i in range(L)]
-        bs = [st[f"mesh_deform_1.layers.{i}.bias"].to(cuda) for i in range(L)]
         with torch.no_grad():
-            ops.gcn_stack(torch.nn.functional.pad(feats, (0, 2)).to(cuda), adj, 50, H, 99, ws, bs, bf16=7)
+            ops.gcn_stack(fd, adj, 50, H, 99, ws, bs, bf16=7)
