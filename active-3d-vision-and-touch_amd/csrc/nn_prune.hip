@@ -99,9 +99,188 @@ struct NNClouds {   // the clouds of one Chamfer call: nx predicted clouds of p 
   int p, q, nx, ny;
   int npx, npy;     // padded points per cloud (multiple of 64)
   f32x4 *sx, *sy;   // sorted clouds  [n?][np?]
-  f32x4 *bx, *by;   // block boxes    [n?][np?/64][2]  (min xyz 0, max xyz 0)
-  f32x4 *ux, *uy;   // group boxes    [n?][np?/16][2]  one per 16 consecutive sorted points (4 per block)
+  f32x4 *bx, *by;   // block boxes    [n?][np?/64][2]  (min xyz 0, max xyz 0): the lane-parallel coarse test
+  float *ox, *oy;   // block ORIENTED boxes [n?][np?/64][16]  (Obb below)
+  float *gx, *gy;   // group oriented boxes [n?][np?/16][16]  one per 16 consecutive sorted points (4 per block)
 };
+
+// ---- oriented bounding boxes ---------------------------------------------------------------------------------------------
+// A sampled surface patch is thin along its normal: the axis-aligned box of 16-64 neighbouring samples of a tilted patch is
+// ~10 x thicker than the patch, and with the untrained network's surfaces 0.1-0.2 apart (patches 0.02-0.05 wide) every
+// patch within ~0.1 of the nearest one passes an axis-aligned bound — 78 groups of 16 candidates evaluated per wave of 64
+// queries at 10 000 points (profiles/r05_nn_pruning_stats.txt).  A box in the patch's own principal frame is as thin as the
+// patch, and a third as many pass.
+//
+// Record (16 floats = one s_load_dwordx16): centre c[3], three unit axes a[3][3], half extents e[3], pad.
+// Bound of a query q:  t_i = a_i . (q - c),  gap_i = max(|t_i| - e_i - mu, 0),  lb = (gap_0^2 + gap_1^2 + gap_2^2) (1 - 2^-16).
+// lb <= the COMPUTED squared distance from q to every point p of the box's group, by construction:
+//   * in exact arithmetic |a_i . (q - p)| >= |t_i(q)| - |t_i(p)| and sum_i (a_i . v)^2 <= (1 + d) |v|^2, where d < 2^-18 is
+//     what the Gram-Schmidt'ed fp32 axes lack of orthonormality (checked per box: norms and dot products within 2^-20);
+//   * t_i is computed by the SAME device function (obb_proj) for the points when the extents are taken and for the queries,
+//     with |rounding error| <= 2^-22 |v|_1 (three subtractions, a product and two fma with |a_ij| <= 1): the extents are
+//     stored inflated by 2^-20 max_p |p - c|_1 and the query pays mu = 2^-20 |q - c|_1;
+//   * the factor (1 - 2^-16) covers d, the roundings of the three squares and their sum, and the 3 x 2^-24 of the distance
+//     itself.
+// A candidate that ties or wins therefore always has lb <= best and is never skipped (the same guarantee the monotone
+// axis-aligned bounds gave, with margins instead of monotonicity).  Groups with no valid point store e = -3e38 (lb = +inf),
+// groups with a non-finite coordinate store e = +3e38 (lb = 0: never pruned by this bound).
+constexpr int kObbFloats = 16;
+constexpr float kObbMu = 9.5367431640625e-07f;          // 2^-20
+constexpr float kObbShrink = 1.0f - 1.52587890625e-05f;   // 1 - 2^-16
+
+__device__ __forceinline__ float obb_proj(float ax, float ay, float az, float dx, float dy, float dz) {
+  return __builtin_fmaf(az, dz, __builtin_fmaf(ay, dy, ax * dx));
+}
+// o: the record as four float4 (wave-uniform: scalar registers in the query kernel)
+struct Obb { f32x4 v[4]; };
+__device__ __forceinline__ float obb_lb(float qx, float qy, float qz, const Obb &o) {
+  const float dx = qx - o.v[0][0], dy = qy - o.v[0][1], dz = qz - o.v[0][2];
+  const float mu = (__builtin_fabsf(dx) + __builtin_fabsf(dy) + __builtin_fabsf(dz)) * kObbMu;
+  const float g0 = fmaxf(__builtin_fabsf(obb_proj(o.v[0][3], o.v[1][0], o.v[1][1], dx, dy, dz)) - (o.v[3][0] + mu), 0.f);
+  const float g1 = fmaxf(__builtin_fabsf(obb_proj(o.v[1][2], o.v[1][3], o.v[2][0], dx, dy, dz)) - (o.v[3][1] + mu), 0.f);
+  const float g2 = fmaxf(__builtin_fabsf(obb_proj(o.v[2][1], o.v[2][2], o.v[2][3], dx, dy, dz)) - (o.v[3][2] + mu), 0.f);
+  return __builtin_fmaf(g2, g2, __builtin_fmaf(g1, g1, g0 * g0)) * kObbShrink;
+}
+
+// Eigenvectors of a symmetric 3 x 3 matrix by cyclic Jacobi rotations (columns of V); any orthonormal V gives a VALID box,
+// the principal frame gives a thin one.
+__device__ inline void eig3_jacobi(float A[3][3], float V[3][3]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) V[i][j] = i == j ? 1.f : 0.f;
+  for (int sweep = 0; sweep < 6; ++sweep) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int p = k == 2 ? 1 : 0, q = k == 0 ? 1 : 2;
+      const float apq = A[p][q];
+      if (!(__builtin_fabsf(apq) > 1.0e-12f * (__builtin_fabsf(A[p][p]) + __builtin_fabsf(A[q][q])))) continue;
+      const float theta = (A[q][q] - A[p][p]) / (2.f * apq);
+      const float t = (theta >= 0.f ? 1.f : -1.f) / (__builtin_fabsf(theta) + __builtin_sqrtf(theta * theta + 1.f));
+      const float c = 1.f / __builtin_sqrtf(t * t + 1.f), sn = t * c;
+      const int r = 3 - p - q;
+      const float app = A[p][p], aqq = A[q][q], arp = A[r][p], arq = A[r][q];
+      A[p][p] = app - t * apq;
+      A[q][q] = aqq + t * apq;
+      A[p][q] = A[q][p] = 0.f;
+      A[r][p] = A[p][r] = c * arp - sn * arq;
+      A[r][q] = A[q][r] = sn * arp + c * arq;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const float vp = V[i][p], vq = V[i][q];
+        V[i][p] = c * vp - sn * vq;
+        V[i][q] = sn * vp + c * vq;
+      }
+    }
+  }
+}
+
+// The oriented box of the valid points among the 2^LOG lanes that share (lane >> LOG): every lane of the group gets the record.
+template <int LOG>
+__device__ inline void group_obb(const f32x4 v, bool valid, float out[kObbFloats]) {
+  auto gsum = [](float x) {
+#pragma unroll
+    for (int off = 1; off < (1 << LOG); off <<= 1) x += __shfl_xor(x, off, 64);
+    return x;
+  };
+  auto gmax = [](float x) {
+#pragma unroll
+    for (int off = 1; off < (1 << LOG); off <<= 1) x = fmaxf(x, __shfl_xor(x, off, 64));
+    return x;
+  };
+  auto gmin = [](float x) {
+#pragma unroll
+    for (int off = 1; off < (1 << LOG); off <<= 1) x = fminf(x, __shfl_xor(x, off, 64));
+    return x;
+  };
+  const float w = valid ? 1.f : 0.f;
+  const float n = gsum(w);
+#pragma unroll
+  for (int i = 0; i < kObbFloats; ++i) out[i] = 0.f;
+  out[3] = out[7] = out[11] = 1.f;
+  if (!(n > 0.f)) {   // no valid point: every bound against this group is +inf
+    out[12] = out[13] = out[14] = -3.0e38f;
+    return;
+  }
+  const float inv = 1.f / n;
+  float c[3], d[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    c[k] = gsum(valid ? v[k] : 0.f) * inv;
+    d[k] = valid ? v[k] - c[k] : 0.f;
+  }
+  float A[3][3], V[3][3];
+  A[0][0] = gsum(d[0] * d[0]), A[0][1] = A[1][0] = gsum(d[0] * d[1]), A[0][2] = A[2][0] = gsum(d[0] * d[2]);
+  A[1][1] = gsum(d[1] * d[1]), A[1][2] = A[2][1] = gsum(d[1] * d[2]), A[2][2] = gsum(d[2] * d[2]);
+  eig3_jacobi(A, V);
+#ifdef A3VT_DBG_NN_AABB   // A/B build: coordinate axes, i.e. the axis-aligned boxes of rounds 2-4 in this record (what the principal frame buys)
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) V[i][j] = i == j ? 1.f : 0.f;
+#endif
+  // axes = columns of V, re-orthonormalised (Gram-Schmidt; the third as the cross product of the first two)
+  float a[3][3];
+  {
+    float l = __builtin_sqrtf(V[0][0] * V[0][0] + V[1][0] * V[1][0] + V[2][0] * V[2][0]);
+    l = l > 0.f ? 1.f / l : 0.f;
+    a[0][0] = V[0][0] * l, a[0][1] = V[1][0] * l, a[0][2] = V[2][0] * l;
+    const float dt = a[0][0] * V[0][1] + a[0][1] * V[1][1] + a[0][2] * V[2][1];
+    float b0 = V[0][1] - dt * a[0][0], b1 = V[1][1] - dt * a[0][1], b2 = V[2][1] - dt * a[0][2];
+    l = __builtin_sqrtf(b0 * b0 + b1 * b1 + b2 * b2);
+    l = l > 0.f ? 1.f / l : 0.f;
+    a[1][0] = b0 * l, a[1][1] = b1 * l, a[1][2] = b2 * l;
+    a[2][0] = a[0][1] * a[1][2] - a[0][2] * a[1][1];
+    a[2][1] = a[0][2] * a[1][0] - a[0][0] * a[1][2];
+    a[2][2] = a[0][0] * a[1][1] - a[0][1] * a[1][0];
+  }
+  // centre of the box in its own frame, then the half extents about THAT centre in the arithmetic the queries use
+  float lo[3], hi[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float t = obb_proj(a[k][0], a[k][1], a[k][2], d[0], d[1], d[2]);
+    lo[k] = gmin(valid ? t : 3.0e38f);
+    hi[k] = gmax(valid ? t : -3.0e38f);
+  }
+  float cc[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    cc[k] = c[k] + 0.5f * ((lo[0] + hi[0]) * a[0][k] + (lo[1] + hi[1]) * a[1][k] + (lo[2] + hi[2]) * a[2][k]);
+  const float ex = valid ? v[0] - cc[0] : 0.f, ey = valid ? v[1] - cc[1] : 0.f, ez = valid ? v[2] - cc[2] : 0.f;
+  const float m1 = gmax(__builtin_fabsf(ex) + __builtin_fabsf(ey) + __builtin_fabsf(ez));
+  float e[3];
+  bool finite = m1 < 3.0e38f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float t = gmax(__builtin_fabsf(obb_proj(a[k][0], a[k][1], a[k][2], ex, ey, ez)));
+    e[k] = t * (1.f + kObbMu) + kObbMu * m1 + 1.0e-37f;
+    finite = finite && e[k] < 3.0e38f && __builtin_fabsf(cc[k]) < 3.0e38f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) finite = finite && __builtin_fabsf(a[k][j]) <= 1.0001f;
+  }
+  // (the axes must be orthonormal to 2^-18 for the bound: a frame that is not — zero vectors from a degenerate rotation,
+  // NaN — is replaced by the coordinate frame with unbounded extents)
+  const float n0 = a[0][0] * a[0][0] + a[0][1] * a[0][1] + a[0][2] * a[0][2];
+  const float n1 = a[1][0] * a[1][0] + a[1][1] * a[1][1] + a[1][2] * a[1][2];
+  const float n2 = a[2][0] * a[2][0] + a[2][1] * a[2][1] + a[2][2] * a[2][2];
+  const float d01 = a[0][0] * a[1][0] + a[0][1] * a[1][1] + a[0][2] * a[1][2];
+  const float d02 = a[0][0] * a[2][0] + a[0][1] * a[2][1] + a[0][2] * a[2][2];
+  const float d12 = a[1][0] * a[2][0] + a[1][1] * a[2][1] + a[1][2] * a[2][2];
+  const float tol = 9.5367431640625e-07f;   // 2^-20
+  finite = finite && __builtin_fabsf(n0 - 1.f) <= tol && __builtin_fabsf(n1 - 1.f) <= tol && __builtin_fabsf(n2 - 1.f) <= tol &&
+           __builtin_fabsf(d01) <= tol && __builtin_fabsf(d02) <= tol && __builtin_fabsf(d12) <= tol;
+  if (!finite) {   // never pruned by this bound (the axis-aligned coarse test and the distances themselves still decide)
+    out[12] = out[13] = out[14] = 3.0e38f;
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    out[k] = cc[k];
+    out[12 + k] = e[k];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) out[3 + 3 * k + j] = a[k][j];
+  }
+}
 
 __host__ __device__ inline int nn_grid_bits(int n) { return n > 20000 ? 5 : 4; }
 
@@ -210,10 +389,26 @@ __global__ __launch_bounds__(1024) void nn_boxes_kernel(NNClouds c, int wgs_per_
       hi[d] = fmaxf(hi[d], __shfl_xor(hi[d], off, 64));
     }
   }
-  f32x4 *sub = (isx ? c.ux + (size_t)cloud * (c.npx / 16) * 2 : c.uy + (size_t)(cloud - c.nx) * (c.npy / 16) * 2) + blk * 8;
-  if ((lane & 15) == 0) {   // a group without valid points keeps (3e38, -3e38): every bound against it is +inf
-    sub[(lane >> 4) * 2] = f32x4{lo[0], lo[1], lo[2], 0.f};
-    sub[(lane >> 4) * 2 + 1] = f32x4{hi[0], hi[1], hi[2], 0.f};
+  // oriented boxes: one per 16-point group (every lane of a group holds its record; lane 0 of the group stores it), one for
+  // the block
+  {
+    float o[kObbFloats];
+    group_obb<4>(v, valid, o);
+    float *go = (isx ? c.gx + (size_t)cloud * (c.npx / 16) * kObbFloats : c.gy + (size_t)(cloud - c.nx) * (c.npy / 16) * kObbFloats) +
+                (size_t)(blk * 4 + (lane >> 4)) * kObbFloats;
+    if ((lane & 15) < 4) {
+      const int k = lane & 15;
+      reinterpret_cast<f32x4 *>(go)[k] = k == 0 ? f32x4{o[0], o[1], o[2], o[3]} : k == 1 ? f32x4{o[4], o[5], o[6], o[7]}
+                                       : k == 2 ? f32x4{o[8], o[9], o[10], o[11]} : f32x4{o[12], o[13], o[14], o[15]};
+    }
+    group_obb<6>(v, valid, o);
+    float *bo = (isx ? c.ox + (size_t)cloud * (c.npx / kPB) * kObbFloats : c.oy + (size_t)(cloud - c.nx) * (c.npy / kPB) * kObbFloats) +
+                (size_t)blk * kObbFloats;
+    if (lane < 4) {
+      const int k = lane;
+      reinterpret_cast<f32x4 *>(bo)[k] = k == 0 ? f32x4{o[0], o[1], o[2], o[3]} : k == 1 ? f32x4{o[4], o[5], o[6], o[7]}
+                                       : k == 2 ? f32x4{o[8], o[9], o[10], o[11]} : f32x4{o[12], o[13], o[14], o[15]};
+    }
   }
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
@@ -229,11 +424,19 @@ __global__ __launch_bounds__(1024) void nn_boxes_kernel(NNClouds c, int wgs_per_
   }
 }
 
+#ifdef A3VT_DBG_NN_TRACE   // per-wave timeline only (tools/nn_trace.py): two s_memrealtime reads and one record per wave
+constexpr int kNNTraceWaves = 1 << 16;
+__device__ unsigned long long nn_trace[kNNTraceWaves][4];   // per wave: start, end (s_memrealtime, 100 MHz), pair / block, groups << 32 | tests
+__device__ unsigned nn_trace_n;
+#endif
 #ifdef A3VT_DBG_NN_STATS   // developer counters (tools/build_variants.sh nn): waves, blocks evaluated, point-box tests, slow paths
-__device__ unsigned long long nn_stats[8];
+__device__ unsigned long long nn_inflight;
+__device__ unsigned long long nn_stats[16];   // [8..13]: shader-clock cycles per phase (whole wave, seed search, tests, evaluations, tail)
 #define NN_STAT(i, v) do { if (lane == 0) atomicAdd(&nn_stats[i], (unsigned long long)(v)); } while (0)
+#define NN_CLOCK() __builtin_readcyclecounter()
 #else
 #define NN_STAT(i, v) do { } while (0)
+#define NN_CLOCK() 0ull
 #endif
 
 // Wave-uniform maximum / minimum of NON-NEGATIVE floats through their bit patterns (they order like unsigned integers):
@@ -265,7 +468,8 @@ __device__ __forceinline__ float wave_umin(float v) {
 }
 
 struct NNQuery {
-  const f32x4 *sx, *sy, *bx, *by, *ux, *uy;
+  const f32x4 *sx, *sy, *bx, *by;
+  const float *ox, *oy, *gx, *gy;   // oriented boxes of the blocks / of the 16-point groups
   int p, q, npx, npy, nz, batch;   // nz = draws * batch cloud pairs; pair z = (x cloud z, y cloud z % batch)
   float *dxy, *dyx;
   int32_t *ixy, *iyx;
@@ -283,39 +487,64 @@ __device__ __forceinline__ void nn_query_wave(const NNQuery &a, int y, int qblk,
   const f32x4 *__restrict__ qbox = fwd ? a.bx + (size_t)zx * nbx * 2 : a.by + (size_t)zy * nby * 2;
   const f32x4 *__restrict__ tpts = fwd ? a.sy + (size_t)zy * a.npy : a.sx + (size_t)zx * a.npx;
   const f32x4 *__restrict__ tbox = fwd ? a.by + (size_t)zy * nby * 2 : a.bx + (size_t)zx * nbx * 2;
-  const f32x4 *__restrict__ tsub = fwd ? a.uy + (size_t)zy * nby * 8 : a.ux + (size_t)zx * nbx * 8;
+  const float *__restrict__ tobb = fwd ? a.oy + (size_t)zy * nby * kObbFloats : a.ox + (size_t)zx * nbx * kObbFloats;
+  const float *__restrict__ tgrp = fwd ? a.gy + (size_t)zy * nby * 4 * kObbFloats : a.gx + (size_t)zx * nbx * 4 * kObbFloats;
   float *od = fwd ? a.dxy + (size_t)z * a.p : a.dyx + (size_t)z * a.q;
   int32_t *oi = fwd ? a.ixy + (size_t)z * a.p : a.iyx + (size_t)z * a.q;
 
   const f32x4 me = qpts[(size_t)qblk * kPB + lane];
   const int qidx = as_int(me[3]);
-  // pad lanes (last block of the cloud) ask for lane 0's point and write nothing
-  const float qx = qidx < 0 ? __shfl(me[0], 0, 64) : me[0];
-  const float qy = qidx < 0 ? __shfl(me[1], 0, 64) : me[1];
-  const float qz = qidx < 0 ? __shfl(me[2], 0, 64) : me[2];
+  // Pad lanes (last block of the cloud) ask for lane 0's point and write nothing.  Lane 0's coordinates are read with
+  // v_readlane BEFORE the select: as `qidx < 0 ? __shfl(me[0], 0, 64) : me[0]` the shuffle ran in the branch of the pad lanes
+  // only, where lane 0 is inactive — a bpermute from an inactive lane returns 0, so the pad lanes asked about the ORIGIN.
+  // Harmless for the results (they write nothing) and ruinous for the time whenever the origin is the centre of the target
+  // (the untrained network's sphere): everything is then equidistant, nothing can be pruned, and the last query block of
+  // every cloud evaluated 440-590 of the 625 groups — 192 waves of 2.2 ms each at the tail of a 1.5 ms launch
+  // (profiles/r05_nn_wave_timeline.txt).
+  const float q0x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(as_int(me[0]), 0));
+  const float q0y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(as_int(me[1]), 0));
+  const float q0z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(as_int(me[2]), 0));
+  const float qx = qidx < 0 ? q0x : me[0];
+  const float qy = qidx < 0 ? q0y : me[1];
+  const float qz = qidx < 0 ? q0z : me[2];
   const f32x4 qb0 = qbox[qblk * 2], qb1 = qbox[qblk * 2 + 1];
 
+  const unsigned long long clk0 = NN_CLOCK();
+  unsigned long long clk_test = 0, clk_eval = 0, clk_ld = 0, clk_bd = 0, clk_gr = 0;
+#ifdef A3VT_DBG_NN_STATS
+  if (lane == 0) clk_ld = atomicAdd(&nn_inflight, 1ull);   // waves of this kernel in flight when this one starts
+#endif
+#ifdef A3VT_DBG_NN_TRACE
+  const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   float best = 3.0e38f;
   int bsub = 0;        // 16-candidate group (block * 4 + quarter) that gave `best`
   bool tie = false;    // another group reproduced `best` exactly
   int n_grp = 0;       // (developer counter) 16-candidate groups evaluated
-  // Scalar loads return out of order, so a wave can only wait for ALL of them: every batch of loads below is issued
-  // back to back and waited for once (block box + the four group boxes; then the 16 candidates of a group).
-  struct GroupBoxes { f32x4 g[8]; };
-  auto load_groups = [&](int blk) {
-    GroupBoxes r;
-    const f32x4 *__restrict__ sb = tsub + (size_t)blk * 8;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) r.g[i] = sb[i];
-    return r;
-  };
-  auto eval = [&](int blk, const GroupBoxes &gb) {   // blk is wave-uniform: boxes and candidates go through the scalar cache
-    const f32x4 *__restrict__ tp = tpts + (size_t)blk * kPB;
+  // Wave-uniform data (a candidate block's oriented boxes, its 64 points) comes through the scalar cache: every batch of
+  // loads is issued back to back and waited for once (scalar loads return out of order).  (Delivering it through the vector
+  // path instead — each lane loads element lane & 15 of a record / one candidate of a group, DPP row broadcasts folded into
+  // the consuming v_sub / v_mul hand element k to the row at no instruction cost — is 17-25 % SLOWER at every size:
+  // tools/experiments/nn_query_vector_path_r05.patch)
+  auto eval = [&](int blk) {
+    // the oriented boxes of the block's four groups: 4 x s_load_dwordx16
+    const f32x4 *__restrict__ sg = reinterpret_cast<const f32x4 *>(tgrp) + (size_t)blk * 16;
     float lbs[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s)   // the group's own box: a quarter of the block's points sit in a box far smaller than the block's
-      lbs[s] = sq3(gap(qx, qx, gb.g[2 * s][0], gb.g[2 * s + 1][0]), gap(qy, qy, gb.g[2 * s][1], gb.g[2 * s + 1][1]),
-                   gap(qz, qz, gb.g[2 * s][2], gb.g[2 * s + 1][2]));
+    for (int s = 0; s < 4; ++s) {   // the group's own box: a quarter of the block's points sit in a box far thinner than the block's
+      Obb o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o.v[k] = sg[s * 4 + k];
+      lbs[s] = obb_lb(qx, qy, qz, o);
+    }
+    // (the four records are 64 scalar registers, a group's 16 candidates another 64: the candidate block index is redefined
+    // behind the four bounds, so that no candidate load is hoisted into the records' live range — that spilled 105 scalar
+    // registers into vector lanes.  Not volatile: a volatile asm counts as a store, and loads behind a store cannot use the
+    // scalar cache; readfirstlane because the compiler takes an asm result for divergent.)
+    int blk_c = blk;
+    asm("" : "+s"(blk_c) : "v"(lbs[0]), "v"(lbs[1]), "v"(lbs[2]), "v"(lbs[3]));
+    blk_c = __builtin_amdgcn_readfirstlane(blk_c);
+    const f32x4 *__restrict__ tp = tpts + (size_t)blk_c * kPB;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       if (__builtin_amdgcn_ballot_w64(lbs[s] <= best) == 0) continue;
@@ -342,8 +571,11 @@ __device__ __forceinline__ void nn_query_wave(const NNQuery &a, int y, int qblk,
     }
   };
   auto point_box = [&](int blk) {   // lower bound of this lane's distance to any point of candidate block blk (uniform)
-    const f32x4 t0 = tbox[blk * 2], t1 = tbox[blk * 2 + 1];
-    return sq3(gap(qx, qx, t0[0], t1[0]), gap(qy, qy, t0[1], t1[1]), gap(qz, qz, t0[2], t1[2]));
+    Obb o;
+    const f32x4 *__restrict__ sb = reinterpret_cast<const f32x4 *>(tobb) + (size_t)blk * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o.v[i] = sb[i];
+    return obb_lb(qx, qy, qz, o);
   };
   auto box_box = [&](int blk) {     // per lane: lower bound between the query block's box and candidate block blk's
     const f32x4 t0 = tbox[blk * 2], t1 = tbox[blk * 2 + 1];
@@ -368,8 +600,10 @@ __device__ __forceinline__ void nn_query_wave(const NNQuery &a, int y, int qblk,
   }
   const int seed = min(__builtin_amdgcn_readfirstlane(sblk), ntb - 1);
   int n_eval = 1, n_test = 0;
-  eval(seed, load_groups(seed));
-  float T = wave_umax(best);   // (wave-uniform) a block whose box-to-box bound exceeds this cannot help any lane
+  const unsigned long long clk1 = NN_CLOCK();
+  eval(seed);
+  float T = wave_umax(best);
+  const unsigned long long clk2 = NN_CLOCK();   // (wave-uniform) a block whose box-to-box bound exceeds this cannot help any lane
 
   for (int it = 0; it < ntb; it += 64) {
     const int b = it + lane;
@@ -377,20 +611,24 @@ __device__ __forceinline__ void nn_query_wave(const NNQuery &a, int y, int qblk,
     unsigned long long mask = __builtin_amdgcn_ballot_w64(lbb <= T && b < ntb && b != seed);
     while (mask) {
       // nearest surviving block first (box to box): the minima tighten early and the later blocks fail their tests
+      const unsigned long long ca = NN_CLOCK();
       const float mine = ((mask >> lane) & 1ull) ? lbb : 3.0e38f;
       const float nearest = wave_umin(mine);
       const unsigned long long pick = __builtin_amdgcn_ballot_w64(mine == nearest) & mask;
       const int bit = __builtin_ctzll(pick ? pick : mask);
       mask &= ~(1ull << bit);
       const int blk = it + bit;
-      const GroupBoxes gb = load_groups(blk);   // issued together with the block's own box: one wait for both
       const float lb = point_box(blk);
       ++n_test;
-      if (__builtin_amdgcn_ballot_w64(lb <= best) == 0) continue;   // <=: a candidate that TIES must still be seen
-      eval(blk, gb);
+      const bool skip = __builtin_amdgcn_ballot_w64(lb <= best) == 0;   // <=: a candidate that TIES must still be seen
+      const unsigned long long cb = NN_CLOCK();
+      clk_test += cb - ca;
+      if (skip) continue;
+      eval(blk);
       ++n_eval;
       T = wave_umax(best);
       mask &= __builtin_amdgcn_ballot_w64(lbb <= T);
+      clk_eval += NN_CLOCK() - cb;
     }
   }
 
@@ -405,12 +643,13 @@ __device__ __forceinline__ void nn_query_wave(const NNQuery &a, int y, int qblk,
       if (sq3(qx - cnd[0], qy - cnd[1], qz - cnd[2]) == best && ci >= 0) bidx = min(bidx, ci);
     }
   }
+  const unsigned long long clk3 = NN_CLOCK();
   NN_STAT(0, 1);
   NN_STAT(1, n_eval);
   NN_STAT(2, n_test);
   NN_STAT(5, n_grp);
 #ifdef A3VT_DBG_NN_STATS
-  if (lane == 0) atomicMax(&nn_stats[6], (unsigned long long)n_grp), atomicMax(&nn_stats[7], (unsigned long long)n_test);
+  if (lane == 0) atomicMax(&nn_stats[6], (unsigned long long)n_grp);
 #endif
 #ifdef A3VT_DBG_NN_STATS
   {   // blocks that HAD to be evaluated given the final minima (slot 3), blocks some lane needs on average (slot 2 reused below)
@@ -443,6 +682,33 @@ __device__ __forceinline__ void nn_query_wave(const NNQuery &a, int y, int qblk,
     od[qidx] = best;
     oi[qidx] = bidx;
   }
+#ifdef A3VT_DBG_NN_STATS
+  if (lane == 0) {
+    atomicMax(&nn_stats[13], clk3 - clk0);                     // slowest wave
+  }
+#endif
+#ifdef A3VT_DBG_NN_STATS
+  if (lane == 0) atomicAdd(&nn_inflight, ~0ull);
+#endif
+#ifdef A3VT_DBG_NN_TRACE
+  if (lane == 0) {
+    const unsigned slot = atomicAdd(&nn_trace_n, 1u);
+    if (slot < kNNTraceWaves) {
+      nn_trace[slot][0] = rt0;
+      nn_trace[slot][1] = __builtin_amdgcn_s_memrealtime();
+      nn_trace[slot][2] = (unsigned long long)y << 16 | (unsigned)(qblk & 0xffff);
+      nn_trace[slot][3] = ((unsigned long long)n_grp << 32) | (unsigned)n_test;
+    }
+  }
+#endif
+  NN_STAT(8, clk3 - clk0);
+  NN_STAT(14, clk_ld);
+  NN_STAT(15, clk_bd);
+  NN_STAT(7, clk_gr);
+  NN_STAT(9, clk1 - clk0);
+  NN_STAT(10, clk2 - clk1);
+  NN_STAT(11, clk_test);
+  NN_STAT(12, clk_eval);
 }
 
 // grid = ceil(query blocks / waves per workgroup) x 2 nz, flattened (the query blocks of one cloud pair are consecutive
@@ -450,7 +716,14 @@ __device__ __forceinline__ void nn_query_wave(const NNQuery &a, int y, int qblk,
 __global__ __launch_bounds__(1024) void nn_query_kernel(NNQuery a, int wgs_per_pair) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int y = blockIdx.x / wgs_per_pair, bx = blockIdx.x % wgs_per_pair;
+  // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one), each with its own 4 MiB L2.  In launch
+  // order every cloud pair's query blocks would be spread over all eight L2s — each of them then needs the sorted points and
+  // boxes of EVERY pair in flight (~40 pairs x 0.2-1 MB) and misses to the Infinity Cache on most candidate fetches.  The
+  // bijective remap below hands every XCD a contiguous eighth of the (pair, query block) list: a pair's workgroups share ONE
+  // L2 and ~5 pairs are live per XCD.  (Placement is a speed matter only; results do not depend on it.)
+  const int nwg = gridDim.x, xq = nwg >> 3, xr = nwg & 7, xcd = blockIdx.x & 7;
+  const int wg = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+  const int y = wg / wgs_per_pair, bx = wg % wgs_per_pair;
   nn_query_wave(a, y, bx * (blockDim.x >> 6) + wave, lane);
 }
 
@@ -467,9 +740,13 @@ static NNClouds nn_layout(const float *x, const float *y, int draws, int batch, 
   w += (size_t)c.nx * (c.npx / kPB) * 2 * sizeof(f32x4);
   c.by = reinterpret_cast<f32x4 *>(w);
   w += (size_t)c.ny * (c.npy / kPB) * 2 * sizeof(f32x4);
-  c.ux = reinterpret_cast<f32x4 *>(w);
-  w += (size_t)c.nx * (c.npx / 16) * 2 * sizeof(f32x4);
-  c.uy = reinterpret_cast<f32x4 *>(w);
+  c.ox = reinterpret_cast<float *>(w);
+  w += (size_t)c.nx * (c.npx / kPB) * kObbFloats * sizeof(float);
+  c.oy = reinterpret_cast<float *>(w);
+  w += (size_t)c.ny * (c.npy / kPB) * kObbFloats * sizeof(float);
+  c.gx = reinterpret_cast<float *>(w);
+  w += (size_t)c.nx * (c.npx / 16) * kObbFloats * sizeof(float);
+  c.gy = reinterpret_cast<float *>(w);
   return c;
 }
 
@@ -477,7 +754,7 @@ size_t nn_pruned_workspace_bytes(int draws, int batch, int p, int q) {
   const size_t nx = (size_t)draws * batch, ny = batch;
   const size_t npx = (size_t)cdiv(p, kPB) * kPB, npy = (size_t)cdiv(q, kPB) * kPB;
   return (nx * npx + ny * npy) * sizeof(f32x4) + (nx * (npx / kPB) + ny * (npy / kPB)) * 2 * sizeof(f32x4) +
-         (nx * (npx / 16) + ny * (npy / 16)) * 2 * sizeof(f32x4);
+         (nx * (npx / kPB) + ny * (npy / kPB) + nx * (npx / 16) + ny * (npy / 16)) * kObbFloats * sizeof(float);
 }
 
 int launch_nn_pruned(const float *x, const float *y, int draws, int batch, int p, int q, float *dxy, int32_t *ixy,
@@ -513,7 +790,7 @@ int launch_nn_pruned(const float *x, const float *y, int draws, int batch, int p
   A3VT_LAUNCH(nn_boxes_kernel, dim3((unsigned)box_wgs), dim3(1024), 0, s, c, cdiv(nbmax, 16));
   A3VT_CHECK_LAUNCH();
   if (stages < 3) return 0;
-  NNQuery a{c.sx, c.sy, c.bx, c.by, c.ux, c.uy, p, q, c.npx, c.npy, c.nx, y_batch, dxy, dyx, ixy, iyx};
+  NNQuery a{c.sx, c.sy, c.bx, c.by, c.ox, c.oy, c.gx, c.gy, p, q, c.npx, c.npy, c.nx, y_batch, dxy, dyx, ixy, iyx};
   A3VT_LAUNCH(nn_query_kernel, dim3((unsigned)query_wgs), dim3(64 * wg_waves_q), 0, s, a, cdiv(nbmax, wg_waves_q));
   A3VT_CHECK_LAUNCH();
   return 0;
@@ -522,8 +799,18 @@ int launch_nn_pruned(const float *x, const float *y, int draws, int batch, int p
 }  // namespace a3vt
 
 #ifdef A3VT_DBG_NN_STATS
+#endif
+#ifdef A3VT_DBG_NN_TRACE
+extern "C" int a3vt_dbg_nn_trace(unsigned long long *out, unsigned *n) {   // per-wave records of the last query launches; clears
+  unsigned zero = 0;
+  if (hipMemcpyFromSymbol(n, HIP_SYMBOL(a3vt::nn_trace_n), sizeof(unsigned)) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(a3vt::nn_trace), sizeof(unsigned long long) * 4 * a3vt::kNNTraceWaves) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(a3vt::nn_trace_n), &zero, sizeof(unsigned)) == hipSuccess ? 0 : -1;
+}
+#endif
+#ifdef A3VT_DBG_NN_STATS
 extern "C" int a3vt_dbg_nn_stats(unsigned long long *out5) {   // reads and clears the counters
-  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (hipMemcpyFromSymbol(out5, HIP_SYMBOL(a3vt::nn_stats), sizeof(z)) != hipSuccess) return -1;
   return hipMemcpyToSymbol(HIP_SYMBOL(a3vt::nn_stats), z, sizeof(z)) == hipSuccess ? 0 : -1;
 }

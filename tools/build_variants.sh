@@ -43,6 +43,8 @@ elif [ "$1" = "env" ]; then   # the developer environment overrides (A3VT_RG_MAX
   build ENV -DA3VT_DBG_ENV
 elif [ "$1" = "nn" ]; then   # pruned nearest-neighbour search with its counters (tools/nn_stats.py)
   build NN_STATS -DA3VT_DBG_NN_STATS
+  build NN_AABB -DA3VT_DBG_NN_AABB       # A/B: the boxes in the coordinate frame (axis-aligned, rounds 2-4) instead of the principal frame
+  build NN_TRACE -DA3VT_DBG_NN_TRACE     # per-wave timeline only (tools/nn_trace.py): start / end / groups evaluated
 elif [ "$1" = "stamps" ]; then   # rowgemm with s_memrealtime stamps at its phase boundaries (tools/rowgemm_stamps.py)
   build RG_STAMPS -DA3VT_DBG_RG_STAMPS
 elif [ "$1" = "adirect" ]; then   # A/B builds for the round-3 product kernels (A3VT_LIB=$GRAFT_REPO_ROOT/gpurun_variants/...)

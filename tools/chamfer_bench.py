@@ -14,6 +14,9 @@ from a3vt_amd import ops  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--algos", default="sweep,pruned")
 ap.add_argument("--shapes", default="3x64x10000,3x64x25000,3x8x50000")
+ap.add_argument("--geometry", default="synthetic", choices=["synthetic", "bench"],
+                help="synthetic: sphere 0.4 (+gap) against the ellipsoid (0.5, 0.3, 0.2); bench: what bench.py's untrained network "
+                     "sees — a sphere of radius 0.25 against ellipsoids with semi-axes U(0.05, 0.16) (a3vt_amd.synthetic.gt_cloud)")
 ap.add_argument("--gap", type=float, default=0.05, help="offset between the predicted and the ground-truth surface")
 ap.add_argument("--reps", type=int, default=5)
 args = ap.parse_args()
@@ -29,8 +32,11 @@ def surface(*shape, radii):
 
 for shape in args.shapes.split(","):
     draws, B, N = (int(v) for v in shape.split("x"))
-    x = surface(draws, B, N, radii=(0.4, 0.4, 0.4)) + args.gap         # the predicted surface: a sphere, a little off
-    y = surface(B, N, radii=(0.5, 0.3, 0.2))                            # ground truth: an ellipsoid
+    if args.geometry == "bench":
+        from a3vt_amd.synthetic import gt_cloud
+        x, y = surface(draws, B, N, radii=(0.25, 0.25, 0.25)), gt_cloud(B, N, 0).to(dev)
+    x = x if args.geometry == "bench" else surface(draws, B, N, radii=(0.4, 0.4, 0.4)) + args.gap         # the predicted surface: a sphere, a little off
+    y = y if args.geometry == "bench" else surface(B, N, radii=(0.5, 0.3, 0.2))                            # ground truth: an ellipsoid
     ref = None
     for algo in args.algos.split(","):
         out = ops.chamfer_nn(x, y, algo=algo)

@@ -14,6 +14,9 @@ from a3vt_amd import lib, ops  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--shapes", default="3x64x10000,3x64x25000,3x8x50000")
+ap.add_argument("--geometry", default="synthetic", choices=["synthetic", "bench"],
+                help="synthetic: sphere 0.4 (+gap) against the ellipsoid (0.5, 0.3, 0.2); bench: what bench.py's untrained network "
+                     "sees — a sphere of radius 0.25 against ellipsoids with semi-axes U(0.05, 0.16) (a3vt_amd.synthetic.gt_cloud)")
 ap.add_argument("--gap", type=float, default=0.05)
 args = ap.parse_args()
 L = lib.load()
@@ -29,9 +32,12 @@ def surface(*shape, radii):
 
 for shape in args.shapes.split(","):
     draws, B, N = (int(v) for v in shape.split("x"))
-    x = surface(draws, B, N, radii=(0.4, 0.4, 0.4)) + args.gap
-    y = surface(B, N, radii=(0.5, 0.3, 0.2))
-    out = (ctypes.c_ulonglong * 8)()
+    if args.geometry == "bench":
+        from a3vt_amd.synthetic import gt_cloud
+        x, y = surface(draws, B, N, radii=(0.25, 0.25, 0.25)), gt_cloud(B, N, 0).to(dev)
+    x = x if args.geometry == "bench" else surface(draws, B, N, radii=(0.4, 0.4, 0.4)) + args.gap
+    y = y if args.geometry == "bench" else surface(B, N, radii=(0.5, 0.3, 0.2))
+    out = (ctypes.c_ulonglong * 16)()
     torch.cuda.synchronize()
     L.a3vt_dbg_nn_stats(out)
     ops.chamfer_nn(x, y, algo="pruned")
@@ -39,4 +45,6 @@ for shape in args.shapes.split(","):
     L.a3vt_dbg_nn_stats(out)
     w = max(out[0], 1)
     print(f"{shape:>14s} gap {args.gap}: {out[0]} waves, {out[1] / w:.1f} blocks ({out[5] / w:.1f} groups of 16) evaluated and {out[2] / w:.1f} point-box tests per wave "
-          f"(of {(N + 63) // 64} blocks); {out[3] / w:.1f} blocks needed by some lane given the final minima, {out[4] / w / 64:.1f} by a lane on average; worst wave: {out[6]} groups, {out[7]} tests")
+          f"(of {(N + 63) // 64} blocks; shader cycles per wave: {out[8] / w:.0f} = seed search {out[9] / w:.0f} + seed evaluation {out[10] / w:.0f} + "
+          f"tests {out[11] / w:.0f} + evaluations {out[12] / w:.0f} + rest {(out[8] - out[9] - out[10] - out[11] - out[12]) / w:.0f}; "
+          f"waves of the kernel in flight when a wave starts: {out[14] / w:.0f} = {out[14] / w / 1024:.2f} per SIMD; slowest wave {out[13]}); {out[3] / w:.1f} blocks needed by some lane given the final minima, {out[4] / w / 64:.1f} by a lane on average; worst wave: {out[6]} groups")
