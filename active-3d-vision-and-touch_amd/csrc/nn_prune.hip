@@ -9,26 +9,33 @@
 //                       sort of the points by the Hilbert-curve position of their cell (histogram and cursors in LDS).  The sorted
 //                       cloud is stored as float4 (x, y, z, original index): 64 consecutive points — a "block" — are a
 //                       compact patch of the surface.
-//   2. nn_boxes_kernel  the axis-aligned bounding box of every block (one wave each); pads the last block.
+//   2. nn_boxes_kernel  per block (one wave each): its axis-aligned bounding box (the lane-parallel coarse test), an ORIENTED box
+//                       in the principal frame of its 64 points and one per 16-point group (below: "oriented bounding
+//                       boxes"); pads the last block.
 //   3. nn_query_kernel  one wave per block of 64 sorted QUERIES (one per lane, so the lanes of a wave ask about the same
 //                       neighbourhood).  The wave tests the candidate blocks 64 at a time, lane-parallel, box against
 //                       box; a block survives if its box-to-box lower bound does not exceed the worst "best so far" of
-//                       the wave, is then tested per lane (point to box) and evaluated — 64 candidates broadcast through
-//                       the scalar cache, 6.5 VALU operations per pair as in the brute-force loop — only if some lane can
-//                       still improve.  Every bound is computed with the same monotone floating-point operations as the
-//                       distances themselves (differences, products, fma), so bound <= distance holds for the COMPUTED
-//                       values and pruning with "bound > best" can never drop a candidate that ties or wins.
+//                       the wave, is then tested per lane (point to oriented box), then its four groups (point to the
+//                       group's oriented box), and only groups some lane can still improve on are evaluated — 16 candidates
+//                       broadcast through the scalar cache, 6.5 VALU operations per pair as in the brute-force loop.
+//                       Every bound is <= the COMPUTED distance to every point it covers (monotone arithmetic for the
+//                       axis-aligned boxes, stated margins for the oriented ones), so pruning with "bound > best" can
+//                       never drop a candidate that ties or wins.
 //                       The arg-min is kept per 16-candidate group in the hot loop and resolved afterwards by rescanning
 //                       that group for the lowest original index; if another group tied the minimum exactly (duplicate
 //                       points), the wave rescans every block that can hold the distance — rare, and exact.
 //
-// Work per query grows slowly with the cloud instead of in proportion to it.  Measured (3 draws x 64 clouds, sphere against
-// ellipsoid, tools/chamfer_bench.py): 10k points 0.9 ms against 3.8 ms for the single-sweep brute force, 25k 2.5 against
-// 20.4, 50k (3 x 8 clouds) 1.7 against 12.0.  The query kernel issues 0.19 VALU instructions per SIMD-cycle (the brute-force
-// loop 0.32) in bursts of ~100 between wave-uniform decisions; variants that halve the scalar fetches per query (two query
-// blocks per wave) or remove them (candidates through vector loads + DPP row_newbcast, next block prefetched) are not
-// faster, a persistent grid is slower — DESIGN.md §4, §8.  All kernels are deterministic in their outputs (the order of points inside a grid cell
-// depends on LDS atomics, the minima do not).
+// Work per query grows slowly with the cloud instead of in proportion to it.  Measured (3 draws x 64 clouds, tools/chamfer_bench.py,
+// profiles/r05_chamfer_search.txt; ms per Chamfer forward): the untrained network's geometry (sphere 0.25 against ellipsoids of
+// 0.05-0.16, concentric) 10k points 1.17, 25k 3.12, 3 x 8 x 50k 1.63 against 3.8 / 20.0 / 12.0 for the single-sweep brute
+// force; a sphere against an offset ellipsoid 0.90 / 2.23 / 1.05.  Round 4 took 2.96 / 8.09 / 8.50 and 0.93 / 2.56 / 1.74:
+// what changed is (a) the oriented boxes — a sampled surface patch is ~10 x thinner along its normal than its axis-aligned
+// box, and with the surfaces 0.1-0.2 apart three times as many axis-aligned boxes passed the bound — and (b) the pad lanes of a
+// cloud's last query block, which asked about the origin instead of repeating lane 0's point (nn_query_wave).
+// Variants that halve the scalar fetches per query (two query blocks per wave), remove them (candidates and boxes through
+// vector loads + DPP row_newbcast, 17-25 % slower) or interleave clouds over CUs (persistent grid) are not faster — DESIGN.md
+// §4, §8.  All kernels are deterministic in their outputs (the order of points inside a grid cell depends on LDS atomics, the
+// minima do not).
 #include <stdlib.h>
 
 #include "common.h"

@@ -252,3 +252,30 @@ def test_shared_ground_truth_equals_repeated(cuda, algo):
         assert torch.equal(ops.ChamferFn.apply(x, y), ops.ChamferFn.apply(x, y.repeat(K, 1, 1)))
     with pytest.raises(RuntimeError, match="forward-only"):
         ops.ChamferFn.apply(x.clone().requires_grad_(True), y).sum().backward()
+
+
+@pytest.mark.parametrize("P,Q", [(10000, 10000), (4133, 9001), (25000, 2500)])
+def test_oriented_boxes_on_concentric_thin_and_tilted_surfaces(cuda, P, Q):
+    """Round 5: the pruning bounds are oriented boxes in the principal frame of every block / group (valid through stated
+    margins, not through monotone arithmetic).  The geometries that lean on them hardest: concentric surfaces 0.1-0.2 apart
+    (the untrained network: a sphere of 0.25 around small ellipsoids — also the configuration in which the pad lanes of a
+    cloud's last query block used to ask about the origin), a sphere sampled from its own centre region, tilted thin slabs
+    (boxes 1000 x thinner than wide), exactly planar tilted patches and a cloud far from the origin (margins relative to the
+    coordinates' magnitude).  Bit for bit the brute force."""
+    g = torch.Generator().manual_seed(P + 7 * Q)
+
+    def unit(n):
+        u = torch.randn(n, 3, generator=g)
+        return u / u.norm(dim=1, keepdim=True)
+
+    rot = torch.linalg.qr(torch.randn(3, 3, generator=g))[0]
+    sphere = 0.25 * unit(P)
+    ell = unit(Q) * torch.tensor([0.05, 0.16, 0.09])
+    tiny = 0.01 * unit(Q)                                             # queries near the centre: everything is about equally far
+    slab = (torch.rand(P, 3, generator=g) - 0.5) * torch.tensor([0.6, 0.6, 6e-4]) @ rot.T
+    plane = torch.cat(((torch.rand(Q, 2, generator=g) - 0.5) * 0.5, torch.zeros(Q, 1)), dim=1) @ rot.T + 0.07
+    far = sphere + torch.tensor([1000.0, -2000.0, 500.0])
+    x = torch.stack([torch.stack([sphere, slab, sphere, far])]).float()
+    y = torch.stack([ell, plane, tiny, ell + torch.tensor([1000.0, -2000.0, 500.0])]).float()
+    _assert_same(*_both(x, y, cuda))
+    _assert_same(*_both(y[None], x[0], cuda))
