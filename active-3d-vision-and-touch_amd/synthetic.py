@@ -63,6 +63,31 @@ class SyntheticLoader:
             yield b
 
 
+def surface_touch_charts(gt, charts, generator):
+    """SURVEY 8d, touch inputs of configs[3]: per sample ``charts`` touch charts — the packaged 25-vertex chart (a 5 x 5 grid,
+    1.7 cm wide, vertex 4 its centre) laid tangent to the ground-truth surface at a randomly chosen point of the cloud, mask
+    token 2 (a successful touch).  ``gt`` (B,P,3) points on an origin-centred ellipsoid.  Returns (B, charts, 25, 4).
+    (Until round 4 the configs[3] stand-in drew every chart VERTEX uniformly in a 0.3 cube: 32 faces per chart spanning the
+    whole volume, which the area-weighted sampler then covered with points — a surface no touch sensor produces, and one
+    whose samples near the centre defeat any nearest-neighbour pruning.)"""
+    from . import mesh as amesh
+    tv = torch.from_numpy(amesh.load_asset("touch_chart")[0]).float()          # (25,3): x = normal, (y,z) = tangent coordinates
+    B, P, _ = gt.shape
+    idx = torch.randint(0, P, (B, charts), generator=generator)
+    p = torch.gather(gt, 1, idx[..., None].expand(B, charts, 3))               # (B,charts,3) surface points
+    ax = gt.abs().amax(dim=1, keepdim=True)                                    # semi-axes of each sample's ellipsoid
+    n = p / (ax * ax)
+    n = n / n.norm(dim=-1, keepdim=True)
+    e = torch.zeros_like(n)
+    e.scatter_(-1, n.abs().argmin(dim=-1, keepdim=True), 1.0)                  # the coordinate axis least aligned with n
+    t1 = torch.linalg.cross(n, e)
+    t1 = t1 / t1.norm(dim=-1, keepdim=True)
+    t2 = torch.linalg.cross(n, t1)
+    v = p[:, :, None, :] + tv[None, None, :, 0:1] * n[:, :, None, :] + tv[None, None, :, 1:2] * t1[:, :, None, :] \
+        + tv[None, None, :, 2:3] * t2[:, :, None, :]
+    return torch.cat((v, torch.full((B, charts, 25, 1), 2.0)), dim=-1)
+
+
 # ---- BASELINE.json configs[3] / configs[4] on one GPU (bench.py `named_configs`, tools/named_configs.py) ----------------
 def gcn_activation_bytes(batch, n_vert, in_features, hidden, layers, stages=3, elem=4):
     """SURVEY §8d ``Bytes_act`` for a whole batch: ``S * 3 * sum_i elem * N * (d_i + d_{i+1})`` with the layer widths
@@ -75,7 +100,7 @@ def gcn_activation_bytes(batch, n_vert, in_features, hidden, layers, stages=3, e
 
 def named_config(which, dev, precision="bf16s", batch=None):
     """Model and synthetic inputs of BASELINE.json configs[3] (vision + touch: image model with the default CNNs + chart
-    atlas with 4 touch charts, N = 1924, 25 000-point Chamfer, bs 64) or configs[4]'s per-GPU shard (10 242-vertex
+    atlas with 4 touch charts laid on the ground-truth surface, N = 1924, 25 000-point Chamfer, bs 64) or configs[4]'s per-GPU shard (10 242-vertex
     icosphere-5, 50 000-point Chamfer, bs 8 of the global 64).  Returns a dict; ``NamedStep`` runs training steps on it."""
     from . import mesh as amesh
     from .pterotactyl.reconstruction.vision import model
@@ -88,9 +113,8 @@ def named_config(which, dev, precision="bf16s", batch=None):
         info, verts = utils.load_mesh_vision(args, "vision_charts")
         torch.manual_seed(0)
         net = model.Deformation(info, verts, args).to(dev)
-        tc = torch.zeros(B, 1, 4, 25, 4)
-        tc[..., :3] = (torch.rand(B, 1, 4, 25, 3, generator=g) - 0.5) * 0.3
-        tc[..., 3] = 2
+        gt = gt_cloud(B, args.number_points, 0)
+        tc = surface_touch_charts(gt, 4, g).view(B, 1, 4, 25, 4)
         img = torch.rand(B, 3, 256, 256, generator=g).to(dev)
         charts = model.prepare_mesh({"img": img, "touch_charts": tc}, verts, args)
         n_vert = int(verts.shape[0]) + 100
@@ -111,7 +135,7 @@ def named_config(which, dev, precision="bf16s", batch=None):
         in_features = 50
     else:
         raise ValueError(which)
-    gt = gt_cloud(B, args.number_points, 0).to(dev)
+    gt = gt_cloud(B, args.number_points, 0).to(dev)   # (the same clouds the touch charts of configs[3] were placed on)
     elem = 2 if precision == "bf16s" else 4
     return {"name": name, "net": net, "info": info, "charts": charts, "img": img, "gt": gt, "args": args, "batch": B,
             "n_vert": n_vert, "in_features": in_features,
