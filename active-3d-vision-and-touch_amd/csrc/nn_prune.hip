@@ -156,15 +156,17 @@ __device__ inline void eig3_jacobi(float A[3][3], float V[3][3]) {
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) V[i][j] = i == j ? 1.f : 0.f;
-  for (int sweep = 0; sweep < 6; ++sweep) {
+  // (hardware reciprocal / square-root approximations: a rotation that is orthonormal to 1e-6 only is good enough — the frame
+  // is re-orthonormalised exactly by the caller and checked; four sweeps bring a 3 x 3 matrix to fp32 convergence)
+  for (int sweep = 0; sweep < 4; ++sweep) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int p = k == 2 ? 1 : 0, q = k == 0 ? 1 : 2;
       const float apq = A[p][q];
       if (!(__builtin_fabsf(apq) > 1.0e-12f * (__builtin_fabsf(A[p][p]) + __builtin_fabsf(A[q][q])))) continue;
-      const float theta = (A[q][q] - A[p][p]) / (2.f * apq);
-      const float t = (theta >= 0.f ? 1.f : -1.f) / (__builtin_fabsf(theta) + __builtin_sqrtf(theta * theta + 1.f));
-      const float c = 1.f / __builtin_sqrtf(t * t + 1.f), sn = t * c;
+      const float theta = (A[q][q] - A[p][p]) * __builtin_amdgcn_rcpf(2.f * apq);
+      const float t = (theta >= 0.f ? 1.f : -1.f) * __builtin_amdgcn_rcpf(__builtin_fabsf(theta) + __builtin_amdgcn_sqrtf(theta * theta + 1.f));
+      const float c = __builtin_amdgcn_rsqf(t * t + 1.f), sn = t * c;
       const int r = 3 - p - q;
       const float app = A[p][p], aqq = A[q][q], arp = A[r][p], arq = A[r][q];
       A[p][p] = app - t * apq;
