@@ -279,3 +279,35 @@ def test_oriented_boxes_on_concentric_thin_and_tilted_surfaces(cuda, P, Q):
     y = torch.stack([ell, plane, tiny, ell + torch.tensor([1000.0, -2000.0, 500.0])]).float()
     _assert_same(*_both(x, y, cuda))
     _assert_same(*_both(y[None], x[0], cuda))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_oriented_boxes_fuzz_over_scales_and_shapes(cuda, seed):
+    """The oriented boxes prune through stated margins (2^-20 of the coordinates' magnitude, 2^-16 on the bound): random
+    clouds under random affine maps — scales from 1e-6 to 1e4, anisotropy up to 1e4 : 1 (needles and sheets), offsets up to
+    1e3 times the extent, mixtures of a surface and a volume, sizes that leave 1-63 valid lanes in the last block — must stay
+    bit for bit the brute force in both directions."""
+    g = torch.Generator().manual_seed(1000 + seed)
+
+    def cloud(n):
+        kind = int(torch.randint(0, 4, (1,), generator=g))
+        u = torch.randn(n, 3, generator=g)
+        if kind == 0:
+            p = u / u.norm(dim=1, keepdim=True)                                  # a sphere
+        elif kind == 1:
+            p = torch.rand(n, 3, generator=g) - 0.5                              # a volume
+        elif kind == 2:
+            p = torch.cat((u[: n // 2] / u[: n // 2].norm(dim=1, keepdim=True), 0.3 * (torch.rand(n - n // 2, 3, generator=g) - 0.5)))
+        else:
+            p = torch.cat((torch.rand(n, 2, generator=g) - 0.5, torch.zeros(n, 1)), dim=1)   # a plane
+        stretch = torch.diag(10.0 ** (torch.rand(3, generator=g) * 4 - 2))       # up to 1e4 : 1
+        rot = torch.linalg.qr(torch.randn(3, 3, generator=g))[0]
+        return p @ stretch @ rot.T
+
+    scale = 10.0 ** float(torch.rand(1, generator=g) * 10 - 6)
+    shift = scale * (10.0 ** float(torch.rand(1, generator=g) * 3)) * torch.randn(3, generator=g) * float(torch.rand(1, generator=g) < 0.5)
+    P = int(torch.randint(2049, 6000, (1,), generator=g))
+    Q = int(torch.randint(2049, 6000, (1,), generator=g))
+    x = torch.stack([torch.stack([scale * cloud(P) + shift for _ in range(2)])]).float()
+    y = torch.stack([scale * cloud(Q) + shift + scale * 0.3 * torch.randn(3, generator=g) for _ in range(2)]).float()
+    _assert_same(*_both(x, y, cuda))
