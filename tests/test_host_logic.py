@@ -406,3 +406,57 @@ def test_bench_refuses_more_gpus_than_visible_before_launching_anything():
     res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(max(n, 2)), "--steps", "1"],
                          capture_output=True, text=True, timeout=300, env=env)
     assert res.returncode != 0 and "visible" in res.stderr and "torch.distributed.run" not in res.stderr
+
+
+def test_named_config_inputs_and_roofline_bytes():
+    """Round 5: the stand-ins bench.py times for BASELINE configs[3] / configs[4].  (i) The algorithmic activation bytes are
+    SURVEY 8d's formula — it reproduces BASELINE.md section 3's figures for cfg-2 / cfg-4 / cfg-5.  (ii) The touch charts of the
+    configs[3] stand-in lie ON the ground-truth surface, are the packaged 1.7 cm chart rigidly placed, and carry the
+    'touched' token."""
+    from a3vt_amd.synthetic import gcn_activation_bytes, gt_cloud, surface_touch_charts
+    assert abs(gcn_activation_bytes(64, 2562, 50, 300, 20, 3, 4) / 1e9 - 67.6) < 0.05
+    assert abs(gcn_activation_bytes(64, 2662, 50, 300, 20, 3, 2) / 1e9 - 35.1) < 0.05
+    assert abs(gcn_activation_bytes(64, 10242, 50, 300, 20, 3, 2) / 1e9 - 135.1) < 0.1
+    g = torch.Generator().manual_seed(3)
+    gt = gt_cloud(5, 4000, 7)
+    tc = surface_touch_charts(gt, 4, g)
+    assert tc.shape == (5, 4, 25, 4) and (tc[..., 3] == 2).all()
+    ax = gt.abs().amax(dim=1)                                             # the ellipsoids' semi-axes
+    centre = tc[:, :, 4, :3]
+    on_surface = ((centre / ax[:, None]) ** 2).sum(-1)
+    assert (on_surface - 1.0).abs().max() < 0.02                          # chart centres are points of the cloud
+    tv = torch.from_numpy(amesh.load_asset("touch_chart")[0]).float()
+    d_ref = torch.cdist(tv, tv)
+    for b in range(5):
+        for k in range(4):                                                # rigid placement: all pairwise distances preserved
+            assert torch.allclose(torch.cdist(tc[b, k, :, :3], tc[b, k, :, :3]), d_ref, atol=2e-6)
+    # tangent to the surface: the chart's normal offsets from its centre are tiny next to its 8.7 mm half-width
+    n = centre / (ax[:, None] ** 2)
+    n = n / n.norm(dim=-1, keepdim=True)
+    off = ((tc[..., :3] - centre[:, :, None]) * n[:, :, None]).sum(-1).abs().max()
+    assert off < 5e-4
+
+
+def test_bench_self_launch_command_line(monkeypatch):
+    """bench.py's launcher-less path builds the driver's launch line from ITS OWN arguments (minus the launcher choice) and
+    starts it as a child process — here with subprocess.call and the device count replaced, on the CPU."""
+    import importlib.util
+    import subprocess
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--launcher", "auto", "--warmup=2", "--launcher=spawn"])
+    a = bench.parse()
+    assert bench.self_launch(a) == 0
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    tail = cmd[cmd.index(os.path.join(ROOT, "bench.py")) + 1:]
+    assert tail == ["--gpus", "4", "--steps", "7", "--warmup=2", "--launcher", "none"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 2)
+    assert bench.self_launch(a) == 2                                      # refused: 4 asked, 2 visible
