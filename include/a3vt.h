@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define A3VT_VERSION 140 /* 140: gemm_bf16 = 3 ("fp32x3": fp32 products as six bf16 MFMA passes on exactly split operands), a3vt_split3_bf16; 0.2.x: bf16 storage mode (gemm_bf16 = 2), a3vt_gcn_stack_stash_bytes / _scratch_bytes_mode, deterministic backward scatters; 120: a3vt_chamfer_fwd_ws (pruned exact search); 130: a3vt_posenc_wide_* (448-wide vertex-feature encoder), larger a3vt_gcn_stack_mask_bytes / _scratch_bytes (channel-sliced aggregation) */
+#define A3VT_VERSION 150 /* 150: a3vt_dbg_path_counts, larger a3vt_chamfer_workspace_bytes (oriented boxes of the pruned search), a3vt_gcn_stack_scratch_bytes covers every gemm mode, gemm_bf16 outside 0..3 refused; 140: gemm_bf16 = 3 ("fp32x3": fp32 products as six bf16 MFMA passes on exactly split operands), a3vt_split3_bf16; 0.2.x: bf16 storage mode (gemm_bf16 = 2), a3vt_gcn_stack_stash_bytes / _scratch_bytes_mode, deterministic backward scatters; 120: a3vt_chamfer_fwd_ws (pruned exact search); 130: a3vt_posenc_wide_* (448-wide vertex-feature encoder), larger a3vt_gcn_stack_mask_bytes / _scratch_bytes (channel-sliced aggregation) */
 
 int a3vt_version(void);
 const char *a3vt_last_error(void);
