@@ -96,6 +96,11 @@ constexpr int kQuadCols = 160;   // quad-major columns of a hybrid layer output:
 static std::atomic<long long> g_path_counts[PATH_COUNT];
 void path_count(int which) { g_path_counts[which].fetch_add(1, std::memory_order_relaxed); }
 static int g_csr_algo = 0;       // 0 = by shape, 1 = half-wave ("rows"), 2 = channel-sliced where it fits, long rows included
+// A split the channel-sliced kernels of gcn_csrqs.hip take (a3vt_adj_split; P short enough for the slots a thread keeps)
+static bool split_usable(const a3vt_adj_split *sp, int n_vert, int cut_len) {
+  return sp && sp->rowptr && sp->col && sp->scale && sp->cls && sp->max_degree > 0 && sp->max_degree <= csrqs_max_degree() &&
+         csrqs_fits(n_vert, cut_len);
+}
 static bool use_csrq(int batch, int n_vert, int hidden, int cut_len, int gemm_bf16, int max_degree) {
   if (gemm_bf16 == 1 || gemm_bf16 == 2) return false;   // the bf16 operand / storage modes keep the half-wave kernels (mode 3 stores fp32: as mode 0)
   // Rows longer than the eight index slots a thread keeps in registers fall back to per-lane CSR walks: on the fused
@@ -270,8 +275,9 @@ static int check_stack16_dims(int num_layers, int hidden, int in_features) {
 
 static int stack_fwd16(const float *feats, int ld_feats, int in_features, const float *const *weights,
                        const float *const *biases, int num_layers, int hidden, int cut_len, const int32_t *rowptr,
-                       const int32_t *col, const float *val, int max_degree, int n_vert, int batch, void *acts,
-                       uint8_t *masks, float *scratch, float *update, hipStream_t s) {
+                       const int32_t *col, const float *val, int max_degree, const a3vt_adj_split *split, int n_vert,
+                       int batch, void *acts, uint8_t *masks, float *scratch, float *update, hipStream_t s) {
+  (void)split;
   if (int rc = check_stack16_dims(num_layers, hidden, in_features)) return rc;
   const float *zeros = zero_page();
   A3VT_CHECK_ARG(zeros != nullptr);
@@ -347,9 +353,10 @@ static int stack_fwd16(const float *feats, int ld_feats, int in_features, const 
 
 static int stack_bwd16(const float *feats, int ld_feats, int in_features, const float *const *weights, int num_layers,
                        int hidden, int cut_len, const int32_t *rowptrT, const int32_t *colT, const float *valT,
-                       int max_degreeT, int n_vert, int batch, const void *acts, const uint8_t *masks,
-                       const float *grad_update, float *const *grad_weights, float *const *grad_biases,
-                       float *grad_feats, float *scratch, int acc, hipStream_t s) {
+                       int max_degreeT, const a3vt_adj_split *split, int n_vert, int batch, const void *acts,
+                       const uint8_t *masks, const float *grad_update, float *const *grad_weights,
+                       float *const *grad_biases, float *grad_feats, float *scratch, int acc, hipStream_t s) {
+  (void)split;
   if (int rc = check_stack16_dims(num_layers, hidden, in_features)) return rc;
   const float *zeros = zero_page();
   A3VT_CHECK_ARG(zeros != nullptr);
@@ -506,6 +513,81 @@ int a3vt_csr_validate(const int32_t *rowptr, const int32_t *col, int n_vert, int
   return 0;
 }
 
+int a3vt_adj_split_validate(const int32_t *rowptr, const int32_t *col, const float *val, int n_vert,
+                            const int32_t *p_rowptr, const int32_t *p_col, const float *scale, const uint8_t *cls) {
+  A3VT_CHECK_ARG(rowptr && col && val && p_rowptr && p_col && scale && cls && n_vert > 0);
+  if (p_rowptr[0] != 0) { set_error("adj_split: p_rowptr[0]=%d", p_rowptr[0]); return -1; }
+  // the two classes, ascending
+  int ns = 0, nc = 0;
+  for (int i = 0; i < n_vert; ++i) {
+    if (cls[i] > 2) { set_error("adj_split: cls[%d]=%d", i, (int)cls[i]); return -1; }
+    ns += cls[i] == 1;
+    nc += cls[i] == 2;
+  }
+  if ((ns == 0) != (nc == 0)) { set_error("adj_split: %d seam vertices but %d centres", ns, nc); return -1; }
+  int32_t *members = static_cast<int32_t *>(malloc(sizeof(int32_t) * (size_t)(ns + nc + 1)));
+  A3VT_CHECK_ARG(members != nullptr);
+  int32_t *seam = members, *centre = members + ns;
+  for (int i = 0, a = 0, b = 0; i < n_vert; ++i) {
+    if (cls[i] == 1) seam[a++] = i;
+    if (cls[i] == 2) centre[b++] = i;
+  }
+  int rc = 0;
+  for (int i = 0; i < n_vert && rc == 0; ++i) {
+    const int e0 = rowptr[i], e1 = rowptr[i + 1], p0 = p_rowptr[i], p1 = p_rowptr[i + 1];
+    const int32_t *other = cls[i] == 1 ? centre : cls[i] == 2 ? seam : nullptr;
+    const int no = cls[i] == 1 ? nc : cls[i] == 2 ? ns : 0;
+    if (p1 < p0 || e1 - e0 != (p1 - p0) + no) {
+      set_error("adj_split: row %d has %d entries, the split gives %d + %d", i, e1 - e0, p1 - p0, no);
+      rc = -1;
+      break;
+    }
+    // merge of the row of P (ascending, in range, no duplicates) with the other class (ascending): must reproduce the row
+    int a = p0, b = 0;
+    for (int e = e0; e < e1; ++e) {
+      const bool has_a = a < p1, has_b = b < no;
+      int next;
+      if (has_a && has_b && p_col[a] == other[b]) {
+        set_error("adj_split: row %d: column %d is in P and in the bipartite block", i, p_col[a]);
+        rc = -1;
+        break;
+      }
+      if (has_a && (!has_b || p_col[a] < other[b])) {
+        next = p_col[a++];
+        if (next < 0 || next >= n_vert || (a - 1 > p0 && p_col[a - 2] >= next)) {
+          set_error("adj_split: row %d of P is not ascending / in range at column %d", i, next);
+          rc = -1;
+          break;
+        }
+        // symmetry of P: (next, i) must be an entry of row `next` (binary search)
+        int lo = p_rowptr[next], hi = p_rowptr[next + 1] - 1;
+        bool found = false;
+        while (lo <= hi) {
+          const int mid = (lo + hi) / 2;
+          if (p_col[mid] == i) { found = true; break; }
+          if (p_col[mid] < i) lo = mid + 1;
+          else hi = mid - 1;
+        }
+        if (!found) { set_error("adj_split: P has (%d, %d) but not (%d, %d)", i, next, next, i); rc = -1; break; }
+      } else {
+        next = other[b++];
+      }
+      if (col[e] != next) {
+        set_error("adj_split: row %d entry %d: column %d, the split gives %d", i, e - e0, col[e], next);
+        rc = -1;
+        break;
+      }
+      if (memcmp(&val[e], &scale[i], sizeof(float)) != 0) {
+        set_error("adj_split: row %d entry %d: value %.9g != scale %.9g", i, e - e0, (double)val[e], (double)scale[i]);
+        rc = -1;
+        break;
+      }
+    }
+  }
+  free(members);
+  return rc;
+}
+
 // ReLU-sign bytes saved by the forward pass for the backward pass: [num_layers-1][pad32(M)][mld],
 // mld = pad4(cut_len)/4 + ceil(hidden/4).  (mask_ld: defined with stack_x3 above)
 size_t a3vt_gcn_stack_mask_bytes(int batch, int n_vert, int hidden, int num_layers, int cut_len) {
@@ -556,6 +638,16 @@ int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const 
                        const int32_t *rowptr, const int32_t *col, const float *val, int max_degree, int n_vert,
                        int batch, int gemm_bf16, void *acts_v, uint8_t *masks, float *scratch, float *update,
                        void *stream) {
+  return a3vt_gcn_stack_fwd_adj(feats, ld_feats, in_features, weights, biases, num_layers, hidden, cut_len, rowptr, col, val,
+                                max_degree, nullptr, n_vert, batch, gemm_bf16, acts_v, masks, scratch, update, stream);
+}
+
+int a3vt_gcn_stack_fwd_adj(const float *feats, int ld_feats, int in_features, const float *const *weights,
+                           const float *const *biases, int num_layers, int hidden, int cut_len,
+                           const int32_t *rowptr, const int32_t *col, const float *val, int max_degree,
+                           const a3vt_adj_split *split, int n_vert,
+                           int batch, int gemm_bf16, void *acts_v, uint8_t *masks, float *scratch, float *update,
+                           void *stream) {
   float *acts = static_cast<float *>(acts_v);
   A3VT_CHECK_ARG(feats && weights && biases && rowptr && col && val && scratch && update);
   A3VT_CHECK_ARG((acts == nullptr) == (masks == nullptr) || num_layers < 2);
@@ -565,7 +657,7 @@ int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const 
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (gemm_bf16 == 2)  // bf16 storage: `acts` holds bf16 rows (a3vt_gcn_stack_stash_bytes)
     return stack_fwd16(feats, ld_feats, in_features, weights, biases, num_layers, hidden, cut_len, rowptr, col, val,
-                       max_degree, n_vert, batch, acts, masks, scratch, update, s);
+                       max_degree, split, n_vert, batch, acts, masks, scratch, update, s);
   const float *zeros = zero_page();
   A3VT_CHECK_ARG(zeros != nullptr);
   const StackLayout L = stack_layout(batch, n_vert, in_features, hidden, num_layers, cut_len, 0, gemm_bf16);
@@ -618,12 +710,19 @@ int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const 
     if (int rc = launch_weight_images(wi, rowgemm_bt_rows(hidden), pad16(ld_feats > hidden ? ld_feats : hidden), s)) return rc;
   }
 
-  const bool quad = use_csrq(batch, n_vert, hidden, cut_len, gemm_bf16, max_degree) && num_layers > 1;
+  // a usable split stands for "every row short": the hub and seam rows are gone from P
+  const bool split_ok = split_usable(split, n_vert, cut_len);
+  const bool quad = use_csrq(batch, n_vert, hidden, cut_len, gemm_bf16, split_ok ? csrq_max_degree() : max_degree) && num_layers > 1;
+  const bool qsplit = quad && split_ok;
   if (num_layers > 1) path_count(quad ? PATH_STACK_QUAD : PATH_STACK_ROWS);
+  if (qsplit) path_count(PATH_STACK_SPLIT);
   if (num_layers > 1) stash_layout_record(masks, quad);
   int32_t *ell = reinterpret_cast<int32_t *>(scratch + L.ell);
-  if (quad)
+  if (qsplit) {
+    if (int rc = launch_csrqs_image(split->rowptr, split->col, split->scale, split->cls, n_vert, ell, s)) return rc;
+  } else if (quad) {
     if (int rc = launch_csrq_ell(rowptr, col, val, n_vert, ell, s)) return rc;
+  }
   // Layer outputs.  Row-major [M][hidden] on the half-wave path; on the channel-sliced path ("hybrid" rows) the block of
   // M * hidden floats holds columns [0, 160) quad-major [batch][40][n_vert] float4 — the aggregated channels written by
   // the aggregation kernel, the rest of the product kernel's first column group by its epilogue — followed by columns
@@ -680,8 +779,11 @@ int a3vt_gcn_stack_fwd(const float *feats, int ld_feats, int in_features, const 
     }
     if (quad) {
       uint8_t *sq = masks ? masks + (size_t)(num_layers - 1) * mpad * mld + (size_t)i * signq_stride(m, cut_len) : nullptr;
-      if (int rc = launch_csrq_fwd(scratch + L.za, biases[i], cut_len, rowptr, col, val, heavy, ell, n_vert, batch, y, qcols / 4, sq, 1, s))
+      if (qsplit) {
+        if (int rc = launch_csrqs_fwd(scratch + L.za, biases[i], cut_len, ell, n_vert, batch, y, qcols / 4, sq, 1, s)) return rc;
+      } else if (int rc = launch_csrq_fwd(scratch + L.za, biases[i], cut_len, rowptr, col, val, heavy, ell, n_vert, batch, y, qcols / 4, sq, 1, s)) {
         return rc;
+      }
       xq = y;
     } else if (cut_len > 0) {
       if (int rc = launch_csr_fwd(scratch + L.za, cpad, biases[i], cut_len, rowptr, col, val, heavy, n_vert, batch, y, hidden, mk, mld, 1, s))
@@ -702,8 +804,8 @@ int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const 
                        const void *acts_v,
                        const uint8_t *masks, const float *grad_update, float *const *grad_weights, float *const *grad_biases,
                        float *grad_feats, float *scratch, void *stream) {
-  return a3vt_gcn_stack_bwd_acc(feats, ld_feats, in_features, weights, biases, num_layers, hidden, cut_len, rowptr, col, val,
-                                rowptrT, colT, valT, max_degreeT, n_vert, batch, gemm_bf16, acts_v, masks, grad_update,
+  return a3vt_gcn_stack_bwd_adj(feats, ld_feats, in_features, weights, biases, num_layers, hidden, cut_len, rowptr, col, val,
+                                rowptrT, colT, valT, max_degreeT, nullptr, n_vert, batch, gemm_bf16, acts_v, masks, grad_update,
                                 grad_weights, grad_biases, grad_feats, scratch, 0, stream);
 }
 
@@ -712,6 +814,18 @@ int a3vt_gcn_stack_bwd_acc(const float *feats, int ld_feats, int in_features, co
                            const int32_t *rowptr, const int32_t *col, const float *val, const int32_t *rowptrT,
                            const int32_t *colT, const float *valT, int max_degreeT, int n_vert, int batch, int gemm_bf16,
                            const void *acts_v,
+                           const uint8_t *masks, const float *grad_update, float *const *grad_weights,
+                           float *const *grad_biases, float *grad_feats, float *scratch, int accumulate, void *stream) {
+  return a3vt_gcn_stack_bwd_adj(feats, ld_feats, in_features, weights, biases, num_layers, hidden, cut_len, rowptr, col, val,
+                                rowptrT, colT, valT, max_degreeT, nullptr, n_vert, batch, gemm_bf16, acts_v, masks, grad_update,
+                                grad_weights, grad_biases, grad_feats, scratch, accumulate, stream);
+}
+
+int a3vt_gcn_stack_bwd_adj(const float *feats, int ld_feats, int in_features, const float *const *weights,
+                           const float *const *biases, int num_layers, int hidden, int cut_len,
+                           const int32_t *rowptr, const int32_t *col, const float *val, const int32_t *rowptrT,
+                           const int32_t *colT, const float *valT, int max_degreeT, const a3vt_adj_split *split,
+                           int n_vert, int batch, int gemm_bf16, const void *acts_v,
                            const uint8_t *masks, const float *grad_update, float *const *grad_weights,
                            float *const *grad_biases, float *grad_feats, float *scratch, int accumulate, void *stream) {
   const int acc = accumulate ? 1 : 0;
@@ -726,7 +840,7 @@ int a3vt_gcn_stack_bwd_acc(const float *feats, int ld_feats, int in_features, co
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (gemm_bf16 == 2)
     return stack_bwd16(feats, ld_feats, in_features, weights, num_layers, hidden, cut_len, rowptrT, colT, valT,
-                       max_degreeT, n_vert, batch, acts, masks, grad_update, grad_weights, grad_biases, grad_feats,
+                       max_degreeT, split, n_vert, batch, acts, masks, grad_update, grad_weights, grad_biases, grad_feats,
                        scratch, acc, s);
   const float *zeros = zero_page();
   A3VT_CHECK_ARG(zeros != nullptr);
@@ -747,10 +861,15 @@ int a3vt_gcn_stack_bwd_acc(const float *feats, int ld_feats, int in_features, co
   // the layout the forward left in this stash (recorded by a3vt_gcn_stack_fwd); a stash this library did not write: by shape
   const int rec = stash_layout_lookup(masks);
   const bool quad = masks != nullptr && num_layers > 1 &&
-                    (rec >= 0 ? rec == 1 : use_csrq(batch, n_vert, hidden, cut_len, gemm_bf16, max_degreeT));
+                    (rec >= 0 ? rec == 1 : use_csrq(batch, n_vert, hidden, cut_len, gemm_bf16,
+                                                    split_usable(split, n_vert, cut_len) ? csrq_max_degree() : max_degreeT));
+  const bool qsplit = quad && split_usable(split, n_vert, cut_len);   // P and J are symmetric: the same image serves A^T
   int32_t *ellT = reinterpret_cast<int32_t *>(scratch + L.ell);
-  if (quad)
+  if (qsplit) {
+    if (int rc = launch_csrqs_image(split->rowptr, split->col, split->scale, split->cls, n_vert, ellT, s)) return rc;
+  } else if (quad) {
     if (int rc = launch_csrq_ell(rowptrT, colT, valT, n_vert, ellT, s)) return rc;
+  }
   const int qcols = quad ? kQuadCols : 0;            // hybrid activation rows (a3vt_gcn_stack_fwd)
   const int rm_ld = hidden - qcols;
   const size_t rm_off = m * qcols;
@@ -828,9 +947,14 @@ int a3vt_gcn_stack_bwd_acc(const float *feats, int ld_feats, int in_features, co
     if (cut_len > 0 && quad) {
       const uint8_t *sq = masks + (size_t)(num_layers - 1) * mpad * mld + (size_t)i * signq_stride(m, cut_len);
       // the (mesh, channel) partials of this layer: summed over the meshes by ONE launch for all layers behind the loop
-      if (int rc = launch_csrq_bwd(scratch + L.gq, cut_len, rowptrT, colT, valT, heavyT, ellT, n_vert, batch, dza, sq,
-                                   scratch + L.db_slab + (size_t)i * db_layer_stride, s))
+      if (qsplit) {
+        if (int rc = launch_csrqs_bwd(scratch + L.gq, cut_len, ellT, n_vert, batch, dza, sq,
+                                      scratch + L.db_slab + (size_t)i * db_layer_stride, s))
+          return rc;
+      } else if (int rc = launch_csrq_bwd(scratch + L.gq, cut_len, rowptrT, colT, valT, heavyT, ellT, n_vert, batch, dza, sq,
+                                          scratch + L.db_slab + (size_t)i * db_layer_stride, s)) {
         return rc;
+      }
     } else if (cut_len > 0) {
       if (int rc = launch_csr_bwd(g, hidden, cut_len, rowptrT, colT, valT, heavyT, n_vert, batch, dza, cpad,
                                   scratch + L.db_slab + (size_t)i * db_layer_stride, s))

@@ -170,6 +170,17 @@ int launch_csrq_fwd(const float *zq, const float *bias, int c, const int32_t *ro
 int launch_csrq_bwd(const float *gq, int c, const int32_t *rowptrT, const int32_t *colT, const float *valT,
                     const int32_t *heavyT, const int32_t *ellT, int n_vert, int batch, float *dzaq, const uint8_t *signq,
                     float *db_slab, hipStream_t s);
+// The same for structured adjacencies D^-1 (P + J), J = a complete bipartite block (gcn_csrqs.hip, a3vt_adj_split): `img` =
+// the index image launch_csrqs_image builds from the split (csrqs_image_ints(n_vert) ints); same layouts as csrq.
+bool csrqs_fits(int n_vert, int cut_len);
+int csrqs_max_degree();   // longest row of P the kernel takes
+size_t csrqs_image_ints(int n_vert);
+int launch_csrqs_image(const int32_t *rowptr, const int32_t *col, const float *scale, const uint8_t *cls, int n_vert,
+                       int32_t *img, hipStream_t s);
+int launch_csrqs_fwd(const float *zq, const float *bias, int c, const int32_t *img, int n_vert, int batch, float *yq,
+                     int yq_quads, uint8_t *signq, int relu, hipStream_t s);
+int launch_csrqs_bwd(const float *gq, int c, const int32_t *img, int n_vert, int batch, float *dzaq, const uint8_t *signq,
+                     float *db_slab, hipStream_t s);
 // True when launch_rowgemm will run (m, n_store) as ONE column block of 19-tile rows whose first epilogue column group
 // holds the cpad aggregated columns — the shape for which the epilogues can write quad-major (RowGemmArgs::zq_nvert).
 bool rowgemm_quad_major_ok(int m, int n_store, int cpad);

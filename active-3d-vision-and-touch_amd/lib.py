@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("A3VT_LIB", os.path.join(_HERE, "liba3vt.so"))  # A3VT_LIB: developer override (variant builds)
-SOURCES = ["capi.hip", "gcn_gemm.hip", "gcn_gemm16.hip", "gcn_gemm3.hip", "gcn_csr.hip", "gcn_csrq.hip", "gcn_bf16s.hip", "posenc.hip", "posenc_wide.hip", "bias_grad.hip", "sample.hip", "chamfer.hip", "nn_prune.hip",
+SOURCES = ["capi.hip", "gcn_gemm.hip", "gcn_gemm16.hip", "gcn_gemm3.hip", "gcn_csr.hip", "gcn_csrq.hip", "gcn_csrqs.hip", "gcn_bf16s.hip", "posenc.hip", "posenc_wide.hip", "bias_grad.hip", "sample.hip", "chamfer.hip", "nn_prune.hip",
            "pooling.hip"]
 # Per-file extra flags (none at present; sample.hip / gcn_csr.hip rely on IEEE NaN semantics — the reference's NaN
 # scrubs, a3vt_check_finite — so fast-math style flags must never be applied globally).
@@ -18,9 +18,16 @@ SOURCES = ["capi.hip", "gcn_gemm.hip", "gcn_gemm16.hip", "gcn_gemm3.hip", "gcn_c
 # which issues at half the rate on gfx950 and needs s_nop hazard padding)
 # gcn_csrq.hip: scalar fma chains keep one register per edge weight (v_pk_fma_f32 wants (w, w) pairs): see the file header
 EXTRA_FLAGS = {"chamfer.hip": ["-fno-slp-vectorize"], "nn_prune.hip": ["-fno-slp-vectorize"],
-               "gcn_csrq.hip": ["-fno-slp-vectorize"]}
+               "gcn_csrq.hip": ["-fno-slp-vectorize"], "gcn_csrqs.hip": ["-fno-slp-vectorize"]}
 
 _vp, _i, _sz, _u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_uint64
+
+
+class AdjSplit(ctypes.Structure):
+    """``a3vt_adj_split`` (include/a3vt.h): the fused vision + touch adjacency as P + a complete bipartite block."""
+    _fields_ = [("rowptr", _vp), ("col", _vp), ("scale", _vp), ("cls", _vp),
+                ("max_degree", ctypes.c_int32), ("n_seam", ctypes.c_int32), ("n_centre", ctypes.c_int32)]
+
 
 # name -> (restype, argtypes); mirrors include/a3vt.h one to one.
 SIGNATURES = {
@@ -35,6 +42,10 @@ SIGNATURES = {
     "a3vt_gcn_stack_bwd": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "a3vt_gcn_stack_bwd_acc": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
+                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "a3vt_adj_split_validate": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "a3vt_gcn_stack_fwd_adj": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "a3vt_gcn_stack_bwd_adj": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "a3vt_gcn_layer_scratch_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "a3vt_gcn_layer_fwd": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp]),

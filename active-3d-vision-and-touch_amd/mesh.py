@@ -186,11 +186,80 @@ class CSRAdjacency:
         rowptr[1:] = np.cumsum(np.bincount(r, minlength=n))
         return cls(rowptr, c.astype(np.int32), a[r, c].astype(np.float32), n)
 
+    def split(self, hub_degree=64, max_local_degree=12):
+        """The matrix as ``D^-1 (P + J)`` (``a3vt_adj_split``, include/a3vt.h): P a sparse symmetric 0/1 pattern, J the complete
+        bipartite block S x C that ``adj_fuse_touch`` writes (utils.py:119-128: every seam vertex of the atlas linked to every
+        touch-chart centre).  Found from the CSR alone — C = the hub rows (more than ``hub_degree`` entries), S = the vertices
+        linked to ALL of them — so a reference-made dense ``adj_info`` entry splits the same way as one built here.  Returns a
+        :class:`SplitAdjacency`, or None when the matrix is not of that form (values not 1/row length, pattern not symmetric,
+        rows of P longer than ``max_local_degree``): callers then keep the plain CSR.  A hub-free matrix with short rows
+        (the vision templates) is the special case S = C = {}."""
+        if getattr(self, "_split", False) is not False:
+            return self._split
+        self._split = None
+        n = self.n
+        deg = np.diff(self.rowptr).astype(np.int64)
+        if n == 0 or deg.min() < 1:
+            return None
+        rows = np.repeat(np.arange(n, dtype=np.int64), deg)
+        scale = (np.float32(1.0) / deg.astype(np.float32)).astype(np.float32)
+        if not np.array_equal(self.val.view(np.uint32), scale[rows].view(np.uint32)):
+            return None                                                       # not D^-1 x (0/1 pattern)
+        if not (np.array_equal(self.t_rowptr, self.rowptr) and np.array_equal(self.t_col, self.col)):
+            return None                                                       # pattern not symmetric
+        cls = np.zeros(n, dtype=np.uint8)
+        centres = np.flatnonzero(deg > hub_degree)
+        keep = np.ones(self.nnz, dtype=bool)
+        if len(centres):
+            is_c = np.zeros(n, dtype=bool)
+            is_c[centres] = True
+            # S = vertices outside C whose row holds every centre
+            hits = np.bincount(rows[is_c[self.col]], minlength=n)
+            seam = np.flatnonzero((hits == len(centres)) & ~is_c)
+            if len(seam) == 0:
+                return None
+            is_s = np.zeros(n, dtype=bool)
+            is_s[seam] = True
+            cls[seam], cls[centres] = 1, 2
+            keep = ~((is_s[rows] & is_c[self.col]) | (is_c[rows] & is_s[self.col]))
+            # J must be complete in both directions: |S| x |C| entries removed from each side
+            if int((is_s[rows] & is_c[self.col]).sum()) != len(seam) * len(centres) or \
+                    int((is_c[rows] & is_s[self.col]).sum()) != len(seam) * len(centres):
+                return None
+        p_deg = np.bincount(rows[keep], minlength=n)
+        if p_deg.max() > max_local_degree:
+            return None
+        p_rowptr = np.zeros(n + 1, dtype=np.int32)
+        p_rowptr[1:] = np.cumsum(p_deg)
+        self._split = SplitAdjacency(p_rowptr, self.col[keep].astype(np.int32), scale, cls)
+        return self._split
+
     def to_dense(self):
         out = np.zeros((self.n, self.n), dtype=np.float32)
         rows = np.repeat(np.arange(self.n), np.diff(self.rowptr))
         out[rows, self.col] = self.val
         return out
+
+
+class SplitAdjacency:
+    """``D^-1 (P + J)`` on the host: CSR pattern of P, ``scale`` = 1 / row length of the full matrix, ``cls`` = 0 / 1 (seam
+    set S) / 2 (centre set C).  Built by :meth:`CSRAdjacency.split`."""
+
+    def __init__(self, rowptr, col, scale, cls):
+        self.rowptr, self.col, self.scale, self.cls = rowptr, col, scale, cls
+        self.n = int(len(cls))
+        self.max_degree = int(np.diff(rowptr).max()) if self.n else 0
+        self.n_seam, self.n_centre = int((cls == 1).sum()), int((cls == 2).sum())
+
+    def to_dense(self):
+        """The full row-normalised matrix again (tests)."""
+        out = np.zeros((self.n, self.n), dtype=np.float32)
+        rows = np.repeat(np.arange(self.n), np.diff(self.rowptr))
+        out[rows, self.col] = 1.0
+        s, c = np.flatnonzero(self.cls == 1), np.flatnonzero(self.cls == 2)
+        out[np.ix_(s, c)] = 1.0
+        out[np.ix_(c, s)] = 1.0
+        return out * self.scale[:, None]
 
 
 def load_asset(name):

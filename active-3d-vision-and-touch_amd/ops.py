@@ -53,6 +53,22 @@ class DeviceCSR:
         self.host = host
         self.max_degree = int(np.diff(host.rowptr).max()) if host.n else 0        # hub rows get their own launch
         self.t_max_degree = int(np.diff(host.t_rowptr).max()) if host.n else 0
+        # the fused vision + touch matrix as P + a complete bipartite block (a3vt_adj_split): found on the host, PROVEN
+        # against the CSR by the library, handed to the stack calls next to the CSR.  Plain meshes keep split = None
+        # (their rows are short already: the generic kernels serve them bit for bit as before).
+        self.split = self.split_struct = None
+        sp = host.split() if self.max_degree > 8 else None
+        if sp is not None:
+            _lib.check(L.a3vt_adj_split_validate(host.rowptr.ctypes.data, host.col.ctypes.data, host.val.ctypes.data, host.n,
+                                                 sp.rowptr.ctypes.data, sp.col.ctypes.data, sp.scale.ctypes.data,
+                                                 sp.cls.ctypes.data), "adj_split_validate")
+            self.split = (to(sp.rowptr), to(sp.col), to(sp.scale), to(sp.cls))
+            self.split_struct = _lib.AdjSplit(*[t.data_ptr() for t in self.split], sp.max_degree, sp.n_seam, sp.n_centre)
+        self.use_split = True     # test hook: False = the plain CSR everywhere (A/B of the two aggregations)
+
+    def split_ref(self):
+        """``const a3vt_adj_split *`` for a stack call (NULL without a split)."""
+        return ctypes.byref(self.split_struct) if (self.split_struct is not None and self.use_split) else None
 
     @property
     def device(self):
@@ -74,7 +90,7 @@ def _ptr_array(tensors):
 GEMM_MODES = {"fp32": 0, "bf16": 1, "bf16s": 2, "fp32x3": 3}
 
 
-PATH_NAMES = ("stack_quad", "stack_rows", "rowgemm_adirect", "rowgemm3", "dw3", "dw_hybrid", "rowgemm16", "stack16_quad")
+PATH_NAMES = ("stack_quad", "stack_rows", "rowgemm_adirect", "rowgemm3", "dw3", "dw_hybrid", "rowgemm16", "stack16_quad", "stack_split")
 
 
 def path_counts(reset=False):
@@ -167,10 +183,10 @@ class GCNStackFn(torch.autograd.Function):
         scratch = workspace("gcn", nbytes, feats.device)
         update = torch.empty((B, N, 3), dtype=torch.float32, device=feats.device)
         wp, bp = _ptr_array(weights), _ptr_array(biases)
-        _lib.check(L.a3vt_gcn_stack_fwd(_lib.ptr(feats), ld, in_features, wp, bp, nl, hidden, cut_len,
-                                        _lib.ptr(adj.rowptr), _lib.ptr(adj.col), _lib.ptr(adj.val), max(adj.max_degree, adj.t_max_degree),
-                                        N, B, mode,
-                                        _lib.ptr(acts), _lib.ptr(masks), _lib.ptr(scratch), _lib.ptr(update), _stream()),
+        _lib.check(L.a3vt_gcn_stack_fwd_adj(_lib.ptr(feats), ld, in_features, wp, bp, nl, hidden, cut_len,
+                                            _lib.ptr(adj.rowptr), _lib.ptr(adj.col), _lib.ptr(adj.val),
+                                            max(adj.max_degree, adj.t_max_degree), adj.split_ref(), N, B, mode,
+                                            _lib.ptr(acts), _lib.ptr(masks), _lib.ptr(scratch), _lib.ptr(update), _stream()),
                    "gcn_stack_fwd")
         ctx.adj, ctx.dims, ctx.mode = adj, (in_features, hidden, cut_len, nl), mode
         ctx.acts, ctx.masks = acts, masks
@@ -210,10 +226,10 @@ class GCNStackFn(torch.autograd.Function):
         gfeats = torch.empty_like(feats)
         nbytes = L.a3vt_gcn_stack_scratch_bytes_mode(B, N, in_features, hidden, nl, cut_len, 1, ctx.mode)
         scratch = workspace("gcn", nbytes, feats.device)
-        _lib.check(L.a3vt_gcn_stack_bwd_acc(_lib.ptr(feats), ld, in_features, _ptr_array(weights), _ptr_array(biases), nl,
+        _lib.check(L.a3vt_gcn_stack_bwd_adj(_lib.ptr(feats), ld, in_features, _ptr_array(weights), _ptr_array(biases), nl,
                                             hidden, cut_len, _lib.ptr(adj.rowptr), _lib.ptr(adj.col), _lib.ptr(adj.val),
                                             _lib.ptr(adj.t_rowptr), _lib.ptr(adj.t_col), _lib.ptr(adj.t_val),
-                                            max(adj.max_degree, adj.t_max_degree), N, B, ctx.mode,
+                                            max(adj.max_degree, adj.t_max_degree), adj.split_ref(), N, B, ctx.mode,
                                             _lib.ptr(ctx.acts), _lib.ptr(ctx.masks), _lib.ptr(grad_update), _ptr_array(gw),
                                             _ptr_array(gb),
                                             _lib.ptr(gfeats), _lib.ptr(scratch), acc, _stream()), "gcn_stack_bwd")

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define A3VT_VERSION 150 /* 150: a3vt_dbg_path_counts, larger a3vt_chamfer_workspace_bytes (oriented boxes of the pruned search), a3vt_gcn_stack_scratch_bytes covers every gemm mode, gemm_bf16 outside 0..3 refused; 140: gemm_bf16 = 3 ("fp32x3": fp32 products as six bf16 MFMA passes on exactly split operands), a3vt_split3_bf16; 0.2.x: bf16 storage mode (gemm_bf16 = 2), a3vt_gcn_stack_stash_bytes / _scratch_bytes_mode, deterministic backward scatters; 120: a3vt_chamfer_fwd_ws (pruned exact search); 130: a3vt_posenc_wide_* (448-wide vertex-feature encoder), larger a3vt_gcn_stack_mask_bytes / _scratch_bytes (channel-sliced aggregation) */
+#define A3VT_VERSION 160 /* 160: a3vt_adj_split, a3vt_adj_split_validate, a3vt_gcn_stack_fwd_adj / _bwd_adj (the fused vision + touch adjacency as P + a complete bipartite block); 150: a3vt_dbg_path_counts, larger a3vt_chamfer_workspace_bytes (oriented boxes of the pruned search), a3vt_gcn_stack_scratch_bytes covers every gemm mode, gemm_bf16 outside 0..3 refused; 140: gemm_bf16 = 3 ("fp32x3": fp32 products as six bf16 MFMA passes on exactly split operands), a3vt_split3_bf16; 0.2.x: bf16 storage mode (gemm_bf16 = 2), a3vt_gcn_stack_stash_bytes / _scratch_bytes_mode, deterministic backward scatters; 120: a3vt_chamfer_fwd_ws (pruned exact search); 130: a3vt_posenc_wide_* (448-wide vertex-feature encoder), larger a3vt_gcn_stack_mask_bytes / _scratch_bytes (channel-sliced aggregation) */
 
 int a3vt_version(void);
 const char *a3vt_last_error(void);
@@ -123,6 +123,56 @@ int a3vt_gcn_stack_bwd_acc(const float *feats, int ld_feats, int in_features,
                            int num_layers, int hidden, int cut_len,
                            const int32_t *csr_rowptr, const int32_t *csr_col, const float *csr_val,
                            const int32_t *csrT_rowptr, const int32_t *csrT_col, const float *csrT_val, int csrT_max_degree,
+                           int n_vert, int batch, int gemm_bf16,
+                           const void *acts, const uint8_t *masks, const float *grad_update,
+                           float *const *grad_weights, float *const *grad_biases, float *grad_feats,
+                           float *scratch, int accumulate, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Structured adjacency (round 6).  The fused vision + touch matrix of utility/utils.py:75-130 links EVERY seam vertex of the
+ * chart atlas (:80-84,119-123) to EVERY touch-chart centre (:95-98,124-128), so the matrix of model.py:356,360 is
+ *     A^ = D^-1 (P + J):  P a sparse symmetric 0/1 pattern (<= 10 entries per row on the reference's graphs),
+ *                         J the COMPLETE bipartite block S x C and C x S (S = seam vertices, C = chart centres, disjoint),
+ *                         D = the row sums of P + J   (every non-zero of row i of A^ is 1 / d_i).
+ * (A^ Z)_i = (sum_{j in P(i)} Z_j + [i in S] sum_{c in C} Z_c + [i in C] sum_{s in S} Z_s) / d_i: two sums per mesh replace
+ * the ~1150-entry centre rows and the 26-30-entry seam rows (75 % of the non-zeros of the 20-chart graph).  A caller that
+ * knows the decomposition passes it NEXT TO the full CSR (which the output layer and every fallback path keep using):
+ * the hidden layers of a3vt_gcn_stack_fwd_adj / _bwd_adj then aggregate with it wherever the shape allows (fp32 storage: the
+ * channel-sliced kernels of csrc/gcn_csrqs.hip under the conditions listed above with max_degree <= 12; bf16 storage: the
+ * row walk over P plus the two sums).  Same values up to fp32 rounding (another association of the same sums), not bit for
+ * bit.  All pointers DEVICE pointers; the struct itself lives on the host.  Vision-only templates are the special case
+ * n_seam = n_centre = 0. */
+typedef struct a3vt_adj_split {
+  const int32_t *rowptr; /* [n_vert + 1]  CSR of P */
+  const int32_t *col;    /* [rowptr[n_vert]]  ascending within a row */
+  const float *scale;    /* [n_vert]  1 / d_i = the value of every non-zero of row i of the full matrix */
+  const uint8_t *cls;    /* [n_vert]  0 = neither, 1 = in S, 2 = in C */
+  int32_t max_degree;    /* longest row of P */
+  int32_t n_seam, n_centre;
+} a3vt_adj_split;
+
+/* Host-side proof that (P, S, C, scale) IS the matrix (csr_rowptr, csr_col, csr_val): for every row the sorted union of its
+ * P entries and of C (rows in S) or S (rows in C) equals the row's columns, every value equals scale[row] bit for bit, P is
+ * symmetric, S and C are disjoint and J is not already part of P.  All pointers HOST pointers.  0 = proven, -1 = refuted
+ * (a3vt_last_error says where). */
+int a3vt_adj_split_validate(const int32_t *csr_rowptr, const int32_t *csr_col, const float *csr_val, int n_vert,
+                            const int32_t *p_rowptr, const int32_t *p_col, const float *scale, const uint8_t *cls);
+
+/* a3vt_gcn_stack_fwd / a3vt_gcn_stack_bwd_acc with the decomposition (`split` may be NULL: exactly the calls above).  The
+ * backward must receive the split the forward received (the stash layout follows the forward's choice). */
+int a3vt_gcn_stack_fwd_adj(const float *feats, int ld_feats, int in_features,
+                           const float *const *weights, const float *const *biases,
+                           int num_layers, int hidden, int cut_len,
+                           const int32_t *csr_rowptr, const int32_t *csr_col, const float *csr_val, int csr_max_degree,
+                           const a3vt_adj_split *split,
+                           int n_vert, int batch, int gemm_bf16,
+                           void *acts, uint8_t *masks, float *scratch, float *update, void *stream);
+int a3vt_gcn_stack_bwd_adj(const float *feats, int ld_feats, int in_features,
+                           const float *const *weights, const float *const *biases,
+                           int num_layers, int hidden, int cut_len,
+                           const int32_t *csr_rowptr, const int32_t *csr_col, const float *csr_val,
+                           const int32_t *csrT_rowptr, const int32_t *csrT_col, const float *csrT_val, int csrT_max_degree,
+                           const a3vt_adj_split *split,
                            int n_vert, int batch, int gemm_bf16,
                            const void *acts, const uint8_t *masks, const float *grad_update,
                            float *const *grad_weights, float *const *grad_biases, float *grad_feats,

@@ -49,6 +49,7 @@ def test_channel_sliced_aggregation_equals_row_kernels_and_oracle(cuda, tname, u
         r, c = amesh.vision_pairs(faces, verts.shape[0])
         nn_ = verts.shape[0]
     adj = ops.DeviceCSR(amesh.CSRAdjacency.from_pairs(r, c, nn_), cuda)
+    adj.use_split = False      # this test pins the GENERIC kernels (any CSR); the P + bipartite split has its own below
     cut_len = og.cut_length(H, cut)
     try:
         ops.dbg_csr_algo("rows")
@@ -140,3 +141,67 @@ def test_backward_follows_the_layout_the_forward_recorded(cuda):
     assert torch.equal(fd.grad, ref[1])
     for i in range(L):
         assert torch.equal(ws[i].grad, ref[2][i]) and torch.equal(bs[i].grad, ref[3][i])
+
+
+@pytest.mark.parametrize("grasps,finger,L,B,cut", [(5, False, 3, 8, 0.33),      # t_g: atlas + 20 charts, N = 2324 (6 vertices per thread)
+                                                   (1, False, 3, 8, 0.33),      # the configs[3] graph: 4 charts, N = 1924
+                                                   (5, True, 4, 8, 0.33),       # t_p: 5 finger charts, N = 1949 (the scoring caller)
+                                                   (1, True, 3, 8, 0.04),       # ONE centre: S absorbs its whole chart ring; 12 aggregated channels
+                                                   (5, False, 20, 6, 0.33)])    # the production depth
+def test_split_aggregation_against_oracle_and_row_kernels(cuda, grasps, finger, L, B, cut):
+    """Round 6: the fused vision + touch matrix (utils.py:75-130) as D^-1 (P + J), J = complete bipartite seam x centres
+    (``a3vt_adj_split``, csrc/gcn_csrqs.hip): two per-mesh sums instead of the hub and seam rows.  Another association of the
+    same sums, so not bit-identical to the row walk over the full CSR — gated by the fp64 oracle at the north-star tolerance,
+    by the row kernels at fp32 rounding, and by bit-repeatability / batch invariance."""
+    from a3vt_amd import mesh as amesh, ops
+    from oracle import gcn as og
+    H = 300
+    args = make_args(use_touch=True, finger=finger, num_GCN_layers=L, hidden_GCN_size=H, num_grasps=grasps, cut=cut)
+    verts, faces = template("atlas")
+    adj_o, _ = oracle_adj(verts, faces, args)
+    n = adj_o[0].numel() - 1
+    assert B * n >= 12288
+    st = og.init_state(50, H, L, seed=5)
+    g = torch.Generator().manual_seed(21)
+    feats = torch.randn(B, n, 50, generator=g) * 0.5
+    gup = torch.randn(B, n, 3, generator=g)
+    sv, sf = amesh.load_asset("touch_chart")
+    r, c, nn_, _ = amesh.fused_pairs(verts, faces, sf, grasps, finger)
+    host = amesh.CSRAdjacency.from_pairs(r, c, nn_)
+    adj = ops.DeviceCSR(host, cuda)
+    assert adj.split is not None and host.split().max_degree <= 10 and host.split().n_centre == (1 if finger else 4) * grasps
+    cut_len = og.cut_length(H, cut)
+    ops.path_counts(reset=True)
+    new = _run(cuda, adj, st, feats, gup, L, H, cut_len)
+    counts = ops.path_counts()
+    assert counts["stack_split"] == 1 and counts["stack_quad"] == 1, counts      # the split kernels ran, on hybrid rows
+    again = _run(cuda, adj, st, feats, gup, L, H, cut_len)
+    for a, b in zip([new[0], new[1], *new[2], *new[3]], [again[0], again[1], *again[2], *again[3]]):
+        assert torch.equal(a, b)                                                  # fixed summation order
+    # the meshes of a batch do not see each other: the first meshes of a LARGER batch (other `parts`, other workgroups) give
+    # the same bits
+    big = _run(cuda, adj, st, torch.cat([feats, feats.flip(0)]), torch.cat([gup, gup.flip(0)]), L, H, cut_len)
+    assert torch.equal(big[0][:B], new[0]) and torch.equal(big[1][:B], new[1])
+    # the row walk over the FULL CSR (hub rows through csr_heavy_kernel): same values to fp32 rounding
+    adj.use_split = False
+    try:
+        ops.dbg_csr_algo("rows")
+        ref = _run(cuda, adj, st, feats, gup, L, H, cut_len)
+    finally:
+        ops.dbg_csr_algo("auto")
+        adj.use_split = True
+    tol = 2e-5 if L <= 4 else 2e-4
+    assert rel_err(new[0], ref[0]) < tol
+    assert_grad_close(new[1], ref[1], "grad_feats vs rows", tol=1e-4, l2_tol=1e-4 if L <= 4 else 1e-3)
+    # the fp64 oracle (dense reference matrix -> CSR)
+    st64 = {k: v.double().requires_grad_(True) for k, v in st.items() if k.startswith("mesh_deform_1")}
+    f64 = feats.double().requires_grad_(True)
+    out_o = og.gcn(f64, st64, "mesh_deform_1", (adj_o[0], adj_o[1], adj_o[2].double()), L, cut)
+    (out_o * gup.double()).sum().backward()
+    assert rel_err(new[0], out_o) < 1e-4
+    assert_grad_close(new[1][..., :50], f64.grad, "grad_feats")
+    for i in range(L):
+        assert_grad_close(new[2][i], st64[f"mesh_deform_1.layers.{i}.weight"].grad, f"dW layer {i}")
+        assert_grad_close(new[3][i], st64[f"mesh_deform_1.layers.{i}.bias"].grad, f"db layer {i}")
+        if i < L - 1 and cut_len < H:
+            assert new[3][i][cut_len:].abs().max().item() == 0.0
