@@ -101,6 +101,9 @@ static bool split_usable(const a3vt_adj_split *sp, int n_vert, int cut_len) {
   return sp && sp->rowptr && sp->col && sp->scale && sp->cls && sp->max_degree > 0 && sp->max_degree <= csrqs_max_degree() &&
          csrqs_fits(n_vert, cut_len);
 }
+static SplitRef split_ref(const a3vt_adj_split *sp) {
+  return sp ? SplitRef{sp->rowptr, sp->col, sp->scale, sp->cls} : SplitRef{nullptr, nullptr, nullptr, nullptr};
+}
 static bool use_csrq(int batch, int n_vert, int hidden, int cut_len, int gemm_bf16, int max_degree) {
   if (gemm_bf16 == 1 || gemm_bf16 == 2) return false;   // the bf16 operand / storage modes keep the half-wave kernels (mode 3 stores fp32: as mode 0)
   // Rows longer than the eight index slots a thread keeps in registers fall back to per-lane CSR walks: on the fused
@@ -277,7 +280,6 @@ static int stack_fwd16(const float *feats, int ld_feats, int in_features, const 
                        const float *const *biases, int num_layers, int hidden, int cut_len, const int32_t *rowptr,
                        const int32_t *col, const float *val, int max_degree, const a3vt_adj_split *split, int n_vert,
                        int batch, void *acts, uint8_t *masks, float *scratch, float *update, hipStream_t s) {
-  (void)split;
   if (int rc = check_stack16_dims(num_layers, hidden, in_features)) return rc;
   const float *zeros = zero_page();
   A3VT_CHECK_ARG(zeros != nullptr);
@@ -348,7 +350,9 @@ static int stack_fwd16(const float *feats, int ld_feats, int in_features, const 
   }
   const int last = num_layers - 1;
   if (int rc = launch_thin16_fwd_product(x, ldx, hidden, weights[last], (long long)m, scratch + L.z3, s)) return rc;
-  return launch_csr3(scratch + L.z3, biases[last], rowptr, col, val, heavy, n_vert, batch, update, 3, s);
+  const SplitRef sref = split_ref(split);
+  return launch_csr3(scratch + L.z3, biases[last], rowptr, col, val, heavy, n_vert, batch, update, 3, s,
+                     split && split->rowptr ? &sref : nullptr, false);
 }
 
 static int stack_bwd16(const float *feats, int ld_feats, int in_features, const float *const *weights, int num_layers,
@@ -356,7 +360,6 @@ static int stack_bwd16(const float *feats, int ld_feats, int in_features, const 
                        int max_degreeT, const a3vt_adj_split *split, int n_vert, int batch, const void *acts,
                        const uint8_t *masks, const float *grad_update, float *const *grad_weights,
                        float *const *grad_biases, float *grad_feats, float *scratch, int acc, hipStream_t s) {
-  (void)split;
   if (int rc = check_stack16_dims(num_layers, hidden, in_features)) return rc;
   const float *zeros = zero_page();
   A3VT_CHECK_ARG(zeros != nullptr);
@@ -381,7 +384,10 @@ static int stack_bwd16(const float *feats, int ld_feats, int in_features, const 
   {
     float *du4 = scratch + L.z3, *res = scratch + L.z3 + m * 4;
     if (int rc = launch_pad3to4(grad_update, (long long)m, du4, s)) return rc;
-    if (int rc = launch_csr3(du4, nullptr, rowptrT, colT, valT, heavyT, n_vert, batch, res, 4, s)) return rc;
+    const SplitRef sref = split_ref(split);
+    if (int rc = launch_csr3(du4, nullptr, rowptrT, colT, valT, heavyT, n_vert, batch, res, 4, s,
+                             split && split->rowptr ? &sref : nullptr, true))
+      return rc;
     const u16 *x = acts16 + (size_t)(last - 1) * m * L.ldh;
     if (int rc = launch_thin16_bwd_main(x, L.ldh, hidden, weights[last], res, grad_update, (long long)m, 1, ping[0], L.ldh,
                                         scratch + L.thin_dw_slab, scratch + L.thin_db_slab, s))
@@ -666,6 +672,9 @@ int a3vt_gcn_stack_fwd_adj(const float *feats, int ld_feats, int in_features, co
   const int mld = mask_ld(hidden, cut_len);
   const size_t mpad = (m + 31) / 32 * 32;
 
+  // the 3-channel aggregation of the output layer through the split (any P: its rows are walked from global memory)
+  const SplitRef sref = split_ref(split);
+  const SplitRef *sp3 = split && split->rowptr && split->col && split->scale && split->cls ? &sref : nullptr;
   // hub rows (if any): listed once, then every layer's aggregation hands them to whole workgroups
   int32_t *heavy = nullptr;
   if (max_degree <= 0 || max_degree > csr_heavy_degree()) {
@@ -794,7 +803,7 @@ int a3vt_gcn_stack_fwd_adj(const float *feats, int ld_feats, int in_features, co
   }
   const int klast = num_layers == 1 ? in_features : hidden;
   return launch_thin_fwd(x, ldx, klast, weights[num_layers - 1], biases[num_layers - 1], rowptr, col, val, heavy, n_vert,
-                         batch, scratch + L.z3, update, xq, qcols / 4, s);
+                         batch, scratch + L.z3, update, xq, qcols / 4, s, sp3);
 }
 
 int a3vt_gcn_stack_bwd(const float *feats, int ld_feats, int in_features, const float *const *weights,
@@ -851,6 +860,8 @@ int a3vt_gcn_stack_bwd_adj(const float *feats, int ld_feats, int in_features, co
   const size_t mpad = (m + 31) / 32 * 32;
   const int last = num_layers - 1;
 
+  const SplitRef sref = split_ref(split);
+  const SplitRef *sp3 = split && split->rowptr && split->col && split->scale && split->cls ? &sref : nullptr;
   // hub rows of A^T (if any): listed once for every aggregation of this call
   int32_t *heavyT = nullptr;
   if (max_degreeT <= 0 || max_degreeT > csr_heavy_degree()) {
@@ -884,7 +895,7 @@ int a3vt_gcn_stack_bwd_adj(const float *feats, int ld_feats, int in_features, co
     if (int rc = launch_thin_bwd(x, ldx, k, weights[last], rowptrT, colT, valT, heavyT, n_vert, batch, grad_update,
                                  scratch + L.z3, num_layers > 1, gprev, ldg, ldg, scratch + L.thin_dw_slab,
                                  scratch + L.thin_db_slab, quad ? scratch + L.gq : nullptr, cpad / 4, quad ? xl : nullptr,
-                                 qcols / 4, s))
+                                 qcols / 4, s, sp3))
       return rc;
     if (int rc = launch_slab_reduce_za(scratch + L.thin_dw_slab, thin_num_slabs(), (size_t)k * 3, (size_t)k * 3, (size_t)k * 3,
                                        grad_weights[last], acc, s))

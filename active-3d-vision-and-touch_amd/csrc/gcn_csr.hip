@@ -506,9 +506,76 @@ __global__ __launch_bounds__(256) void csr3_heavy_kernel(const float *__restrict
   }
 }
 
+// The same aggregation through the split D^-1 (P + J) of the fused vision + touch matrix (a3vt_adj_split; gcn_csrqs.hip has the
+// algebra): a workgroup per (mesh, part of its vertices) keeps the mesh's [n_vert] float4 rows in LDS, forms the two class
+// sums, and walks the short rows of P.  TRANSPOSED = the product with A^T: P and J are symmetric, so it is the same walk
+// over rows scaled on their way in instead of sums scaled on their way out.  No hub list, no second launch.
+template <bool TRANSPOSED>
+__global__ __launch_bounds__(256) void csr3s_kernel(const float *__restrict__ z, const float *__restrict__ bias,
+                                                    const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+                                                    const float *__restrict__ scale, const uint8_t *__restrict__ cls,
+                                                    int n_vert, int parts, float *__restrict__ out, int ldo) {
+  extern __shared__ __attribute__((aligned(16))) float lds3[];
+  __shared__ f32x4 red[2][4];
+  f32x4 *zs = reinterpret_cast<f32x4 *>(lds3);
+  const int b = blockIdx.x / parts, part = blockIdx.x - b * parts;
+  const f32x4 *zb = reinterpret_cast<const f32x4 *>(z) + (size_t)b * n_vert;
+  f32x4 ps = {0.f, 0.f, 0.f, 0.f}, pc = ps;
+  for (int v = threadIdx.x; v < n_vert; v += 256) {
+    f32x4 x = zb[v];
+    if (TRANSPOSED) x *= scale[v];
+    zs[v] = x;
+    const int cl = cls[v];
+    if (cl == 1) ps += x;
+    if (cl == 2) pc += x;
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) ps[t] = wave_sum(ps[t]), pc[t] = wave_sum(pc[t]);
+  if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = ps, red[1][threadIdx.x >> 6] = pc;
+  __syncthreads();
+  const f32x4 sig_s = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+  const f32x4 sig_c = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+  const int v0 = (int)((long long)part * n_vert / parts), v1 = (int)((long long)(part + 1) * n_vert / parts);
+  for (int v = v0 + threadIdx.x; v < v1; v += 256) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int e = rowptr[v]; e < rowptr[v + 1]; ++e) acc += zs[colidx[e]];
+    const int cl = cls[v];
+    if (cl == 1) acc += sig_c;
+    if (cl == 2) acc += sig_s;
+    if (!TRANSPOSED) acc *= scale[v];
+    if (bias) {
+      acc[0] += bias[0];
+      acc[1] += bias[1];
+      acc[2] += bias[2];
+    }
+    const long long row = (long long)b * n_vert + v;
+    if (ldo == 4) {
+      acc[3] = 0.f;
+      *reinterpret_cast<f32x4 *>(out + row * 4) = acc;
+    } else {
+      out[row * ldo + 0] = acc[0];
+      out[row * ldo + 1] = acc[1];
+      out[row * ldo + 2] = acc[2];
+    }
+  }
+}
+
 int launch_csr3(const float *z, const float *bias, const int32_t *rowptr, const int32_t *col, const float *val,
-                       const int32_t *heavy, int n_vert, int batch, float *out, int ldo, hipStream_t s) {
+                       const int32_t *heavy, int n_vert, int batch, float *out, int ldo, hipStream_t s, const SplitRef *sp,
+                       bool transposed) {
   const long long m = (long long)batch * n_vert;
+  if (sp && (size_t)n_vert * 16 <= 60 * 1024) {
+    int parts = 512 / batch;   // ~two workgroups per CU
+    parts = parts < 1 ? 1 : parts > 8 ? 8 : parts;
+    if (transposed)
+      A3VT_LAUNCH(csr3s_kernel<true>, dim3(batch * parts), dim3(256), (size_t)n_vert * 16, s, z, bias, sp->rowptr, sp->col,
+                  sp->scale, sp->cls, n_vert, parts, out, ldo);
+    else
+      A3VT_LAUNCH(csr3s_kernel<false>, dim3(batch * parts), dim3(256), (size_t)n_vert * 16, s, z, bias, sp->rowptr, sp->col,
+                  sp->scale, sp->cls, n_vert, parts, out, ldo);
+    A3VT_CHECK_LAUNCH();
+    return 0;
+  }
   A3VT_LAUNCH(csr3_kernel, dim3(cdiv(m, 256)), dim3(256), 0, s, z, bias, rowptr, col, val, n_vert, m, out, ldo,
               heavy ? kHeavyDeg : 0x7fffffff);
   A3VT_CHECK_LAUNCH();
@@ -521,7 +588,7 @@ int launch_csr3(const float *z, const float *bias, const int32_t *rowptr, const 
 
 int launch_thin_fwd(const float *x, int ldx, int k, const float *w, const float *bias, const int32_t *rowptr,
                     const int32_t *col, const float *val, const int32_t *heavy, int n_vert, int batch, float *z3,
-                    float *update, const float *xq, int xq_quads, hipStream_t s) {
+                    float *update, const float *xq, int xq_quads, hipStream_t s, const SplitRef *sp) {
   if (k > kThinPieces * 64 || ldx % 4 != 0) {
     set_error("thin_fwd: k=%d (max %d) ldx=%d unsupported", k, kThinPieces * 64, ldx);
     return -1;
@@ -530,7 +597,7 @@ int launch_thin_fwd(const float *x, int ldx, int k, const float *w, const float 
   const int grid = (int)(cdiv(m, 16) < kThinFwdBlocks ? cdiv(m, 16) : kThinFwdBlocks);
   A3VT_LAUNCH(thin_fwd_kernel, dim3(grid), dim3(256), 0, s, x, ldx, k, w, m, z3, xq, xq_quads, n_vert);
   A3VT_CHECK_LAUNCH();
-  return launch_csr3(z3, bias, rowptr, col, val, heavy, n_vert, batch, update, 3, s);
+  return launch_csr3(z3, bias, rowptr, col, val, heavy, n_vert, batch, update, 3, s, sp, false);
 }
 
 // Backward of the output layer.  dz3 = A^T dU (csr3 with the transposed CSR, no bias), then one pass over X:
@@ -675,7 +742,7 @@ int launch_pad3to4(const float *in, long long m, float *out, hipStream_t s) {
 int launch_thin_bwd(const float *x, int ldx, int k, const float *w, const int32_t *rowptrT, const int32_t *colT,
                     const float *valT, const int32_t *heavyT, int n_vert, int batch, const float *grad_update,
                     float *dz3, int apply_mask, float *g_prev, int ldg, int n_store, float *dw_slab, float *db_slab,
-                    float *gq, int nq, const float *xq, int xq_quads, hipStream_t s) {
+                    float *gq, int nq, const float *xq, int xq_quads, hipStream_t s, const SplitRef *sp) {
   if (k > kThinPieces * 64 || ldx % 4 != 0 || ldg % 4 != 0) {
     set_error("thin_bwd: k=%d ldx=%d ldg=%d unsupported", k, ldx, ldg);
     return -1;
@@ -686,7 +753,7 @@ int launch_thin_bwd(const float *x, int ldx, int k, const float *w, const int32_
   float *du4 = dz3;
   float *res = dz3 + m * 4;
   if (int rc = launch_pad3to4(grad_update, m, du4, s)) return rc;
-  if (int rc = launch_csr3(du4, nullptr, rowptrT, colT, valT, heavyT, n_vert, batch, res, 4, s)) return rc;
+  if (int rc = launch_csr3(du4, nullptr, rowptrT, colT, valT, heavyT, n_vert, batch, res, 4, s, sp, true)) return rc;
   A3VT_LAUNCH(thin_bwd_kernel, dim3(kThinBlocks), dim3(256), 0, s, x, ldx, k, w, res, grad_update, m, apply_mask,
                      g_prev, ldg, n_store, dw_slab, db_slab, gq, nq, n_vert, xq, xq_quads);
   A3VT_CHECK_LAUNCH();

@@ -170,6 +170,12 @@ int launch_csrq_fwd(const float *zq, const float *bias, int c, const int32_t *ro
 int launch_csrq_bwd(const float *gq, int c, const int32_t *rowptrT, const int32_t *colT, const float *valT,
                     const int32_t *heavyT, const int32_t *ellT, int n_vert, int batch, float *dzaq, const uint8_t *signq,
                     float *db_slab, hipStream_t s);
+// D^-1 (P + J) as device pointers (a3vt_adj_split without the counts): the 3-channel aggregations of the output layer take it
+struct SplitRef {
+  const int32_t *rowptr, *col;
+  const float *scale;
+  const uint8_t *cls;
+};
 // The same for structured adjacencies D^-1 (P + J), J = a complete bipartite block (gcn_csrqs.hip, a3vt_adj_split): `img` =
 // the index image launch_csrqs_image builds from the split (csrqs_image_ints(n_vert) ints); same layouts as csrq.
 bool csrqs_fits(int n_vert, int cut_len);
@@ -191,13 +197,13 @@ int launch_thin_fwd(const float *x, int ldx, int k, const float *w /*[k][3]*/, c
                     const int32_t *rowptr, const int32_t *col, const float *val, const int32_t *heavy, int n_vert,
                     int batch, float *z3 /*[M][4] scratch*/, float *update /*[M][3]*/,
                     const float *xq /*quad-major X columns [0, 4 xq_quads) or nullptr (then x holds them all)*/, int xq_quads,
-                    hipStream_t s);
+                    hipStream_t s, const SplitRef *sp = nullptr);
 int launch_thin_bwd(const float *x, int ldx, int k, const float *w, const int32_t *rowptrT, const int32_t *colT,
                     const float *valT, const int32_t *heavyT, int n_vert, int batch,
                     const float *grad_update /*[M][3]*/, float *dz3 /*[2][M][4] scratch*/, int apply_mask,
                     float *g_prev /*[M][ldg]*/, int ldg, int n_store, float *dw_slab /*[thin_num_slabs()][k*3]*/,
                     float *db_slab /*[thin_num_slabs()][3]*/, float *gq /*quad-major columns [0, 4 nq) or nullptr*/, int nq,
-                    const float *xq /*as launch_thin_fwd*/, int xq_quads, hipStream_t s);
+                    const float *xq /*as launch_thin_fwd*/, int xq_quads, hipStream_t s, const SplitRef *sp = nullptr);
 
 int launch_vertex_update(const float *vin, const float *upd, int batch, int n_vert, int n_vision, float *vout,
                          hipStream_t s);
@@ -230,7 +236,9 @@ int launch_thin16_bwd_main(const void *x, int ldx, int k, const float *w, const 
                            int apply_mask, void *gprev, int ldg, float *dw_slab, float *db_slab, hipStream_t s);
 // 3-channel aggregation / padding helpers of the output layer (gcn_csr.hip), shared with the bf16-storage path
 int launch_csr3(const float *z, const float *bias, const int32_t *rowptr, const int32_t *col, const float *val,
-                const int32_t *heavy, int n_vert, int batch, float *out, int ldo, hipStream_t s);
+                const int32_t *heavy, int n_vert, int batch, float *out, int ldo, hipStream_t s,
+                const SplitRef *sp = nullptr /* the split of THIS matrix, or of its transpose with transposed = true */,
+                bool transposed = false);
 int launch_pad3to4(const float *in, long long m, float *out, hipStream_t s);
 
 // posenc.hip

@@ -127,8 +127,22 @@ def test_batched_scoring(cuda, use_img):
         assert torch.equal(m, m_all[k])
         if use_img:   # torch/MIOpen ops of the image branch (448-wide encoders, grid_sample) pick batch-size dependent
             assert rel_err(v_all[k], v) < 1e-5 and rel_err(score[k], s) < 1e-4   # GEMM tilings: rounding-level differences
-        else:         # the HIP kernels are batch-position invariant: bit-identical
-            assert torch.equal(v, v_all[k]) and torch.equal(s, score[k])
+        else:
+            # round 6: the batched call (>= 12 288 rows) aggregates through the P + bipartite split (gcn_csrqs.hip), the
+            # few-row calls of the loop walk the full CSR — the same sums in another association
+            assert rel_err(v_all[k], v) < 1e-5 and rel_err(score[k], s) < 1e-4
+    if not use_img:   # on ONE kernel family the HIP path is batch-position invariant: bit-identical to the loop
+        info["csr"].use_split = False
+        try:
+            with torch.no_grad():
+                score_g, v_g, _ = scoring.score_actions(net, img, charts_list, gt, info["faces"], P, args.loss_coeff, samples=samples)
+                for k in range(K):
+                    v, m = net(img, charts_list[k])
+                    s = args.loss_coeff * utils.chamfer_distance(v, info["faces"], gt, num=P, samples=samples)
+                    assert torch.equal(v, v_g[k]) and torch.equal(s, score_g[k])
+        finally:
+            info["csr"].use_split = True
+        assert rel_err(v_g, v_all) < 1e-5 and rel_err(score_g, score) < 1e-4
     taken = torch.zeros(E, K)
     taken[0, int(score[:, 0].argmin())] = 1               # best candidate of element 0 already performed
     best = scoring.best_actions(score, taken)
