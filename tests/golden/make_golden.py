@@ -24,6 +24,8 @@ Fixtures (names follow SURVEY §8c):
                        19-tile products with the A operand in registers, the split-operand kernels of gemm mode 3):
                        forward verts, Chamfer with injected samples, the gradient norm of every parameter tensor and a few
                        whole gradients
+  g13_touch_b8.npz     the same on the production topology t_g (atlas + 20 touch charts, N = 2324) at B = 8 = 18 592 rows,
+                       touch charts with empty / touched / untouched slots: reaches the P + bipartite split kernels (round 6)
   g11_loader_batch.npz the reference's ``mesh_loader_vision`` (utility/data_loaders.py:132-258) on the miniature dataset
                        ``golden_util.write_mini_dataset`` writes: instance list, seeded validation grasp choices, seeded
                        training draws, one collated batch (touch_charts, gt_points, image samples), finger variant
@@ -203,6 +205,51 @@ def g12():
     # one hidden-layer weight gradient, subsampled (300 x 300 floats would be 360 KB): every 7th row, every 5th column
     arrs["g:mesh_deform_2.layers.9.weight[::7,::5]"] = sd["mesh_deform_2.layers.9.weight"].grad.numpy()[0, ::7, ::5]
     save("g12_atlas_b8.npz", **arrs)
+
+
+def g13():
+    """Full-size Deformation on the PRODUCTION topology t_g (atlas + 5 grasps x 4 fingers = 20 touch charts, N = 2324, hub rows
+    of 1153 entries, utils.py:75-130) at B = 8 = 18 592 rows: enough for the kernels a touch training step runs — since round
+    6 the P + bipartite split of the fused adjacency (csrc/gcn_csrqs.hip) on hybrid rows."""
+    a = args_of(use_touch=True, finger=False, num_grasps=5)
+    torch.manual_seed(0)
+    info, verts = ref.utils.load_mesh_vision(a, OBJ)
+    net = ref.model.Deformation(info, verts, a)
+    B, P, Q = 8, 1000, 1500
+    tc = touch_batch(B, a, 13)                 # status 0 / 1 / 2 per chart: empty, touched and untouched slots
+    batch = {"img": torch.zeros(B, 1), "touch_charts": tc}
+    charts = ref.model.prepare_mesh(batch, verts, a)
+    g = torch.Generator().manual_seed(13)
+    amp = torch.linspace(0.004, 0.02, B).view(B, 1, 1)
+    charts["vision_charts"] = charts["vision_charts"] + amp * torch.randn(B, verts.shape[0], 3, generator=g)
+    verts_in = charts["vision_charts"].clone()
+    out, mask = net(batch["img"], charts)
+    d = torch.randn(B, Q, 3, generator=g)
+    gt = d / d.norm(dim=-1, keepdim=True) * (0.05 + 0.11 * torch.rand(B, 1, 3, generator=g))
+    samples = injected(B, info["faces"].shape[0], P, 113)
+    cd = ref_chamfer_injected(out, info["faces"], gt, samples)
+    loss = 9000.0 * cd.mean()
+    loss.backward()
+    arrs = {"verts_in": verts_in.numpy(), "touch_charts": tc.numpy(), "verts_out": out.detach().numpy(),
+            "mask": mask.numpy().astype(np.int8), "cd": cd.detach().numpy(),
+            "loss": np.float32(loss.item()), "gt": gt.numpy(),
+            "face_idx": torch.stack([s_[0] for s_ in samples]).numpy().astype(np.int16),
+            "u": torch.stack([s_[1] for s_ in samples]).numpy(), "v": torch.stack([s_[2] for s_ in samples]).numpy(),
+            "weight_sha256": state_checksum(net.state_dict()), "pytorch3d_restated": np.bool_(True)}
+    names, norms = [], []
+    for k, p in net.named_parameters():
+        names.append(k)
+        norms.append(0.0 if p.grad is None else float(p.grad.double().norm()))
+    arrs["grad_names"] = np.array(names)
+    arrs["grad_norms"] = np.array(norms, dtype=np.float64)
+    keep = ["mesh_deform_1.layers.0.weight", "mesh_deform_1.layers.10.bias", "mesh_deform_2.layers.7.bias",
+            "mesh_deform_2.layers.19.weight", "mesh_deform_2.layers.19.bias", "mesh_deform_1.layers.19.weight",
+            "positional_encoder.model.0.weight", "mask_encoder.model.0.weight"]
+    sd = dict(net.named_parameters())
+    for k in keep:
+        arrs["g:" + k] = sd[k].grad.numpy()
+    arrs["g:mesh_deform_2.layers.9.weight[::7,::5]"] = sd["mesh_deform_2.layers.9.weight"].grad.numpy()[0, ::7, ::5]
+    save("g13_touch_b8.npz", **arrs)
 
 
 def g5():
@@ -513,6 +560,6 @@ def g11():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     for w in which:
         globals()[w]()

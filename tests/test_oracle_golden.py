@@ -180,6 +180,40 @@ def test_g12_atlas_b8_forward_loss_and_gradient_norms():
             assert float((got - ref).norm() / ref.norm()) < 2e-4, key
 
 
+def test_g13_touch_b8_forward_loss_and_gradient_norms():
+    """The touch counterpart of g12 (round 6): the reference on the production topology t_g (N = 2324, hub rows) at B = 8; the
+    oracle reproduces positions, mask, per-sample Chamfer distances and every gradient norm."""
+    from helpers import make_args
+    from a3vt_amd.pterotactyl.reconstruction.vision import model
+    z = load("g13_touch_b8.npz")
+    g1 = load("g1_adjacency.npz")
+    args = make_args(use_touch=True, finger=False, num_grasps=5)
+    torch.manual_seed(0)
+    net = model.Deformation({}, torch.from_numpy(g1["verts"]), args)
+    st = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    B = z["verts_in"].shape[0]
+    ch = og.prepare_mesh(torch.from_numpy(z["touch_charts"]), torch.from_numpy(g1["verts"]), B, True)
+    ch["vision_charts"] = torch.from_numpy(z["verts_in"])
+    out, mask = og.deformation_forward(st, {"adj": csr_from(g1, "t_g", "adj")}, ch, True, 20, 0.33)
+    assert np.array_equal(mask.numpy().astype(np.int8), z["mask"])
+    np.testing.assert_allclose(out.detach().numpy(), z["verts_out"], rtol=0, atol=2e-6)
+    faces = torch.from_numpy(g1["t_g_faces"].astype(np.int64))
+    samples = [(torch.from_numpy(z["face_idx"][r].astype(np.int64)), torch.from_numpy(z["u"][r]), torch.from_numpy(z["v"][r]))
+               for r in range(3)]
+    cd = och.chamfer_distance(out, faces, torch.from_numpy(z["gt"]), num=z["u"].shape[-1], samples=samples)
+    np.testing.assert_allclose(cd.detach().numpy(), z["cd"], rtol=1e-5)
+    (9000.0 * cd.mean()).backward()
+    for k, n in zip(z["grad_names"], z["grad_norms"]):
+        g = st[str(k)].grad
+        got = 0.0 if g is None else float(g.double().norm())
+        assert abs(got - n) <= 2e-4 * max(n, 1e-12), (k, got, n)
+    for key in z.files:
+        if key.startswith("g:") and "[" not in key:
+            ref = torch.from_numpy(z[key])
+            got = st[key[2:]].grad
+            assert float((got - ref).norm() / ref.norm()) < 2e-4, key
+
+
 @pytest.mark.parametrize("stages", [3, 1])
 def test_g7_train_step(stages):
     """BASELINE.json configs[0]: bs=2, 10k Chamfer points, reference trainer arithmetic (loss_coeff*mean, Adam 3e-4)."""
