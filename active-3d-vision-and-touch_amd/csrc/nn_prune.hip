@@ -482,7 +482,12 @@ struct NNQuery {
   int p, q, npx, npy, nz, batch;   // nz = draws * batch cloud pairs; pair z = (x cloud z, y cloud z % batch)
   float *dxy, *dyx;
   int32_t *ixy, *iyx;
+  unsigned long long *work;   // a3vt_dbg_nn_work: nullptr (the product: no counter is touched) or 8 counters
 };
+// Work counters of the search for regression tests (a3vt_dbg_nn_work): [0] waves, [1] groups of 16 candidates evaluated,
+// [2] blocks evaluated, [3] point-to-box tests, [4] most groups evaluated by one wave.  Off unless a test turns them on.
+__device__ unsigned long long g_nn_work[8];
+static bool g_nn_work_on = false;
 
 // One wave = one block of 64 sorted queries.  y < nz: the x cloud asks the y cloud; y >= nz: the y cloud asks the x cloud.
 __device__ __forceinline__ void nn_query_wave(const NNQuery &a, int y, int qblk, int lane) {
@@ -652,6 +657,13 @@ __device__ __forceinline__ void nn_query_wave(const NNQuery &a, int y, int qblk,
       if (sq3(qx - cnd[0], qy - cnd[1], qz - cnd[2]) == best && ci >= 0) bidx = min(bidx, ci);
     }
   }
+  if (a.work != nullptr && lane == 0) {
+    atomicAdd(&a.work[0], 1ull);
+    atomicAdd(&a.work[1], (unsigned long long)n_grp);
+    atomicAdd(&a.work[2], (unsigned long long)n_eval);
+    atomicAdd(&a.work[3], (unsigned long long)n_test);
+    atomicMax(&a.work[4], (unsigned long long)n_grp);
+  }
   const unsigned long long clk3 = NN_CLOCK();
   NN_STAT(0, 1);
   NN_STAT(1, n_eval);
@@ -799,7 +811,12 @@ int launch_nn_pruned(const float *x, const float *y, int draws, int batch, int p
   A3VT_LAUNCH(nn_boxes_kernel, dim3((unsigned)box_wgs), dim3(1024), 0, s, c, cdiv(nbmax, 16));
   A3VT_CHECK_LAUNCH();
   if (stages < 3) return 0;
-  NNQuery a{c.sx, c.sy, c.bx, c.by, c.ox, c.oy, c.gx, c.gy, p, q, c.npx, c.npy, c.nx, y_batch, dxy, dyx, ixy, iyx};
+  unsigned long long *work = nullptr;
+  if (g_nn_work_on) {
+    void *sym = nullptr;
+    if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_nn_work)) == hipSuccess) work = static_cast<unsigned long long *>(sym);
+  }
+  NNQuery a{c.sx, c.sy, c.bx, c.by, c.ox, c.oy, c.gx, c.gy, p, q, c.npx, c.npy, c.nx, y_batch, dxy, dyx, ixy, iyx, work};
   A3VT_LAUNCH(nn_query_kernel, dim3((unsigned)query_wgs), dim3(64 * wg_waves_q), 0, s, a, cdiv(nbmax, wg_waves_q));
   A3VT_CHECK_LAUNCH();
   return 0;
@@ -817,6 +834,16 @@ extern "C" int a3vt_dbg_nn_trace(unsigned long long *out, unsigned *n) {   // pe
   return hipMemcpyToSymbol(HIP_SYMBOL(a3vt::nn_trace_n), &zero, sizeof(unsigned)) == hipSuccess ? 0 : -1;
 }
 #endif
+extern "C" int a3vt_dbg_nn_work(int enable, unsigned long long *out8) {
+  // Synchronises the device (a test hook).  out8 != NULL: receives the counters accumulated so far; enable != 0: counters
+  // cleared and switched on for the searches that follow, enable == 0: switched off.
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (out8 != nullptr && hipMemcpyFromSymbol(out8, HIP_SYMBOL(a3vt::g_nn_work), sizeof(z)) != hipSuccess) return -1;
+  if (enable && hipMemcpyToSymbol(HIP_SYMBOL(a3vt::g_nn_work), z, sizeof(z)) != hipSuccess) return -1;
+  a3vt::g_nn_work_on = enable != 0;
+  return 0;
+}
 #ifdef A3VT_DBG_NN_STATS
 extern "C" int a3vt_dbg_nn_stats(unsigned long long *out5) {   // reads and clears the counters
   unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};

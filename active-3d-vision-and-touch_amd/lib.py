@@ -81,6 +81,7 @@ SIGNATURES = {
     "a3vt_chamfer_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "a3vt_dbg_csr_algo": (_i, [_i]),
     "a3vt_dbg_path_counts": (_i, [_vp, _i, _i]),
+    "a3vt_dbg_nn_work": (_i, [_i, _vp]),
     "a3vt_split3_bf16": (_i, [_vp, _sz, _vp, _vp, _vp, _vp]),
     "a3vt_check_finite": (_i, [_vp, _sz, _vp, _vp]),
     "a3vt_profile_enable": (_i, [_i]),

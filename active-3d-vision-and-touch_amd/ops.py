@@ -102,6 +102,16 @@ def path_counts(reset=False):
     return dict(zip(PATH_NAMES, (int(x) for x in buf)))
 
 
+def nn_work(enable):
+    """Work counters of the pruned nearest-neighbour search (``a3vt_dbg_nn_work``; a test hook, synchronises the device):
+    returns what was counted since they were switched on, then switches them on (True: cleared first) or off (False)."""
+    import ctypes
+    buf = (ctypes.c_ulonglong * 8)()
+    _lib.check(_lib.load().a3vt_dbg_nn_work(1 if enable else 0, buf), "dbg_nn_work")
+    names = ("waves", "groups", "blocks", "box_tests", "max_groups_per_wave")
+    return dict(zip(names, (int(x) for x in buf)))
+
+
 def gemm_mode(bf16):
     """0 exact fp32 MFMA; 1 bf16 operands, fp32 storage; 2 bf16 storage (activations / gradients / weight images bf16 in
     HBM, fp32 accumulation); 3 "fp32x3": fp32 storage, the hidden-layer products as six bf16 MFMA passes on operands split

@@ -347,8 +347,18 @@ int a3vt_dbg_csr_algo(int algo);
  *   [2] rowgemm_kernel<19,...,ADIRECT> launches (exact fp32 hidden-layer products: the headline kernel)
  *   [3] rowgemm3_kernel launches (gemm mode 3)   [4] dw3_kernel launches   [5] dw_kernel launches on quad-major operands
  *   [6] rowgemm16_kernel launches (bf16 storage)  [7] bf16-storage stack forward calls on the channel-sliced aggregation
+ *   [8] stack forward calls that aggregated through the P + bipartite split (struct a3vt_adj_split)
  * Returns the number of counters the library keeps (entries beyond it are written as 0); reset != 0 clears them. */
 int a3vt_dbg_path_counts(long long *counts, int n, int reset);
+
+/* Test hook: WORK counters of the pruned nearest-neighbour search (a3vt_chamfer_fwd_ws and friends) — values cannot show a
+ * search that does too much work (round 5: pad lanes that asked about the origin cost 1.85 ms of a 1.5 ms launch for three
+ * rounds, every result bit-exact).  enable != 0 clears the counters and switches them on for the searches that follow (a
+ * handful of atomics per wave: not for timing), enable == 0 switches them off; out8 != NULL receives what was counted so
+ * far: [0] waves of 64 queries, [1] groups of 16 candidates evaluated, [2] blocks of 64 evaluated, [3] point-to-box tests,
+ * [4] the most groups any one wave evaluated, [5..7] 0.  Synchronises the device.  Off by default (the product touches no
+ * counter). */
+int a3vt_dbg_nn_work(int enable, unsigned long long *out8);
 
 /* The operand split of gemm mode 3 (replaces nothing in the reference: it is how torch.matmul(features, self.weight),
  * model.py:352, is fed to the bf16 matrix pipe without losing fp32 bits).  hi / mid / lo receive bf16 bit patterns with

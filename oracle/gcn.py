@@ -178,10 +178,10 @@ def deformation_forward_img(state, adj_info, charts, img, use_touch, num_layers=
     return vertices, mask
 
 
-def deformation_forward(state, adj_info, charts, use_touch, num_layers=20, cut=0.33, num_stages=3):
+def deformation_forward(state, adj_info, charts, use_touch, num_layers=20, cut=0.33, num_stages=3, bf16=False):
     """model.py:203-286 for ``use_img=False``.  ``adj_info`` holds 'adj' (dense tensor or CSR triple).
     Returns (vertices (B,N,3), mask (B,N,1)).  ``num_stages`` < 3 truncates after that many
-    refinement stages (BASELINE.json configs[0] asks for 1)."""
+    refinement stages (BASELINE.json configs[0] asks for 1).  ``bf16``: the device's bf16 modes emulated (:func:`gcn_layer`)."""
     vc = charts["vision_charts"].shape[1]
     adj = adj_info["adj"]  # mesh_deform_1 uses 'origional' only when use_img (model.py:198-200,317-320)
     if use_touch:
@@ -192,12 +192,12 @@ def deformation_forward(state, adj_info, charts, use_touch, num_layers=20, cut=0
         mask = charts["vision_masks"].clone()
     mask_features = mask_encoder(mask, state)
     feats = positional_encoder(vertices, state) + mask_features
-    update = gcn(feats, state, "mesh_deform_1", adj, num_layers, cut)
+    update = gcn(feats, state, "mesh_deform_1", adj, num_layers, cut, bf16=bf16)
     vertices = torch.cat((vertices[:, :vc] + update[:, :vc], vertices[:, vc:]), dim=1)
     for _ in range(1, num_stages):
         # stage 2 re-uses stage-1 mask features (model.py:262); stage 3 recomputes them (:274) — same values.
         feats = positional_encoder(vertices, state) + mask_features
-        update = gcn(feats, state, "mesh_deform_2", adj, num_layers, cut)
+        update = gcn(feats, state, "mesh_deform_2", adj, num_layers, cut, bf16=bf16)
         vertices = torch.cat((vertices[:, :vc] + update[:, :vc], vertices[:, vc:]), dim=1)
     return vertices, mask
 

@@ -324,3 +324,116 @@ def test_config3_fullsize_is_finite_and_repeatable(cuda):
     with torch.no_grad():
         gmaps, lmaps = net.img_encoder_global(img), net.img_encoder_local(img)
     _repeatable_training_step(cuda, net, lambda: net.deform_with_maps(charts, gmaps, lmaps)[0], info["faces"], gt, P, nf)
+
+
+# ---- (e) VALUES at the full sizes of configs[3] and of the configs[4] shard (round 6, verdict r05 #2b) ----------------------
+def _step_values(cuda, forward, faces, gt, P, n_faces, params, seed=1):
+    """Forward + 3-draw Chamfer (injected samples, the same for every copy of a mesh) + backward: positions, per-sample
+    distances, the gradients of ``params``."""
+    from a3vt_amd.pterotactyl.utility import utils
+    g = torch.Generator().manual_seed(seed)
+    B = gt.shape[0]
+    rep = B // 2
+    one = (torch.randint(0, n_faces, (3, 2, P), generator=g).to(torch.int32), torch.rand(3, 2, P, generator=g), torch.rand(3, 2, P, generator=g))
+    samples = tuple(t.repeat(1, rep, 1).to(cuda) for t in one)           # copy c of mesh m = row 2 c + m
+    for p_ in params:
+        p_.grad = None
+    out = forward()
+    cd = utils.chamfer_distance(out, faces, gt, num=P, samples=samples)
+    (9000.0 * cd.sum()).backward()
+    torch.cuda.synchronize()
+    return out.detach(), cd.detach(), [p_.grad.clone() for p_ in params], one
+
+
+def test_config4_shard_values_fullsize(cuda):
+    """BASELINE configs[4] per-GPU shard (10 242-vertex template, bs 8, 50 000-point Chamfer, full 20 x 300 x 3, bf16 storage)
+    pinned to VALUES, in the shape of ``test_benchmark_configuration_values_fullsize``: the batch is four copies of two
+    differently perturbed meshes with two different targets; (a) every copy reproduces bit for bit what the same two meshes
+    give as a batch of 2 — positions and Chamfer distances — and the weight gradients of the summed loss are 4 x those of the
+    pair; (b) the pair's positions agree with the oracle's bf16-STORAGE emulation (float64 arithmetic, bf16 rounding where the
+    device stores) to 5e-3 and with the exact fp32 oracle to 5e-3, and the Chamfer distances of the device's positions with
+    the plain-C oracle on the same samples to 1e-4."""
+    from a3vt_amd.pterotactyl.reconstruction.vision import model
+    from a3vt_amd.pterotactyl.utility import utils
+    from oracle import chamfer as och, gcn as og
+    args = make_args(gemm_precision="bf16s", number_points=50000)
+    v, f = template("ico5")
+    vt, ft = torch.from_numpy(v).to(cuda), torch.from_numpy(f).to(cuda)
+    info = utils.adj_init(vt, ft, args)
+    torch.manual_seed(0)
+    net = model.Deformation(info, vt, args).to(cuda)
+    P = 50000
+    g = torch.Generator().manual_seed(5)
+    pair = torch.from_numpy(v)[None].repeat(2, 1, 1) + torch.tensor([0.004, 0.012]).view(2, 1, 1) * torch.randn(2, v.shape[0], 3, generator=g)
+    gt2 = random_cloud(2, P, 9)
+    params = [p_ for n, p_ in net.named_parameters() if n.startswith("mesh_deform")]
+
+    def run(B):
+        charts = model.prepare_mesh({"img": torch.zeros(B, 1)}, vt, args)
+        charts["vision_charts"] = pair.repeat(B // 2, 1, 1).to(cuda)
+        return _step_values(cuda, lambda: net(torch.zeros(B, 1), charts)[0], info["faces"], gt2.repeat(B // 2, 1, 1).to(cuda), P,
+                            f.shape[0], params)
+    out2, cd2, g2, one = run(2)
+    out8, cd8, g8, _ = run(8)
+    for c in range(4):
+        assert torch.equal(out8[2 * c:2 * c + 2], out2) and torch.equal(cd8[2 * c:2 * c + 2], cd2), c
+    for a, b in zip(g8, g2):
+        assert rel_l2(a, 4.0 * b) < 1e-4                       # the same terms, summed over other row groups
+    # (b) the oracle on the pair
+    adj_o, faces_o = oracle_adj(v, f, args)
+    st = {k: t.detach().cpu() for k, t in net.state_dict().items()}
+    ch = og.prepare_mesh(None, torch.from_numpy(v), 2, False)
+    ch["vision_charts"] = pair
+    st64 = {k: t.double() for k, t in st.items()}
+    ch64 = {k: t.double() for k, t in ch.items()}
+    with torch.no_grad():
+        emu, _ = og.deformation_forward(st64, {"adj": (adj_o[0], adj_o[1], adj_o[2].double())}, ch64, False, 20, 0.33, bf16="storage")
+        exact, _ = og.deformation_forward(st, {"adj": adj_o}, ch, False, 20, 0.33)
+    e_emu, e_fp = rel_err(out2, emu), rel_err(out2, exact)
+    print(f"\n[configs[4] shard] positions vs bf16-storage emulation {e_emu:.2e}, vs exact fp32 {e_fp:.2e}")
+    assert e_emu < 5e-3 and e_fp < 5e-3, (e_emu, e_fp)
+    cd_o = och.chamfer_distance(out2.cpu(), faces_o, gt2, num=P, samples=[(one[0][r].long(), one[1][r], one[2][r]) for r in range(3)],
+                                use_c=True)
+    assert rel_err(cd2, cd_o) < 1e-4
+
+
+def test_config3_values_fullbatch(cuda):
+    """BASELINE configs[3] at its full batch (image model + 4 touch charts, bs 64, 25 000-point Chamfer, bf16 storage) pinned
+    to values: 32 copies of two different samples (images, touch charts, targets), the image feature maps held fixed
+    (MIOpen picks batch-size dependent convolution algorithms: they are not this library's arithmetic).  Every copy
+    reproduces bit for bit what the two samples give in a batch of 6 — whose values ``test_config3_composite_bs2`` pins to the
+    oracle's bf16-storage emulation — and the GCN weight gradients of the summed loss scale with the number of copies."""
+    from a3vt_amd.pterotactyl.reconstruction.vision import model
+    from a3vt_amd.pterotactyl.utility import utils
+    args = make_args(use_img=True, use_touch=True, num_grasps=1, finger=False, gemm_precision="bf16s",
+                     CNN_ker_size=5, num_CNN_blocks=6, layers_per_block=3, number_points=25000)
+    info, verts = utils.load_mesh_vision(args, "vision_charts")
+    torch.manual_seed(0)
+    net = model.Deformation(info, verts, args).to(cuda).eval()
+    P = 25000
+    g = torch.Generator().manual_seed(23)
+    img2 = torch.rand(2, 3, 256, 256, generator=g).to(cuda)
+    tc2 = torch.zeros(2, 1, 4, 25, 4)
+    tc2[..., :3] = (torch.rand(2, 1, 4, 1, 3, generator=g) - 0.5) * 0.3 + 0.004 * torch.randn(2, 1, 4, 25, 3, generator=g)
+    tc2[..., 3] = 2
+    tc2[1, 0, 3] = 0                                           # one empty slot
+    gt2 = random_cloud(2, P, 41)
+    with torch.no_grad():
+        gm2, lm2 = net.img_encoder_global(img2), net.img_encoder_local(img2)
+    params = [p_ for n, p_ in net.named_parameters() if n.startswith("mesh_deform")]
+    nf = info["faces"].shape[0]
+
+    def run(B):
+        rep = B // 2
+        charts = model.prepare_mesh({"img": img2.repeat(rep, 1, 1, 1), "touch_charts": tc2.repeat(rep, 1, 1, 1, 1)}, verts, args)
+        gm = [m.repeat(rep, 1, 1, 1) for m in gm2] if isinstance(gm2, (list, tuple)) else gm2.repeat(rep, 1, 1, 1)
+        lm = [m.repeat(rep, 1, 1, 1) for m in lm2] if isinstance(lm2, (list, tuple)) else lm2.repeat(rep, 1, 1, 1)
+        return _step_values(cuda, lambda: net.deform_with_maps(charts, gm, lm)[0], info["faces"], gt2.repeat(rep, 1, 1).to(cuda), P, nf,
+                            params)
+    out6, cd6, g6, _ = run(6)
+    out64, cd64, g64, _ = run(64)
+    assert out64.shape == (64, 1924, 3)
+    for c in range(32):
+        assert torch.equal(out64[2 * c:2 * c + 2], out6[:2]) and torch.equal(cd64[2 * c:2 * c + 2], cd6[:2]), c
+    for a, b in zip(g64, g6):
+        assert rel_l2(a, (32.0 / 3.0) * b) < 1e-4
