@@ -45,7 +45,8 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 
 // ---- optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg).
 // Off by default; when on, every MFMA launch of the GCN stack is bracketed by an event pair.
-enum { PROF_GEMM_FWD = 0, PROF_GEMM_DX = 1, PROF_DW = 2, PROF_CLASSES = 3 };
+enum { PROF_GEMM_FWD = 0, PROF_GEMM_DX = 1, PROF_DW = 2, PROF_AGG = 3, PROF_OUT = 4, PROF_SEARCH = 5, PROF_LOSS = 6, PROF_ENC = 7,
+       PROF_CLASSES = 8 };   // a3vt_profile_read: the first three; a3vt_profile_read_classes: all
 struct Prof {
   bool on = false;
   static constexpr int kMax = 8192;
@@ -342,13 +343,16 @@ static int stack_fwd16(const float *feats, int ld_feats, int in_features, const 
       ProfScope ps(PROF_GEMM_FWD, s);
       if (int rc = launch_rowgemm(g, EPI_FWD_HIDDEN, s)) return rc;
     }
-    if (cut_len > 0)
+    if (cut_len > 0) {
+      ProfScope psa(PROF_AGG, s);
       if (int rc = launch_csr16_fwd(za, g.ldc2, biases[i], cut_len, rowptr, col, val, heavy, n_vert, batch, y, L.ldh, mk, mld, 1, s))
         return rc;
+    }
     x = y;
     ldx = L.ldh;
   }
   const int last = num_layers - 1;
+  ProfScope pso(PROF_OUT, s);
   if (int rc = launch_thin16_fwd_product(x, ldx, hidden, weights[last], (long long)m, scratch + L.z3, s)) return rc;
   const SplitRef sref = split_ref(split);
   return launch_csr3(scratch + L.z3, biases[last], rowptr, col, val, heavy, n_vert, batch, update, 3, s,
@@ -383,6 +387,7 @@ static int stack_bwd16(const float *feats, int ld_feats, int in_features, const 
   u16 *ping[2] = {reinterpret_cast<u16 *>(scratch + L.ping[0]), reinterpret_cast<u16 *>(scratch + L.ping[1])};
   {
     float *du4 = scratch + L.z3, *res = scratch + L.z3 + m * 4;
+    ProfScope pso(PROF_OUT, s);
     if (int rc = launch_pad3to4(grad_update, (long long)m, du4, s)) return rc;
     const SplitRef sref = split_ref(split);
     if (int rc = launch_csr3(du4, nullptr, rowptrT, colT, valT, heavyT, n_vert, batch, res, 4, s,
@@ -425,6 +430,7 @@ static int stack_bwd16(const float *feats, int ld_feats, int in_features, const 
     const int ldx = i == 0 ? L.ld0 : L.ldh;
     const int kin = i == 0 ? in_features : hidden;
     if (cut_len > 0) {
+      ProfScope psa(PROF_AGG, s);
       if (int rc = launch_csr16_bwd(g, L.ldh, cut_len, cpad, rowptrT, colT, valT, heavyT, n_vert, batch, dza, ldza,
                                     scratch + L.db_slab + (size_t)i * db_layer_stride, s))
         return rc;
@@ -788,6 +794,7 @@ int a3vt_gcn_stack_fwd_adj(const float *feats, int ld_feats, int in_features, co
     }
     if (quad) {
       uint8_t *sq = masks ? masks + (size_t)(num_layers - 1) * mpad * mld + (size_t)i * signq_stride(m, cut_len) : nullptr;
+      ProfScope psa(PROF_AGG, s);
       if (qsplit) {
         if (int rc = launch_csrqs_fwd(scratch + L.za, biases[i], cut_len, ell, n_vert, batch, y, qcols / 4, sq, 1, s)) return rc;
       } else if (int rc = launch_csrq_fwd(scratch + L.za, biases[i], cut_len, rowptr, col, val, heavy, ell, n_vert, batch, y, qcols / 4, sq, 1, s)) {
@@ -795,6 +802,7 @@ int a3vt_gcn_stack_fwd_adj(const float *feats, int ld_feats, int in_features, co
       }
       xq = y;
     } else if (cut_len > 0) {
+      ProfScope psa(PROF_AGG, s);
       if (int rc = launch_csr_fwd(scratch + L.za, cpad, biases[i], cut_len, rowptr, col, val, heavy, n_vert, batch, y, hidden, mk, mld, 1, s))
         return rc;
     }
@@ -802,6 +810,7 @@ int a3vt_gcn_stack_fwd_adj(const float *feats, int ld_feats, int in_features, co
     ldx = rm_ld;
   }
   const int klast = num_layers == 1 ? in_features : hidden;
+  ProfScope pso(PROF_OUT, s);
   return launch_thin_fwd(x, ldx, klast, weights[num_layers - 1], biases[num_layers - 1], rowptr, col, val, heavy, n_vert,
                          batch, scratch + L.z3, update, xq, qcols / 4, s, sp3);
 }
@@ -892,6 +901,7 @@ int a3vt_gcn_stack_bwd_adj(const float *feats, int ld_feats, int in_features, co
     const int k = num_layers == 1 ? in_features : hidden;
     float *gprev = num_layers == 1 ? grad_feats : scratch + L.ping[0];
     const int ldg = num_layers == 1 ? ld_feats : hidden;
+    ProfScope pso(PROF_OUT, s);
     if (int rc = launch_thin_bwd(x, ldx, k, weights[last], rowptrT, colT, valT, heavyT, n_vert, batch, grad_update,
                                  scratch + L.z3, num_layers > 1, gprev, ldg, ldg, scratch + L.thin_dw_slab,
                                  scratch + L.thin_db_slab, quad ? scratch + L.gq : nullptr, cpad / 4, quad ? xl : nullptr,
@@ -957,6 +967,7 @@ int a3vt_gcn_stack_bwd_adj(const float *feats, int ld_feats, int in_features, co
     // bias gradient + A^T gather on the aggregated channels
     if (cut_len > 0 && quad) {
       const uint8_t *sq = masks + (size_t)(num_layers - 1) * mpad * mld + (size_t)i * signq_stride(m, cut_len);
+      ProfScope psa(PROF_AGG, s);
       // the (mesh, channel) partials of this layer: summed over the meshes by ONE launch for all layers behind the loop
       if (qsplit) {
         if (int rc = launch_csrqs_bwd(scratch + L.gq, cut_len, ellT, n_vert, batch, dza, sq,
@@ -967,6 +978,7 @@ int a3vt_gcn_stack_bwd_adj(const float *feats, int ld_feats, int in_features, co
         return rc;
       }
     } else if (cut_len > 0) {
+      ProfScope psa(PROF_AGG, s);
       if (int rc = launch_csr_bwd(g, hidden, cut_len, rowptrT, colT, valT, heavyT, n_vert, batch, dza, cpad,
                                   scratch + L.db_slab + (size_t)i * db_layer_stride, s))
         return rc;
@@ -1300,12 +1312,14 @@ size_t a3vt_posenc_scratch_bytes(int m, int input_size) {
 int a3vt_posenc_mask_fwd(const float *verts, const float *mask, int m, int input_size, const float *pe_params,
                          float *feats, int ld_feats, void *stream) {
   A3VT_CHECK_ARG(verts && mask && pe_params && feats && m > 0 && ld_feats >= input_size);
+  ProfScope psc(PROF_ENC, static_cast<hipStream_t>(stream));
   return launch_posenc_fwd(verts, mask, m, input_size, pe_params, feats, ld_feats, static_cast<hipStream_t>(stream));
 }
 int a3vt_posenc_mask_bwd(const float *verts, const float *mask, int m, int input_size, const float *pe_params,
                          const float *grad_feats, int ld_feats, float *grad_verts, float *grad_params, float *scratch,
                          void *stream) {
   A3VT_CHECK_ARG(verts && mask && pe_params && grad_feats && grad_verts && grad_params && scratch && m > 0);
+  ProfScope psc(PROF_ENC, static_cast<hipStream_t>(stream));
   return launch_posenc_bwd(verts, mask, m, input_size, pe_params, grad_feats, ld_feats, grad_verts, grad_params,
                            scratch, static_cast<hipStream_t>(stream));
 }
@@ -1355,6 +1369,7 @@ int a3vt_sample_points_fwd(const float *verts, const int32_t *faces, const float
                            const float *v_in, uint64_t seed, uint64_t offset, float *points, int32_t *face_idx_out,
                            float *u_out, float *v_out, void *stream) {
   A3VT_CHECK_ARG(verts && faces && points && batch > 0 && n_vert > 0 && n_faces > 0 && draws > 0 && num > 0);
+  ProfScope psc(PROF_LOSS, static_cast<hipStream_t>(stream));
   return launch_sample_fwd(verts, faces, cdf, batch, n_vert, n_faces, draws, num, face_idx_in, u_in, v_in, seed,
                            offset, points, face_idx_out, u_out, v_out, static_cast<hipStream_t>(stream));
 }
@@ -1363,6 +1378,7 @@ int a3vt_sample_points_bwd(const int32_t *faces, int batch, int n_vert, int n_fa
                            const int32_t *face_idx, const float *u, const float *v, const float *grad_points,
                            float *grad_verts, void *stream) {
   A3VT_CHECK_ARG(faces && face_idx && u && v && grad_points && grad_verts && batch > 0 && draws > 0 && num > 0);
+  ProfScope psc(PROF_LOSS, static_cast<hipStream_t>(stream));
   return launch_sample_bwd(faces, batch, n_vert, n_faces, draws, num, face_idx, u, v, grad_points, grad_verts,
                            static_cast<hipStream_t>(stream));
 }
@@ -1376,6 +1392,7 @@ int a3vt_chamfer_fwd(const float *x, const float *y, int draws, int batch, int p
                      int32_t *idx_xy, float *dist_yx, int32_t *idx_yx, float *cd, void *scratch, void *stream) {
   A3VT_CHECK_ARG(x && y && dist_xy && idx_xy && dist_yx && idx_yx && cd);
   // brute force only: the scratch of this entry point is a3vt_chamfer_scratch_bytes() (the column minima of the sweep)
+  ProfScope psc(PROF_SEARCH, static_cast<hipStream_t>(stream));
   return launch_chamfer_fwd(x, y, draws, batch, p, q, dist_xy, idx_xy, dist_yx, idx_yx, cd, scratch,
                             scratch ? a3vt_chamfer_scratch_bytes(draws, batch, p, q) : 0,
                             scratch ? NN_BRUTE_SWEEP : NN_BRUTE_TWO_PASS, static_cast<hipStream_t>(stream));
@@ -1389,6 +1406,7 @@ int a3vt_chamfer_fwd_ws(const float *x, const float *y, int draws, int batch, in
                         int32_t *idx_xy, float *dist_yx, int32_t *idx_yx, float *cd, void *workspace,
                         size_t workspace_bytes, int algo, void *stream) {
   A3VT_CHECK_ARG(x && y && dist_xy && idx_xy && dist_yx && idx_yx && cd);
+  ProfScope psc(PROF_SEARCH, static_cast<hipStream_t>(stream));
   return launch_chamfer_fwd(x, y, draws, batch, p, q, dist_xy, idx_xy, dist_yx, idx_yx, cd, workspace,
                             workspace ? workspace_bytes : 0, algo, static_cast<hipStream_t>(stream));
 }
@@ -1397,6 +1415,7 @@ int a3vt_chamfer_fwd_shared(const float *x, const float *y, int draws, int batch
                             int32_t *idx_xy, float *dist_yx, int32_t *idx_yx, float *cd, void *workspace,
                             size_t workspace_bytes, int algo, void *stream) {
   A3VT_CHECK_ARG(x && y && dist_xy && idx_xy && dist_yx && idx_yx && cd && y_batch > 0);
+  ProfScope psc(PROF_SEARCH, static_cast<hipStream_t>(stream));
   return launch_chamfer_fwd(x, y, draws, batch, p, q, dist_xy, idx_xy, dist_yx, idx_yx, cd, workspace,
                             workspace ? workspace_bytes : 0, algo, static_cast<hipStream_t>(stream), y_batch);
 }
@@ -1404,6 +1423,7 @@ int a3vt_chamfer_fwd_shared(const float *x, const float *y, int draws, int batch
 int a3vt_chamfer_bwd(const float *x, const float *y, int draws, int batch, int p, int q, const int32_t *idx_xy,
                      const int32_t *idx_yx, const float *grad_cd, float *grad_x, float *grad_y, void *stream) {
   A3VT_CHECK_ARG(x && y && idx_xy && idx_yx && grad_cd && grad_x && draws > 0 && batch > 0 && p > 0 && q > 0);
+  ProfScope psc(PROF_LOSS, static_cast<hipStream_t>(stream));
   return launch_chamfer_bwd(x, y, draws, batch, p, q, idx_xy, idx_yx, grad_cd, grad_x, grad_y,
                             static_cast<hipStream_t>(stream));
 }
@@ -1438,6 +1458,7 @@ int a3vt_image_pool_fwd(const float *verts, int batch, int n_vert, const float *
   if (int rc = fill_pool_args(a, verts, batch, n_vert, proj, n_maps, maps, chans, heights, widths, ld_feats)) return rc;
   A3VT_CHECK_ARG(feats != nullptr);
   a.feats = feats;
+  ProfScope psc(PROF_ENC, static_cast<hipStream_t>(stream));
   return launch_pool_fwd(a, static_cast<hipStream_t>(stream));
 }
 
@@ -1454,6 +1475,7 @@ int a3vt_image_pool_bwd(const float *verts, int batch, int n_vert, const float *
   }
   a.gfeats = grad_feats;
   a.gverts = grad_verts;
+  ProfScope psc(PROF_ENC, static_cast<hipStream_t>(stream));
   return launch_pool_bwd(a, static_cast<hipStream_t>(stream));
 }
 
@@ -1478,18 +1500,24 @@ int a3vt_profile_enable(int on) {
   return 0;
 }
 
-int a3vt_profile_read(double *total_ms, int *count) {
-  A3VT_CHECK_ARG(total_ms && count);
-  for (int c = 0; c < PROF_CLASSES; ++c) { total_ms[c] = 0.0; count[c] = 0; }
+int a3vt_profile_read_classes(double *total_ms, int *count, int n) {
+  A3VT_CHECK_ARG(total_ms && count && n >= 0);
+  for (int c = 0; c < n; ++c) { total_ms[c] = 0.0; count[c] = 0; }
   for (int i = 0; i < g_prof.used; ++i) {
     if (hipEventSynchronize(g_prof.ev[i][1]) != hipSuccess) { set_error("profile_read: event sync failed"); return -2; }
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, g_prof.ev[i][0], g_prof.ev[i][1]) != hipSuccess) continue;
+    if (g_prof.cls[i] >= n) continue;
     total_ms[g_prof.cls[i]] += ms;
     count[g_prof.cls[i]] += 1;
   }
   g_prof.used = 0;
-  return 0;
+  return PROF_CLASSES;
+}
+
+int a3vt_profile_read(double *total_ms, int *count) {
+  const int rc = a3vt_profile_read_classes(total_ms, count, 3);
+  return rc < 0 ? rc : 0;
 }
 
 int a3vt_dbg_path_counts(long long *counts, int n, int reset) {

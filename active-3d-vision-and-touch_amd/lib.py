@@ -86,6 +86,7 @@ SIGNATURES = {
     "a3vt_check_finite": (_i, [_vp, _sz, _vp, _vp]),
     "a3vt_profile_enable": (_i, [_i]),
     "a3vt_profile_read": (_i, [_vp, _vp]),
+    "a3vt_profile_read_classes": (_i, [_vp, _vp, _i]),
 }
 
 _LIB = None

@@ -183,6 +183,45 @@ class NamedStep:
         self.bucket.close()
 
 
+PROFILE_CLASSES = ("product_fwd", "product_dx", "product_dw", "aggregation", "output_layer", "search", "sampling_and_chamfer_bwd",
+                   "encoders_and_pooling")
+
+
+def kernel_classes(step, cfg, precision, step_ms):
+    """Where one training step's device time goes, by kernel class, from the library's own HIP events (``a3vt_profile_*``: an
+    event pair around every call of the class on its launch stream) over ONE extra step: ms per step, launches, and — for the
+    GCN classes whose algorithmic bytes are a closed form — the HBM rate they reach against 8 TB/s.  ``not_this_library`` is
+    the rest of the step: MIOpen convolutions / batch-norm, torch element-wise kernels, Adam, gaps between kernels."""
+    import ctypes
+    from . import lib as _lib
+    L = _lib.load()
+    L.a3vt_profile_enable(1)
+    step()
+    torch.cuda.synchronize()
+    n = len(PROFILE_CLASSES)
+    tot, cnt = (ctypes.c_double * n)(), (ctypes.c_int * n)()
+    _lib.check(min(L.a3vt_profile_read_classes(tot, cnt, n), 0), "profile_read_classes")
+    L.a3vt_profile_enable(0)
+    e = 2 if precision == "bf16s" else 4
+    a = cfg["args"]
+    m, h, c = cfg["batch"] * cfg["n_vert"], a.hidden_GCN_size, round(a.hidden_GCN_size * a.cut)
+    hidden_launches = 3 * (a.num_GCN_layers - 2)          # hidden x hidden products per direction and step (3 stages)
+    per_launch = {"product_fwd": m * 2 * h * e, "product_dx": m * 2 * h * e, "product_dw": m * 2 * h * e,
+                  "aggregation": m * 2 * c * e}           # rows read + rows written (dW: X and dZ read)
+    out = {}
+    for i, k in enumerate(PROFILE_CLASSES):
+        rec = {"ms_per_step": tot[i], "launches": cnt[i]}
+        if k in per_launch and tot[i] > 0:
+            launches = 2 * 3 * (a.num_GCN_layers - 1) if k == "aggregation" else hidden_launches
+            gbs = per_launch[k] * launches / (tot[i] * 1e-3) / 1e9
+            rec.update({"algorithmic_GBps": gbs, "frac_of_8TBps": gbs / 8000.0})
+        out[k] = rec
+    ours = sum(tot[i] for i in range(n))
+    out["not_this_library"] = {"ms_per_step": max(step_ms - ours, 0.0),
+                               "what": "MIOpen convolutions and batch-norm, torch element-wise kernels, fused Adam, gaps between kernels"}
+    return out
+
+
 def time_named_config(which, dev, precision="bf16s", batch=None, steps=10, warm=8):
     """Build, warm up (MIOpen's find mode and the allocator's growth take several steps to settle in the image mode), time
     ``steps`` training steps; returns the JSON-able record ``bench.py`` prints under ``named_configs``."""
@@ -204,6 +243,7 @@ def time_named_config(which, dev, precision="bf16s", batch=None, steps=10, warm=
     ms = 1e3 * (time.perf_counter() - t0) / steps
     dev_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
     search = step.chamfer_forward_ms()
+    classes = kernel_classes(step, cfg, precision, dev_ms[len(dev_ms) // 2])
     nbytes = cfg["activation_bytes"]
     gbs = nbytes / (ms * 1e-3) / 1e9
     rec = {"config": cfg["name"], "ms_per_step": ms, "device_ms_median": dev_ms[len(dev_ms) // 2], "iters_per_s": 1e3 / ms,
@@ -215,6 +255,7 @@ def time_named_config(which, dev, precision="bf16s", batch=None, steps=10, warm=
                                      f"{cfg['args'].num_GCN_layers - 1},3], B={cfg['batch']}, S=3 (GCN activations only: no CNN, "
                                      f"no Chamfer bytes)",
                         "hbm_ms_at_peak": nbytes / 8e12 * 1e3,
-                        "chamfer_forward_ms": search, "chamfer_share": search / ms}}
+                        "chamfer_forward_ms": search, "chamfer_share": search / ms},
+           "kernel_classes": classes}
     step.close()
     return rec

@@ -381,6 +381,13 @@ int a3vt_check_finite(const float *data, size_t n, int32_t *flag, void *stream);
  * Only hidden x hidden launches are of the headline shape; bench.py divides by the counts it expects. */
 int a3vt_profile_enable(int on);
 int a3vt_profile_read(double *total_ms /*[3]*/, int *count /*[3]*/);
+/* The same for n classes (round 6; every call of this library on a step, so that a bench line can say where a step's time
+ * goes without a profiler): [0..2] as above, [3] neighbour aggregation of the hidden layers (forward and A^T backward),
+ * [4] output layer (300 -> 3 product, its aggregation, their backward), [5] Chamfer forward (sort, boxes, exact search,
+ * reduction), [6] surface sampling forward / backward + Chamfer backward, [7] vertex-feature encoders and image pooling
+ * (forward and backward).  A class's time is the span from the first to the last launch of each call, summed over calls.
+ * Returns the number of classes the library keeps. */
+int a3vt_profile_read_classes(double *total_ms, int *count, int n);
 
 #ifdef __cplusplus
 }
