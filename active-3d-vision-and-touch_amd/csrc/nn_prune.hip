@@ -134,6 +134,9 @@ struct NNClouds {   // the clouds of one Chamfer call: nx predicted clouds of p 
 constexpr int kObbFloats = 16;
 constexpr float kObbMu = 9.5367431640625e-07f;          // 2^-20
 constexpr float kObbShrink = 1.0f - 1.52587890625e-05f;   // 1 - 2^-16
+// (The multiplication stops shrinking once the sum of squared gaps is denormal — coordinates below ~1e-19 — where the absolute
+// 1e-37 slack on the extents is what is left; tests/test_gpu_nn_pruned.py::test_oriented_boxes_at_denormal_squared_distances
+// holds the search to the brute force bit for bit at coordinate scales 1e-15 .. 1e-22.)
 
 __device__ __forceinline__ float obb_proj(float ax, float ay, float az, float dx, float dy, float dz) {
   return __builtin_fmaf(az, dz, __builtin_fmaf(ay, dy, ax * dx));

@@ -65,7 +65,13 @@ class FlatGradBucket:
         self.params = [p for p in params if id(p) in early_ids] + [p for p in params if id(p) not in early_ids]
         self.n_early = sum(1 for p in params if id(p) in early_ids)
         n = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(n, dtype=self.params[0].dtype, device=self.params[0].device)
+        # one element behind the gradients travels with the [rest] reduce: the "an early gradient arrived late" flag of
+        # all_reduce_mean(), so that every rank learns of a rank's late gradient without a collective of its own
+        self._store = torch.zeros(n + 1, dtype=self.params[0].dtype, device=self.params[0].device)
+        self.flat = self._store[:n]
+        self._flag = self._store[n:]
+        self._flag_host = torch.zeros(1, dtype=self.flat.dtype).pin_memory() if self.flat.is_cuda else None
+        self._flag_event = None
         self.views = []
         off = 0
         for k, p in enumerate(self.params):
@@ -137,6 +143,7 @@ class FlatGradBucket:
             # skipped those parameters
             raise RuntimeError("a3vt: FlatGradBucket.all_reduce_mean() (or gather()) must run between backward() and "
                                "optimizer.step(); the previous step skipped it")
+        self._check_peer_flag()
         self._open = True
         for p in self.params:
             p.grad = None
@@ -167,12 +174,15 @@ class FlatGradBucket:
             torch._foreach_zero_(unused)
         self._rehome(lo, hi)
 
-    def gather(self):
-        """Collect every gradient into the flat buffer (the early chunk only if ``reduce_early`` has not already)."""
+    def gather(self, wait=True):
+        """Collect every gradient into the flat buffer (the early chunk only if ``reduce_early`` has not already).
+        ``wait=False`` (all_reduce_mean): leave an early-chunk reduce in flight — the caller waits for it after it has issued
+        the [rest] reduce, so the two overlap."""
         if not self._early_done:
             self._gather(0, self.n_early)
         self._gather(self.n_early, len(self.params))
-        self.wait_early()                       # callers that read `flat` without all_reduce_mean()
+        if wait:
+            self.wait_early()                   # callers that read `flat` without all_reduce_mean()
         self._open = False
         self._early_live = self._fired     # what the next step's countdown waits for
 
@@ -196,13 +206,18 @@ class FlatGradBucket:
         here; both are complete on return (on the current stream for RCCL)."""
         started = self._early_done
         # `_late`: more early parameters received a gradient than in the previous step, so the countdown fired before the last
-        # of them: that gradient is not in the chunk whose reduce is in flight.  Never silently — but the collective sequence
-        # [early][rest] is still completed first, so that a rank where this happens (a per-rank, data-dependent graph change)
-        # does not leave its peers blocked in the [rest] collective.
+        # of them: that gradient is not in the chunk whose reduce is in flight.  Never silently, and never on one rank alone:
+        # the collective sequence [early][rest] is completed first (a rank where this happens — a per-rank, data-dependent graph
+        # change — must not leave its peers blocked in [rest]), and a flag element behind the gradients travels with [rest], so
+        # EVERY rank learns that some rank's early chunk was averaged without a gradient and raises: at once where the flag
+        # can be read without stalling the device (CPU tensors / gloo; the late rank itself), at the start of its next step
+        # otherwise (the flag is copied to pinned memory behind the reduce; the check waits for that copy alone).
         late = self._late
-        self.gather()
+        self._check_peer_flag()
+        self.gather(wait=False)
         if late:
             self._early_live = self.n_early     # (gather() set it to what fired this step)
+        peer_late = False
         if self._active():
             world = dist.get_world_size()
             if self.n_early and not started:
@@ -211,20 +226,42 @@ class FlatGradBucket:
                 chunk = self.flat[:self.early_numel]
                 chunk.div_(world)
                 dist.all_reduce(chunk, op=dist.ReduceOp.SUM)
-            rest = self.flat[self.early_numel:]
-            if rest.numel():
-                rest.div_(world)
-                dist.all_reduce(rest, op=dist.ReduceOp.SUM)
+            self._flag.fill_(float(world) if late else 0.0)
+            rest = self._store[self.early_numel:]           # the other gradients + the flag (>= 1 after the mean: some rank was late)
+            rest.div_(world)
+            dist.all_reduce(rest, op=dist.ReduceOp.SUM)
             if self._early_work is not None:
                 self._early_work.wait()
                 self._early_work = None
-        if late:
-            raise RuntimeError("a3vt: FlatGradBucket: an early parameter received its gradient after the early chunk had been "
-                               "gathered — the set of parameters that receive gradients changed since the previous step. "
-                               "Both collectives of this step have completed (the ranks stay in lock-step), but the early "
-                               "chunk was averaged WITHOUT that late gradient: do not apply this step's gradients; repeat the "
-                               "step (the countdown now expects every early parameter).")
+            if self._flag_host is None:
+                peer_late = bool(self._flag.item() >= 0.5)
+            else:
+                self._flag_host.copy_(self._flag, non_blocking=True)
+                self._flag_event = torch.cuda.Event()
+                self._flag_event.record()
+        else:
+            self.wait_early()
+        if late or peer_late:
+            raise RuntimeError(self._late_message(late))
         return None
+
+    def _late_message(self, here):
+        return ("a3vt: FlatGradBucket: an early parameter received its gradient after the early chunk had been gathered"
+                + (" on this rank" if here else " on another rank") + " — the set of parameters that receive gradients "
+                "changed since the previous step, so the early chunk was averaged WITHOUT that gradient.  Both collectives of "
+                "the step have completed on every rank and the flag travelled with them: every rank raises this error (the "
+                "late rank and CPU groups in the same step, GPU peers at the start of their next one).  In a multi-process job "
+                "do NOT repeat the step on one rank — that would pair its collectives with the peers' next step: stop the job "
+                "on all ranks and resume from the last checkpoint.  Single process: discard this step's gradients and repeat "
+                "it (the countdown now expects every early parameter).")
+
+    def _check_peer_flag(self):
+        """The late flag of the previous step's [rest] reduce (GPU groups: copied to pinned memory behind the reduce)."""
+        if self._flag_event is not None:
+            self._flag_event.synchronize()      # that copy alone: the stream is long past it
+            self._flag_event = None
+            if float(self._flag_host[0]) >= 0.5:
+                raise RuntimeError(self._late_message(False))
 
     def wait_early(self):
         """Wait for an early-chunk reduce that is still in flight (callers that read ``flat`` without ``all_reduce_mean``)."""

@@ -450,7 +450,8 @@ def invalidate_bf16_copies():
     """Forget every cached bf16 weight copy.  The cache notices in-place torch ops (``_version``), re-allocations
     (``data_ptr``) and optimizer steps (the step hook); writes through ``.data`` (``p.data.copy_``, ``.data.uniform_``) or a
     hand-written update move none of these and MUST be followed by this call — ``distributed.broadcast_parameters``,
-    ``GCN_layer.reset_parameters`` and the checkpoint loaders of this package do it themselves."""
+    ``GCN_layer.reset_parameters`` and ``Engine.load`` (vision/train.py) do it themselves; ``load_state_dict`` alone is also
+    caught (its ``copy_`` moves ``_version``)."""
     _OPT_EPOCH[0] += 1
     _BF16_COPIES.clear()
 

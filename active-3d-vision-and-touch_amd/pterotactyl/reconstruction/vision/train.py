@@ -28,6 +28,7 @@ import torch.optim as optim
 from . import model
 from ...utility import data_loaders, utils
 from .... import distributed as adist
+from .... import ops as _ops
 
 try:
     from torch.utils.tensorboard import SummaryWriter
@@ -225,10 +226,12 @@ class Engine:
             self.n_vision_charts = self.initial_mesh.shape[0]
             self.encoder = model.Deformation(self.mesh_info, self.initial_mesh, vision_args).to(self.initial_mesh.device)
             self.encoder.load_state_dict(torch.load(os.path.join(location, "model"), map_location=self.initial_mesh.device))
+            _ops.invalidate_bf16_copies()       # (load_state_dict's copy_ moves _version already; explicit for loaders that do not)
             return
         try:
             dev = self.initial_mesh.device
             self.encoder.load_state_dict(torch.load(self.checkpoint_dir + "/model", map_location=dev))
+            _ops.invalidate_bf16_copies()
             self.optimizer.load_state_dict(torch.load(self.checkpoint_dir + "/optim", map_location=dev))
             self.epoch = int(np.load(self.checkpoint_dir + "/epoch.npy")[0])
         except (FileNotFoundError, AttributeError):

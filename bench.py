@@ -82,9 +82,12 @@ def parse():
 
 def self_launch(a):
     """``python bench.py --gpus N`` without a launcher: start ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N
-    --master-addr 127.0.0.1 --master-port <free> bench.py <same args>`` as a child process — BEFORE anything in this process
-    touches the GPU (``torch.cuda.device_count()`` does not initialise it on this image), never ``os.exec*`` — relay its
-    stdout / stderr and return its exit code."""
+    --master-addr 127.0.0.1 --master-port <free> bench.py <same args>`` as a CHILD process, relay its stdout / stderr and
+    return its exit code.  A child is the ONLY permitted relaunch: never ``os.exec*`` from here — ``torch.cuda.device_count()``
+    below happens not to initialise the GPU on this image (amdsmi), but on a build where it falls through to
+    hipGetDeviceCount it does, and an exec from a process that has initialised the GPU takes this pool's machines down.  (The
+    free port is found by bind-then-close: a small window before torchrun rebinds it; the driver's own launch line passes its
+    port and never comes through here.)"""
     import socket
     ndev = torch.cuda.device_count()
     if ndev < a.gpus:

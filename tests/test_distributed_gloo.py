@@ -329,3 +329,55 @@ def test_validation_score_and_early_stop_agree_across_ranks_with_injected_loader
     assert res[0]["stopped"] == res[1]["stopped"] == 3                # 5.x, 4.x (best), 4.5+, 4.6+ -> patience 2 spent
     assert res[0]["best"] == res[1]["best"]
     assert res[0]["saves"] == [0, 1] and res[1]["saves"] == [0, 1]    # (save() itself writes on rank 0 only)
+
+
+def _worker_late(rank, world, port, out):
+    import sys
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from a3vt_amd import distributed as adist
+    adist.init_from_env("gloo")
+    torch.manual_seed(3)
+    a, b, c = torch.nn.Linear(4, 4), torch.nn.Linear(4, 4), torch.nn.Linear(4, 2)
+    params = list(a.parameters()) + list(b.parameters()) + list(c.parameters())
+    bucket = adist.FlatGradBucket(params, early=list(a.parameters()) + list(b.parameters()))
+    x = torch.randn(6, 4, generator=torch.Generator().manual_seed(rank))
+    events = []
+    for step in range(3):
+        bucket.zero()
+        # rank 1 leaves `b` out of the graph in step 0 (its countdown then expects two early gradients, not four) and uses it
+        # again in step 1: the countdown fires after a's two, b's arrive LATE — on rank 1 only
+        use_b = not (rank == 1 and step == 0)
+        # c(a(x)) first in the expression: autograd reaches b's parameters BEFORE a's in the backward pass?  No order is assumed:
+        # what matters is that MORE early parameters receive gradients than the countdown expects
+        y = c(a(x)).sum() + (b(x).sum() if use_b else 0.0)
+        y.backward()
+        try:
+            bucket.all_reduce_mean()
+            events.append("ok")
+        except RuntimeError as e:
+            events.append("late-here" if "on this rank" in str(e) else "late-peer")
+            break
+    out.put((rank, events))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_late_early_gradient_raises_on_every_rank():
+    """a rank whose early chunk was gathered before its last early gradient arrived used to raise ALONE, after both
+    collectives: its peers applied a step whose early average missed that gradient and met mis-paired collectives afterwards.
+    The late flag now travels with the [rest] reduce: with two ranks over gloo, rank 1 is late in step 1 and BOTH ranks raise
+    in that step, after the same two collectives (nobody hangs, nobody steps)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_late, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[1] == ["ok", "late-here"], res
+    assert res[0] == ["ok", "late-peer"], res

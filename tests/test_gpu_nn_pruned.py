@@ -345,3 +345,18 @@ def test_search_work_stays_bounded(cuda):
     for a, b in zip(d0, d1):
         assert torch.equal(a, b)
     assert ops.nn_work(False)["waves"] == w["waves"]                   # off: nothing was counted by the second search
+
+
+@pytest.mark.parametrize("scale", [1e-15, 1e-19, 1e-20, 1e-22])
+def test_oriented_boxes_at_denormal_squared_distances(cuda, scale):
+    """the oriented-box bound is shrunk by (1 - 2^-16) — a multiplication that no longer shrinks once the squared
+    distances are denormal (coordinates below ~1e-19), where only the absolute 1e-37 slack on the extents is left.  Sphere
+    against ellipsoid at coordinate scales whose squares are tiny normals (1e-30), at the edge (1e-38), denormal (1e-40) and
+    mostly zero (1e-44, where nearly every distance flushes to +0 and ties go to the lowest index): bit for bit the brute
+    force in both directions."""
+    g = torch.Generator().manual_seed(77)
+    u = torch.randn(1, 2, 3000, 3, generator=g)
+    v = torch.randn(2, 2500, 3, generator=g)
+    x = (scale * 0.25 * u / u.norm(dim=-1, keepdim=True)).float()
+    y = (scale * (v / v.norm(dim=-1, keepdim=True)) * torch.tensor([0.15, 0.1, 0.06])).float()
+    _assert_same(*_both(x, y, cuda))
