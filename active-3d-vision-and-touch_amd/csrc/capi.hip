@@ -787,6 +787,7 @@ int a3vt_gcn_stack_fwd_adj(const float *feats, int ld_feats, int in_features, co
       g.zq_quads = cpad / 4;
       g.yq = y;
       g.yq_quads = qcols / 4;
+      g.trash = scratch + L.z3;   // (the output layer's scratch: idle while the hidden layers run)
     }
     {
       ProfScope ps(PROF_GEMM_FWD, s);
@@ -1078,6 +1079,7 @@ int a3vt_gcn_stack_bwd_adj(const float *feats, int ld_feats, int in_features, co
         r.c2 = scratch + L.gq;
         r.zq_nvert = n_vert;
         r.zq_quads = cpad / 4;
+        r.trash = scratch + L.z3;
       }
       {
         ProfScope ps(PROF_GEMM_DX, s);

@@ -57,9 +57,15 @@ struct RowGemmArgs {
   // Quad-major a0 (0 = row-major): a0 is [m / a0q_nvert][a0q_quads][a0q_nvert] float4 holding A columns [0, ksplit),
   // ksplit = 4 a0q_quads (the aggregation kernels' outputs: activations / dZa); lda0 is ignored.
   int a0q_nvert, a0q_quads;
+  // >= 1 KiB of device memory nobody reads (rowgemmw_kernel: lanes whose columns fall behind n_store store there instead of
+  // branching around the store); nullptr = the caller has none (the kernel is then not used)
+  float *trash;
 };
 int rowgemm_bt_rows(int n_store);
 int launch_rowgemm(const RowGemmArgs &a, int epi, hipStream_t s);
+// gcn_gemmw.hip: the exact fp32 hidden layers on hybrid rows with the weights resident in registers (round 6)
+bool rowgemmw_ok(const RowGemmArgs &a, int epi);
+int launch_rowgemmw(const RowGemmArgs &a, int epi, hipStream_t s);
 // gcn_gemm16.hip: the hidden layers of the bf16 storage mode with the weight image held in registers
 bool rowgemm16_ok(const RowGemmArgs &a, int epi);
 int launch_rowgemm16(const RowGemmArgs &a, int epi, hipStream_t s);

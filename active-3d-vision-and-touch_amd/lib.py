@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("A3VT_LIB", os.path.join(_HERE, "liba3vt.so"))  # A3VT_LIB: developer override (variant builds)
-SOURCES = ["capi.hip", "gcn_gemm.hip", "gcn_gemm16.hip", "gcn_gemm3.hip", "gcn_csr.hip", "gcn_csrq.hip", "gcn_csrqs.hip", "gcn_bf16s.hip", "posenc.hip", "posenc_wide.hip", "bias_grad.hip", "sample.hip", "chamfer.hip", "nn_prune.hip",
+SOURCES = ["capi.hip", "gcn_gemm.hip", "gcn_gemmw.hip", "gcn_gemm16.hip", "gcn_gemm3.hip", "gcn_csr.hip", "gcn_csrq.hip", "gcn_csrqs.hip", "gcn_bf16s.hip", "posenc.hip", "posenc_wide.hip", "bias_grad.hip", "sample.hip", "chamfer.hip", "nn_prune.hip",
            "pooling.hip"]
 # Per-file extra flags (none at present; sample.hip / gcn_csr.hip rely on IEEE NaN semantics — the reference's NaN
 # scrubs, a3vt_check_finite — so fast-math style flags must never be applied globally).
@@ -18,7 +18,8 @@ SOURCES = ["capi.hip", "gcn_gemm.hip", "gcn_gemm16.hip", "gcn_gemm3.hip", "gcn_c
 # which issues at half the rate on gfx950 and needs s_nop hazard padding)
 # gcn_csrq.hip: scalar fma chains keep one register per edge weight (v_pk_fma_f32 wants (w, w) pairs): see the file header
 EXTRA_FLAGS = {"chamfer.hip": ["-fno-slp-vectorize"], "nn_prune.hip": ["-fno-slp-vectorize"],
-               "gcn_csrq.hip": ["-fno-slp-vectorize"], "gcn_csrqs.hip": ["-fno-slp-vectorize"]}
+               "gcn_csrq.hip": ["-fno-slp-vectorize"], "gcn_csrqs.hip": ["-fno-slp-vectorize"],
+               "gcn_gemmw.hip": ["-std=c++20"]}   # (templated lambdas over the chunk / column-tile index)
 
 _vp, _i, _sz, _u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_uint64
 
@@ -104,7 +105,7 @@ def build(force=False, verbose=False, defines=(), out=None):
 
 def _build(force, verbose, defines, lib_path, objdir):
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in ("common.h", "kernels.h")] + \
+    deps = srcs + [os.path.join(CSRC, h) for h in ("common.h", "kernels.h", "gemm_tile.h")] + \
         [os.path.join(_HERE, "..", "include", "a3vt.h")]
     force = force or os.environ.get("A3VT_FORCE_BUILD", "0") not in ("", "0")   # prove on any box that it compiles
     if not force and os.path.exists(lib_path) and all(

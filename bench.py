@@ -328,7 +328,7 @@ def _run_child(cmd, timeout_s, cwd):
         return -9
 
 
-def measure_traffic(batch, level, hidden, kernel_tag="rowgemm_kernel<19, 2"):
+def measure_traffic(batch, level, hidden, kernel_tag="rowgemmw_kernel<2>"):
     """HBM bytes per launch of the dominant kernel: FETCH_SIZE x 2 (MI355X_MICROARCH.md "HBM": gfx950 tallies the 128-B
     requests of wide coalesced reads at 64 B) + WRITE_SIZE, each from its own --pmc pass (they do not fit one pass);
     kernel-trace only, no other trace domain.  Returns (bytes or None, note)."""
@@ -470,7 +470,8 @@ def main():
         peak = 157.3 if fp32 else {"bf16s": 2500.0, "fp32x3": 2500.0 / 6.0}.get(a.gemm_precision, 1250.0)
         instr = {"fp32": "v_mfma_f32_16x16x4_f32", "bf16": "v_mfma_f32_16x16x16_bf16", "bf16s": "v_mfma_f32_16x16x32_bf16",
                  "fp32x3": "6 x v_mfma_f32_16x16x32_bf16 on split operands"}
-        roof = {"bound": "mfma", "kernel": f"rowgemm_kernel<19,EPI_DX_MASK> ({instr.get(a.gemm_precision, '?')}, M x 300 x 300, "
+        kname = "rowgemmw_kernel<EPI_DX_MASK> (weights resident in registers; " if fp32 else "rowgemm_kernel<19,EPI_DX_MASK> ("
+        roof = {"bound": "mfma", "kernel": f"{kname}{instr.get(a.gemm_precision, '?')}, M x 300 x 300, "
                                            f"dX = dZ W^T{'' if fp32 else ', fp32 accumulate'})",
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "traffic": None, "avg_launch_ms": t_ms, "launches": n_dx, "flop_per_launch": flop,

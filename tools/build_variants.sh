@@ -12,7 +12,13 @@ build() { # name defines...
   for d in "$@"; do defs="$defs'${d#-D}',"; done
   (cd "$ROOT" && python -c "from a3vt_amd import lib; lib.build(defines=[$defs], out='$ROOT/gpurun_variants/liba3vt_$name.so')")
 }
-if [ "$1" = "csr" ]; then   # csr_fwd / csr16_fwd without their stores: tools/kstats.sh with A3VT_LIB=...
+if [ "$1" = "rgw" ]; then   # rowgemmw_kernel (round 6) ablations + the round-5 kernel for A/B: python tools/stack_bench.py with A3VT_LIB=...
+  build RGW_OFF -DA3VT_DBG_RGW_OFF
+  build RGW_NODMA -DA3VT_DBG_RGW_NODMA
+  build RGW_NOEPI -DA3VT_DBG_RGW_NOEPI
+  build RGW_MFMAONLY -DA3VT_DBG_RGW_NODMA -DA3VT_DBG_RGW_NOEPI
+  build RGW_STAMPS -DA3VT_DBG_RGW_STAMPS   # per-tile phase stamps (tools/rowgemmw_stamps.py)
+elif [ "$1" = "csr" ]; then   # csr_fwd / csr16_fwd without their stores: tools/kstats.sh with A3VT_LIB=...
   build CSR_NOSTORE -DA3VT_DBG_CSR_NOSTORE
 elif [ "$1" = "csrq" ]; then   # channel-sliced aggregation without its LDS gathers (what the gathers cost)
   build CSRQ_NOGATHER -DA3VT_DBG_CSRQ_NOGATHER

@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""Phase stamps of rowgemmw_kernel (gpurun_variants/liba3vt_RGW_STAMPS.so, tools/build_variants.sh rgw): per 16-row tile the
+shader-clock time of the K loop (with the side work dealt into it), of the s_waitcnt vmcnt(0) behind it and of the workgroup
+barrier, per wave.  Run:  A3VT_LIB=$GRAFT_REPO_ROOT/gpurun_variants/liba3vt_RGW_STAMPS.so python tools/rowgemmw_stamps.py"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+
+def main():
+    from a3vt_amd import lib, mesh as amesh, ops
+    dev = torch.device("cuda", 0)
+    L, H, B = 4, 300, 64
+    verts, faces = amesh.icosphere(4)
+    n = verts.shape[0]
+    adj = ops.DeviceCSR(amesh.CSRAdjacency.from_pairs(*amesh.vision_pairs(faces, n), n), dev)
+    g = torch.Generator().manual_seed(0)
+    ws = [((torch.rand(1, 50 if i == 0 else H, H if i < L - 1 else 3, generator=g) - 0.5) * 0.2).to(dev).requires_grad_(True) for i in range(L)]
+    bs = [((torch.rand(H if i < L - 1 else 3, generator=g) - 0.5) * 0.2).to(dev).requires_grad_(True) for i in range(L)]
+    feats = torch.nn.functional.pad(torch.randn(B, n, 50, generator=g) * 0.5, (0, 2)).to(dev).requires_grad_(True)
+    for _ in range(2):
+        out = ops.gcn_stack(feats, adj, 50, H, 99, ws, bs)
+        out.sum().backward()
+    torch.cuda.synchronize()
+    buf = np.zeros(256 * 4 * 48 * 4, dtype=np.uint64)
+    fn = lib.load().a3vt_dbg_rgw_stamps if hasattr(ctypes.CDLL(lib.LIB_PATH), "a3vt_dbg_rgw_stamps") else None
+    if fn is None:
+        raise SystemExit("this library has no stamps: build the RGW_STAMPS variant and select it with A3VT_LIB")
+    dll = ctypes.CDLL(lib.LIB_PATH)
+    dll.a3vt_dbg_rgw_stamps(ctypes.c_void_p(buf.ctypes.data))
+    s = buf.reshape(256, 4, 48, 4).astype(np.int64)   # the LAST launch that ran (a dX product)
+    tiles = 40
+    loop = (s[:, :, 1:tiles, 1] - s[:, :, 1:tiles, 0])
+    wait = (s[:, :, 1:tiles, 2] - s[:, :, 1:tiles, 1])
+    barr = (s[:, :, 1:tiles, 3] - s[:, :, 1:tiles, 2])
+    whole = (s[:, :, 2:tiles, 0] - s[:, :, 1:tiles - 1, 0])
+    pc = lambda a: "p10 %6d  median %6d  p90 %6d  max %7d" % tuple(np.percentile(a, [10, 50, 90, 100]).astype(int))  # noqa: E731
+    print("shader-clock ticks (s_memtime) per 16-row tile; 380 MFMAs x 32 cycles = 12 160")
+    print("K loop + side work :", pc(loop))
+    print("s_waitcnt vmcnt(0) :", pc(wait))
+    print("barrier            :", pc(barr))
+    print("tile to tile       :", pc(whole))
+    for w in range(4):
+        print(f"  wave {w}: loop {np.median(loop[:, w]):7.0f}  wait {np.median(wait[:, w]):6.0f}  barrier {np.median(barr[:, w]):6.0f}")
+    print("whole kernel per workgroup (first stamp to last):", pc((s[:, :, tiles - 1, 3] - s[:, :, 0, 0]).ravel()))
+
+
+if __name__ == "__main__":
+    main()
