@@ -182,7 +182,7 @@ static StackLayout stack_layout(int batch, int n_vert, int in_features, int hidd
     const size_t kin = kmax;
     // its own region: with hidden < 300 a ping buffer ([M][hidden]) is smaller than a 300-column block of X_0
     L.panel = take(pad4(in_features) > 304 ? m * 300 : 0);
-    L.dw_slab = take((size_t)dw_num_slabs(hidden) * kin * hidden);
+    L.dw_slab = take((size_t)dw_slab_capacity(hidden) * kin * hidden);
     const size_t nslab = (size_t)csr_bwd_num_slabs(batch, n_vert) > (size_t)batch ? csr_bwd_num_slabs(batch, n_vert) : batch;
     // one block of partial rows PER LAYER ([batch][cpad] on the channel-sliced path, [row-walk workgroups][cpad] otherwise),
     // reduced by one launch at the end of the backward
@@ -1035,7 +1035,7 @@ int a3vt_gcn_stack_bwd_adj(const float *feats, int ld_feats, int in_features, co
         ProfScope ps(PROF_DW, s);
         if (int rc = launch_dw(d, s)) return rc;
       }
-      if (int rc = launch_slab_reduce_za(scratch + L.dw_slab, dw_num_slabs(hidden), (size_t)w * hidden, (size_t)w * hidden,
+      if (int rc = launch_slab_reduce_za(scratch + L.dw_slab, dw_images(d), (size_t)w * hidden, (size_t)w * hidden,
                                          (size_t)w * hidden, grad_weights[i] + (size_t)c0 * hidden, acc, s))
         return rc;
     }

@@ -66,6 +66,7 @@ enum PathCount {
   PATH_RG16,             // rowgemm16_kernel launches (bf16 storage, weights in registers)
   PATH_STACK16_QUAD,     // bf16-storage stack forward calls on the channel-sliced aggregation
   PATH_RGW,              // rowgemmw_kernel launches (exact fp32, weights resident in registers; round 6)
+  PATH_DWW,              // dww_kernel launches (exact fp32 dW on specialised waves; round 6)
   PATH_STACK_SPLIT,      // stack forward calls whose hidden layers aggregated with the P + bipartite split (gcn_csrqs.hip / csr16 split)
   PATH_COUNT
 };

@@ -1326,6 +1326,9 @@ int dw_num_slabs(int n_out) {
   return 256 / g > 0 ? 256 / g : 1;
 }
 
+int dw_images(const DwArgs &a) { return a.bf16 != 3 && dww_ok(a) ? dww_images() : dw_num_slabs(a.n_out); }
+int dw_slab_capacity(int n_out) { return dw_num_slabs(n_out) > dww_images() ? dw_num_slabs(n_out) : dww_images(); }
+
 int launch_dw(const DwArgs &a0, hipStream_t s) {
   if (a0.bf16 == 3) return launch_dw3(a0, s);   // split-operand mode (gcn_gemm3.hip)
   DwArgs a = a0;
@@ -1348,6 +1351,7 @@ int launch_dw(const DwArgs &a0, hipStream_t s) {
     set_error("dw: unsupported dims k_in=%d n_out=%d ldx=%d ldz0=%d ldz1=%d", a.k_in, a.n_out, a.ldx, a.ldz0, a.ldz1);
     return -1;
   }
+  if (dww_ok(a)) return launch_dww(a, s);
   const bool hyb = a.xq_nvert > 0 || a.z0q_nvert > 0;
   if (hyb) path_count(PATH_DW_HYBRID);
   const int nbq = a.xq_nvert > 0 ? a.xq_quads / 4 : 0, wrm = a.ldx - nbq * 16;   // as dw_kernel

@@ -86,7 +86,6 @@ __device__ __forceinline__ void w_mfma(bool first, bool a_in_agpr, f32x4 &acc, f
 // a 16x16x4 fp32 MFMA is 8 passes: its result may be read by a non-MFMA instruction 18 wait states after issue
 __device__ __forceinline__ void w_mfma_done() { asm volatile("s_nop 15\n\ts_nop 3" ::: "memory"); }
 
-__device__ __forceinline__ const char *w_at(const void *base, unsigned off) { return reinterpret_cast<const char *>(base) + (size_t)off; }
 
 // ---- waves 0-2: multiply -------------------------------------------------------------------------------------------------
 template <int EPI>

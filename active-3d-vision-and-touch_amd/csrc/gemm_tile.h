@@ -163,4 +163,7 @@ __device__ __forceinline__ void rowtile_unit(const RowGemmArgs &p, int row_base,
   }
 }
 
+// base + a 32-bit byte offset: the form the compiler turns into a scalar base + a vector offset (no 64-bit vector arithmetic)
+__device__ __forceinline__ const char *w_at(const void *base, unsigned off) { return reinterpret_cast<const char *>(base) + (size_t)off; }
+
 }  // namespace a3vt

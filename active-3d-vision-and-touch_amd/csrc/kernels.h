@@ -129,12 +129,19 @@ struct DwArgs {
   int ldx_src, xq_nvert, xq_quads, z0q_nvert, z0q_quads;
 };
 int dw_num_slabs(int n_out);
+// slab images the launch that takes `a` will write (launch_dw picks the kernel): what launch_slab_reduce* must sum
+int dw_images(const DwArgs &a);
+int dw_slab_capacity(int n_out);   // images to allocate: enough for either kernel
 // dW = X^T dZ of a hidden layer in mode 3 (DwArgs::bf16 == 3, gcn_gemm3.hip; same slabs as launch_dw); dw3_ok: the shapes it takes
 bool dw3_ok(const DwArgs &a);
 int launch_dw3(const DwArgs &a, hipStream_t s);
 // True when dw_kernel can take the first 4 * quads columns of a k_in-wide X quad-major (they must end where a wave's input tiles end).
 bool dw_quad_major_ok(int k_in, int quads);
 int launch_dw(const DwArgs &a, hipStream_t s);
+// gcn_dww.hip: the hidden layers' dW on hybrid rows, waves specialised (round 6); same slab images as launch_dw
+bool dww_ok(const DwArgs &a);
+int dww_images();   // slab images a dww launch writes (>= dw_num_slabs(300): size the slab array with dw_slab_capacity)
+int launch_dww(const DwArgs &a, hipStream_t s);
 int launch_copy_cols(const float *src, int ld_src, int c0, int w, float *dst, long long m, hipStream_t s);
 int launch_slab_reduce(const float *slab, int nslab, size_t stride, size_t n, float *out, hipStream_t s);
 // same, and out[n .. n_out) = 0

@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("A3VT_LIB", os.path.join(_HERE, "liba3vt.so"))  # A3VT_LIB: developer override (variant builds)
-SOURCES = ["capi.hip", "gcn_gemm.hip", "gcn_gemmw.hip", "gcn_gemm16.hip", "gcn_gemm3.hip", "gcn_csr.hip", "gcn_csrq.hip", "gcn_csrqs.hip", "gcn_bf16s.hip", "posenc.hip", "posenc_wide.hip", "bias_grad.hip", "sample.hip", "chamfer.hip", "nn_prune.hip",
+SOURCES = ["capi.hip", "gcn_gemm.hip", "gcn_gemmw.hip", "gcn_dww.hip", "gcn_gemm16.hip", "gcn_gemm3.hip", "gcn_csr.hip", "gcn_csrq.hip", "gcn_csrqs.hip", "gcn_bf16s.hip", "posenc.hip", "posenc_wide.hip", "bias_grad.hip", "sample.hip", "chamfer.hip", "nn_prune.hip",
            "pooling.hip"]
 # Per-file extra flags (none at present; sample.hip / gcn_csr.hip rely on IEEE NaN semantics — the reference's NaN
 # scrubs, a3vt_check_finite — so fast-math style flags must never be applied globally).

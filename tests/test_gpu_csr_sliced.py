@@ -70,7 +70,13 @@ def test_channel_sliced_aggregation_equals_row_kernels_and_oracle(cuda, tname, u
     assert torch.equal(new[0], ref[0])
     assert torch.equal(new[1], ref[1])
     for i in range(L):
-        assert torch.equal(new[2][i], ref[2][i]), f"dW layer {i}"
+        # weight gradients are sums over all rows too: dw_kernel cuts them into the same row groups on both paths (same bits);
+        # round 6's dww_kernel (hidden layers of cut-0.33 stacks on hybrid rows with whole 16-row tiles) cuts them elsewhere
+        if torch.equal(new[2][i], ref[2][i]):
+            continue
+        assert 0 < i < L - 1 and cut == 0.33 and (B * n) % 16 == 0, f"dW layer {i}"
+        assert rel_err(new[2][i], ref[2][i]) < 2e-5, f"dW layer {i}"
+    for i in range(L):
         # bias gradients are sums over all rows: the partial sums are grouped per mesh here, per workgroup there
         assert rel_err(new[3][i], ref[3][i]) < 2e-5, f"db layer {i}"
         if i < L - 1 and cut_len < H:

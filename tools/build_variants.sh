@@ -13,7 +13,7 @@ build() { # name defines...
   (cd "$ROOT" && python -c "from a3vt_amd import lib; lib.build(defines=[$defs], out='$ROOT/gpurun_variants/liba3vt_$name.so')")
 }
 if [ "$1" = "rgw" ]; then   # rowgemmw_kernel (round 6) ablations + the round-5 kernel for A/B: python tools/stack_bench.py with A3VT_LIB=...
-  build RGW_OFF -DA3VT_DBG_RGW_OFF
+  build RGW_OFF -DA3VT_DBG_RGW_OFF -DA3VT_DBG_DWW_OFF   # the round-5 product kernels (rowgemm_kernel<ADIRECT>, dw_kernel<fast, hybrid>)
   build RGW_NODMA -DA3VT_DBG_RGW_NODMA
   build RGW_NOEPI -DA3VT_DBG_RGW_NOEPI
   build RGW_MFMAONLY -DA3VT_DBG_RGW_NODMA -DA3VT_DBG_RGW_NOEPI

@@ -53,3 +53,26 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def dww():
+    """The same for dww_kernel (gcn_dww.hip): per 16-row stage, per wave, stage start -> in front of the barrier."""
+    from a3vt_amd import lib
+    dll = ctypes.CDLL(lib.LIB_PATH)
+    if not hasattr(dll, "a3vt_dbg_dww_stamps"):
+        return
+    buf = np.zeros(256 * 4 * 96 * 2, dtype=np.uint64)
+    dll.a3vt_dbg_dww_stamps(ctypes.c_void_p(buf.ctypes.data))
+    s = buf.reshape(256, 4, 96, 2).astype(np.int64)
+    n = 78
+    work = s[:, :, 1:n, 1] - s[:, :, 1:n, 0]
+    whole = s[:, :, 2:n, 0] - s[:, :, 1:n - 1, 0]
+    print("\ndww_kernel, shader-clock ticks per 16-row stage; 50 MFMAs x 4 steps x 32 cycles = 6 400 (half B: 45 -> 5 760; wave 3: 40 / 36)")
+    for half in (0, 1):
+        blk = [b for b in range(256) if ((b >> 3) & 1) == half]
+        print(f"  half {'A' if half == 0 else 'B'}: stage to stage median {np.median(whole[blk]):6.0f}; per wave work (start -> barrier): "
+              + "  ".join(f"w{w} {np.median(work[blk][:, w]):6.0f}" for w in range(4)))
+
+
+if __name__ == "__main__":
+    dww()
