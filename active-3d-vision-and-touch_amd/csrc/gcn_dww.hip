@@ -50,8 +50,9 @@ __device__ unsigned long long g_dww_stamps[256 * 4 * 96 * 2];
 #endif
 
 // MFMA with the accumulator in an AGPR tuple, operands in VGPRs (see w_mfma in gcn_gemmw.hip)
+// (volatile: the order written below — one fragment read of the NEXT k-step behind every third MFMA — is the schedule)
 __device__ __forceinline__ void d_mfma(f32x4 &acc, float a, float b) {
-  asm("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+  asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
 // One fragment element from the stage, as a written instruction: from a C++ load the compiler places "s_waitcnt lgkmcnt(0)" in
 // front of the MFMAs of every second k-step — behind the reads it has just issued for the NEXT step, i.e. a full LDS round
@@ -188,24 +189,21 @@ __device__ __forceinline__ void dww_wave(const DwArgs &p, float *lds, int lane, 
   // step 3 already requests step 0 of the NEXT stage.  Four buffers: behind the barrier of tile t the service wave starts the
   // loads of tile t + 3 (into the buffer tile t - 1 has just left) and spreads them over step 3 of t and steps 0-2 of t + 1;
   // they must have landed at the barrier of t + 2 — a whole stage later.
-  auto frags = [&](int stg, auto sc, float (&xf)[NKT], float (&zf)[NNT]) {
-    constexpr int s = decltype(sc)::value;
+  // fragment k of k-step s of the stage in buffer `stg`: k < NKT: X of k-tile kt0 + k; else dZ of n-tile NT0 + k - NKT
+  auto frag = [&](int stg, auto sc, auto kc, float (&xf)[NKT], float (&zf)[NNT]) {
+    constexpr int s = decltype(sc)::value, k = decltype(kc)::value;
     const unsigned sb = lds0 + (unsigned)(stg * kDStage * 4);
-    const unsigned xb = sb + (XROW ? xr_lane : xq_lane);
-    const unsigned zqb = sb + zq_lane, zrb = sb + (HALF == 0 ? zra_lane : zrb_lane), z6b = sb + z6_lane + (unsigned)s * z6_step;
-#pragma unroll
-    for (int t = 0; t < NKT; ++t) {
-      // k-tile kt0 + t: quad-major planes (1 KiB per tile, 64 B per step) or row-major columns (64 B per tile, 2240 B per step)
-      if (XROW) d_lds(xf[t], xb, (kt0x + t) * 64 + s * 4 * kDXRW * 4);
-      else d_lds(xf[t], xb, (kt0x + t) * 1024 + s * 64);
-    }
-#pragma unroll
-    for (int n = 0; n < NNT; ++n) {
-      const int T = NT0 + n;
-      if (HALF == 0 && T < 6) d_lds(zf[n], zqb, T * 1024 + s * 64);
-      else if (HALF == 0 && T == 6) d_lds(zf[n], z6b, 0);
-      else if (HALF == 0) d_lds(zf[n], zrb, (T * 16 - 100) * 4 + s * 4 * 60 * 4);
-      else d_lds(zf[n], zrb, (T * 16 - 160) * 4 + s * 4 * kDXRW * 4);
+    if constexpr (k < NKT) {
+      // quad-major planes (1 KiB per tile, 64 B per step) or row-major columns (64 B per tile, 2240 B per step)
+      const unsigned xb = sb + (XROW ? xr_lane : xq_lane);
+      if (XROW) d_lds(xf[k], xb, (kt0x + k) * 64 + s * 4 * kDXRW * 4);
+      else d_lds(xf[k], xb, (kt0x + k) * 1024 + s * 64);
+    } else if constexpr (k < NKT + NNT) {
+      constexpr int n = k - NKT, T = NT0 + n;
+      if (HALF == 0 && T < 6) d_lds(zf[n], sb + zq_lane, T * 1024 + s * 64);
+      else if (HALF == 0 && T == 6) d_lds(zf[n], sb + z6_lane + (unsigned)s * z6_step, 0);
+      else if (HALF == 0) d_lds(zf[n], sb + zra_lane, (T * 16 - 100) * 4 + s * 4 * 60 * 4);
+      else d_lds(zf[n], sb + zrb_lane, (T * 16 - 160) * 4 + s * 4 * kDXRW * 4);
     }
   };
   auto dma_part = [&](int part, int dtile, int dst) {
@@ -215,20 +213,25 @@ __device__ __forceinline__ void dww_wave(const DwArgs &p, float *lds, int lane, 
       if (part * PER + u < NDMA) dma(part * PER + u, dtile < tile1 ? dtile : tile1 - 1, dst);
   };
   float xc[NKT], zc[NNT];
-  frags(0, std::integral_constant<int, 0>{}, xc, zc);
+  [&]<int... K>(std::integer_sequence<int, K...>) {
+    (frag(0, std::integral_constant<int, 0>{}, std::integral_constant<int, K>{}, xc, zc), ...);
+  }(std::make_integer_sequence<int, NKT + NNT>{});
+  d_wait<0>(xc, zc);
   for (int tile = tile0; tile < tile1; ++tile) {
     DWW_STAMP(tile - tile0, 0);
     auto step = [&](auto sc) {
       constexpr int s = decltype(sc)::value;
       float xn[NKT], zn[NNT];
-      if (s < 3) frags(st, std::integral_constant<int, (s + 1) & 3>{}, xn, zn);
-      else frags((st + 1) & 3, std::integral_constant<int, 0>{}, xn, zn);
-      d_wait<NKT + NNT>(xc, zc);   // the current step's fragments: everything but the reads just issued has returned
-#pragma unroll
-      for (int t = 0; t < NKT; ++t)
-#pragma unroll
-        for (int n = 0; n < NNT; ++n) d_mfma(acc[t][n], zc[n], xc[t]);
-      __builtin_amdgcn_sched_barrier(0);
+      constexpr int EVERY = (NKT * NNT) / (NKT + NNT);   // 3 (50 or 45 MFMAs, 15 or 14 fragments) or 2 (40 or 36, 14 or 13)
+      // 50 MFMAs; behind every third one a fragment of the next k-step (step 3: step 0 of the next stage, behind the barrier):
+      // issued in one burst the 15 reads — 4-way bank conflicts on the quad-major planes — held up the MFMAs behind them
+      [&]<int... I>(std::integer_sequence<int, I...>) {
+        ((d_mfma(acc[I / NNT][I % NNT], zc[I % NNT], xc[I / NNT]),
+          (I % EVERY == 0 ? frag(s < 3 ? st : ((st + 1) & 3), std::integral_constant<int, (s + 1) & 3>{}, std::integral_constant<int, I / EVERY>{}, xn, zn)
+                          : (void)0)),
+         ...);
+      }(std::make_integer_sequence<int, NKT * NNT>{});
+      d_wait<0>(xn, zn);   // (the last read was issued >= 5 MFMAs ago)
 #pragma unroll
       for (int t = 0; t < NKT; ++t) xc[t] = xn[t];
 #pragma unroll

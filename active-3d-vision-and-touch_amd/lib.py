@@ -19,7 +19,7 @@ SOURCES = ["capi.hip", "gcn_gemm.hip", "gcn_gemmw.hip", "gcn_dww.hip", "gcn_gemm
 # gcn_csrq.hip: scalar fma chains keep one register per edge weight (v_pk_fma_f32 wants (w, w) pairs): see the file header
 EXTRA_FLAGS = {"chamfer.hip": ["-fno-slp-vectorize"], "nn_prune.hip": ["-fno-slp-vectorize"],
                "gcn_csrq.hip": ["-fno-slp-vectorize"], "gcn_csrqs.hip": ["-fno-slp-vectorize"],
-               "gcn_gemmw.hip": ["-std=c++20"]}   # (templated lambdas over the chunk / column-tile index)
+               "gcn_gemmw.hip": ["-std=c++20"], "gcn_dww.hip": ["-std=c++20"]}   # (templated lambdas over the chunk / column-tile index)
 
 _vp, _i, _sz, _u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_uint64
 
