@@ -16,7 +16,7 @@ f = glob.glob("$OUT/pass/*/*counter_collection.csv")[0]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
-    if any(t in k for t in ("rowgemm", "dw_kernel", "dw16", "dw3", "csr", "slab", "thin")):
+    if any(t in k for t in ("rowgemm", "dw_kernel", "dww_kernel", "dw16", "dw3", "csr", "slab", "thin")):
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for k, d in agg.items():

@@ -1,8 +1,8 @@
 #!/bin/bash
 # One pass over everything under profiles/ that a kernel change can move (run on the GPU box from the repo root; ~6 min):
-#   tools/refresh_artifacts.sh r05      -> gpurun_out/refresh/r05_*   (copy what should be kept into profiles/)
+#   tools/refresh_artifacts.sh r06      -> gpurun_out/refresh/r06_*   (copy what should be kept into profiles/)
 set -x
-R=${1:-r05}
+R=${1:-r06}
 cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/refresh
 mkdir -p $O
@@ -24,6 +24,10 @@ python tools/touch_bench.py --precision fp32x3 2>/dev/null | tail -1 >> $O/${R}_
 # gemm mode 3: ablation builds (tools/build_variants.sh x3), phase stamps (stamps3), error table against the fp64 oracle
 [ -f gpurun_variants/liba3vt_X3_NOMFMA.so ] && bash tools/x3_ablate.sh > $O/${R}_x3_ablation.txt 2>&1
 [ -f gpurun_variants/liba3vt_RG3_STAMPS.so ] && A3VT_LIB=$GRAFT_REPO_ROOT/gpurun_variants/liba3vt_RG3_STAMPS.so python tools/rowgemm3_stamps.py > $O/${R}_rowgemm3_phase_stamps.txt 2>/dev/null
+# round 6 product kernels: per-tile / per-stage phase stamps of rowgemmw_kernel and dww_kernel (tools/build_variants.sh rgw)
+[ -f gpurun_variants/liba3vt_RGW_STAMPS.so ] && A3VT_LIB=$GRAFT_REPO_ROOT/gpurun_variants/liba3vt_RGW_STAMPS.so python tools/rowgemmw_stamps.py > $O/${R}_rowgemmw_dww_stamps.txt 2>/dev/null
+[ -f gpurun_variants/liba3vt_RGW_OFF.so ] && (echo '== round-5 product kernels (liba3vt_RGW_OFF.so)'; A3VT_LIB=$GRAFT_REPO_ROOT/gpurun_variants/liba3vt_RGW_OFF.so python tools/stack_bench.py | tail -4; echo '== shipped'; python tools/stack_bench.py | tail -4) > $O/${R}_product_kernels_ab.txt 2>/dev/null
+(./tools/ubench/mfma_plus_valu; ./tools/ubench/mfma_gap_budget; ./tools/ubench/mfma_one_wave) > $O/${R}_fp32_pipe_ubench.txt 2>&1
 # channel-sliced aggregation: phase stamps per quad (tools/build_variants.sh stampsq) and the gather ablations (csrq)
 [ -f gpurun_variants/liba3vt_CSRQ_STAMPS.so ] && A3VT_LIB=$GRAFT_REPO_ROOT/gpurun_variants/liba3vt_CSRQ_STAMPS.so python tools/csrq_stamps.py > $O/${R}_csrq_stamps.txt 2>/dev/null
 [ -f gpurun_variants/liba3vt_CSRQ_NOINDEX.so ] && bash tools/csrq_ablate.sh > /dev/null 2>&1
