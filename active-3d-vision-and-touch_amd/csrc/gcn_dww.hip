@@ -45,8 +45,15 @@ __device__ unsigned long long g_dww_stamps[256 * 4 * 96 * 2];
     if ((threadIdx.x & 63) == 0 && blockIdx.x < 256 && (tl) < 96)                                              \
       g_dww_stamps[((blockIdx.x * 4 + (threadIdx.x >> 6)) * 96 + (tl)) * 2 + (k)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
+// wall-clock (s_memrealtime, 100 MHz) of wave 0 at: kernel entry, first stage, behind the last stage, kernel end
+__device__ unsigned long long g_dww_rt[256 * 4];
+#define DWW_RT(k)                                                                                              \
+  do {                                                                                                         \
+    if (threadIdx.x == 0 && blockIdx.x < 256) g_dww_rt[blockIdx.x * 4 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
 #else
 #define DWW_STAMP(tl, k) do { } while (0)
+#define DWW_RT(k) do { } while (0)
 #endif
 
 // MFMA with the accumulator in an AGPR tuple, operands in VGPRs (see w_mfma in gcn_gemmw.hip)
@@ -217,6 +224,7 @@ __device__ __forceinline__ void dww_wave(const DwArgs &p, float *lds, int lane, 
     (frag(0, std::integral_constant<int, 0>{}, std::integral_constant<int, K>{}, xc, zc), ...);
   }(std::make_integer_sequence<int, NKT + NNT>{});
   d_wait<0>(xc, zc);
+  DWW_RT(1);
   for (int tile = tile0; tile < tile1; ++tile) {
     DWW_STAMP(tile - tile0, 0);
     auto step = [&](auto sc) {
@@ -260,6 +268,7 @@ __device__ __forceinline__ void dww_wave(const DwArgs &p, float *lds, int lane, 
     }
     st = (st + 1) & 3;
   }
+  DWW_RT(2);
   // ---- this workgroup's partial sums -> its half of slab image `image`: dW[k = 16 Tk + l16][n = 16 Tn + 4 q + r]
   asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");   // (the last MFMAs' results: see w_mfma_done in gcn_gemmw.hip)
   float *img = p.slab + (size_t)image * kDK * kDN;
@@ -287,6 +296,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // 16-row tiles of this row group (the groups of a half differ by at most one tile)
   const int tiles = p.m / kDStageRows;
   const int t0 = (int)((long long)group * tiles / ngroups), t1 = (int)((long long)(group + 1) * tiles / ngroups);
+  DWW_RT(0);
   if (half == 1 && group < kDwwGroupsA - kDwwGroupsB) {
     float *img = p.slab + (size_t)(kDwwGroupsB + group) * kDK * kDN;
     for (int i = threadIdx.x; i < kDK * 35; i += 256) {
@@ -305,6 +315,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     else if (wave == 2) dww_wave<1, true, 5, false, 10>(p, lds, lane, t0, t1, group);
     else dww_wave<1, true, 4, true, 15>(p, lds, lane, t0, t1, group);
   }
+  DWW_RT(3);
 }
 
 // The shape this kernel takes: exact fp32, a hidden layer of a stack on hybrid rows (dw_kernel<fast, hybrid>'s), enough rows.
@@ -323,6 +334,9 @@ bool dww_ok(const DwArgs &a) {
 }  // namespace a3vt
 extern "C" int a3vt_dbg_dww_stamps(unsigned long long *host_dst) {
   return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(a3vt::g_dww_stamps), sizeof(unsigned long long) * 256 * 4 * 96 * 2);
+}
+extern "C" int a3vt_dbg_dww_rt(unsigned long long *host_dst) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(a3vt::g_dww_rt), sizeof(unsigned long long) * 256 * 4);
 }
 namespace a3vt {
 #endif

@@ -48,8 +48,15 @@ __device__ unsigned long long g_rgw_stamps[256 * 4 * 48 * 4];
     if ((threadIdx.x & 63) == 0 && blockIdx.x < 256 && (tl) < 48)                                              \
       g_rgw_stamps[((blockIdx.x * 4 + (threadIdx.x >> 6)) * 48 + (tl)) * 4 + (k)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
+// wall-clock (s_memrealtime, 100 MHz) of wave 0 at: kernel entry, first tile, behind the last tile, kernel end
+__device__ unsigned long long g_rgw_rt[256 * 4];
+#define RGW_RT(k)                                                                                              \
+  do {                                                                                                         \
+    if (threadIdx.x == 0 && blockIdx.x < 256) g_rgw_rt[blockIdx.x * 4 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
 #else
 #define RGW_STAMP(tl, k) do { } while (0)
+#define RGW_RT(k) do { } while (0)
 #endif
 
 template <int V>
@@ -113,6 +120,7 @@ __device__ __forceinline__ void rowgemmw_compute(const RowGemmArgs &p, float *ld
   wait_vmcnt<0>();
   wait_lgkm0();
   __builtin_amdgcn_s_barrier();   // (prologue barrier: the first two tiles' rows are in the ring)
+  RGW_RT(1);
   int st = 0;
   for (int tile = t0; tile < t1; ++tile) {
     RGW_STAMP(tile - t0, 0);
@@ -145,6 +153,7 @@ __device__ __forceinline__ void rowgemmw_compute(const RowGemmArgs &p, float *ld
     st = st == 2 ? 0 : st + 1;
   }
   __builtin_amdgcn_s_barrier();     // (drain barrier: wave 3 has finished the last tile's epilogue)
+  RGW_RT(2);
 }
 
 // ---- wave 3: 4 column tiles, the rows' DMA, every epilogue ------------------------------------------------------------------
@@ -423,6 +432,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // the main part: the same number of 16-row tiles for every workgroup; the rest is the launch's tail (below)
   const int per = (p.m >> 4) / (int)gridDim.x;
   const int t0 = blockIdx.x * per, t1 = t0 + per;
+  RGW_RT(0);
   if (wave < 3) rowgemmw_compute<EPI>(p, lds, wave, lane, t0, t1);
   else rowgemmw_service<EPI>(p, lds, lane, t0, t1);
   // ---- leftover tiles of the even split: one 16 x 16 output tile per wave, dealt across the workgroups (rowtile_unit)
@@ -432,6 +442,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int u = wave * gridDim.x + blockIdx.x; u < units; u += 4 * gridDim.x)
       rowtile_unit<EPI, 0>(p, p.rem_row0, p.rem_row0 + p.rem_rows, u / ntl, (u % ntl) * 16, lane);
   }
+  RGW_RT(3);
 }
 
 // The shapes this kernel takes: exact fp32, a hidden layer of a stack on hybrid rows (quad-major a0 and side outputs),
@@ -479,6 +490,9 @@ static int launch_rowgemmw_epi(const RowGemmArgs &a0, hipStream_t s) {
 }  // namespace a3vt
 extern "C" int a3vt_dbg_rgw_stamps(unsigned long long *host_dst) {
   return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(a3vt::g_rgw_stamps), sizeof(unsigned long long) * 256 * 4 * 48 * 4);
+}
+extern "C" int a3vt_dbg_rgw_rt(unsigned long long *host_dst) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(a3vt::g_rgw_rt), sizeof(unsigned long long) * 256 * 4);
 }
 namespace a3vt {
 #endif

@@ -36,9 +36,9 @@ python -m pytest tests/test_gpu_fp32x3.py -q -s -k vs_fp64 2>&1 | grep "^\[\|pas
 # configs[3]: the first steps run MIOpen's find mode, so the table is cut from the kernel TRACE after 5 steps (tools/trace_steady.py)
 (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/c3 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/c3 -- python $GRAFT_REPO_ROOT/tools/named_configs.py --only 3 --steps 10 > /tmp/c3.log 2>&1; python $GRAFT_REPO_ROOT/tools/trace_steady.py $(find /tmp/c3 -name '*kernel_trace.csv' | head -1) --skip 5 --top 60 > $O/${R}_config3_bf16s_steady_kernels.txt; head -8 $O/${R}_config3_bf16s_steady_kernels.txt)
 # the exact search: both geometries ("bench" = the untrained network's concentric sphere / ellipsoids), counters, per-wave timeline
-(python tools/chamfer_bench.py --geometry bench; python tools/chamfer_bench.py) > $O/${R}_chamfer_search_refresh.txt 2>/dev/null; cat $O/${R}_chamfer_search_refresh.txt
-[ -f gpurun_variants/liba3vt_NN_STATS.so ] && (A3VT_LIB=gpurun_variants/liba3vt_NN_STATS.so python tools/nn_stats.py --geometry bench; A3VT_LIB=gpurun_variants/liba3vt_NN_STATS.so python tools/nn_stats.py; A3VT_LIB=gpurun_variants/liba3vt_NN_STATS.so python tools/nn_stats_config.py --which 3 --batch 16 | tail -1; A3VT_LIB=gpurun_variants/liba3vt_NN_STATS.so python tools/nn_stats_config.py --which 4 | tail -1) > $O/${R}_nn_pruning_stats_refresh.txt 2>/dev/null
-[ -f gpurun_variants/liba3vt_NN_TRACE.so ] && A3VT_LIB=gpurun_variants/liba3vt_NN_TRACE.so python tools/nn_trace.py > $O/${R}_nn_wave_timeline_refresh.txt 2>/dev/null
+(python tools/chamfer_bench.py --geometry bench; python tools/chamfer_bench.py) > $O/${R}_chamfer_search.txt 2>/dev/null; cat $O/${R}_chamfer_search.txt
+[ -f gpurun_variants/liba3vt_NN_STATS.so ] && (A3VT_LIB=gpurun_variants/liba3vt_NN_STATS.so python tools/nn_stats.py --geometry bench; A3VT_LIB=gpurun_variants/liba3vt_NN_STATS.so python tools/nn_stats.py; A3VT_LIB=gpurun_variants/liba3vt_NN_STATS.so python tools/nn_stats_config.py --which 3 --batch 16 | tail -1; A3VT_LIB=gpurun_variants/liba3vt_NN_STATS.so python tools/nn_stats_config.py --which 4 | tail -1) > $O/${R}_nn_pruning_stats.txt 2>/dev/null
+[ -f gpurun_variants/liba3vt_NN_TRACE.so ] && A3VT_LIB=gpurun_variants/liba3vt_NN_TRACE.so python tools/nn_trace.py > $O/${R}_nn_wave_timeline.txt 2>/dev/null
 [ -f gpurun_variants/liba3vt_NN_AABB.so ] && (A3VT_LIB=gpurun_variants/liba3vt_NN_AABB.so python tools/chamfer_bench.py --geometry bench --algos pruned; A3VT_LIB=gpurun_variants/liba3vt_NN_AABB.so python tools/chamfer_bench.py --algos pruned) > $O/${R}_chamfer_search_axis_aligned_boxes.txt 2>/dev/null
 python tools/score_bench.py 2>/dev/null | tail -1 > $O/${R}_scoring_batched_vs_sequential.json; cut -c 1-400 $O/${R}_scoring_batched_vs_sequential.json
 python tools/host_bound.py 2>/dev/null | tail -2 > $O/${R}_named_configs_host_time.txt

@@ -49,6 +49,29 @@ def main():
     for w in range(4):
         print(f"  wave {w}: loop {np.median(loop[:, w]):7.0f}  wait {np.median(wait[:, w]):6.0f}  barrier {np.median(barr[:, w]):6.0f}")
     print("whole kernel per workgroup (first stamp to last):", pc((s[:, :, tiles - 1, 3] - s[:, :, 0, 0]).ravel()))
+    if hasattr(dll, "a3vt_dbg_rgw_rt"):
+        realtime(dll.a3vt_dbg_rgw_rt, "rowgemmw_kernel", s[:, 0, tiles - 1, 3] - s[:, 0, 0, 0])
+
+
+def realtime(fn, name, loop_ticks=None):
+    """Wall-clock stamps (s_memrealtime, 100 MHz) of wave 0 of every workgroup: entry, first tile, behind the last, end."""
+    rt = np.zeros(256 * 4, dtype=np.uint64)
+    fn(ctypes.c_void_p(rt.ctypes.data))
+    r = rt.reshape(256, 4).astype(np.int64)
+    r = r[r[:, 0] > 0]
+    if r.shape[0] == 0:
+        return
+    t0 = r[:, 0].min()
+    us = lambda a: "min %6.2f  median %6.2f  max %6.2f us" % (a.min() / 100.0, np.median(a) / 100.0, a.max() / 100.0)  # noqa: E731
+    print(f"{name}, wall clock of wave 0 per workgroup (s_memrealtime, 10 ns ticks), {r.shape[0]} workgroups:")
+    print("  entry after the first workgroup's :", us(r[:, 0] - t0))
+    print("  entry -> first tile (weights etc.) :", us(r[:, 1] - r[:, 0]))
+    print("  the tile loop                      :", us(r[:, 2] - r[:, 1]))
+    print("  behind the loop -> kernel end      :", us(r[:, 3] - r[:, 2]))
+    print("  first entry -> last end            : %.2f us" % ((r[:, 3].max() - t0) / 100.0))
+    if loop_ticks is not None:
+        lt = loop_ticks[: r.shape[0]]
+        print("  shader clock during the loop       : %.3f GHz (s_memtime ticks / wall clock)" % (np.median(lt / ((r[:, 2] - r[:, 1]) * 10.0))))
 
 
 if __name__ == "__main__":
@@ -72,6 +95,8 @@ def dww():
         blk = [b for b in range(256) if ((b >> 3) & 1) == half]
         print(f"  half {'A' if half == 0 else 'B'}: stage to stage median {np.median(whole[blk]):6.0f}; per wave work (start -> barrier): "
               + "  ".join(f"w{w} {np.median(work[blk][:, w]):6.0f}" for w in range(4)))
+    if hasattr(dll, "a3vt_dbg_dww_rt"):
+        realtime(dll.a3vt_dbg_dww_rt, "dww_kernel")
 
 
 if __name__ == "__main__":
