@@ -1496,6 +1496,53 @@ int a3vt_bias_grad_nhwc(const void *grad, int bf16, long long rows, int channels
   return launch_bias_grad(grad, bf16, rows, channels, out, static_cast<float *>(scratch), static_cast<hipStream_t>(stream));
 }
 
+size_t a3vt_bnrelu_scratch_bytes(int channels) { return channels > 0 ? bnrelu_scratch_bytes(channels) : 0; }
+
+int a3vt_bnrelu_fwd(const void *x, long long rows, int channels, const float *gamma, const float *beta, float eps,
+                    float momentum, float *running_mean, float *running_var, long long *num_batches_tracked, void *y,
+                    float *save, void *scratch, size_t scratch_bytes, void *stream) {
+  A3VT_CHECK_ARG(x && y && gamma && beta && save && scratch);
+  A3VT_CHECK_ARG(rows >= 2 && channels > 0 && rows <= (1ll << 40) / channels);
+  A3VT_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr));
+  A3VT_CHECK_ARG(eps >= 0.f && momentum >= 0.f && momentum <= 1.f);
+  A3VT_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(scratch)) & 15) == 0);
+  A3VT_CHECK_ARG(bnrelu_wgs(rows * channels, channels, 4, 1024) > 0 && scratch_bytes >= bnrelu_scratch_bytes(channels));
+  ProfScope psc(PROF_ENC, static_cast<hipStream_t>(stream));
+  return launch_bnrelu_fwd(x, rows, channels, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, y,
+                           save, scratch, static_cast<hipStream_t>(stream));
+}
+
+int a3vt_bnrelu_bwd(const void *dy, const void *x, long long rows, int channels, const float *save, void *dx, float *dgamma,
+                    float *dbeta, void *scratch, size_t scratch_bytes, void *stream) {
+  A3VT_CHECK_ARG(dy && x && save && dx && dgamma && dbeta && scratch);
+  A3VT_CHECK_ARG(rows >= 2 && channels > 0 && rows <= (1ll << 40) / channels);
+  A3VT_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) |
+                   reinterpret_cast<uintptr_t>(scratch)) & 15) == 0);
+  A3VT_CHECK_ARG(bnrelu_wgs(rows * channels, channels, 4, 1024) > 0 && scratch_bytes >= bnrelu_scratch_bytes(channels));
+  ProfScope psc(PROF_ENC, static_cast<hipStream_t>(stream));
+  return launch_bnrelu_bwd(dy, x, rows, channels, save, dx, dgamma, dbeta, scratch, static_cast<hipStream_t>(stream));
+}
+
+int a3vt_cast_weights_bf16(int n, const float *const *src, void *const *dst, const long long *outer, const int *inner,
+                           const int *hw, void *stream) {
+  A3VT_CHECK_ARG(n >= 0 && n <= kCastBatchMax);
+  A3VT_CHECK_ARG(n == 0 || (src && dst && outer && inner && hw));
+  CastBatch b;
+  b.n = n;
+  b.start[0] = 0;
+  for (int k = 0; k < n; ++k) {
+    A3VT_CHECK_ARG(src[k] && dst[k] && outer[k] > 0 && inner[k] > 0 && hw[k] > 0);
+    A3VT_CHECK_ARG(outer[k] <= (1ll << 31) / inner[k] / hw[k]);
+    b.src[k] = src[k];
+    b.dst[k] = static_cast<uint16_t *>(dst[k]);
+    b.inner[k] = inner[k];
+    b.hw[k] = hw[k];
+    b.start[k + 1] = b.start[k] + outer[k] * inner[k] * hw[k];
+  }
+  ProfScope psc(PROF_ENC, static_cast<hipStream_t>(stream));
+  return launch_cast_weights(b, static_cast<hipStream_t>(stream));
+}
+
 int a3vt_profile_enable(int on) {
   g_prof.on = on != 0;
   g_prof.used = 0;

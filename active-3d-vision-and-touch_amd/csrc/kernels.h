@@ -306,6 +306,26 @@ int launch_pool_bwd(PoolArgs a, hipStream_t s);
 int bias_grad_wgs(long long n_elem, int c);
 int launch_bias_grad(const void *g, int bf16, long long rows, int c, float *out, float *slab, hipStream_t s);
 
+// bnrelu.hip: training BatchNorm2d + ReLU on channels-last bf16 maps (save: [4][c] mean, invstd, scale, shift)
+int bnrelu_wgs(long long n_elem, int c, int per_thread, int cap);
+size_t bnrelu_scratch_bytes(int c);
+int launch_bnrelu_fwd(const void *x, long long rows, int c, const float *gamma, const float *beta, float eps, float momentum,
+                      float *running_mean, float *running_var, long long *num_batches, void *y, float *save, void *scratch,
+                      hipStream_t s);
+int launch_bnrelu_bwd(const void *dy, const void *x, long long rows, int c, const float *save, void *dx, float *dgamma,
+                      float *dbeta, void *scratch, hipStream_t s);
+
+// bnrelu.hip: up to kCastBatchMax fp32 tensors [outer][inner][hw] -> bf16 [outer][hw][inner] in one launch
+constexpr int kCastBatchMax = 96;
+struct CastBatch {
+  int n;
+  const float *src[kCastBatchMax];
+  uint16_t *dst[kCastBatchMax];
+  int inner[kCastBatchMax], hw[kCastBatchMax];
+  long long start[kCastBatchMax + 1];   // first destination element of tensor k in the launch's index space
+};
+int launch_cast_weights(const CastBatch &b, hipStream_t s);
+
 // chamfer.hip
 size_t chamfer_scratch_bytes(int draws, int batch, int q);
 // algo: 0 = choose (pruned search when the workspace holds it and the clouds are large enough to pay for the sort),

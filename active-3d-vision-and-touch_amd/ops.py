@@ -499,6 +499,41 @@ def _bf16_copy(t, channels_last):
     return c
 
 
+def prefetch_bf16_copies(items):
+    """Refresh the cached bf16 copies of many convolution weights / biases at once: ``items`` = [(tensor, channels_last)].
+    Everything whose cache entry is stale (see :func:`_bf16_copy`) is converted by ONE ``a3vt_cast_weights_bf16`` launch
+    instead of two or three torch copy launches per tensor (84 per training step of the image model); the following
+    :func:`_bf16_copy` calls hit the cache.  Tensors the kernel does not take (not fp32 / not contiguous) are left to them."""
+    if not _bf16_cache_on():
+        return
+    stale = []
+    for t, cl in items:
+        hit = _BF16_COPIES.get(id(t))
+        if (hit is not None and hit[0]() is t and hit[1] == t._version and hit[2] == t.data_ptr() and hit[3] == _OPT_EPOCH[0]):
+            continue
+        if t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.dim() in (1, 4):
+            stale.append((t, cl))
+    L = _lib.load()
+    for i0 in range(0, len(stale), 96):
+        part = stale[i0:i0 + 96]
+        n = len(part)
+        dsts = []
+        for t, cl in part:
+            fmt = torch.channels_last if (cl and t.dim() == 4) else torch.contiguous_format
+            dsts.append(torch.empty(t.shape, dtype=torch.bfloat16, device=t.device, memory_format=fmt))
+        src = (ctypes.c_void_p * n)(*[t.data_ptr() for t, _ in part])
+        dst = (ctypes.c_void_p * n)(*[d.data_ptr() for d in dsts])
+        outer = (ctypes.c_longlong * n)(*[t.shape[0] for t, _ in part])
+        # a channels-last (O, I, KH, KW) tensor is [O][KH KW][I] in memory; everything else keeps its order (inner = 1)
+        inner = (ctypes.c_int * n)(*[(t.shape[1] if (cl and t.dim() == 4) else 1) for t, cl in part])
+        hw = (ctypes.c_int * n)(*[((t.shape[2] * t.shape[3]) if (cl and t.dim() == 4) else (t.numel() // t.shape[0])) for t, cl in part])
+        _lib.check(L.a3vt_cast_weights_bf16(n, src, dst, outer, inner, hw, _stream()), "cast_weights_bf16")
+        for (t, _), d in zip(part, dsts):
+            key = id(t)
+            ref = weakref.ref(t, lambda r, key=key: _bf16_forget(key, r))
+            _BF16_COPIES[key] = (ref, t._version, t.data_ptr(), _OPT_EPOCH[0], d)
+
+
 class ConvNHWCFn(torch.autograd.Function):
     """``nn.Conv2d`` of the image pyramid (vision/model.py:15-23) in the channels-last bf16 branch: MIOpen's NHWC bf16
     kernels for the convolution and its data / weight gradients, the bias gradient from the library (torch's own column
@@ -522,6 +557,60 @@ class ConvNHWCFn(torch.autograd.Function):
                                                         [ctx.needs_input_grad[0], True, False])
         gb = bias_grad_nhwc(gy)
         return (gx.to(xdt) if gx is not None else None), gw.to(wdt, memory_format=torch.contiguous_format), gb.to(bdt), None, None
+
+
+_BNRELU_SCRATCH = {}   # (device index, stream) -> zero-initialised scratch of a3vt_bnrelu_*; the launches leave it zero
+_BNRELU_MAX_C = 1024
+
+
+def _bnrelu_scratch(dev):
+    L = _lib.load()
+    key = (dev.index, int(torch.cuda.current_stream().cuda_stream))
+    buf = _BNRELU_SCRATCH.get(key)
+    if buf is None:
+        buf = torch.zeros(L.a3vt_bnrelu_scratch_bytes(_BNRELU_MAX_C), dtype=torch.uint8, device=dev)
+        _BNRELU_SCRATCH[key] = buf
+    return buf
+
+
+class BNReLUFn(torch.autograd.Function):
+    """Training-mode ``nn.BatchNorm2d`` followed by ``nn.ReLU`` of a ``CNN_layer`` (vision/model.py:15-23) on a channels-last
+    bf16 map: ``a3vt_bnrelu_fwd / _bwd``, two launches each way.  Updates the module's running statistics and
+    ``num_batches_tracked`` in place like the module does.  Returns a channels-last bf16 tensor."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, num_batches, eps, momentum):
+        L = _lib.load()
+        if not x.is_cuda or x.dim() != 4 or x.dtype != torch.bfloat16:
+            raise RuntimeError("a3vt: bnrelu takes a bfloat16 (B,C,H,W) tensor on the GPU")
+        x = x.contiguous(memory_format=torch.channels_last)
+        B, C, H, W = x.shape
+        if C > _BNRELU_MAX_C:
+            raise RuntimeError(f"a3vt: bnrelu supports up to {_BNRELU_MAX_C} channels")
+        rows = B * H * W
+        gamma, beta = _req(gamma, "bn weight"), _req(beta, "bn bias")
+        y = torch.empty_like(x, memory_format=torch.channels_last)
+        save = torch.empty((4, C), dtype=torch.float32, device=x.device)
+        scratch = _bnrelu_scratch(x.device)
+        _lib.check(L.a3vt_bnrelu_fwd(_lib.ptr(x), rows, C, _lib.ptr(gamma), _lib.ptr(beta), float(eps), float(momentum),
+                                     _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(num_batches),
+                                     _lib.ptr(y), _lib.ptr(save), _lib.ptr(scratch), scratch.numel(), _stream()), "bnrelu_fwd")
+        ctx.save_for_backward(x, save)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        L = _lib.load()
+        x, save = ctx.saved_tensors
+        B, C, H, W = x.shape
+        gy = gy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        gx = torch.empty_like(x, memory_format=torch.channels_last)
+        dg = torch.empty(C, dtype=torch.float32, device=x.device)
+        db = torch.empty(C, dtype=torch.float32, device=x.device)
+        scratch = _bnrelu_scratch(x.device)
+        _lib.check(L.a3vt_bnrelu_bwd(_lib.ptr(gy), _lib.ptr(x), B * H * W, C, _lib.ptr(save), _lib.ptr(gx), _lib.ptr(dg),
+                                     _lib.ptr(db), _lib.ptr(scratch), scratch.numel(), _stream()), "bnrelu_bwd")
+        return gx, dg, db, None, None, None, None, None
 
 
 class VertexUpdateFn(torch.autograd.Function):

@@ -110,6 +110,7 @@ class Image_Encoder(nn.Module):
         return img.is_cuda and prec in ("bf16", "bf16s")
 
     library_bias_grad = True   # (tools flip it to time torch's own reduction)
+    fused_bn_relu = True       # training BatchNorm2d + ReLU through a3vt_bnrelu_* (False: MIOpen's BatchNorm + torch's ReLU)
     # MIOpen's training BatchNorm crashes the HOST on bf16 NHWC input at batch sizes below 4 (seen for 3 x 254^2, 3 x 64^2 and
     # 64 x 27^2 maps on the ROCm 7.2 image this was built on: tools/experiments/miopen_bn_nhwc_c3_crash.py).  Batches
     # smaller than this take the NCHW kernel instead (a last partial batch of an epoch, or a small per-rank shard: same
@@ -122,8 +123,19 @@ class Image_Encoder(nn.Module):
     def _block_nhwc(block, x):
         """One ``CNN_layer`` Sequential in the bf16 channels-last branch: BatchNorm / ReLU as they are (MIOpen under
         autocast), the convolution through ``ops.ConvNHWCFn`` (same MIOpen kernels, bias gradient from the library)."""
-        for m in block:
-            if isinstance(m, nn.BatchNorm2d) and m.training and x.shape[0] < Image_Encoder.bn_nhwc_min_batch:
+        mods, skip = list(block), False
+        for i, m in enumerate(mods):
+            if skip:          # the ReLU behind a fused BatchNorm
+                skip = False
+                continue
+            if (Image_Encoder.fused_bn_relu and isinstance(m, nn.BatchNorm2d) and m.training and m.affine and m.track_running_stats
+                    and m.momentum is not None and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                    and x.dtype == torch.bfloat16 and m.running_mean.dtype == torch.float32
+                    and m.num_batches_tracked.dtype == torch.int64):
+                # BatchNorm2d + ReLU as one operator (csrc/bnrelu.hip): two launches each way, any batch size
+                x = _ops.BNReLUFn.apply(x, m.weight, m.bias, m.running_mean, m.running_var, m.num_batches_tracked, m.eps, m.momentum)
+                skip = True
+            elif isinstance(m, nn.BatchNorm2d) and m.training and x.shape[0] < Image_Encoder.bn_nhwc_min_batch:
                 if not Image_Encoder._bn_fallback_reported:
                     Image_Encoder._bn_fallback_reported = True
                     import warnings
@@ -148,6 +160,16 @@ class Image_Encoder(nn.Module):
         low = self._bf16_branch(img)   # (parameters keep their NCHW strides — the flat gradient bucket and fused Adam see one
         #                                layout; the convolutions take a channels-last bf16 copy of their weights per call)
         x, maps = (img.contiguous(memory_format=torch.channels_last) if low else img), []
+        if low and Image_Encoder.library_bias_grad:   # every weight / bias this call will use -> bf16 in one launch (cached per step)
+            size, convs = img.shape[-1], []
+            for layer in self.layers:
+                if size < self.args.CNN_ker_size:
+                    break
+                for m in layer:
+                    if isinstance(m, nn.Conv2d):
+                        convs.append(m)
+                        size = (size + 2 * m.padding[0] - m.kernel_size[0]) // m.stride[0] + 1
+            _ops.prefetch_bf16_copies([(m.weight, True) for m in convs] + [(m.bias, False) for m in convs if m.bias is not None])
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=low):
             for e, layer in enumerate(self.layers):
                 if x.shape[-1] < self.args.CNN_ker_size:

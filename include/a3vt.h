@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define A3VT_VERSION 160 /* 160: a3vt_adj_split, a3vt_adj_split_validate, a3vt_gcn_stack_fwd_adj / _bwd_adj (the fused vision + touch adjacency as P + a complete bipartite block); 150: a3vt_dbg_path_counts, larger a3vt_chamfer_workspace_bytes (oriented boxes of the pruned search), a3vt_gcn_stack_scratch_bytes covers every gemm mode, gemm_bf16 outside 0..3 refused; 140: gemm_bf16 = 3 ("fp32x3": fp32 products as six bf16 MFMA passes on exactly split operands), a3vt_split3_bf16; 0.2.x: bf16 storage mode (gemm_bf16 = 2), a3vt_gcn_stack_stash_bytes / _scratch_bytes_mode, deterministic backward scatters; 120: a3vt_chamfer_fwd_ws (pruned exact search); 130: a3vt_posenc_wide_* (448-wide vertex-feature encoder), larger a3vt_gcn_stack_mask_bytes / _scratch_bytes (channel-sliced aggregation) */
+#define A3VT_VERSION 161 /* 161: a3vt_bnrelu_fwd / _bwd (training BatchNorm2d + ReLU of the image pyramid on channels-last bf16 maps), a3vt_cast_weights_bf16; 160: a3vt_adj_split, a3vt_adj_split_validate, a3vt_gcn_stack_fwd_adj / _bwd_adj (the fused vision + touch adjacency as P + a complete bipartite block); 150: a3vt_dbg_path_counts, larger a3vt_chamfer_workspace_bytes (oriented boxes of the pruned search), a3vt_gcn_stack_scratch_bytes covers every gemm mode, gemm_bf16 outside 0..3 refused; 140: gemm_bf16 = 3 ("fp32x3": fp32 products as six bf16 MFMA passes on exactly split operands), a3vt_split3_bf16; 0.2.x: bf16 storage mode (gemm_bf16 = 2), a3vt_gcn_stack_stash_bytes / _scratch_bytes_mode, deterministic backward scatters; 120: a3vt_chamfer_fwd_ws (pruned exact search); 130: a3vt_posenc_wide_* (448-wide vertex-feature encoder), larger a3vt_gcn_stack_mask_bytes / _scratch_bytes (channel-sliced aggregation) */
 
 int a3vt_version(void);
 const char *a3vt_last_error(void);
@@ -269,6 +269,30 @@ int a3vt_image_pool_bwd(const float *verts, int batch, int n_vert, const float *
 size_t a3vt_bias_grad_scratch_bytes(long long rows, int channels);
 int a3vt_bias_grad_nhwc(const void *grad, int bf16, long long rows, int channels, float *out, void *scratch,
                         size_t scratch_bytes, void *stream);
+
+/* Training-mode BatchNorm2d + ReLU of a `CNN_layer` (model.py:15-23: BatchNorm2d -> ReLU -> Conv2d; 13 per encoder and
+ * step, model.py:147-164) on a channels-last bf16 map, three launches each way instead of 3 + 1 (+ the counter increment):
+ *   y = relu(gamma * (x - mean_c) / sqrt(var_c + eps) + beta),  statistics over the rows per channel (biased variance);
+ *   running_mean / running_var (unbiased variance, `momentum`) and *num_batches_tracked (+1) are updated as nn.BatchNorm2d
+ *   does (pass NULL to skip either).  x, y, dy, dx: [rows = N*H*W][channels] bf16, 16-byte aligned; gamma, beta, dgamma,
+ *   dbeta: fp32 [channels]; save: fp32 [4][channels] written by the forward (mean, 1/std, scale, shift), read by the backward.
+ * Backward: dgamma = sum g * xhat, dbeta = sum g, dx = scale * (g - dbeta / rows - xhat * dgamma / rows), g = dy where y > 0
+ * (the mask is recomputed from x with the forward's own coefficients).  Fixed summation order, float64 final sums: repeatable
+ * bit for bit.  rows >= 2.  scratch: a3vt_bnrelu_scratch_bytes(channels) bytes; one buffer may serve every layer of a stream. */
+size_t a3vt_bnrelu_scratch_bytes(int channels);
+int a3vt_bnrelu_fwd(const void *x, long long rows, int channels, const float *gamma, const float *beta, float eps,
+                    float momentum, float *running_mean, float *running_var, long long *num_batches_tracked, void *y,
+                    float *save, void *scratch, size_t scratch_bytes, void *stream);
+int a3vt_bnrelu_bwd(const void *dy, const void *x, long long rows, int channels, const float *save, void *dx, float *dgamma,
+                    float *dbeta, void *scratch, size_t scratch_bytes, void *stream);
+
+/* bf16 copies of the pyramid's fp32 convolution weights and biases (the nn.Conv2d parameters of model.py:15-47) for MIOpen's
+ * NHWC bf16 kernels, all in one launch per optimizer step instead of two or three per tensor: tensor k is
+ * src[k] fp32 [outer[k]][inner[k]][hw[k]] (a weight: O x I x (KH KW), contiguous; a bias: inner = hw = 1) and becomes
+ * dst[k] bf16 [outer][hw][inner] (channels-last), round to nearest even.  n <= 96; the five arrays are HOST arrays of n
+ * entries holding device pointers / sizes. */
+int a3vt_cast_weights_bf16(int n, const float *const *src, void *const *dst, const long long *outer, const int *inner,
+                           const int *hw, void *stream);
 
 /* Vertex update, model.py:250,270,283:  out[b][v] = in[b][v] + (v < n_vision ? update[b][v] : 0). */
 int a3vt_vertex_update(const float *verts_in, const float *update, int batch, int n_vert, int n_vision,

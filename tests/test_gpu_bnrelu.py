@@ -1,0 +1,147 @@
+"""Training BatchNorm2d + ReLU of the image pyramid as one operator (csrc/bnrelu.hip, a3vt_bnrelu_fwd / _bwd) against
+torch's own fp32 batch_norm + relu on the same bf16-rounded inputs (reference: CNN_layer, vision/model.py:15-23)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference(x, gamma, beta, rm, rv, eps, momentum, gy):
+    """fp32 BatchNorm2d (training) + ReLU by torch ops on the bf16 VALUES of x; gradients for the bf16 values of gy."""
+    xf = x.float().detach().requires_grad_(True)
+    g = gamma.detach().clone().requires_grad_(True)
+    b = beta.detach().clone().requires_grad_(True)
+    rm, rv = rm.clone(), rv.clone()
+    y = torch.relu(torch.nn.functional.batch_norm(xf, rm, rv, g, b, True, momentum, eps))
+    y.backward(gy.float())
+    return y.detach(), rm, rv, xf.grad, g.grad, b.grad
+
+
+# the pyramid's channel counts (3, 16 ... 256) on odd map sizes; 3 x 17 x 19 x 3 elements is not a multiple of 8 (ragged last piece)
+@pytest.mark.parametrize("shape", [(3, 3, 17, 19), (64, 3, 62, 62), (5, 16, 31, 29), (64, 16, 60, 60), (7, 32, 13, 11),
+                                   (4, 64, 27, 27), (2, 128, 9, 9), (64, 256, 3, 3), (1, 48, 5, 7)])
+def test_bnrelu_against_torch(shape):
+    from a3vt_amd import ops
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(sum(shape))
+    B, C, H, W = shape
+    x = (torch.randn(shape, generator=g) * 1.7 + torch.randn(1, C, 1, 1, generator=g)).to(dev).to(torch.bfloat16)
+    x = x.contiguous(memory_format=torch.channels_last)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(dev)
+    beta = (torch.randn(C, generator=g) * 0.3).to(dev)
+    rm0 = (torch.randn(C, generator=g) * 0.1).to(dev)
+    rv0 = (torch.rand(C, generator=g) + 0.5).to(dev)
+    gy = torch.randn(shape, generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    eps, momentum = 1e-5, 0.1
+    y_ref, rm_ref, rv_ref, gx_ref, gg_ref, gb_ref = _reference(x, gamma, beta, rm0, rv0, eps, momentum, gy)
+
+    outs = []
+    for _ in range(2):   # twice: the second call finds the arrival counter as the first left it, and must repeat bit for bit
+        xx = x.clone().requires_grad_(True)
+        gm, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        rm, rv, nb = rm0.clone(), rv0.clone(), torch.tensor(5, dtype=torch.int64, device=dev)
+        y = ops.BNReLUFn.apply(xx, gm, bt, rm, rv, nb, eps, momentum)
+        y.backward(gy)
+        outs.append((y.detach(), rm, rv, nb, xx.grad, gm.grad, bt.grad))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    y, rm, rv, nb, gx, gg, gb = outs[0]
+    assert y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last) and gx.dtype == torch.bfloat16
+    assert int(nb) == 6
+    # forward: the fp32 value rounded to bf16 (one rounding: 2^-8 relative), a different but equivalent fp32 expression inside
+    err = (y.float() - y_ref).abs()
+    assert bool((err <= y_ref.abs() * 2.0 ** -7 + 2e-5).all()), float(err.max())
+    torch.testing.assert_close(rm, rm_ref, rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(rv, rv_ref, rtol=2e-5, atol=2e-6)
+    # backward: fp32 sums in another order; ReLU arguments within rounding of zero may take the other branch
+    rel = lambda a, b: float((a.float() - b).norm() / b.norm().clamp_min(1e-20))  # noqa: E731
+    assert rel(gg, gg_ref) < 2e-3 and rel(gb, gb_ref) < 2e-3, (rel(gg, gg_ref), rel(gb, gb_ref))
+    assert rel(gx, gx_ref) < 6e-3, rel(gx, gx_ref)
+
+
+def test_bnrelu_propagates_nan_and_checks_arguments():
+    from a3vt_amd import ops
+    dev = torch.device("cuda", 0)
+    x = torch.randn(4, 16, 6, 6, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x[1, 3, 2, 2] = float("nan")
+    one, zero = torch.ones(16, device=dev), torch.zeros(16, device=dev)
+    y = ops.BNReLUFn.apply(x, one, zero, zero.clone(), one.clone(), None, 1e-5, 0.1)
+    assert bool(torch.isnan(y[:, 3]).all()) and bool(torch.isfinite(y[:, 2]).all())   # the channel's statistics are NaN
+    with pytest.raises(RuntimeError):
+        ops.BNReLUFn.apply(x.float(), one, zero, None, None, None, 1e-5, 0.1)          # fp32 maps stay on torch's kernels
+    with pytest.raises(RuntimeError):
+        ops.BNReLUFn.apply(x, one, zero, zero.clone(), None, None, 1e-5, 0.1)           # running_mean without running_var
+
+
+def test_image_encoder_fused_matches_miopen_branch():
+    """The bf16 channels-last image pyramid with the fused operator against the same pyramid on MIOpen's BatchNorm + torch's
+    ReLU, both measured against the fp32 pyramid: the two bf16 pipelines differ from each other by what each differs from fp32
+    (bf16 activations through 13 normalised layers); running statistics and counters alike."""
+    from types import SimpleNamespace
+    from a3vt_amd.pterotactyl.reconstruction.vision import model
+    dev = torch.device("cuda", 0)
+    mk = lambda **kw: SimpleNamespace(CNN_ker_size=5, num_CNN_blocks=6, layers_per_block=3, gemm_precision="bf16s", **kw)  # noqa: E731
+    torch.manual_seed(3)
+    enc_a = model.Image_Encoder(mk()).to(dev).train()
+    enc_b = model.Image_Encoder(mk()).to(dev).train()
+    enc_f = model.Image_Encoder(mk(cnn_precision="fp32")).to(dev).train()
+    enc_b.load_state_dict(enc_a.state_dict())
+    enc_f.load_state_dict(enc_a.state_dict())
+    img = torch.rand(6, 3, 256, 256, device=dev)
+
+    def run(enc, fused):
+        model.Image_Encoder.fused_bn_relu = fused
+        try:
+            maps = enc(img)
+            loss = sum((m.float() * m.float()).mean() for m in maps)
+            loss.backward()
+        finally:
+            model.Image_Encoder.fused_bn_relu = True
+        return [m.detach().float() for m in maps]
+
+    ma, mb, mf = run(enc_a, True), run(enc_b, False), run(enc_f, False)
+    rel = lambda u, v: float((u - v).norm() / v.norm().clamp_min(1e-20))  # noqa: E731
+    ea, eb = [rel(a, f) for a, f in zip(ma, mf)], [rel(b, f) for b, f in zip(mb, mf)]
+    print(f"[image pyramid, bf16 vs fp32 maps] fused {ea}  MIOpen BatchNorm + ReLU {eb}")
+    for x, y in zip(ea, eb):
+        assert x < 1.5 * y + 5e-3 and x < 0.1, (ea, eb)
+    sa, sb = enc_a.state_dict(), enc_b.state_dict()
+    for k in sa:
+        if "running" in k:
+            torch.testing.assert_close(sa[k], sb[k], rtol=5e-2, atol=5e-3)
+        if "num_batches" in k:   # (the pyramid stops at its 14th layer on a 256-pixel image: the layers behind it stay at 0)
+            assert int(sa[k]) == int(sb[k]) == (1 if int(k.split(".")[1]) < 14 else 0), k
+    ga, gb = [], []
+    for (n, pa), (_, pb), (_, pf) in zip(enc_a.named_parameters(), enc_b.named_parameters(), enc_f.named_parameters()):
+        if int(n.split(".")[1]) >= 14:
+            assert pa.grad is None and pb.grad is None
+            continue
+        assert pa.grad is not None and pb.grad is not None and pf.grad is not None, n
+        ga.append(rel(pa.grad, pf.grad))
+        gb.append(rel(pb.grad, pf.grad))
+    print(f"[image pyramid, bf16 vs fp32 parameter gradients] worst fused {max(ga):.3f}  MIOpen {max(gb):.3f}; median {sorted(ga)[len(ga) // 2]:.3f} / {sorted(gb)[len(gb) // 2]:.3f}")
+    assert max(ga) < 1.5 * max(gb) + 0.02, (max(ga), max(gb))
+
+
+def test_batched_weight_cast_matches_torch_copies():
+    """a3vt_cast_weights_bf16 (one launch for all conv weights and biases) against torch's own bf16 channels-last copies."""
+    from a3vt_amd import ops
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(5)
+    shapes = [(3, 3, 5, 5), (16, 3, 5, 5), (32, 16, 5, 5), (7, 5, 3, 2), (256, 128, 5, 5)]
+    ws = [torch.randn(s, generator=g).to(dev) for s in shapes]
+    bs = [torch.randn(s[0], generator=g).to(dev) for s in shapes]
+    ops.invalidate_bf16_copies()
+    ops.prefetch_bf16_copies([(w, True) for w in ws] + [(b, False) for b in bs])
+    for w in ws:
+        c = ops._bf16_copy(w, True)
+        assert c.dtype == torch.bfloat16 and c.is_contiguous(memory_format=torch.channels_last)
+        assert torch.equal(c, w.to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
+    for b in bs:
+        assert torch.equal(ops._bf16_copy(b, False), b.to(torch.bfloat16))
+    # a stale entry (in-place update) is refreshed by the next prefetch, fresh ones are left alone
+    ws[1].mul_(2.0)
+    keep = ops._bf16_copy(ws[0], True)
+    ops.prefetch_bf16_copies([(w, True) for w in ws])
+    assert ops._bf16_copy(ws[0], True) is keep
+    assert torch.equal(ops._bf16_copy(ws[1], True), ws[1].to(torch.bfloat16).contiguous(memory_format=torch.channels_last))

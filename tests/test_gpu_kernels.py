@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 def test_library_loads(cuda):
     from a3vt_amd import lib
-    assert lib.load().a3vt_version() == 160
+    assert lib.load().a3vt_version() == 161
 
 
 @pytest.mark.parametrize("m,k,n", [(128, 16, 16), (1000, 52, 300), (4099, 300, 300), (300, 300, 50), (77, 300, 3),
@@ -600,9 +600,11 @@ def test_posenc_wide_bf16_operand_mode(cuda):
 
 
 def test_image_encoder_bf16_branch_batches_1_to_4(cuda):   # (batches 1, 3 and 4: both sides of the threshold)
-    """the bf16 channels-last image encoder at the batch sizes around the BatchNorm workaround's threshold
-    (``Image_Encoder.bn_nhwc_min_batch``: MIOpen's bf16 NHWC training BatchNorm takes the host down below 4 samples, so those
-    batches use the NCHW kernel).  Every batch size trains, and the maps agree with the fp32 branch to bf16 rounding."""
+    """the bf16 channels-last image encoder at the batch sizes around MIOpen's BatchNorm defect (its bf16 NHWC
+    training BatchNorm takes the host down below 4 samples).  With the library's own BatchNorm + ReLU (round 6, the default)
+    every batch size runs the same kernels and nothing is reported; with ``fused_bn_relu = False`` the small batches take the
+    NCHW kernel (``Image_Encoder.bn_nhwc_min_batch``) and say so once.  Every batch size trains, and the maps agree with the
+    fp32 branch to bf16 rounding."""
     import warnings
     from a3vt_amd.pterotactyl.reconstruction.vision import model
     # (a three-block pyramid: every new convolution shape costs a MIOpen search)
@@ -613,22 +615,27 @@ def test_image_encoder_bf16_branch_batches_1_to_4(cuda):   # (batches 1, 3 and 4
     enc32 = model.Image_Encoder(args32).to(cuda)
     enc32.load_state_dict(enc16.state_dict())
     g = torch.Generator().manual_seed(1)
-    model.Image_Encoder._bn_fallback_reported = False
-    with warnings.catch_warnings(record=True) as w:
-        warnings.simplefilter("always")
-        for B in (1, 3, 4):
-            img = torch.rand(B, 3, 256, 256, generator=g).to(cuda)
-            enc16.train(), enc32.train()
-            maps16 = enc16(img)
-            maps32 = enc32(img)
-            assert len(maps16) == len(maps32)
-            for a, b in zip(maps16, maps32):
-                assert a.shape == b.shape and torch.isfinite(a.float()).all()
-                assert ((a.float() - b).norm() / b.norm()).item() < 0.1, B    # 16 bf16 convolutions + tiny-batch BatchNorm deep
-            sum(m.float().square().mean() for m in maps16).backward()
-            assert all(torch.isfinite(p.grad).all() for p in enc16.parameters() if p.grad is not None)
-            enc16.zero_grad()
-    assert sum("bn_nhwc_min_batch" in str(x.message) for x in w) == 1      # reported once
+    for fused, reports in ((True, 0), (False, 1)):
+        model.Image_Encoder._bn_fallback_reported = False
+        model.Image_Encoder.fused_bn_relu = fused
+        try:
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                for B in (1, 3, 4):
+                    img = torch.rand(B, 3, 256, 256, generator=g).to(cuda)
+                    enc16.train(), enc32.train()
+                    maps16 = enc16(img)
+                    maps32 = enc32(img)
+                    assert len(maps16) == len(maps32)
+                    for a, b in zip(maps16, maps32):
+                        assert a.shape == b.shape and torch.isfinite(a.float()).all()
+                        assert ((a.float() - b).norm() / b.norm()).item() < 0.1, (fused, B)   # 16 bf16 convolutions + tiny-batch BatchNorm deep
+                    sum(m.float().square().mean() for m in maps16).backward()
+                    assert all(torch.isfinite(p.grad).all() for p in enc16.parameters() if p.grad is not None)
+                    enc16.zero_grad()
+        finally:
+            model.Image_Encoder.fused_bn_relu = True
+        assert sum("bn_nhwc_min_batch" in str(x.message) for x in w) == reports, fused      # reported once, by the MIOpen branch only
 
 
 def test_bf16_weight_copies_follow_the_fused_optimizer(cuda):

@@ -34,7 +34,7 @@ python tools/touch_bench.py --precision fp32x3 2>/dev/null | tail -1 >> $O/${R}_
 python -m pytest tests/test_gpu_fullsize.py -q -s -k benchmark_configuration 2>&1 | grep "^\[configs\|passed\|failed" > $O/${R}_mode_error_table.txt; cat $O/${R}_mode_error_table.txt
 python -m pytest tests/test_gpu_fp32x3.py -q -s -k vs_fp64 2>&1 | grep "^\[\|passed\|failed" >> $O/${R}_mode_error_table.txt
 # configs[3]: the first steps run MIOpen's find mode, so the table is cut from the kernel TRACE after 5 steps (tools/trace_steady.py)
-(cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/c3 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/c3 -- python $GRAFT_REPO_ROOT/tools/named_configs.py --only 3 --steps 10 > /tmp/c3.log 2>&1; python $GRAFT_REPO_ROOT/tools/trace_steady.py $(find /tmp/c3 -name '*kernel_trace.csv' | head -1) --skip 5 --top 60 > $O/${R}_config3_bf16s_steady_kernels.txt; head -8 $O/${R}_config3_bf16s_steady_kernels.txt)
+(cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/c3 && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/c3 -- python $GRAFT_REPO_ROOT/tools/named_configs.py --only 3 --steps 10 > /tmp/c3.log 2>&1; python $GRAFT_REPO_ROOT/tools/trace_steady.py $(find /tmp/c3 -name "*kernel_trace.csv" | head -1) --marker chamfer_bwd --skip 5 --top 70 > $O/${R}_config3_bf16s_steady_kernels.txt; head -8 $O/${R}_config3_bf16s_steady_kernels.txt)
 # the exact search: both geometries ("bench" = the untrained network's concentric sphere / ellipsoids), counters, per-wave timeline
 (python tools/chamfer_bench.py --geometry bench; python tools/chamfer_bench.py) > $O/${R}_chamfer_search.txt 2>/dev/null; cat $O/${R}_chamfer_search.txt
 [ -f gpurun_variants/liba3vt_NN_STATS.so ] && (A3VT_LIB=gpurun_variants/liba3vt_NN_STATS.so python tools/nn_stats.py --geometry bench; A3VT_LIB=gpurun_variants/liba3vt_NN_STATS.so python tools/nn_stats.py; A3VT_LIB=gpurun_variants/liba3vt_NN_STATS.so python tools/nn_stats_config.py --which 3 --batch 16 | tail -1; A3VT_LIB=gpurun_variants/liba3vt_NN_STATS.so python tools/nn_stats_config.py --which 4 | tail -1) > $O/${R}_nn_pruning_stats.txt 2>/dev/null
