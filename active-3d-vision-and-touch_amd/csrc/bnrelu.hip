@@ -287,7 +287,8 @@ struct BnBwd {
   const float *save;   // [4][c] of the forward
   float *dgamma, *dbeta;
   float *coef;         // [2][c]: dx = scale * g + a * x + b
-  float *partial;      // [wgs][2][c]
+  float *partial;      // [wgs][2][c]; the dx launch reuses it for its column sums ([wgs][c])
+  float *dx_colsum;    // optional [c]: sum over the rows of dx AS STORED (bf16) = the bias gradient of the convolution in front
 };
 
 // d beta = sum g, d gamma = sum g * xhat with g = dy where the forward's output was positive
@@ -364,7 +365,11 @@ __global__ __launch_bounds__(kBnThreads) void bnrelu_bwd_final_kernel(BnBwd p, i
   }
 }
 
+// dx = scale * g + a * x + b.  COLSUM: also the per-channel sums of the bf16 values written — the producer of x is a Conv2d,
+// and its bias gradient is exactly this sum (bias_grad.hip would read dx again for it: 22 us + a reduce launch per layer).
+template <bool COLSUM>
 __global__ __launch_bounds__(kBnThreads) void bnrelu_bwd_dx_kernel(BnBwd p) {
+  __shared__ float part[COLSUM ? kBnThreads * 9 : 1];
   const long long stride = (long long)gridDim.x * kBnThreads;
   const long long n_piece = (p.n_elem + 7) / 8;
   long long q = (long long)blockIdx.x * kBnThreads + threadIdx.x;
@@ -380,6 +385,9 @@ __global__ __launch_bounds__(kBnThreads) void bnrelu_bwd_dx_kernel(BnBwd p) {
       ch = ch + 1 == p.c ? 0 : ch + 1;
     }
   }
+  float acc[1][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[0][j] = 0.f;
   for (; q < n_piece; q += 4 * stride) {
     float v[4][8], g[4][8];
 #pragma unroll
@@ -395,6 +403,43 @@ __global__ __launch_bounds__(kBnThreads) void bnrelu_bwd_dx_kernel(BnBwd p) {
         v[u][j] = fmaf(sc[j], gg, fmaf(ca[j], v[u][j], cb[j]));
       }
       bn_store(p.dx, q + u * stride, p.n_elem, v[u]);
+      if (COLSUM) {
+        const long long e0 = (q + u * stride) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (e0 + j < p.n_elem) acc[0][j] += bn_lo(bn_pack(v[u][j], 0.f));   // the value as stored
+      }
+    }
+  }
+  if (COLSUM) bn_fold<1>(part, acc, p.c, p.partial);
+}
+
+// one workgroup: out[ch] = sum over the nwg partial rows ([nwg][c]) in float64, fixed order
+__global__ __launch_bounds__(kBnThreads) void bnrelu_colsum_final_kernel(const float *partial, int nwg, int c, float *out) {
+  __shared__ double red[kBnThreads];
+  const int t = threadIdx.x;
+  for (int c0 = 0; c0 < c; c0 += kBnThreads) {
+    const int cw = c - c0 < kBnThreads ? c - c0 : kBnThreads;
+    const int nsub = kBnThreads / cw;
+    const int ch = t % cw, sub = t / cw;
+    double s = 0.0;
+    if (sub < nsub) {
+      int g = sub;
+      for (; g + 7 * nsub < nwg; g += 8 * nsub) {
+        float a[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = __builtin_nontemporal_load(partial + (size_t)(g + k * nsub) * c + c0 + ch);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += (double)a[k];
+      }
+      for (; g < nwg; g += nsub) s += (double)partial[(size_t)g * c + c0 + ch];
+    }
+    __syncthreads();
+    red[t] = s;
+    __syncthreads();
+    if (sub == 0) {
+      for (int k = 1; k < nsub; ++k) s += red[k * cw + ch];
+      out[c0 + ch] = (float)s;
     }
   }
 }
@@ -471,7 +516,7 @@ int launch_bnrelu_fwd(const void *x, long long rows, int c, const float *gamma, 
 }
 
 int launch_bnrelu_bwd(const void *dy, const void *x, long long rows, int c, const float *save, void *dx, float *dgamma,
-                      float *dbeta, void *scratch, hipStream_t s) {
+                      float *dbeta, float *dx_colsum, void *scratch, hipStream_t s) {
   BnBwd p;
   p.dy = static_cast<const uint16_t *>(dy);
   p.x = static_cast<const uint16_t *>(x);
@@ -482,6 +527,7 @@ int launch_bnrelu_bwd(const void *dy, const void *x, long long rows, int c, cons
   p.save = save;
   p.dgamma = dgamma;
   p.dbeta = dbeta;
+  p.dx_colsum = dx_colsum;
   p.coef = reinterpret_cast<float *>(static_cast<char *>(scratch) + 64);
   p.partial = p.coef + 2 * c;
   const int g1 = bnrelu_reduce_wgs(p.n_elem, c), g2 = bnrelu_wgs(p.n_elem, c, 4, kBnMaxWgs);
@@ -490,7 +536,17 @@ int launch_bnrelu_bwd(const void *dy, const void *x, long long rows, int c, cons
   A3VT_CHECK_LAUNCH();
   A3VT_LAUNCH(bnrelu_bwd_final_kernel, dim3(1), dim3(kBnThreads), 0, s, p, g1);
   A3VT_CHECK_LAUNCH();
-  A3VT_LAUNCH(bnrelu_bwd_dx_kernel, dim3(g2), dim3(kBnThreads), 0, s, p);
+  if (dx_colsum == nullptr) {
+    A3VT_LAUNCH(bnrelu_bwd_dx_kernel<false>, dim3(g2), dim3(kBnThreads), 0, s, p);
+    A3VT_CHECK_LAUNCH();
+    return 0;
+  }
+  // (fewer, longer workgroups where the channel count is large: the one-workgroup sum behind adds a row per workgroup)
+  const int g3 = bnrelu_wgs(p.n_elem, c, 4, 16384 / c < 16 ? 16 : 16384 / c);
+  A3VT_CHECK_ARG(g3 > 0);
+  A3VT_LAUNCH(bnrelu_bwd_dx_kernel<true>, dim3(g3), dim3(kBnThreads), 0, s, p);
+  A3VT_CHECK_LAUNCH();
+  A3VT_LAUNCH(bnrelu_colsum_final_kernel, dim3(1), dim3(kBnThreads), 0, s, (const float *)p.partial, g3, c, dx_colsum);
   A3VT_CHECK_LAUNCH();
   return 0;
 }

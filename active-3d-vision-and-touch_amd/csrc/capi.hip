@@ -1513,14 +1513,14 @@ int a3vt_bnrelu_fwd(const void *x, long long rows, int channels, const float *ga
 }
 
 int a3vt_bnrelu_bwd(const void *dy, const void *x, long long rows, int channels, const float *save, void *dx, float *dgamma,
-                    float *dbeta, void *scratch, size_t scratch_bytes, void *stream) {
+                    float *dbeta, float *dx_colsum, void *scratch, size_t scratch_bytes, void *stream) {
   A3VT_CHECK_ARG(dy && x && save && dx && dgamma && dbeta && scratch);
   A3VT_CHECK_ARG(rows >= 2 && channels > 0 && rows <= (1ll << 40) / channels);
   A3VT_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) |
                    reinterpret_cast<uintptr_t>(scratch)) & 15) == 0);
   A3VT_CHECK_ARG(bnrelu_wgs(rows * channels, channels, 4, 1024) > 0 && scratch_bytes >= bnrelu_scratch_bytes(channels));
   ProfScope psc(PROF_ENC, static_cast<hipStream_t>(stream));
-  return launch_bnrelu_bwd(dy, x, rows, channels, save, dx, dgamma, dbeta, scratch, static_cast<hipStream_t>(stream));
+  return launch_bnrelu_bwd(dy, x, rows, channels, save, dx, dgamma, dbeta, dx_colsum, scratch, static_cast<hipStream_t>(stream));
 }
 
 int a3vt_cast_weights_bf16(int n, const float *const *src, void *const *dst, const long long *outer, const int *inner,

@@ -313,7 +313,7 @@ int launch_bnrelu_fwd(const void *x, long long rows, int c, const float *gamma, 
                       float *running_mean, float *running_var, long long *num_batches, void *y, float *save, void *scratch,
                       hipStream_t s);
 int launch_bnrelu_bwd(const void *dy, const void *x, long long rows, int c, const float *save, void *dx, float *dgamma,
-                      float *dbeta, void *scratch, hipStream_t s);
+                      float *dbeta, float *dx_colsum, void *scratch, hipStream_t s);
 
 // bnrelu.hip: up to kCastBatchMax fp32 tensors [outer][inner][hw] -> bf16 [outer][hw][inner] in one launch
 constexpr int kCastBatchMax = 96;

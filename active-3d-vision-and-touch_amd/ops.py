@@ -555,7 +555,12 @@ class ConvNHWCFn(torch.autograd.Function):
         gy = gy.contiguous(memory_format=torch.channels_last)
         gx, gw, _ = torch.ops.aten.convolution_backward(gy, xb, wb, None, stride, padding, [1, 1], False, [0, 0], 1,
                                                         [ctx.needs_input_grad[0], True, False])
-        gb = bias_grad_nhwc(gy)
+        cs = getattr(gy, "_a3vt_colsum", None)
+        if cs is not None and cs[1] == gy._version and cs[2] == gy.data_ptr() and cs[0].numel() == gy.shape[1]:
+            gb = cs[0]            # formed by BNReLUFn.backward while it wrote gy
+            STATS["bias_grad_from_bnrelu"] = STATS.get("bias_grad_from_bnrelu", 0) + 1
+        else:
+            gb = bias_grad_nhwc(gy)
         return (gx.to(xdt) if gx is not None else None), gw.to(wdt, memory_format=torch.contiguous_format), gb.to(bdt), None, None
 
 
@@ -607,9 +612,13 @@ class BNReLUFn(torch.autograd.Function):
         gx = torch.empty_like(x, memory_format=torch.channels_last)
         dg = torch.empty(C, dtype=torch.float32, device=x.device)
         db = torch.empty(C, dtype=torch.float32, device=x.device)
+        colsum = torch.empty(C, dtype=torch.float32, device=x.device)
         scratch = _bnrelu_scratch(x.device)
         _lib.check(L.a3vt_bnrelu_bwd(_lib.ptr(gy), _lib.ptr(x), B * H * W, C, _lib.ptr(save), _lib.ptr(gx), _lib.ptr(dg),
-                                     _lib.ptr(db), _lib.ptr(scratch), scratch.numel(), _stream()), "bnrelu_bwd")
+                                     _lib.ptr(db), _lib.ptr(colsum), _lib.ptr(scratch), scratch.numel(), _stream()), "bnrelu_bwd")
+        # x is a Conv2d output in the pyramid: that layer's bias gradient is the column sum of gx, which the dx launch formed
+        # on its way (ConvNHWCFn.backward picks it up if THIS tensor, unmodified, arrives as its output gradient)
+        gx._a3vt_colsum = (colsum, gx._version, gx.data_ptr())
         return gx, dg, db, None, None, None, None, None
 
 

@@ -277,14 +277,16 @@ int a3vt_bias_grad_nhwc(const void *grad, int bf16, long long rows, int channels
  *   does (pass NULL to skip either).  x, y, dy, dx: [rows = N*H*W][channels] bf16, 16-byte aligned; gamma, beta, dgamma,
  *   dbeta: fp32 [channels]; save: fp32 [4][channels] written by the forward (mean, 1/std, scale, shift), read by the backward.
  * Backward: dgamma = sum g * xhat, dbeta = sum g, dx = scale * (g - dbeta / rows - xhat * dgamma / rows), g = dy where y > 0
- * (the mask is recomputed from x with the forward's own coefficients).  Fixed summation order, float64 final sums: repeatable
+ * (the mask is recomputed from x with the forward's own coefficients).  dx_colsum (optional, fp32 [channels]): the column sums
+ * of dx as stored in bf16 — when x is the output of a Conv2d this is that layer's bias gradient, which a3vt_bias_grad_nhwc would
+ * otherwise compute by reading dx again.  Fixed summation order, float64 final sums: repeatable
  * bit for bit.  rows >= 2.  scratch: a3vt_bnrelu_scratch_bytes(channels) bytes; one buffer may serve every layer of a stream. */
 size_t a3vt_bnrelu_scratch_bytes(int channels);
 int a3vt_bnrelu_fwd(const void *x, long long rows, int channels, const float *gamma, const float *beta, float eps,
                     float momentum, float *running_mean, float *running_var, long long *num_batches_tracked, void *y,
                     float *save, void *scratch, size_t scratch_bytes, void *stream);
 int a3vt_bnrelu_bwd(const void *dy, const void *x, long long rows, int channels, const float *save, void *dx, float *dgamma,
-                    float *dbeta, void *scratch, size_t scratch_bytes, void *stream);
+                    float *dbeta, float *dx_colsum, void *scratch, size_t scratch_bytes, void *stream);
 
 /* bf16 copies of the pyramid's fp32 convolution weights and biases (the nn.Conv2d parameters of model.py:15-47) for MIOpen's
  * NHWC bf16 kernels, all in one launch per optimizer step instead of two or three per tensor: tensor k is

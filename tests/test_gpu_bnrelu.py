@@ -99,7 +99,13 @@ def test_image_encoder_fused_matches_miopen_branch():
             model.Image_Encoder.fused_bn_relu = True
         return [m.detach().float() for m in maps]
 
-    ma, mb, mf = run(enc_a, True), run(enc_b, False), run(enc_f, False)
+    from a3vt_amd import ops
+    ops.STATS["bias_grad_from_bnrelu"] = 0
+    ma = run(enc_a, True)
+    # 13 convolutions feed a BatchNorm; the outputs of layers 9 and 12 are also pooled (their gradient is a sum of two): 11 of the
+    # 13 bias gradients come out of the BatchNorm backward's dx launch, the others (and the last layer's) from bias_grad_nhwc
+    assert ops.STATS["bias_grad_from_bnrelu"] == 11, ops.STATS
+    mb, mf = run(enc_b, False), run(enc_f, False)
     rel = lambda u, v: float((u - v).norm() / v.norm().clamp_min(1e-20))  # noqa: E731
     ea, eb = [rel(a, f) for a, f in zip(ma, mf)], [rel(b, f) for b, f in zip(mb, mf)]
     print(f"[image pyramid, bf16 vs fp32 maps] fused {ea}  MIOpen BatchNorm + ReLU {eb}")
@@ -145,3 +151,28 @@ def test_batched_weight_cast_matches_torch_copies():
     ops.prefetch_bf16_copies([(w, True) for w in ws])
     assert ops._bf16_copy(ws[0], True) is keep
     assert torch.equal(ops._bf16_copy(ws[1], True), ws[1].to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
+
+
+def test_conv_bias_gradient_from_the_batchnorm_backward():
+    """Conv2d -> BatchNorm2d -> ReLU: the convolution's bias gradient is the column sum of the BatchNorm's input gradient, which
+    a3vt_bnrelu_bwd forms while writing it; against bias_grad_nhwc reading the same bf16 tensor again."""
+    from a3vt_amd import ops
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(11)
+    for cin, cout, hw, B in ((3, 16, 40, 5), (16, 32, 21, 8), (3, 3, 33, 3)):
+        x = torch.randn(B, cin, hw, hw, device=dev)
+        w = (torch.randn(cout, cin, 5, 5, device=dev) * 0.1).requires_grad_(True)
+        b = (torch.randn(cout, device=dev) * 0.1).requires_grad_(True)
+        gamma, beta = (torch.rand(cout, device=dev) + 0.5).requires_grad_(True), torch.zeros(cout, device=dev, requires_grad=True)
+        grads = []
+        for fast in (True, False):
+            ops.STATS["bias_grad_from_bnrelu"] = 0
+            w.grad = b.grad = None
+            h = ops.ConvNHWCFn.apply(x, w, b, [1, 1], [1, 1])
+            h2 = h if fast else h * 1.0          # (a second consumer-side node: the gradient that reaches the convolution is a new tensor)
+            y = ops.BNReLUFn.apply(h2, gamma, beta, None, None, None, 1e-5, 0.1)
+            (y.float() * torch.linspace(-1, 1, y.numel(), device=dev).reshape(y.shape)).sum().backward()
+            assert ops.STATS["bias_grad_from_bnrelu"] == (1 if fast else 0)
+            grads.append((b.grad.clone(), w.grad.clone()))
+        torch.testing.assert_close(grads[0][0], grads[1][0], rtol=1e-3, atol=5e-3)
+        torch.testing.assert_close(grads[0][1], grads[1][1], rtol=2e-2, atol=2e-2)   # (MIOpen's weight gradient: fp32 atomics, bf16 result)
