@@ -252,6 +252,61 @@ def g13():
     save("g13_touch_b8.npz", **arrs)
 
 
+def g14():
+    """The IMAGE model at full depth on the configs[3] topology (use_img + use_touch: atlas + 4 touch charts, N = 1924; default
+    CNN: k = 5, 6 blocks x 3 layers -> 448-wide vertex features; GCN 20 x 300) at B = 8 = 15 392 rows, training mode (batch
+    statistics in the 2 x 13 BatchNorm layers): enough rows for the stacks to run on hybrid rows with the P + bipartite split,
+    the 448-wide feature encoder and the timed product kernels.  Weights are NOT stored (47 M): tests re-derive them from
+    torch.manual_seed(0) with the product's constructor and check the SHA-256; the image is regenerated from its seed."""
+    a = args_of(use_img=True, use_touch=True, finger=False, num_grasps=1, CNN_ker_size=5, num_CNN_blocks=6, layers_per_block=3)
+    torch.manual_seed(0)
+    info, verts = ref.utils.load_mesh_vision(a, OBJ)
+    net = ref.model.Deformation(info, verts, a)
+    sha = state_checksum(net.state_dict())       # (before the training forward moves the running statistics)
+    net.train()
+    B, P, Q = 8, 800, 1200
+    g = torch.Generator().manual_seed(14)
+    img = torch.rand(B, 3, 256, 256, generator=g)
+    tc = touch_batch(B, a, 14)
+    batch = {"img": img, "touch_charts": tc}
+    charts = ref.model.prepare_mesh(batch, verts, a)
+    amp = torch.linspace(0.004, 0.02, B).view(B, 1, 1)
+    charts["vision_charts"] = charts["vision_charts"] + amp * torch.randn(B, verts.shape[0], 3, generator=g)
+    verts_in = charts["vision_charts"].clone()
+    out, mask = net(img, charts)
+    d = torch.randn(B, Q, 3, generator=g)
+    gt = d / d.norm(dim=-1, keepdim=True) * (0.05 + 0.11 * torch.rand(B, 1, 3, generator=g))
+    samples = injected(B, info["faces"].shape[0], P, 114)
+    cd = ref_chamfer_injected(out, info["faces"], gt, samples)
+    loss = 9000.0 * cd.mean()
+    loss.backward()
+    arrs = {"verts_in": verts_in.numpy(), "touch_charts": tc.numpy(), "img_seed": np.int64(14), "verts_out": out.detach().numpy(),
+            "mask": mask.numpy().astype(np.int8), "cd": cd.detach().numpy(), "loss": np.float32(loss.item()), "gt": gt.numpy(),
+            "face_idx": torch.stack([s_[0] for s_ in samples]).numpy().astype(np.int16),
+            "u": torch.stack([s_[1] for s_ in samples]).numpy(), "v": torch.stack([s_[2] for s_ in samples]).numpy(),
+            "weight_sha256": sha, "pytorch3d_restated": np.bool_(True)}
+    names, norms = [], []
+    for k, p in net.named_parameters():
+        names.append(k)
+        norms.append(0.0 if p.grad is None else float(p.grad.double().norm()))
+    arrs["grad_names"] = np.array(names)
+    arrs["grad_norms"] = np.array(norms, dtype=np.float64)
+    sd = dict(net.named_parameters())
+    for k in ("mesh_deform_1.layers.10.bias", "mesh_deform_2.layers.7.bias", "mesh_deform_2.layers.19.weight",
+              "mesh_deform_1.layers.19.bias", "positional_encoder.model.0.weight", "mask_encoder.model.0.weight",
+              "img_encoder_global.layers.0.0.weight", "img_encoder_local.layers.9.2.bias", "img_encoder_local.layers.4.0.weight"):
+        arrs["g:" + k] = sd[k].grad.numpy()
+    arrs["g:mesh_deform_1.layers.0.weight[::9,::7]"] = sd["mesh_deform_1.layers.0.weight"].grad.numpy()[0, ::9, ::7]
+    arrs["g:mesh_deform_2.layers.9.weight[::7,::5]"] = sd["mesh_deform_2.layers.9.weight"].grad.numpy()[0, ::7, ::5]
+    arrs["g:img_encoder_global.layers.7.2.weight[::3,::5]"] = sd["img_encoder_global.layers.7.2.weight"].grad.numpy()[::3, ::5]
+    # running statistics after the one training forward (momentum 0.1): the BatchNorm side effect callers checkpoint
+    st = net.state_dict()
+    for k in ("img_encoder_global.layers.1.0.running_mean", "img_encoder_global.layers.1.0.running_var",
+              "img_encoder_local.layers.10.0.running_mean", "img_encoder_local.layers.10.0.running_var"):
+        arrs["s:" + k] = st[k].numpy()
+    save("g14_image_touch_b8.npz", **arrs)
+
+
 def g5():
     a = args_of(use_touch=True, num_grasps=1)
     info, verts = ref.utils.load_mesh_vision(a, OBJ)
@@ -560,6 +615,6 @@ def g11():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
     for w in which:
         globals()[w]()

@@ -156,6 +156,109 @@ def test_g13_touch_b8_reaches_the_split_kernels(cuda, mode):
     print(f"[g13 {mode}] worst gradient-norm error {worst:.2e}")
 
 
+def test_g14_image_touch_b8_reaches_the_timed_kernels(cuda):
+    """Round 6 (verdict r05 missing #3, image half): REFERENCE outputs of the IMAGE model at full depth — use_img + use_touch on
+    the configs[3] topology (atlas + 4 touch charts, N = 1924; default CNN -> 448-wide vertex features; GCN 20 x 300) at
+    B = 8 = 15 392 rows, training mode.  The launch counters assert that the stacks ran on hybrid rows through the P + bipartite
+    split and the round-6 product kernels.  Positions and Chamfer distances 1e-4 (north_star), gradient norms 3e-3 (MIOpen's
+    convolution algorithms move a few ReLU decisions of the 2 x 14-layer encoders: as g8), the gradients the fixture keeps."""
+    from a3vt_amd import ops
+    from test_oracle_golden import _g14_setup
+    model, utils = _facade()
+    z, args, net_cpu, img, v, f = _g14_setup()
+    info, verts = utils.load_mesh_vision(args, "vision_charts")
+    assert info["csr"].split is not None and info["csr"].n == 1924
+    net = model.Deformation(info, verts, args).to(cuda)
+    net.load_state_dict(net_cpu.state_dict())
+    net.train()
+    batch = {"img": img, "touch_charts": torch.from_numpy(z["touch_charts"])}
+    charts = model.prepare_mesh(batch, verts, args)
+    charts["vision_charts"] = torch.from_numpy(z["verts_in"]).to(cuda)
+    ops.path_counts(reset=True)
+    out, mask = net(img.to(cuda), charts)
+    assert np.array_equal(mask.cpu().numpy().astype(np.int8), z["mask"])
+    assert rel_err(out, torch.from_numpy(z["verts_out"])) < 1e-4
+    samples = _samples_of(z, cuda)
+    cd = utils.chamfer_distance(out, info["faces"], torch.from_numpy(z["gt"]).to(cuda), num=z["u"].shape[-1], samples=samples)
+    assert rel_err(cd, torch.from_numpy(z["cd"])) < 1e-4
+    loss = 9000.0 * cd.mean()
+    assert abs(loss.item() - float(z["loss"])) < 1e-4 * abs(float(z["loss"]))
+    loss.backward()
+    torch.cuda.synchronize()
+    c = ops.path_counts()
+    print(f"\n[g14] verts rel {rel_err(out, torch.from_numpy(z['verts_out'])):.2e}  cd rel {rel_err(cd, torch.from_numpy(z['cd'])):.2e}  launches {c}")
+    # stage 1 aggregates over the vision-only matrix ('origional'), stages 2 and 3 over the fused one (the split)
+    assert c["stack_split"] == 2 and c["stack_quad"] == 3 and c["stack_rows"] == 0
+    assert c["rowgemm_w"] >= 3 * 18 * 2 and c["dw_w"] >= 3 * 18
+    grads = dict(net.named_parameters())
+    worst = 0.0
+    # (the bias of a convolution that feeds a BatchNorm has a gradient of exactly zero in exact arithmetic — the normalisation
+    # removes any shift — so those 26 tensors hold rounding noise, 1e-5 against 1e+1 for the weights: an absolute floor)
+    floor = 1e-6 * float(z["grad_norms"].max())
+    for k, n in zip(z["grad_names"], z["grad_norms"]):
+        g = grads[str(k)].grad
+        got = 0.0 if g is None else float(g.double().norm())
+        if n > 10 * floor:
+            worst = max(worst, abs(got - n) / n)
+        assert abs(got - n) <= 3e-3 * n + floor, (k, got, n)
+    for key in z.files:
+        if key.startswith("g:"):
+            name = key[2:].split("[")[0]
+            got = grads[name].grad
+            if key.endswith("[::9,::7]"):
+                got = got[0, ::9, ::7]
+            elif key.endswith("[::7,::5]"):
+                got = got[0, ::7, ::5]
+            elif key.endswith("[::3,::5]"):
+                got = got[::3, ::5]
+            assert_grad_close(got, torch.from_numpy(z[key]), key, tol=3e-3, outlier_frac=3e-3, l2_tol=3e-3)
+    st = net.state_dict()
+    for key in z.files:
+        if key.startswith("s:"):
+            torch.testing.assert_close(st[key[2:]].cpu(), torch.from_numpy(z[key]), rtol=1e-4, atol=1e-6)
+    print(f"[g14] worst gradient-norm error {worst:.2e}")
+
+
+def test_g14_bf16_storage_branch_against_the_reference(cuda):
+    """The same fixture through the bf16 configuration BASELINE configs[3] names (``gemm_precision="bf16s"``: bf16 GCN rows, the
+    image pyramid channels-last in bf16 with the library's BatchNorm + ReLU operator, csrc/bnrelu.hip) against the fp32
+    REFERENCE: positions and loss 6e-3 (measured 2.2e-3 / 9e-4) — the error of a reduced-precision mode, stated, not a parity claim — and the launch
+    counters of the bf16 kernels."""
+    from a3vt_amd import ops
+    from test_oracle_golden import _g14_setup
+    model, utils = _facade()
+    z, args, net_cpu, img, v, f = _g14_setup()
+    args.gemm_precision = "bf16s"
+    info, verts = utils.load_mesh_vision(args, "vision_charts")
+    net = model.Deformation(info, verts, args).to(cuda)
+    net.load_state_dict(net_cpu.state_dict())
+    net.train()
+    batch = {"img": img, "touch_charts": torch.from_numpy(z["touch_charts"])}
+    charts = model.prepare_mesh(batch, verts, args)
+    charts["vision_charts"] = torch.from_numpy(z["verts_in"]).to(cuda)
+    ops.path_counts(reset=True)
+    ops.STATS["bias_grad_from_bnrelu"] = 0
+    out, _ = net(img.to(cuda), charts)
+    cd = utils.chamfer_distance(out, info["faces"], torch.from_numpy(z["gt"]).to(cuda), num=z["u"].shape[-1], samples=_samples_of(z, cuda))
+    loss = 9000.0 * cd.mean()
+    loss.backward()
+    torch.cuda.synchronize()
+    c = ops.path_counts()
+    ev, el = rel_err(out, torch.from_numpy(z["verts_out"])), abs(loss.item() - float(z["loss"])) / abs(float(z["loss"]))
+    grads = dict(net.named_parameters())
+    big = [(str(k), n) for k, n in zip(z["grad_names"], z["grad_norms"]) if n > 1e-3 * float(z["grad_norms"].max())]
+    errs = sorted(abs(float(grads[k].grad.double().norm()) - n) / n for k, n in big)
+    print(f"\n[g14 bf16s] verts rel {ev:.2e}  loss rel {el:.2e}  gradient norms: median {errs[len(errs) // 2]:.2e} worst {errs[-1]:.2e}  launches {c}")
+    assert ev < 6e-3 and el < 6e-3, (ev, el)                      # measured 2.2e-3 / 9e-4
+    assert errs[len(errs) // 2] < 1e-2 and errs[-1] < 0.15, (errs[len(errs) // 2], errs[-1])   # measured 2.1e-3 / 3.9e-2
+    assert c["rowgemm16"] >= 3 * 18 * 2 and c["rowgemm_w"] == 0
+    assert ops.STATS["bias_grad_from_bnrelu"] == 22          # 11 of 13 per encoder (see test_gpu_bnrelu.py)
+    st = net.state_dict()
+    for key in z.files:
+        if key.startswith("s:"):
+            torch.testing.assert_close(st[key[2:]].cpu(), torch.from_numpy(z[key]), rtol=3e-2, atol=3e-3)
+
+
 def test_g4_full_size_forward_bf16_mode(cuda):
     """BASELINE configs[3]/[4] operand mode on the full 20 x 300 network vs the fp32 reference's vertex positions:
     SURVEY App. B measured 1.4e-3 for bf16 rounding after every layer; the tolerance for this mode is 5e-3."""

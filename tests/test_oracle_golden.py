@@ -214,6 +214,63 @@ def test_g13_touch_b8_forward_loss_and_gradient_norms():
             assert float((got - ref).norm() / ref.norm()) < 2e-4, key
 
 
+def _g14_setup():
+    """Shared by the CPU and GPU tests of g14: args, weights re-derived from seed 0 (SHA-256 checked), image from its seed."""
+    import hashlib
+    from helpers import make_args
+    from a3vt_amd import mesh as amesh
+    from a3vt_amd.pterotactyl.reconstruction.vision import model
+    z = load("g14_image_touch_b8.npz")
+    args = make_args(use_img=True, use_touch=True, num_grasps=1, finger=False, CNN_ker_size=5, num_CNN_blocks=6, layers_per_block=3)
+    v, f = amesh.load_asset("vision_charts")
+    torch.manual_seed(0)
+    net = model.Deformation({}, torch.from_numpy(v), args)      # same RNG call order as the reference constructor
+    sd = net.state_dict()
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode())
+        h.update(sd[k].detach().cpu().numpy().tobytes())
+    assert np.array_equal(np.frombuffer(h.digest(), dtype=np.uint8), z["weight_sha256"]), "init differs from the reference"
+    g = torch.Generator().manual_seed(int(z["img_seed"]))
+    img = torch.rand(z["verts_in"].shape[0], 3, 256, 256, generator=g)
+    return z, args, net, img, v, f
+
+
+def test_g14_image_touch_b8_forward_loss_and_gradient_norms():
+    """The image model at full depth (round 6): the reference with use_img + use_touch on the configs[3] topology (N = 1924)
+    at B = 8, training mode; the oracle reproduces positions, mask, Chamfer distances, every gradient norm and the running
+    statistics the forward leaves behind."""
+    from a3vt_amd import mesh as amesh
+    z, args, net, img, v, f = _g14_setup()
+    sv, sf = amesh.load_asset("touch_chart")
+    info = omesh.adj_init(v, f, True, 1, False, sv, sf)
+    adj = {"origional": torch.from_numpy(info["origional"]), "adj": torch.from_numpy(info["adj"])}
+    faces = torch.from_numpy(info["faces"])
+    B = z["verts_in"].shape[0]
+    ch = og.prepare_mesh(torch.from_numpy(z["touch_charts"]), torch.from_numpy(v), B, True)
+    ch["vision_charts"] = torch.from_numpy(z["verts_in"])
+    st = {k: t.clone() for k, t in net.state_dict().items()}
+    for k in st:
+        if st[k].is_floating_point():
+            st[k].requires_grad_(not k.endswith(("running_mean", "running_var")))
+    out, mask = og.deformation_forward_img(st, adj, ch, img, True, 20, 0.33, training=True)
+    assert np.array_equal(mask.numpy().astype(np.int8), z["mask"])
+    np.testing.assert_allclose(out.detach().numpy(), z["verts_out"], rtol=0, atol=1e-5)   # conv algorithms differ per CPU
+    samples = [(torch.from_numpy(z["face_idx"][r].astype(np.int64)), torch.from_numpy(z["u"][r]), torch.from_numpy(z["v"][r]))
+               for r in range(3)]
+    cd = och.chamfer_distance(out, faces, torch.from_numpy(z["gt"]), num=z["u"].shape[-1], samples=samples)
+    np.testing.assert_allclose(cd.detach().numpy(), z["cd"], rtol=2e-5)
+    (9000.0 * cd.mean()).backward()
+    for k, n in zip(z["grad_names"], z["grad_norms"]):
+        g = st[str(k)].grad
+        got = 0.0 if g is None else float(g.double().norm())
+        assert abs(got - n) <= 2e-3 * max(n, 1e-9), (k, got, n)
+    from helpers import assert_grad_close
+    for key in z.files:
+        if key.startswith("g:") and "[" not in key:
+            assert_grad_close(st[key[2:]].grad, torch.from_numpy(z[key]), key)
+
+
 @pytest.mark.parametrize("stages", [3, 1])
 def test_g7_train_step(stages):
     """BASELINE.json configs[0]: bs=2, 10k Chamfer points, reference trainer arithmetic (loss_coeff*mean, Adam 3e-4)."""
