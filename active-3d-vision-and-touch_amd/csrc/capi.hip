@@ -226,6 +226,7 @@ struct Stack16Layout {
   size_t z3;              // [2][M][4] fp32
   size_t ping[2];         // [M][ldh] bf16 each
   size_t dw_slab, db_slab, thin_dw_slab, thin_db_slab, heavy, total;
+  size_t tplan;           // the tiled aggregation's plan (csr16t_plan_ints)
   int ld0, ldh, cpad;
 };
 
@@ -255,6 +256,7 @@ static Stack16Layout stack16_layout(int batch, int n_vert, int in_features, int 
   L.ping[0] = take16(m * L.ldh);
   L.ping[1] = take16(m * L.ldh);
   L.heavy = take(csr_heavy_scratch_ints(n_vert));
+  L.tplan = take(csr16t_plan_ints(n_vert));
   if (need_backward) {
     const size_t kin = in_features > hidden ? in_features : hidden;
     L.dw_slab = take((size_t)dw16_num_slabs(hidden) * (kin > 304 ? 304 : kin) * hidden);
@@ -314,6 +316,11 @@ static int stack_fwd16(const float *feats, int ld_feats, int in_features, const 
   }
   u16 *f16 = reinterpret_cast<u16 *>(scratch + L.feats16);
   if (int rc = launch_cvt_rows(feats, ld_feats, in_features, f16, L.ld0, (long long)m, s)) return rc;
+  // bounded-degree graphs: the aggregation reads its neighbour rows from LDS tiles (gcn_bf16s.hip, csr16t); plan per call
+  const bool tiled = heavy == nullptr && cut_len > 0 && g_csr_algo != 1 && csr16t_ok(n_vert, cut_len, max_degree, (long long)m);
+  int32_t *tplan = reinterpret_cast<int32_t *>(scratch + L.tplan);
+  if (tiled)
+    if (int rc = launch_csr16t_build(rowptr, col, val, n_vert, tplan, s)) return rc;
 
   const u16 *x = f16;
   int ldx = L.ld0;
@@ -345,8 +352,12 @@ static int stack_fwd16(const float *feats, int ld_feats, int in_features, const 
     }
     if (cut_len > 0) {
       ProfScope psa(PROF_AGG, s);
-      if (int rc = launch_csr16_fwd(za, g.ldc2, biases[i], cut_len, rowptr, col, val, heavy, n_vert, batch, y, L.ldh, mk, mld, 1, s))
+      if (tiled) {
+        if (int rc = launch_csr16t_fwd(za, g.ldc2, biases[i], cut_len, tplan, rowptr, col, val, n_vert, batch, y, L.ldh, mk, mld, 1, s))
+          return rc;
+      } else if (int rc = launch_csr16_fwd(za, g.ldc2, biases[i], cut_len, rowptr, col, val, heavy, n_vert, batch, y, L.ldh, mk, mld, 1, s)) {
         return rc;
+      }
     }
     x = y;
     ldx = L.ldh;
@@ -382,6 +393,11 @@ static int stack_bwd16(const float *feats, int ld_feats, int in_features, const 
   // the stack's input in bf16 again (the scratch is shared between calls: the forward's copy may be gone)
   u16 *f16 = reinterpret_cast<u16 *>(scratch + L.feats16);
   if (int rc = launch_cvt_rows(feats, ld_feats, in_features, f16, L.ld0, (long long)m, s)) return rc;
+  // the tiled aggregation's plan for A^T (see stack_fwd16)
+  const bool tiled = heavyT == nullptr && cut_len > 0 && g_csr_algo != 1 && csr16t_ok(n_vert, cut_len, max_degreeT, (long long)m);
+  int32_t *tplan = reinterpret_cast<int32_t *>(scratch + L.tplan);
+  if (tiled)
+    if (int rc = launch_csr16t_build(rowptrT, colT, valT, n_vert, tplan, s)) return rc;
 
   // ---- output layer: dz3 = A^T dU, then one pass over X_{L-1}: G (bf16, ReLU-masked), dW, db partials
   u16 *ping[2] = {reinterpret_cast<u16 *>(scratch + L.ping[0]), reinterpret_cast<u16 *>(scratch + L.ping[1])};
@@ -431,9 +447,14 @@ static int stack_bwd16(const float *feats, int ld_feats, int in_features, const 
     const int kin = i == 0 ? in_features : hidden;
     if (cut_len > 0) {
       ProfScope psa(PROF_AGG, s);
-      if (int rc = launch_csr16_bwd(g, L.ldh, cut_len, cpad, rowptrT, colT, valT, heavyT, n_vert, batch, dza, ldza,
-                                    scratch + L.db_slab + (size_t)i * db_layer_stride, s))
+      if (tiled) {
+        if (int rc = launch_csr16t_bwd(g, L.ldh, cut_len, cpad, tplan, rowptrT, colT, valT, n_vert, batch, dza, ldza,
+                                       scratch + L.db_slab + (size_t)i * db_layer_stride, s))
+          return rc;
+      } else if (int rc = launch_csr16_bwd(g, L.ldh, cut_len, cpad, rowptrT, colT, valT, heavyT, n_vert, batch, dza, ldza,
+                                           scratch + L.db_slab + (size_t)i * db_layer_stride, s)) {
         return rc;
+      }
     } else if (!acc) {
       if (int rc = launch_fill_zero(grad_biases[i], hidden, s)) return rc;
     }

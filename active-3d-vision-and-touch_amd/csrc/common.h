@@ -68,6 +68,7 @@ enum PathCount {
   PATH_RGW,              // rowgemmw_kernel launches (exact fp32, weights resident in registers; round 6)
   PATH_DWW,              // dww_kernel launches (exact fp32 dW on specialised waves; round 6)
   PATH_STACK_SPLIT,      // stack forward calls whose hidden layers aggregated with the P + bipartite split (gcn_csrqs.hip / csr16 split)
+  PATH_CSR16T,           // csr16t_fwd_kernel launches (bf16 storage: tiled aggregation, neighbour rows from LDS; round 6)
   PATH_COUNT
 };
 void path_count(int which);

@@ -639,6 +639,506 @@ int launch_csr16_bwd(const void *g, int ldg, int c, int cpad, const int32_t *row
 }
 
 // ------------------------------------------------------------------------------------------------
+// Tiled aggregation on bf16 rows (round 6): the same sums as csr16_fwd / csr16_bwd for graphs of bounded degree, with the
+// neighbour rows read from LDS instead of L2.  The row walk gathers every neighbour's 208-byte row from L2 — seven times
+// the array per launch (231 MB at 164 k rows), which is what bounds it (35 us).  The templates number their vertices along a
+// surface-filling curve, so a tile of 96 consecutive vertices needs its own rows plus a HALO of 50-95 others: a workgroup
+// brings tile + halo into LDS once (LDS-DMA, 1.6x the array instead of 7x, mostly L2 hits on the neighbouring tiles'
+// rows), and every gather is a ds_read_b128.  The row-major layout of both arrays is unchanged: rowgemm16 / dw16 / thin16
+// read the results in place.
+//
+// A per-adjacency PLAN, built on the device at the start of a stack call (csr16t_build_kernel), holds per tile the halo's
+// vertex list and per vertex eight 16-bit LDS positions (row x 13 pieces) + eight weights (unused slots: the zero row, weight 0).  A tile
+// whose halo or degrees exceed the plan's bounds is marked and walks its rows from L2 as before (same kernel, same sums).
+// Sums are formed in CSR order with the row walk's own expression: results are bit-identical to csr16_fwd / csr16_bwd.
+// ------------------------------------------------------------------------------------------------
+constexpr int kT16Tile = 64, kT16Halo = 79, kT16Slots = 8, kT16Pieces = 13;
+constexpr int kT16Rows = kT16Tile + kT16Halo + 1;      // LDS rows; the last one is zeros
+constexpr int kT16Zero = kT16Rows - 1;
+constexpr int kT16Hdr = 1 + kT16Halo;                  // ints per tile: halo count (-1: row walk), halo vertices
+constexpr int kT16MaxVerts = 16384;                    // bit mask of the builder
+#ifndef A3VT_T16_BUFS
+#define A3VT_T16_BUFS 1
+#endif
+constexpr int kT16Bufs = A3VT_T16_BUFS;                // staging buffers per workgroup: 2 = the next unit's rows arrive during the gathers
+constexpr int kT16MaxUnits = kT16Bufs == 2 ? 32 : 12;  // units per persistent workgroup (their plan headers sit in LDS)
+constexpr int kT16Wgs = kT16Bufs == 2 ? 512 : 1024;    // persistent workgroups of a launch: two (75 KB of LDS each) or four (37 KB) per CU
+
+__host__ __device__ static inline int t16_tiles(int n_vert) { return (n_vert + kT16Tile - 1) / kT16Tile; }
+size_t csr16t_plan_ints(int n_vert) { return (size_t)t16_tiles(n_vert) * kT16Hdr + (size_t)n_vert * (4 + 8) + 16; }
+bool csr16t_ok(int n_vert, int c, int max_degree, long long m) {
+  return n_vert >= kT16Tile && n_vert <= kT16MaxVerts && ((c + 7) >> 3) == kT16Pieces && max_degree > 0 &&
+         max_degree <= kT16Slots && m >= 6144 && (m / n_vert + 7) / 8 * 8 * (long long)t16_tiles(n_vert) <= (long long)kT16MaxUnits * kT16Wgs;
+}
+struct T16Plan {
+  const int32_t *hdr;     // [tiles][kT16Hdr]
+  const u16 *slot;        // [n_vert][8]
+  const float *wgt;       // [n_vert][8]
+};
+static inline T16Plan t16_plan(const int32_t *plan, int n_vert) {
+  T16Plan p;
+  p.hdr = plan;
+  p.slot = reinterpret_cast<const u16 *>(plan + (size_t)t16_tiles(n_vert) * kT16Hdr);
+  p.wgt = reinterpret_cast<const float *>(plan + (size_t)t16_tiles(n_vert) * kT16Hdr + (size_t)n_vert * 4);
+  return p;
+}
+
+// one workgroup per tile: halo = the set of out-of-tile neighbours in increasing vertex order (a bit mask in LDS, ranks by
+// popcount prefix), slots = tile-relative row or kT16Tile + rank, in the CSR order of the row's entries
+__global__ __launch_bounds__(256) void csr16t_build_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                           const float *__restrict__ val, int n_vert, int32_t *plan) {
+  __shared__ unsigned words[kT16MaxVerts / 32];
+  __shared__ int prefix[kT16MaxVerts / 32 + 1];
+  __shared__ int bad;
+  const int t = threadIdx.x, k = blockIdx.x;
+  const int t0 = k * kT16Tile, t1 = min(n_vert, t0 + kT16Tile);
+  const int nwords = (n_vert + 31) >> 5;
+  int32_t *hdr = plan + (size_t)k * kT16Hdr;
+  u16 *slot = reinterpret_cast<u16 *>(plan + (size_t)t16_tiles(n_vert) * kT16Hdr);
+  float *wgt = reinterpret_cast<float *>(plan + (size_t)t16_tiles(n_vert) * kT16Hdr + (size_t)n_vert * 4);
+  for (int i = t; i < nwords; i += 256) words[i] = 0u;
+  if (t == 0) bad = 0;
+  __syncthreads();
+  const int e0 = rowptr[t0], e1 = rowptr[t1];
+  for (int e = e0 + t; e < e1; e += 256) {
+    const int c = col[e];
+    if (c < t0 || c >= t1) atomicOr(&words[c >> 5], 1u << (c & 31));
+  }
+  for (int r = t0 + t; r < t1; r += 256)
+    if (rowptr[r + 1] - rowptr[r] > kT16Slots) bad = 1;
+  __syncthreads();
+  if (t == 0) {
+    int run = 0;
+    for (int i = 0; i < nwords; ++i) {
+      prefix[i] = run;
+      run += __popc(words[i]);
+    }
+    prefix[nwords] = run;
+    if (run > kT16Halo) bad = 1;
+  }
+  __syncthreads();
+  const bool walk = bad != 0;
+  if (t == 0) hdr[0] = walk ? -1 : prefix[nwords];
+  if (!walk)
+    for (int i = t; i < nwords; i += 256) {
+      unsigned w = words[i];
+      int rank = prefix[i];
+      while (w) {
+        const int b = __ffs(w) - 1;
+        w &= w - 1;
+        hdr[1 + rank++] = i * 32 + b;
+      }
+    }
+  for (int i = t; i < (t1 - t0) * kT16Slots; i += 256) {
+    const int r = t0 + i / kT16Slots, sidx = i % kT16Slots;
+    const int e = rowptr[r] + sidx;
+    int sl = kT16Zero;
+    float w = 0.f;
+    if (!walk && e < rowptr[r + 1]) {
+      const int c = col[e];
+      sl = (c >= t0 && c < t1) ? c - t0 : kT16Tile + prefix[c >> 5] + __popc(words[c >> 5] & ((1u << (c & 31)) - 1u));
+      w = val[e];
+    }
+    slot[(size_t)r * kT16Slots + sidx] = (u16)(sl * kT16Pieces);   // in 16-byte pieces from the start of the staged rows
+    wgt[(size_t)r * kT16Slots + sidx] = w;
+  }
+}
+
+int launch_csr16t_build(const int32_t *rowptr, const int32_t *col, const float *val, int n_vert, int32_t *plan, hipStream_t s) {
+  A3VT_LAUNCH(csr16t_build_kernel, dim3(t16_tiles(n_vert)), dim3(256), 0, s, rowptr, col, val, n_vert, plan);
+  A3VT_CHECK_LAUNCH();
+  return 0;
+}
+
+#ifdef A3VT_DBG_T16_STAMPS   // diagnostic build (tools/build_variants.sh t16): wall clock (s_memrealtime, 100 MHz) of thread 0 at the
+// phase boundaries of csr16t_kernel, per workgroup: [0] entry, [1] first unit requested, [3] all units gathered and stored
+__device__ unsigned long long g_t16_stamps[4096 * 4];
+#define T16_STAMP(k)                                                                                             \
+  do {                                                                                                           \
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_t16_stamps[blockIdx.x * 4 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define T16_STAMP(k) do { } while (0)
+#endif
+
+struct T16Args {
+  const u16 *src;        // [M][ld_src] bf16: raw aggregated columns (forward) / output gradient rows (backward)
+  int ld_src;
+  u16 *dst;              // forward: layer output rows; backward: dZa [M][ld_dst]
+  int ld_dst;
+  const float *bias;     // forward
+  uint8_t *maskb;        // forward, optional
+  int mld, relu;
+  float *db_slab;        // backward: [gridDim.x][cpad]
+  int c, cpad, n_vert, batch, n_tiles;
+  T16Plan plan;
+  const int32_t *rowptr, *col;   // the CSR itself, for the tiles that walk their rows
+  const float *val;
+};
+
+// LDS, per staging buffer: rows [kT16Rows][13] x 16 B, slot records [tile] x 16 B, weights [tile] x 32 B, the halo list.
+// Two buffers per workgroup: the rows of its NEXT tile arrive while it gathers the current one.
+constexpr int kT16LdsRows = kT16Rows * kT16Pieces * 16;
+constexpr int kT16LdsSlots = kT16Tile * 16, kT16LdsWgt = kT16Tile * 32;
+constexpr int kT16LdsBuf = kT16LdsRows + kT16LdsSlots + kT16LdsWgt;
+constexpr int kT16LdsHdrs = kT16MaxUnits * kT16Hdr * 4;
+constexpr int kT16Lds = kT16Bufs * kT16LdsBuf + kT16LdsHdrs;
+static_assert(16 * 128 * 4 <= kT16LdsRows, "bias-gradient staging reuses a rows region");
+
+// blockIdx -> (mesh, tile): the tiles of a mesh on neighbouring workgroups of ONE die (they share halo rows in its L2)
+__device__ __forceinline__ bool t16_unit(long long u, int batch, int n_tiles, long long &b, int &k) {
+  const int xcd = (int)(u & 7);
+  const long long loc = u >> 3;
+  b = xcd + 8 * (loc / n_tiles);
+  k = (int)(loc % n_tiles);
+  return b < batch;
+}
+
+// LDS reads as written instructions.  The compiler orders every LDS read it knows of behind ALL outstanding vector-memory
+// operations once an LDS-DMA is in flight (it cannot tell which buffer the DMA fills): as plain loads the gathers below sat
+// behind an s_waitcnt vmcnt(0) per row — the previous row's global stores and the NEXT unit's DMA — 2 200 cycles per row of 16-lane
+// groups, 32 / 27 us per launch, no better than the row walk.  Written out, only the waits that are needed remain.
+__device__ __forceinline__ u32x4 t16_lds128(unsigned addr) {
+  u32x4 r;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr));
+  return r;
+}
+__device__ __forceinline__ int t16_lds32(unsigned addr) {
+  int r;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(addr));
+  return r;
+}
+__device__ __forceinline__ void t16_wait3(u32x4 &a, u32x4 &b, u32x4 &c) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c));
+}
+__device__ __forceinline__ void t16_wait9(u32x4 (&v)[kT16Slots], u32x4 &o) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(o));
+}
+
+// The tile's own rows and its records -> LDS (LDS-DMA: wave-contiguous 16-byte pieces); they need nothing from the plan's header.
+__device__ __forceinline__ void t16_stage_tile(const T16Args &a, char *buf, long long b, int k) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t0 = k * kT16Tile, rows_here = min(a.n_vert - t0, kT16Tile);
+  const u16 *sb = a.src + b * a.n_vert * (long long)a.ld_src;
+  constexpr int kTilePieces = kT16Tile * kT16Pieces;       // 832 = 13 wave instructions
+  for (int i0 = wave * 64; i0 < kTilePieces; i0 += 256) {
+    const int i = i0 + lane;
+    const int r = (i * 5042) >> 16, p = i - r * kT16Pieces;       // i / 13 (exact below 2^12)
+    glds16b(sb + (long long)(t0 + (r < rows_here ? r : 0)) * a.ld_src + p * 8, buf + i0 * 16);
+  }
+  if (t < rows_here) glds16b(a.plan.slot + (size_t)(t0 + t) * kT16Slots, buf + kT16LdsRows + wave * 64 * 16);
+  if (t < rows_here * 2) glds16b(a.plan.wgt + (size_t)t0 * kT16Slots + t * 4, buf + kT16LdsRows + kT16LdsSlots + wave * 64 * 16);
+  if (t < kT16Pieces) *reinterpret_cast<u32x4 *>(buf + (kT16Zero * kT16Pieces + t) * 16) = u32x4{0u, 0u, 0u, 0u};
+}
+// The halo rows, from the unit's header in LDS (list = LDS byte address of its first entry).
+__device__ __forceinline__ void t16_stage_halo(const T16Args &a, char *buf, long long b, int halo, unsigned list) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const u16 *sb = a.src + b * a.n_vert * (long long)a.ld_src;
+  const int total = halo * kT16Pieces;
+  for (int i0 = wave * 64; i0 < total; i0 += 256) {
+    const int i = i0 + lane;
+    if (i < total) {
+      const int r = (i * 5042) >> 16, p = i - r * kT16Pieces;
+      const int v = t16_lds32(list + r * 4);       // (a written read: see t16_lds128)
+      glds16b(sb + (long long)v * a.ld_src + p * 8, buf + (kT16Tile * kT16Pieces + i0) * 16);
+    }
+  }
+}
+
+// weighted sum of row r's neighbour rows from LDS (8 slots; unused ones add 0 x the zero row), CSR order; own = row r itself
+__device__ __forceinline__ F8 t16_gather(unsigned buf, int r, int hl, bool on, u32x4 &own) {
+  u32x4 sl = t16_lds128(buf + kT16LdsRows + r * 16);
+  u32x4 wa = t16_lds128(buf + kT16LdsRows + kT16LdsSlots + r * 32);
+  u32x4 wb = t16_lds128(buf + kT16LdsRows + kT16LdsSlots + r * 32 + 16);
+  t16_wait3(sl, wa, wb);
+  const f32x4 w0 = __builtin_bit_cast(f32x4, wa), w1 = __builtin_bit_cast(f32x4, wb);
+  u32x4 v[kT16Slots];
+  const unsigned lane_base = buf + hl * 16;
+#pragma unroll
+  for (int q = 0; q < kT16Slots; ++q) {
+    const unsigned idx = (q & 1) ? sl[q >> 1] >> 16 : sl[q >> 1] & 0xffffu;     // the neighbour row's first piece
+    v[q] = t16_lds128(lane_base + (idx << 4));       // (lanes 13..15 of a group read past the row: unused)
+  }
+  own = t16_lds128(buf + (r * kT16Pieces + hl) * 16);
+  t16_wait9(v, own);
+  F8 acc;
+  acc.lo = acc.hi = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (on) {
+#pragma unroll
+    for (int q = 0; q < kT16Slots; ++q) {
+      const F8 x = unpack8(v[q]);
+      const float w = q < 4 ? w0[q] : w1[q - 4];
+      acc.lo += w * x.lo;
+      acc.hi += w * x.hi;
+    }
+  }
+  return acc;
+}
+
+// The forward epilogue of one vertex's 8-channel group, written for instruction count (the kernel is bound by it: 290
+// instructions per four rows with csr16_fwd_store, a third of them here): ReLU and sign bits as rowgemmw's relu_bits
+// (v_max_f32 / v_min_u32 / v_lshl_or_b32: bit = ReLU output != 0, the same bit as pre > 0), the last, partial group of a row
+// stored as dword + short instead of element by element.  Same values and bytes as csr16_fwd_store with relu = 1.
+__device__ __forceinline__ unsigned t16_relu_bits(f32x4 &v) {
+  float o0, o1, o2, o3;
+  unsigned b0, b1, b2, b3;
+  asm("v_max_f32 %0, 0, %8\n\tv_max_f32 %1, 0, %9\n\tv_max_f32 %2, 0, %10\n\tv_max_f32 %3, 0, %11\n\t"
+      "v_min_u32 %4, 1, %0\n\tv_min_u32 %5, 1, %1\n\tv_min_u32 %6, 1, %2\n\tv_min_u32 %7, 1, %3\n\t"
+      "v_lshl_or_b32 %4, %5, 1, %4\n\tv_lshl_or_b32 %4, %6, 2, %4\n\tv_lshl_or_b32 %4, %7, 3, %4"
+      : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
+      : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+  v = f32x4{o0, o1, o2, o3};
+  return b0;
+}
+__device__ __forceinline__ void t16_fwd_store(const F8 &acc, int ch, int c, const F8 &bs, unsigned valid_bits,
+                                              u16 *__restrict__ yo, uint8_t *__restrict__ mrow) {
+  F8 o;
+  o.lo = acc.lo + bs.lo;
+  o.hi = acc.hi + bs.hi;
+  const unsigned bits = (t16_relu_bits(o.lo) | (t16_relu_bits(o.hi) << 8)) & valid_bits;   // [3:0] channels ch..ch+3, [11:8] ch+4..ch+7
+  const u32x4 pk = pack8(o);
+  if (ch + 7 < c) {
+    *reinterpret_cast<u32x4 *>(yo) = pk;
+  } else {   // the row's last group: channels ch .. c - 1
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      if (ch + 2 * d + 1 < c) reinterpret_cast<unsigned *>(yo)[d] = pk[d];
+      else if (ch + 2 * d < c) yo[2 * d] = (u16)(pk[d] & 0xffffu);
+    }
+  }
+  if (mrow) *reinterpret_cast<u16 *>(mrow + (ch >> 2)) = (u16)bits;
+}
+
+// One persistent kernel for both directions.  BWD: the A^T plan; channels [c, cpad) pass the own gradient through; bias-gradient
+// partial sums per workgroup (rows of db_slab beyond the persistent workgroups are written as zeros).
+// Pipeline per workgroup, units u0, u1, ... (stride = the persistent workgroups): while unit j is gathered out of buffer j & 1,
+// unit j + 1's rows arrive in the other buffer and unit j + 2's plan header is on its way into registers.
+template <bool BWD>
+__global__ __launch_bounds__(256) void csr16t_kernel(T16Args a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int t = threadIdx.x, hl = t & 15, sub = t >> 4;
+  const int ch = hl * 8;
+  const bool on = ch < (BWD ? a.cpad : a.c);
+  F8 bsum;
+  bsum.lo = bsum.hi = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nwg = min((int)gridDim.x, kT16Wgs);
+  if (BWD && (int)blockIdx.x >= nwg) {      // not a worker: its row of partial sums is zero
+    if (t < a.cpad) a.db_slab[(size_t)blockIdx.x * a.cpad + t] = 0.f;
+    return;
+  }
+  const long long units = 8ll * ((a.batch + 7) / 8) * a.n_tiles;
+  F8 bs0;
+  unsigned valid_bits = 0;      // sign-bit positions of this lane's channels that exist (ch + t < c)
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    if (ch + q < a.c) valid_bits |= 1u << (q < 4 ? q : q + 4);
+  if (!BWD) {
+    bs0 = csr16_load_bias(a.bias, ch, a.c);
+    // used here once, so that the compiler waits for these loads HERE and not at their first use inside the unit loop — where
+    // its s_waitcnt vmcnt(0) would also wait for the next unit's rows, requested a moment before
+    asm volatile("" : "+v"(bs0.lo), "+v"(bs0.hi));
+  }
+  // The plan headers (halo count + list) of ALL this workgroup's units go to LDS once, up front: fetched per unit they were
+  // vector loads in flight across the gather loop, and the compiler then put an s_waitcnt vmcnt(0) in front of that loop
+  // ("flush before a loop that stores and uses loaded registers") — behind the next unit's DMA.  In the steady state the
+  // kernel issues no global load but its DMA.
+  char *hdrs = lds + kT16Bufs * kT16LdsBuf;
+  const unsigned hdrs_a = (unsigned)(size_t)(__attribute__((address_space(3))) char *)hdrs;
+  auto valid = [&](long long u) {
+    long long b;
+    int k;
+    return u < units && t16_unit(u, a.batch, a.n_tiles, b, k);
+  };
+  {
+    int j = 0;
+    for (long long u = blockIdx.x; u < units && j < kT16MaxUnits; u += nwg, ++j) {
+      long long b;
+      int k;
+      if (!t16_unit(u, a.batch, a.n_tiles, b, k)) continue;
+      if (t < kT16Hdr) reinterpret_cast<int *>(hdrs)[j * kT16Hdr + t] = a.plan.hdr[(size_t)k * kT16Hdr + t];
+    }
+  }
+  __syncthreads();
+  auto count_of = [&](int j) { return __builtin_amdgcn_readfirstlane(t16_lds32(hdrs_a + j * kT16Hdr * 4)); };
+  auto issue = [&](long long u, int j, int halo, char *buf) {     // all DMA of unit u (valid; its header is slot j) into buf
+    long long b;
+    int k;
+    t16_unit(u, a.batch, a.n_tiles, b, k);
+    t16_stage_tile(a, buf, b, k);
+    if (halo > 0) t16_stage_halo(a, buf, b, halo, hdrs_a + (j * kT16Hdr + 1) * 4);
+  };
+  long long u = blockIdx.x;
+  T16_STAMP(0);
+  int halo_c = valid(u) ? count_of(0) : -2;
+  if (halo_c > -2) issue(u, 0, halo_c, lds);
+  T16_STAMP(1);
+  int par = 0, j = 0;
+  for (; u < units; u += nwg, par ^= (kT16Bufs - 1), ++j) {
+    char *buf = lds + par * kT16LdsBuf;
+    // (the builtin, not an asm: the compiler's own bookkeeping must see that nothing is outstanding here)
+    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();         // unit u's rows are in buf; everyone has left the other buffer (unit u - nwg)
+    const int halo = halo_c;
+    halo_c = valid(u + nwg) ? count_of(j + 1) : -2;
+    if (kT16Bufs == 2 && halo_c > -2) issue(u + nwg, j + 1, halo_c, lds + (par ^ 1) * kT16LdsBuf);
+    if (kT16Bufs == 2 && halo == -2) continue;     // (a padding unit: batch not a multiple of 8)
+    if (halo > -2) {
+    long long b;
+    int k;
+    t16_unit(u, a.batch, a.n_tiles, b, k);
+    const int t0 = k * kT16Tile, rows_here = min(a.n_vert - t0, kT16Tile);
+    const u16 *sb = a.src + b * a.n_vert * (long long)a.ld_src;
+    const unsigned bufa = (unsigned)(size_t)(__attribute__((address_space(3))) char *)buf;
+    // the epilogue of one row: forward bias / ReLU / sign bytes / bf16 store; backward pass-through columns, bias-gradient sums
+    auto finish = [&](int r, const F8 &acc, const u32x4 &own_raw) {
+      const long long row = b * a.n_vert + t0 + r;
+      if (!BWD) {
+        if (on) {
+          t16_fwd_store(acc, ch, a.c, bs0, valid_bits, a.dst + row * a.ld_dst + ch, a.maskb ? a.maskb + row * a.mld : nullptr);
+        }
+      } else {
+        F8 own;
+        own.lo = own.hi = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (on) own = unpack8(own_raw);
+        bsum.lo += own.lo;
+        bsum.hi += own.hi;
+        if (on) {
+          F8 out;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const float x = ch + q < a.c ? f8_get(acc, q) : f8_get(own, q);
+            if (q < 4) out.lo[q] = x;
+            else out.hi[q - 4] = x;
+          }
+          *reinterpret_cast<u32x4 *>(a.dst + row * a.ld_dst + ch) = pack8(out);
+        }
+      }
+    };
+    // (two loops: with the row walk's global loads inside it, the compiler made every LDS read of the tiled loop wait for
+    // vector memory — a load of a previous trip could still own the register)
+    if (halo >= 0) {
+      // (no loop: in front of a loop that stores and reads registers it believes loaded, the compiler "flushes" with an
+      // s_waitcnt vmcnt(0) — here that is a wait for the next unit's DMA; kT16Tile / 16 = 4 rows per 16-lane group)
+#pragma unroll
+      for (int i = 0; i < kT16Tile / 16; ++i) {
+        const int r = sub + 16 * i;
+        if (r < rows_here) {
+          u32x4 own_raw;
+          const F8 acc = t16_gather(bufa, r, hl, on, own_raw);
+          finish(r, acc, own_raw);
+        }
+      }
+    } else {
+      for (int r = sub; r < rows_here; r += 16) {
+        const int v = t0 + r;
+        u32x4 own_raw = u32x4{0u, 0u, 0u, 0u};
+        if (BWD && on) own_raw = *reinterpret_cast<const u32x4 *>(sb + (long long)v * a.ld_src + ch);
+        const F8 acc = gather_row16(sb, a.ld_src, ch, on, a.rowptr[v], a.rowptr[v + 1], hl, a.col, a.val);
+        finish(r, acc, own_raw);
+      }
+      // (nothing of this path's vector memory stays outstanding — in the compiler's books, too: registers its loads "may still
+      // own" made every LDS read of the tiled path above wait for vector memory)
+      __builtin_amdgcn_s_waitcnt(0x0070);
+    }
+    }   // (unit u valid)
+    if (kT16Bufs == 1 && halo_c > -2) {   // one buffer: the next unit's rows are requested when everyone has left this one's
+      __builtin_amdgcn_s_barrier();
+      issue(u + nwg, j + 1, halo_c, buf);
+    }
+  }
+  T16_STAMP(3);
+  if (BWD) {
+    wait_vm<0>();
+    __syncthreads();          // (no DMA in flight, nobody reads a buffer any more)
+    float(*red)[128] = reinterpret_cast<float(*)[128]>(lds);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) red[sub][hl * 8 + q] = f8_get(bsum, q);
+    __syncthreads();
+    if (t < 128 && t < a.cpad) {
+      float sm = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sm += red[r][t];
+      a.db_slab[(size_t)blockIdx.x * a.cpad + t] = sm;
+    }
+  }
+}
+
+#ifdef A3VT_DBG_T16_STAMPS
+}  // namespace a3vt
+extern "C" int a3vt_dbg_t16_stamps(unsigned long long *host_dst) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(a3vt::g_t16_stamps), sizeof(unsigned long long) * 4096 * 4);
+}
+namespace a3vt {
+#endif
+
+int launch_csr16t_fwd(const void *za, int ldza, const float *bias, int c, const int32_t *plan, const int32_t *rowptr,
+                      const int32_t *col, const float *val, int n_vert, int batch, void *y, int ldy, uint8_t *maskb, int mld,
+                      int relu, hipStream_t s) {
+  if (ldza % 8 != 0 || ldza < ((c + 7) & ~7) || ((c + 7) >> 3) != kT16Pieces || !relu) {   // (the epilogue is the ReLU one)
+    set_error("csr16t_fwd: ldza=%d c=%d relu=%d not taken", ldza, c, relu);
+    return -1;
+  }
+  T16Args a{};
+  a.src = static_cast<const u16 *>(za);
+  a.ld_src = ldza;
+  a.dst = static_cast<u16 *>(y);
+  a.ld_dst = ldy;
+  a.bias = bias;
+  a.maskb = maskb;
+  a.mld = mld;
+  a.relu = relu;
+  a.c = c;
+  a.cpad = (c + 7) & ~7;
+  a.n_vert = n_vert;
+  a.batch = batch;
+  a.n_tiles = t16_tiles(n_vert);
+  a.plan = t16_plan(plan, n_vert);
+  a.rowptr = rowptr;
+  a.col = col;
+  a.val = val;
+  static OncePerDevice once;
+  once.run([] { (void)hipFuncSetAttribute((const void *)csr16t_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kT16Lds); });
+  const long long units = 8ll * ((batch + 7) / 8) * a.n_tiles;
+  const int grid = (int)(units < kT16Wgs ? units : kT16Wgs);
+  path_count(PATH_CSR16T);
+  A3VT_LAUNCH(csr16t_kernel<false>, dim3(grid), dim3(256), kT16Lds, s, a);
+  A3VT_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_csr16t_bwd(const void *g, int ldg, int c, int cpad, const int32_t *planT, const int32_t *rowptrT,
+                      const int32_t *colT, const float *valT, int n_vert, int batch, void *dza, int lddza, float *db_slab,
+                      hipStream_t s) {
+  if (ldg % 8 != 0 || lddza % 8 != 0 || cpad != ((c + 7) & ~7) || (cpad >> 3) != kT16Pieces || lddza < cpad || ldg < cpad) {
+    set_error("csr16t_bwd: ldg=%d lddza=%d c=%d cpad=%d not taken", ldg, lddza, c, cpad);
+    return -1;
+  }
+  T16Args a{};
+  a.src = static_cast<const u16 *>(g);
+  a.ld_src = ldg;
+  a.dst = static_cast<u16 *>(dza);
+  a.ld_dst = lddza;
+  a.db_slab = db_slab;
+  a.c = c;
+  a.cpad = cpad;
+  a.n_vert = n_vert;
+  a.batch = batch;
+  a.n_tiles = t16_tiles(n_vert);
+  a.plan = t16_plan(planT, n_vert);
+  a.rowptr = rowptrT;
+  a.col = colT;
+  a.val = valT;
+  static OncePerDevice once;
+  once.run([] { (void)hipFuncSetAttribute((const void *)csr16t_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kT16Lds); });
+  // exactly the rows of partial bias sums the caller reduces (csr_bwd_num_slabs): the first kT16Wgs workgroups work, the
+  // others write a zero row
+  const int grid = csr_bwd_num_slabs(batch, n_vert);
+  A3VT_LAUNCH(csr16t_kernel<true>, dim3(grid), dim3(256), kT16Lds, s, a);
+  A3VT_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Output layer (3 channels) on bf16 rows: z3 = X W (16 lanes per row, 3 x 8-channel pieces per lane: k <= 384), then
 // the fp32 3-channel aggregation of gcn_csr.hip; backward fuses G_prev (bf16, ReLU-masked by X > 0), dW and db partials.
 // ------------------------------------------------------------------------------------------------

@@ -244,6 +244,16 @@ int launch_csr16_fwd(const void *za, int ldza, const float *bias, int c, const i
 int launch_csr16_bwd(const void *g, int ldg, int c, int cpad, const int32_t *rowptrT, const int32_t *colT,
                      const float *valT, const int32_t *heavyT, int n_vert, int batch, void *dza, int lddza,
                      float *db_slab, hipStream_t s);
+// tiled aggregation on bf16 rows (gcn_bf16s.hip, round 6): plan = csr16t_plan_ints(n_vert) ints built by launch_csr16t_build
+size_t csr16t_plan_ints(int n_vert);
+bool csr16t_ok(int n_vert, int c, int max_degree, long long m);
+int launch_csr16t_build(const int32_t *rowptr, const int32_t *col, const float *val, int n_vert, int32_t *plan, hipStream_t s);
+int launch_csr16t_fwd(const void *za, int ldza, const float *bias, int c, const int32_t *plan, const int32_t *rowptr,
+                      const int32_t *col, const float *val, int n_vert, int batch, void *y, int ldy, uint8_t *maskb, int mld,
+                      int relu, hipStream_t s);
+int launch_csr16t_bwd(const void *g, int ldg, int c, int cpad, const int32_t *planT, const int32_t *rowptrT,
+                      const int32_t *colT, const float *valT, int n_vert, int batch, void *dza, int lddza, float *db_slab,
+                      hipStream_t s);
 int launch_thin16_fwd_product(const void *x, int ldx, int k, const float *w, long long m, float *z3, hipStream_t s);
 int launch_thin16_bwd_main(const void *x, int ldx, int k, const float *w, const float *dz3, const float *du, long long m,
                            int apply_mask, void *gprev, int ldg, float *dw_slab, float *db_slab, hipStream_t s);

@@ -90,7 +90,7 @@ def _ptr_array(tensors):
 GEMM_MODES = {"fp32": 0, "bf16": 1, "bf16s": 2, "fp32x3": 3}
 
 
-PATH_NAMES = ("stack_quad", "stack_rows", "rowgemm_adirect", "rowgemm3", "dw3", "dw_hybrid", "rowgemm16", "stack16_quad", "rowgemm_w", "dw_w", "stack_split")
+PATH_NAMES = ("stack_quad", "stack_rows", "rowgemm_adirect", "rowgemm3", "dw3", "dw_hybrid", "rowgemm16", "stack16_quad", "rowgemm_w", "dw_w", "stack_split", "csr16_tiles")
 
 
 def path_counts(reset=False):

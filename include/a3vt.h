@@ -363,8 +363,9 @@ int a3vt_chamfer_bwd(const float *x, const float *y, int draws, int batch, int p
 
 /* Test hook (tests/test_gpu_csr_sliced.py): which neighbour-aggregation kernels the fp32 stacks use — 0 = chosen by shape
  * (default), 1 = the half-wave-per-vertex kernels everywhere, 2 = the channel-sliced kernels wherever a mesh slice fits
- * LDS, graphs with long rows included.  Every choice gives the same outputs; process-wide; not a tuning knob.  The
- * library reads NO environment variable. */
+ * LDS, graphs with long rows included.  In the bf16 storage mode 1 also keeps the row walk where the tiled aggregation
+ * (neighbour rows from LDS, bit-identical sums) would run.  Every choice gives the same outputs; process-wide; not a tuning
+ * knob.  The library reads NO environment variable. */
 int a3vt_dbg_csr_algo(int algo);
 
 /* Test hook: how many launch decisions of this process took each kernel family since the last reset — so that a parity test
@@ -373,7 +374,9 @@ int a3vt_dbg_csr_algo(int algo);
  *   [2] rowgemm_kernel<19,...,ADIRECT> launches (exact fp32 hidden-layer products: the headline kernel)
  *   [3] rowgemm3_kernel launches (gemm mode 3)   [4] dw3_kernel launches   [5] dw_kernel launches on quad-major operands
  *   [6] rowgemm16_kernel launches (bf16 storage)  [7] bf16-storage stack forward calls on the channel-sliced aggregation
- *   [8] stack forward calls that aggregated through the P + bipartite split (struct a3vt_adj_split)
+ *   [8] rowgemmw_kernel launches  [9] dww_kernel launches (exact fp32 hidden-layer products, round 6)
+ *   [10] stack forward calls that aggregated through the P + bipartite split (struct a3vt_adj_split)
+ *   [11] csr16t forward launches (bf16 storage: aggregation from LDS tiles)
  * Returns the number of counters the library keeps (entries beyond it are written as 0); reset != 0 clears them. */
 int a3vt_dbg_path_counts(long long *counts, int n, int reset);
 

@@ -133,3 +133,45 @@ def test_training_step_bf16_storage_fullsize(cuda):
     ref = res["fp32"][0]
     assert rel_err(a[0], ref[0]) < 5e-3 and abs(a[1] - ref[1]) < 2e-2 * abs(ref[1])
     assert rel_l2(a[2], ref[2]) < 0.15                         # whole-network gradient, 60 bf16-rounded layers deep
+
+
+@pytest.mark.parametrize("tname,B,spatial", [("ico4", 6, True), ("ico5", 2, True), ("atlas", 8, True), ("ico4", 5, False)])
+def test_tiled_aggregation_is_the_row_walk_bit_for_bit(cuda, tname, B, spatial):
+    """Round 6: on graphs of degree <= 8 the bf16 stacks aggregate from LDS tiles (csr16t_*, gcn_bf16s.hip: tile + halo rows
+    staged once, neighbour sums in CSR order) instead of gathering every neighbour row from L2.  Same sums in the same order:
+    outputs, feature and weight gradients equal the row walk's bit for bit (``dbg_csr_algo("rows")``); the bias gradients are
+    sums over the rows in another grouping (fp32, 1e-5).  ``spatial=False``: icosphere vertices in subdivision order — every
+    tile's halo exceeds the plan's bound, and the tiles walk their rows inside the same kernel."""
+    from a3vt_amd import mesh as amesh, ops
+    from oracle import gcn as og
+    L, H, I, cut = 3, 300, 50, 0.33
+    if tname.startswith("ico"):
+        verts, faces = amesh.icosphere(int(tname[3:]), spatial_order=spatial)
+    else:
+        verts, faces = template(tname)
+    n = verts.shape[0]
+    adj = ops.DeviceCSR(amesh.CSRAdjacency.from_pairs(*amesh.vision_pairs(faces, n), n), cuda)
+    st = og.init_state(I, H, L, seed=4)
+    g = torch.Generator().manual_seed(21)
+    feats = torch.nn.functional.pad(torch.randn(B, n, I, generator=g) * 0.5, (0, 2)).to(cuda)
+    gup = torch.randn(B, n, 3, generator=g).to(cuda)
+    res = {}
+    try:
+        for algo in ("rows", "auto"):
+            ops.dbg_csr_algo(algo)
+            ops.path_counts(reset=True)
+            ws = [st[f"mesh_deform_1.layers.{i}.weight"].to(cuda).requires_grad_(True) for i in range(L)]
+            bs = [st[f"mesh_deform_1.layers.{i}.bias"].to(cuda).requires_grad_(True) for i in range(L)]
+            fd = feats.clone().requires_grad_(True)
+            out = ops.gcn_stack(fd, adj, I, H, round(H * cut), ws, bs, bf16="bf16s")
+            (out * gup).sum().backward()
+            res[algo] = (out.detach(), fd.grad, [w.grad for w in ws], [b.grad for b in bs], ops.path_counts()["csr16_tiles"])
+    finally:
+        ops.dbg_csr_algo("auto")
+    r, t = res["rows"], res["auto"]
+    assert r[4] == 0 and t[4] == L - 1, (r[4], t[4])
+    assert torch.equal(r[0], t[0]) and torch.equal(r[1], t[1])
+    for a, b in zip(r[2], t[2]):
+        assert torch.equal(a, b)
+    for a, b in zip(r[3], t[3]):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5 * float(a.abs().max()))
