@@ -898,7 +898,11 @@ __device__ __forceinline__ void t16_fwd_store(const F8 &acc, int ch, int c, cons
   const unsigned bits = (t16_relu_bits(o.lo) | (t16_relu_bits(o.hi) << 8)) & valid_bits;   // [3:0] channels ch..ch+3, [11:8] ch+4..ch+7
   const u32x4 pk = pack8(o);
   if (ch + 7 < c) {
+#ifndef A3VT_T16_NO_NT   // streaming stores: the results are not read again by this launch, and the L2 write-back at its end shrinks (forward 30.9 -> 28.2 us)
+    __builtin_nontemporal_store(pk, reinterpret_cast<u32x4 *>(yo));
+#else
     *reinterpret_cast<u32x4 *>(yo) = pk;
+#endif
   } else {   // the row's last group: channels ch .. c - 1
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
@@ -1010,7 +1014,11 @@ __global__ __launch_bounds__(256) void csr16t_kernel(T16Args a) {
             if (q < 4) out.lo[q] = x;
             else out.hi[q - 4] = x;
           }
+#ifndef A3VT_T16_NO_NT   // streaming stores: the results are not read again by this launch, and the L2 write-back at its end shrinks (forward 30.9 -> 28.2 us)
+          __builtin_nontemporal_store(pack8(out), reinterpret_cast<u32x4 *>(a.dst + row * a.ld_dst + ch));
+#else
           *reinterpret_cast<u32x4 *>(a.dst + row * a.ld_dst + ch) = pack8(out);
+#endif
         }
       }
     };

@@ -239,6 +239,7 @@ __global__ __launch_bounds__(kCsrqThreads) void csrq_kernel(const float *__restr
         for (int t = 0; t < 4; ++t) o[t] = ch + t < c ? acc[t] : own[t];
       }
       // quad-major like the input (1 KiB per wave-instruction); the output array may hold more planes per mesh (nq_dst)
+      // (streaming stores — which take 2.7 us off the bf16 tiled aggregation — were measured here and change nothing: 35.1 / 37.0 -> 34.5 / 37.9 us)
       *reinterpret_cast<f32x4 *>(dst + ((((size_t)b * nq_dst + q) * n_vert) + v) * 4) = o;
     }
     __builtin_amdgcn_sched_barrier(0);

@@ -20,6 +20,8 @@ if [ "$1" = "rgw" ]; then   # rowgemmw_kernel (round 6) ablations + the round-5 
   build RGW_STAMPS -DA3VT_DBG_RGW_STAMPS   # per-tile phase stamps (tools/rowgemmw_stamps.py)
 elif [ "$1" = "t16" ]; then   # csr16t_fwd_kernel (bf16 tiled aggregation) with wall-clock stamps at its phase boundaries (tools/csr16t_stamps.py)
   build T16_STAMPS -DA3VT_DBG_T16_STAMPS
+  build T16_NO_NT -DA3VT_T16_NO_NT    # A/B: plain instead of streaming (nontemporal) stores of the results
+  build T16_2BUF -DA3VT_T16_BUFS=2    # A/B: two staging buffers, two workgroups per CU
 elif [ "$1" = "csr" ]; then   # csr_fwd / csr16_fwd without their stores: tools/kstats.sh with A3VT_LIB=...
   build CSR_NOSTORE -DA3VT_DBG_CSR_NOSTORE
 elif [ "$1" = "csrq" ]; then   # channel-sliced aggregation without its LDS gathers (what the gathers cost)
