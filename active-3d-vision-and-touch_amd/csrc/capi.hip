@@ -624,7 +624,7 @@ int a3vt_adj_split_validate(const int32_t *rowptr, const int32_t *col, const flo
 // ReLU-sign bytes saved by the forward pass for the backward pass: [num_layers-1][pad32(M)][mld],
 // mld = pad4(cut_len)/4 + ceil(hidden/4).  (mask_ld: defined with stack_x3 above)
 size_t a3vt_gcn_stack_mask_bytes(int batch, int n_vert, int hidden, int num_layers, int cut_len) {
-  if (num_layers < 2) return 0;
+  if (num_layers < 2 || batch <= 0 || n_vert <= 0 || hidden <= 0 || cut_len < 0) return 0;
   const size_t mpad = ((size_t)batch * n_vert + 31) / 32 * 32;
   // row-major sign bytes, then the quad-major signs of the aggregated channels (channel-sliced aggregation)
   return (size_t)(num_layers - 1) * (mpad * mask_ld(hidden, cut_len) + signq_stride((size_t)batch * n_vert, cut_len));
@@ -645,6 +645,9 @@ size_t a3vt_gcn_stack_scratch_bytes(int batch, int n_vert, int in_features, int 
 
 size_t a3vt_gcn_stack_scratch_bytes_mode(int batch, int n_vert, int in_features, int hidden, int num_layers,
                                          int cut_len, int need_backward, int gemm_bf16) {
+  // (a size query never fails: sizes no stack call accepts give 0 — the layouts below divide by some of them)
+  if (batch <= 0 || n_vert <= 0 || in_features <= 0 || hidden <= 0 || num_layers <= 0 || cut_len < 0 || gemm_bf16 < 0 || gemm_bf16 > 3)
+    return 0;
   if (gemm_bf16 == 2)
     return stack16_layout(batch, n_vert, in_features, hidden, num_layers, cut_len, need_backward).total * sizeof(float);
   return stack_layout(batch, n_vert, in_features, hidden, num_layers, cut_len, need_backward, gemm_bf16).total * sizeof(float);
@@ -652,7 +655,7 @@ size_t a3vt_gcn_stack_scratch_bytes_mode(int batch, int n_vert, int in_features,
 
 int a3vt_gcn_stack_stash_bytes(int batch, int n_vert, int hidden, int num_layers, int cut_len, int gemm_bf16,
                                size_t *acts_bytes, size_t *mask_bytes) {
-  A3VT_CHECK_ARG(acts_bytes && mask_bytes && batch > 0 && n_vert > 0);
+  A3VT_CHECK_ARG(acts_bytes && mask_bytes && batch > 0 && n_vert > 0 && hidden > 0 && cut_len >= 0);
   *acts_bytes = *mask_bytes = 0;
   if (num_layers < 2) return 0;
   const size_t m = (size_t)batch * n_vert, mpad = (m + 31) / 32 * 32;
