@@ -18,6 +18,7 @@ p.add_argument("--batch", type=int, default=64)
 p.add_argument("--level", type=int, default=4)
 p.add_argument("--reps", type=int, default=5)
 p.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16s", "fp32x3"])
+p.add_argument("--csr-algo", default="auto", choices=["auto", "rows", "sliced"], help="ops.dbg_csr_algo: which aggregation kernels")
 p.add_argument("--subdivision-order", action="store_true", help="icosphere vertices in subdivision order (poor locality)")
 a = p.parse_args()
 
@@ -38,6 +39,7 @@ feats[..., :50] = torch.randn(a.batch, verts.shape[0], 50, device=dev) * 0.5
 feats.requires_grad_(True)
 gup = torch.randn(a.batch, verts.shape[0], 3, device=dev)
 L = lib.load()
+ops.dbg_csr_algo(a.csr_algo)
 
 
 def run():
