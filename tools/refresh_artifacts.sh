@@ -26,13 +26,19 @@ python tools/touch_bench.py --precision fp32x3 2>/dev/null | tail -1 >> $O/${R}_
 [ -f gpurun_variants/liba3vt_RG3_STAMPS.so ] && A3VT_LIB=$GRAFT_REPO_ROOT/gpurun_variants/liba3vt_RG3_STAMPS.so python tools/rowgemm3_stamps.py > $O/${R}_rowgemm3_phase_stamps.txt 2>/dev/null
 # round 6 product kernels: per-tile / per-stage phase stamps of rowgemmw_kernel and dww_kernel (tools/build_variants.sh rgw)
 [ -f gpurun_variants/liba3vt_RGW_STAMPS.so ] && A3VT_LIB=$GRAFT_REPO_ROOT/gpurun_variants/liba3vt_RGW_STAMPS.so python tools/rowgemmw_stamps.py > $O/${R}_rowgemmw_dww_stamps.txt 2>/dev/null
-[ -f gpurun_variants/liba3vt_RGW_OFF.so ] && (echo '== round-5 product kernels (liba3vt_RGW_OFF.so)'; A3VT_LIB=$GRAFT_REPO_ROOT/gpurun_variants/liba3vt_RGW_OFF.so python tools/stack_bench.py | tail -4; echo '== shipped'; python tools/stack_bench.py | tail -4) > $O/${R}_product_kernels_ab.txt 2>/dev/null
+[ -f gpurun_variants/liba3vt_RGW_OFF.so ] && (echo '== round-5 product kernels (liba3vt_RGW_OFF.so)'; A3VT_LIB=$GRAFT_REPO_ROOT/gpurun_variants/liba3vt_RGW_OFF.so python tools/stack_bench.py | tail -4 | head -3; A3VT_LIB=$GRAFT_REPO_ROOT/gpurun_variants/liba3vt_RGW_OFF.so python tools/stack_bench.py --reps 20 --no-profile | tail -1; echo '== shipped'; python tools/stack_bench.py | tail -4 | head -3; python tools/stack_bench.py --reps 20 --no-profile | tail -1) > $O/${R}_product_kernels_ab.txt 2>/dev/null
 # round 6, bf16 configurations: the fused BatchNorm + ReLU operator against MIOpen's per map shape; the tiled aggregation's stamps and its A/B builds
 python tools/bnrelu_bench.py > $O/${R}_bnrelu_vs_miopen.txt 2>/dev/null
 [ -f gpurun_variants/liba3vt_T16_STAMPS.so ] && A3VT_LIB=$GRAFT_REPO_ROOT/gpurun_variants/liba3vt_T16_STAMPS.so python tools/csr16t_stamps.py > $O/${R}_csr16t_stamps.txt 2>/dev/null
-(echo '== shipped (tiles of 64, one staging buffer, four workgroups per CU, streaming stores)'; python tools/stack_bench.py --precision bf16s --layers 20 | tail -1
- for v in T16_NO_NT T16_2BUF; do [ -f gpurun_variants/liba3vt_$v.so ] && (echo "== $v"; A3VT_LIB=$GRAFT_REPO_ROOT/gpurun_variants/liba3vt_$v.so python tools/stack_bench.py --precision bf16s --layers 20 | tail -1); done
- echo '== the row walk (a3vt_dbg_csr_algo = 1)'; python tools/stack_bench.py --precision bf16s --layers 20 --csr-algo rows | tail -1) > $O/${R}_csr16t_ab.txt 2>/dev/null
+# (whole forward + backward calls of one 20-layer stack without per-launch events, the builds interleaved, three rounds behind a warm-up process:
+#  a launch's isolated rocprofv3 average overstates what the tiles gain in situ — 35 / 33 -> 28 / 24 us isolated, ~3 us per launch in the stack)
+t16ab() { if [ "$1" = shipped ]; then python tools/stack_bench.py --precision bf16s --layers 20 --reps 30 --no-profile $2 | tail -1; else A3VT_LIB=$GRAFT_REPO_ROOT/gpurun_variants/liba3vt_$1.so python tools/stack_bench.py --precision bf16s --layers 20 --reps 30 --no-profile | tail -1; fi; }
+[ -f gpurun_variants/liba3vt_T16_2BUF.so ] && (t16ab shipped > /dev/null; for round in 1 2 3; do
+  echo "shipped (tiles of 64, one staging buffer, four workgroups per CU, streaming stores): $(t16ab shipped)"
+  echo "T16_NO_NT (plain stores):                                                            $(t16ab T16_NO_NT)"
+  echo "T16_2BUF (two staging buffers, two workgroups per CU):                               $(t16ab T16_2BUF)"
+  echo "the row walk (a3vt_dbg_csr_algo = 1):                                                $(t16ab shipped '--csr-algo rows')"
+done) > $O/${R}_csr16t_ab.txt 2>/dev/null
 (./tools/ubench/mfma_plus_valu; ./tools/ubench/mfma_gap_budget; ./tools/ubench/mfma_one_wave) > $O/${R}_fp32_pipe_ubench.txt 2>&1
 # channel-sliced aggregation: phase stamps per quad (tools/build_variants.sh stampsq) and the gather ablations (csrq)
 [ -f gpurun_variants/liba3vt_CSRQ_STAMPS.so ] && A3VT_LIB=$GRAFT_REPO_ROOT/gpurun_variants/liba3vt_CSRQ_STAMPS.so python tools/csrq_stamps.py > $O/${R}_csrq_stamps.txt 2>/dev/null
