@@ -146,6 +146,143 @@ __global__ __launch_bounds__(256) void pool_bwd_verts_kernel(PoolArgs a) {
   }
 }
 
+// ---- round 6: the same two kernels with every lane busy.  One wave per vertex with a lane per float4 channel group of ONE map
+// leaves 48 of 64 lanes idle on the 64-channel map and 32 on the 128-channel one, and a wave has four loads in flight per pass:
+// 120 / 164 us for 220 MB of features at bs 64 (1.8 / 1.3 TB/s).  Here a lane owns up to two of the vertex's (<= 128) channel
+// groups ACROSS the maps — its map, channel offset, size and bilinear set-up are its own — and a wave handles two vertices per
+// trip: sixteen 16-byte loads in flight per lane.  Same arithmetic per element as above (forward: bit-identical).
+struct LaneGroup {
+  int k, c;        // map and first channel of this lane's group (k < 0: none)
+  int C, H, W, off;
+};
+__device__ __forceinline__ LaneGroup lane_group(const PoolArgs &a, int g) {
+  LaneGroup r;
+  r.k = -1;
+  r.c = r.C = r.H = r.W = r.off = 0;
+  for (int k = 0; k < a.n_maps; ++k) {
+    const int g0 = a.off[k] >> 2, g1 = (a.off[k] + a.C[k]) >> 2;
+    if (g >= g0 && g < g1) {
+      r.k = k;
+      r.c = (g - g0) * 4;
+      r.C = a.C[k];
+      r.H = a.H[k];
+      r.W = a.W[k];
+      r.off = a.off[k];
+    }
+  }
+  return r;
+}
+__device__ __forceinline__ const float *lane_map(const PoolArgs &a, const LaneGroup &lg, int b) {
+  const float *mp = a.maps[0];
+#pragma unroll
+  for (int k = 1; k < kMaxMaps; ++k)
+    if (lg.k == k) mp = a.maps[k];
+  return mp + (long long)b * lg.H * lg.W * lg.C;
+}
+
+__global__ __launch_bounds__(256) void pool_fwd2_kernel(PoolArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long long m = (long long)a.batch * a.n_vert;
+  const LaneGroup lg[2] = {lane_group(a, lane), lane_group(a, lane + 64)};
+  const long long stride = (long long)gridDim.x * 4;
+  for (long long v0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); v0 < m; v0 += 2 * stride) {
+    f32x4 acc[2][2];
+    f32x4 c4[2][2][4];
+    float w4[2][2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const long long v = v0 + u * stride;
+      const bool von = v < m;
+      const long long vv = von ? v : v0;
+      const int b = (int)(vv / a.n_vert);
+      const Projected p = project(a.verts + vv * 3, a.proj);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        c4[u][j][0] = c4[u][j][1] = c4[u][j][2] = c4[u][j][3] = z4;
+        w4[u][j][0] = w4[u][j][1] = w4[u][j][2] = w4[u][j][3] = 0.f;
+        if (lg[j].k >= 0 && von) {
+          const Bilinear bl = bilinear_setup(p.gx, p.gy, lg[j].H, lg[j].W);
+          const float *nw = lane_map(a, lg[j], b) + ((long long)bl.y0 * lg[j].W + bl.x0) * lg[j].C + lg[j].c;
+          w4[u][j][0] = bl.wnw; w4[u][j][1] = bl.wne; w4[u][j][2] = bl.wsw; w4[u][j][3] = bl.wse;
+          if (bl.in_nw) c4[u][j][0] = *reinterpret_cast<const f32x4 *>(nw);
+          if (bl.in_ne) c4[u][j][1] = *reinterpret_cast<const f32x4 *>(nw + lg[j].C);
+          if (bl.in_sw) c4[u][j][2] = *reinterpret_cast<const f32x4 *>(nw + (long long)lg[j].W * lg[j].C);
+          if (bl.in_se) c4[u][j][3] = *reinterpret_cast<const f32x4 *>(nw + (long long)(lg[j].W + 1) * lg[j].C);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const long long v = v0 + u * stride;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        // (a corner outside the map contributes w * 0: the same sum as skipping it)
+        acc[u][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[u][j] += w4[u][j][q] * c4[u][j][q];
+        if (lg[j].k >= 0 && v < m) *reinterpret_cast<f32x4 *>(a.feats + v * a.ld + lg[j].off + lg[j].c) = acc[u][j];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void pool_bwd_verts2_kernel(PoolArgs a) {
+  const int lane = threadIdx.x & 63;
+  const long long m = (long long)a.batch * a.n_vert;
+  const LaneGroup lg[2] = {lane_group(a, lane), lane_group(a, lane + 64)};
+  const long long stride = (long long)gridDim.x * 4;
+  for (long long v0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); v0 < m; v0 += 2 * stride) {
+    float ggx[2] = {0.f, 0.f}, ggy[2] = {0.f, 0.f};
+    Projected pr[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const long long v = v0 + u * stride;
+      const bool von = v < m;
+      const long long vv = von ? v : v0;
+      const int b = (int)(vv / a.n_vert);
+      pr[u] = project(a.verts + vv * 3, a.proj);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (lg[j].k >= 0 && von) {
+          const Bilinear bl = bilinear_setup(pr[u].gx, pr[u].gy, lg[j].H, lg[j].W);
+          const float *nw = lane_map(a, lg[j], b) + ((long long)bl.y0 * lg[j].W + bl.x0) * lg[j].C + lg[j].c;
+          const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+          const f32x4 gv = *reinterpret_cast<const f32x4 *>(a.gfeats + vv * a.ld + lg[j].off + lg[j].c);
+          const f32x4 vnw = bl.in_nw ? *reinterpret_cast<const f32x4 *>(nw) : z4;
+          const f32x4 vne = bl.in_ne ? *reinterpret_cast<const f32x4 *>(nw + lg[j].C) : z4;
+          const f32x4 vsw = bl.in_sw ? *reinterpret_cast<const f32x4 *>(nw + (long long)lg[j].W * lg[j].C) : z4;
+          const f32x4 vse = bl.in_se ? *reinterpret_cast<const f32x4 *>(nw + (long long)(lg[j].W + 1) * lg[j].C) : z4;
+          const float x1 = (float)(bl.x0 + 1), y1 = (float)(bl.y0 + 1), x0 = (float)bl.x0, y0 = (float)bl.y0;
+          float gix = 0.f, giy = 0.f;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            gix += gv[t] * (-vnw[t] * (y1 - bl.iy) + vne[t] * (y1 - bl.iy) - vsw[t] * (bl.iy - y0) + vse[t] * (bl.iy - y0));
+            giy += gv[t] * (-vnw[t] * (x1 - bl.ix) - vne[t] * (bl.ix - x0) + vsw[t] * (x1 - bl.ix) + vse[t] * (bl.ix - x0));
+          }
+          ggx[u] += gix * ((float)(lg[j].W - 1) / 2.f);
+          ggy[u] += giy * ((float)(lg[j].H - 1) / 2.f);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const long long v = v0 + u * stride;
+      const float sx = wave_sum(ggx[u]), sy = wave_sum(ggy[u]);
+      if (lane == 0 && v < m) {
+        const Projected &p = pr[u];
+        const float gys = p.ys_patched ? 0.f : 2.f * sx, gxs = p.xs_patched ? 0.f : 2.f * sy;
+        const float inv = 1.f / (p.p2 * 256.f);
+        const float gp0 = gys * inv, gp1 = gxs * inv;
+        const float gp2 = p.z_patched ? 0.f : -(gys * p.p0 + gxs * p.p1) * inv / p.p2;
+        float *o = a.gverts + v * 3;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) o[d] = gp0 * a.proj[d] + gp1 * a.proj[4 + d] + gp2 * a.proj[8 + d];
+      }
+    }
+  }
+}
+
 // ---- backward, maps: workgroup = (sample, map, block of CB channels); the block's gradient image [H*W][CB] lives in
 // LDS, every vertex of the sample adds its four weighted corners, then the image is written once.  The accumulators
 // are 64-bit fixed point (common.h): integer sums do not depend on the order in which the vertices arrive, so the map
@@ -213,11 +350,22 @@ static int check_pool(const PoolArgs &a) {
   return 0;
 }
 
+// the lane-per-group kernels take a vertex whose maps are contiguous in the output row and hold <= 128 float4 groups in all
+static bool pool_lanes_cover(const PoolArgs &a) {
+  int off = 0;
+  for (int k = 0; k < a.n_maps; ++k) {
+    if (a.off[k] != off) return false;
+    off += a.C[k];
+  }
+  return off <= 512;
+}
+
 int launch_pool_fwd(PoolArgs a, hipStream_t s) {
   if (int rc = check_pool(a)) return rc;
   const long long m = (long long)a.batch * a.n_vert;
   const int grid = (int)(cdiv(m, 4) < 8192 ? cdiv(m, 4) : 8192);
-  A3VT_LAUNCH(pool_fwd_kernel, dim3(grid), dim3(256), 0, s, a);
+  if (pool_lanes_cover(a)) A3VT_LAUNCH(pool_fwd2_kernel, dim3(grid), dim3(256), 0, s, a);
+  else A3VT_LAUNCH(pool_fwd_kernel, dim3(grid), dim3(256), 0, s, a);
   A3VT_CHECK_LAUNCH();
   return 0;
 }
@@ -226,7 +374,8 @@ int launch_pool_bwd(PoolArgs a, hipStream_t s) {
   if (int rc = check_pool(a)) return rc;
   const long long m = (long long)a.batch * a.n_vert;
   const int grid = (int)(cdiv(m, 4) < 8192 ? cdiv(m, 4) : 8192);
-  A3VT_LAUNCH(pool_bwd_verts_kernel, dim3(grid), dim3(256), 0, s, a);
+  if (pool_lanes_cover(a)) A3VT_LAUNCH(pool_bwd_verts2_kernel, dim3(grid), dim3(256), 0, s, a);
+  else A3VT_LAUNCH(pool_bwd_verts_kernel, dim3(grid), dim3(256), 0, s, a);
   A3VT_CHECK_LAUNCH();
   for (int k = 0; k < a.n_maps; ++k) {
     const int px = a.H[k] * a.W[k];
