@@ -291,12 +291,10 @@ __global__ __launch_bounds__(256) void pool_bwd_verts2_kernel(PoolArgs a) {
 // |grad_feats| of the block's channels over the sample's vertices bounds every term (a first pass over the same values),
 // and a pixel receives at most one term per vertex and corner.
 constexpr int kPoolLdsCells = 8192;  // 64 KB of accumulators: 23*23 pixels x 8 channels, 7*7 x 128, 3*3 x 256 all fit
-__global__ __launch_bounds__(256) void pool_bwd_maps_kernel(PoolArgs a, int k, int CB) {
-  extern __shared__ long long img[];
-  __shared__ float red[4];
+__device__ __forceinline__ void pool_bwd_maps_body(const PoolArgs &a, int k, int CB, int block, long long *img, float *red) {
   const int C = a.C[k], H = a.H[k], W = a.W[k];
   const int nblk = (C + CB - 1) / CB;
-  const int b = blockIdx.x / nblk, c0 = (blockIdx.x % nblk) * CB;
+  const int b = block / nblk, c0 = (block % nblk) * CB;
   const int cb = min(CB, C - c0);
   const int lanes_c = CB >> 2;               // float4 groups per vertex
   const int vpar = 256 / lanes_c;            // vertices in flight
@@ -334,6 +332,21 @@ __global__ __launch_bounds__(256) void pool_bwd_maps_kernel(PoolArgs a, int k, i
     const int px = i / cb, c = i - px * cb;
     gm[(long long)px * C + c0 + c] = finite ? fix_to(img[px * CB + c], fs) : __builtin_nanf("");
   }
+}
+
+// all maps in ONE launch (round 6): the three launches of a pyramid are independent, each fills the chip twice over at most and
+// is bound by the latency of its serial vertex loop — 3 x 75 us back to back.  first[k] = first workgroup of map k.
+struct PoolMapsPlan {
+  int first[kMaxMaps + 1], cb[kMaxMaps];
+};
+__global__ __launch_bounds__(256) void pool_bwd_maps_all_kernel(PoolArgs a, PoolMapsPlan pl) {
+  extern __shared__ long long img[];
+  __shared__ float red[4];
+  int k = 0;
+#pragma unroll
+  for (int j = 1; j < kMaxMaps; ++j)
+    if (j < a.n_maps && (int)blockIdx.x >= pl.first[j]) k = j;
+  pool_bwd_maps_body(a, k, pl.cb[k], blockIdx.x - pl.first[k], img, red);
 }
 
 static int check_pool(const PoolArgs &a) {
@@ -377,6 +390,8 @@ int launch_pool_bwd(PoolArgs a, hipStream_t s) {
   if (pool_lanes_cover(a)) A3VT_LAUNCH(pool_bwd_verts2_kernel, dim3(grid), dim3(256), 0, s, a);
   else A3VT_LAUNCH(pool_bwd_verts_kernel, dim3(grid), dim3(256), 0, s, a);
   A3VT_CHECK_LAUNCH();
+  PoolMapsPlan pl{};
+  size_t lds = 0;
   for (int k = 0; k < a.n_maps; ++k) {
     const int px = a.H[k] * a.W[k];
     int CB = a.C[k];                                   // channel block: largest power-of-two split that fits LDS ...
@@ -384,10 +399,13 @@ int launch_pool_bwd(PoolArgs a, hipStream_t s) {
     if (px * CB > kPoolLdsCells) { set_error("image_pool: map %d x %d too large for the LDS image", a.H[k], a.W[k]); return -1; }
     while (CB > 8 && a.batch * cdiv(a.C[k], CB) < 512) CB >>= 1;   // ... and leaves every CU a couple of workgroups
     CB = (CB + 3) & ~3;
-    const int nblk = cdiv(a.C[k], CB);
-    A3VT_LAUNCH(pool_bwd_maps_kernel, dim3(a.batch * nblk), dim3(256), (size_t)px * CB * sizeof(long long), s, a, k, CB);
-    A3VT_CHECK_LAUNCH();
+    pl.cb[k] = CB;
+    pl.first[k + 1] = pl.first[k] + a.batch * cdiv(a.C[k], CB);
+    const size_t need = (size_t)px * CB * sizeof(long long);
+    lds = need > lds ? need : lds;
   }
+  A3VT_LAUNCH(pool_bwd_maps_all_kernel, dim3(pl.first[a.n_maps]), dim3(256), lds, s, a, pl);
+  A3VT_CHECK_LAUNCH();
   return 0;
 }
 
