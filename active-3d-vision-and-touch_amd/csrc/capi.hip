@@ -219,6 +219,7 @@ static inline int pad8(int n) { return (n + 7) & ~7; }
 // even so that the 2-byte groups of an 8-column epilogue store never straddle rows
 static inline int mask_ld16(int hidden, int cut_len) { return (pad8(cut_len) / 4 + (hidden + 3) / 4 + 1) & ~1; }
 
+constexpr int kStashInputLd = 608;   // pad8 of the widest stack input (check_stack16_dims: in_features <= 600)
 struct Stack16Layout {
   size_t wt, wt_stride;   // bf16 weight images (offsets / stride in floats)
   size_t feats16;         // [M][ld0] bf16: the stack's fp32 input features, converted
@@ -314,7 +315,8 @@ static int stack_fwd16(const float *feats, int ld_feats, int in_features, const 
     wi.transpose = 1;
     if (int rc = launch_weight_images16(wi, rowgemm_bt_rows(hidden), max_ld, s)) return rc;
   }
-  u16 *f16 = reinterpret_cast<u16 *>(scratch + L.feats16);
+  // the input rows in bf16: behind the hidden layers' rows in the stash when there is one (the backward reads them there)
+  u16 *f16 = acts ? static_cast<u16 *>(acts) + (size_t)(num_layers - 1) * m * L.ldh : reinterpret_cast<u16 *>(scratch + L.feats16);
   if (int rc = launch_cvt_rows(feats, ld_feats, in_features, f16, L.ld0, (long long)m, s)) return rc;
   // bounded-degree graphs: the aggregation reads its neighbour rows from LDS tiles (gcn_bf16s.hip, csr16t); plan per call
   const bool tiled = heavy == nullptr && cut_len > 0 && g_csr_algo != 1 && csr16t_ok(n_vert, cut_len, max_degree, (long long)m);
@@ -390,9 +392,10 @@ static int stack_bwd16(const float *feats, int ld_feats, int in_features, const 
     heavyT = reinterpret_cast<int32_t *>(scratch + L.heavy);
     if (int rc = launch_csr_heavy_list(rowptrT, n_vert, heavyT, s)) return rc;
   }
-  // the stack's input in bf16 again (the scratch is shared between calls: the forward's copy may be gone)
-  u16 *f16 = reinterpret_cast<u16 *>(scratch + L.feats16);
-  if (int rc = launch_cvt_rows(feats, ld_feats, in_features, f16, L.ld0, (long long)m, s)) return rc;
+  // the stack's input in bf16: the forward left it behind the hidden layers' rows in the stash (a3vt_gcn_stack_stash_bytes)
+  const u16 *f16 = acts16 + (size_t)last * m * L.ldh;
+  (void)feats;
+  (void)ld_feats;
   // the tiled aggregation's plan for A^T (see stack_fwd16)
   const bool tiled = heavyT == nullptr && cut_len > 0 && g_csr_algo != 1 && csr16t_ok(n_vert, cut_len, max_degreeT, (long long)m);
   int32_t *tplan = reinterpret_cast<int32_t *>(scratch + L.tplan);
@@ -660,7 +663,10 @@ int a3vt_gcn_stack_stash_bytes(int batch, int n_vert, int hidden, int num_layers
   if (num_layers < 2) return 0;
   const size_t m = (size_t)batch * n_vert, mpad = (m + 31) / 32 * 32;
   if (gemm_bf16 == 2) {
-    *acts_bytes = (size_t)(num_layers - 1) * m * pad8(hidden) * 2 + 256;   // + slack: 16-byte reads of the last row's tail
+    // the hidden layers' bf16 rows, then the stack's INPUT rows in bf16 (the backward needs them for dW_0 and would otherwise
+    // convert the fp32 features a second time; sized for the widest input a stack accepts: in_features <= 600), + slack for
+    // 16-byte reads of the last row's tail
+    *acts_bytes = (size_t)(num_layers - 1) * m * pad8(hidden) * 2 + m * (size_t)kStashInputLd * 2 + 256;
     *mask_bytes = (size_t)(num_layers - 1) * mpad * mask_ld16(hidden, cut_len);
   } else {
     *acts_bytes = (size_t)(num_layers - 1) * m * hidden * sizeof(float);

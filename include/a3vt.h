@@ -86,7 +86,8 @@ size_t a3vt_gcn_stack_scratch_bytes(int batch, int n_vert, int in_features, int 
 size_t a3vt_gcn_stack_mask_bytes(int batch, int n_vert, int hidden, int num_layers, int cut_len);
 /* gemm_bf16 == 2, "bf16 storage" (BASELINE configs[3]/[4]): activations, their gradients and the weight images are kept
  * as bf16 in HBM (fp32 accumulation; fp32 weights, gradients of the weights, features and update at this boundary).
- * `acts` then holds bf16 rows of pad8(hidden) elements and the sign bytes use another row length: query both sizes
+ * `acts` then holds bf16 rows of pad8(hidden) elements — and, behind them, the stack's input rows in bf16, which the backward
+ * reads instead of converting `feats` again — and the sign bytes use another row length: query both sizes
  * with a3vt_gcn_stack_stash_bytes, and the scratch size with a3vt_gcn_stack_scratch_bytes_mode (or the all-modes
  * maximum a3vt_gcn_stack_scratch_bytes).  Needs >= 2 layers. */
 size_t a3vt_gcn_stack_scratch_bytes_mode(int batch, int n_vert, int in_features, int hidden, int num_layers,
