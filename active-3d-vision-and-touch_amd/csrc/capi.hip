@@ -1494,6 +1494,21 @@ int a3vt_image_pool_fwd(const float *verts, int batch, int n_vert, const float *
   return launch_pool_fwd(a, static_cast<hipStream_t>(stream));
 }
 
+int a3vt_image_pool_fwd_add(const float *verts, int batch, int n_vert, const float *proj, int n_maps,
+                            const float *const *maps, const int *chans, const int *heights, const int *widths,
+                            const float *base, float *feats, int ld_feats, void *stream) {
+  PoolArgs a{};
+  if (int rc = fill_pool_args(a, verts, batch, n_vert, proj, n_maps, maps, chans, heights, widths, ld_feats)) return rc;
+  A3VT_CHECK_ARG(feats != nullptr && base != nullptr);
+  int width = 0;
+  for (int k = 0; k < n_maps; ++k) width += chans[k];
+  A3VT_CHECK_ARG(width == ld_feats);     // every column of a row is written: feats = base + pooled
+  a.feats = feats;
+  a.base = base;
+  ProfScope psc(PROF_ENC, static_cast<hipStream_t>(stream));
+  return launch_pool_fwd(a, static_cast<hipStream_t>(stream));
+}
+
 int a3vt_image_pool_bwd(const float *verts, int batch, int n_vert, const float *proj, int n_maps,
                         const float *const *maps, const int *chans, const int *heights, const int *widths,
                         const float *grad_feats, int ld_feats, float *const *grad_maps, float *grad_verts,

@@ -305,6 +305,7 @@ struct PoolArgs {
   float *gmaps[kMaxMaps];        // backward: gradient of the maps, same layout (overwritten)
   int C[kMaxMaps], H[kMaxMaps], W[kMaxMaps], off[kMaxMaps];  // off = first output channel of the map
   float *feats;         // fwd out  [B*N][ld]
+  const float *base;    // fwd, optional [B*N][ld]: feats = base + pooled (the reference's `positional + mask + image` sum)
   const float *gfeats;  // bwd in   [B*N][ld]
   int ld;
   float *gverts;        // bwd out  [B*N][3]

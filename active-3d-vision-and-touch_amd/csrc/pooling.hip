@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(PoolArgs a) {
         if (bl.in_ne) acc += bl.wne * *reinterpret_cast<const f32x4 *>(nw + C + c);
         if (bl.in_sw) acc += bl.wsw * *reinterpret_cast<const f32x4 *>(nw + (long long)W * C + c);
         if (bl.in_se) acc += bl.wse * *reinterpret_cast<const f32x4 *>(nw + (long long)(W + 1) * C + c);
+        if (a.base) acc = *reinterpret_cast<const f32x4 *>(a.base + v * a.ld + a.off[k] + c) + acc;
         *reinterpret_cast<f32x4 *>(out + a.off[k] + c) = acc;
       }
     }
@@ -221,7 +222,10 @@ __global__ __launch_bounds__(256) void pool_fwd2_kernel(PoolArgs a) {
         acc[u][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[u][j] += w4[u][j][q] * c4[u][j][q];
-        if (lg[j].k >= 0 && v < m) *reinterpret_cast<f32x4 *>(a.feats + v * a.ld + lg[j].off + lg[j].c) = acc[u][j];
+        if (lg[j].k >= 0 && v < m) {
+          if (a.base) acc[u][j] = *reinterpret_cast<const f32x4 *>(a.base + v * a.ld + lg[j].off + lg[j].c) + acc[u][j];
+          *reinterpret_cast<f32x4 *>(a.feats + v * a.ld + lg[j].off + lg[j].c) = acc[u][j];
+        }
       }
     }
   }

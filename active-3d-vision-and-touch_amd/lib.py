@@ -66,6 +66,7 @@ SIGNATURES = {
     "a3vt_posenc_wide_fwd": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp]),
     "a3vt_posenc_wide_bwd": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "a3vt_image_pool_fwd": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "a3vt_image_pool_fwd_add": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "a3vt_image_pool_bwd": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "a3vt_bias_grad_scratch_bytes": (_sz, [ctypes.c_longlong, _i]),
     "a3vt_bias_grad_nhwc": (_i, [_vp, _i, ctypes.c_longlong, _i, _vp, _vp, _sz, _vp]),

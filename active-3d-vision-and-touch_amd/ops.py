@@ -379,7 +379,9 @@ class ImagePoolFn(torch.autograd.Function):
     Maps are consumed in torch's channels_last memory format (converted here if they are not already)."""
 
     @staticmethod
-    def forward(ctx, verts, matrix, *maps):
+    def forward(ctx, verts, matrix, base, *maps):
+        """``base`` (optional, (B,N,sum C_k) fp32): the result is ``base + pooled`` — the sum of vision/model.py:243,265,277 in
+        the pooling's own pass (``a3vt_image_pool_fwd_add``); its gradient is the output gradient itself."""
         L = _lib.load()
         verts = _req(verts, "verts")
         B, N, _ = verts.shape
@@ -395,10 +397,17 @@ class ImagePoolFn(torch.autograd.Function):
         proj = (ctypes.c_float * 12)(*[float(x) for x in matrix])
         ints = lambda xs: (ctypes.c_int * len(xs))(*xs)  # noqa: E731
         geo = (ints(chans), ints([int(m.shape[2]) for m in cl]), ints([int(m.shape[3]) for m in cl]))
-        _lib.check(L.a3vt_image_pool_fwd(_lib.ptr(verts), B, N, proj, len(cl), _ptr_array(cl), *geo, _lib.ptr(feats), ld,
-                                         _stream()), "image_pool_fwd")
+        if base is not None:
+            base = _req(base, "base")
+            if tuple(base.shape) != (B, N, ld):
+                raise RuntimeError(f"a3vt: image_pool base must be {(B, N, ld)}, got {tuple(base.shape)}")
+            _lib.check(L.a3vt_image_pool_fwd_add(_lib.ptr(verts), B, N, proj, len(cl), _ptr_array(cl), *geo, _lib.ptr(base),
+                                                 _lib.ptr(feats), ld, _stream()), "image_pool_fwd_add")
+        else:
+            _lib.check(L.a3vt_image_pool_fwd(_lib.ptr(verts), B, N, proj, len(cl), _ptr_array(cl), *geo, _lib.ptr(feats), ld,
+                                             _stream()), "image_pool_fwd")
         ctx.save_for_backward(verts, *cl)
-        ctx.proj, ctx.geo = proj, geo
+        ctx.proj, ctx.geo, ctx.has_base = proj, geo, base is not None
         return feats
 
     @staticmethod
@@ -412,11 +421,12 @@ class ImagePoolFn(torch.autograd.Function):
         _lib.check(L.a3vt_image_pool_bwd(_lib.ptr(verts), B, N, ctx.proj, len(cl), _ptr_array(cl), *ctx.geo,
                                          _lib.ptr(gfeats), gfeats.shape[-1], _ptr_array(gmaps), _lib.ptr(gverts),
                                          _stream()), "image_pool_bwd")
-        return (gverts, None, *gmaps)
+        return (gverts, None, gfeats if ctx.has_base else None, *gmaps)
 
 
-def image_pool(verts, matrix, maps):
-    return ImagePoolFn.apply(verts, matrix, *maps)
+def image_pool(verts, matrix, maps, base=None):
+    """Image_Encoder.pooling; with ``base``: ``base + pooling`` in one pass (the vertex-feature sum of the image models)."""
+    return ImagePoolFn.apply(verts, matrix, base, *maps)
 
 
 def bias_grad_nhwc(grad):

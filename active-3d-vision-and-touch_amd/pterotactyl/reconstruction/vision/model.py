@@ -182,10 +182,10 @@ class Image_Encoder(nn.Module):
             maps = [m.float().contiguous(memory_format=torch.channels_last) for m in maps]
         return maps
 
-    def pooling(self, blocks, verts_pos):
+    def pooling(self, blocks, verts_pos, base=None):
         """Project vertices with K.RT, bilinear-sample every map at the projected pixel, concatenate (:70-103) — one
         fused HIP kernel (``a3vt_image_pool_fwd/bwd``) instead of three ``grid_sample`` calls and the concatenations."""
-        return _ops.image_pool(verts_pos.to(torch.float32), self._matrix_host, list(blocks))
+        return _ops.image_pool(verts_pos.to(torch.float32), self._matrix_host, list(blocks), base=base)
 
 
 _NERF_FREQS = [np.pi if i == 0 else np.pi * 2 * i for i in range(10)]   # reference :383-389
@@ -361,7 +361,11 @@ class Deformation(nn.Module):
         else:  # input sizes the library does not take (not a multiple of 8): torch ops, padded to the 4-float row granule
             feats = self.positional_encoder(vertices) + self.mask_encoder(mask)
         if img_maps is not None:
-            feats = feats + self.img_encoder_global.pooling(img_maps, vertices)       # always the global encoder's
+            enc = self.img_encoder_global                                                  # always the global encoder's
+            if feats.is_cuda and feats.dtype == torch.float32 and feats.shape[-1] == sum(int(m.shape[1]) for m in img_maps):
+                feats = enc.pooling(img_maps, vertices, base=feats)     # the sum in the pooling's own pass
+            else:
+                feats = feats + enc.pooling(img_maps, vertices)
         if packed is None and self.ld_feats != self.input_size:                       # projection (:243,265,277)
             feats = F.pad(feats, (0, self.ld_feats - self.input_size))
         return feats.contiguous()
@@ -372,6 +376,9 @@ class Deformation(nn.Module):
             global_maps, local_maps = img_features
         elif use_img:
             img = img.to(charts["vision_charts"].device)
+            if self.img_encoder_global._bf16_branch(img) and not img.requires_grad:
+                # both encoders read the image channels-last in bf16: one conversion for the two (each made its own: 4 copies)
+                img = img.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
             global_maps, local_maps = self.img_encoder_global(img), self.img_encoder_local(img)
         else:
             global_maps, local_maps = [], []

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define A3VT_VERSION 161 /* 161: a3vt_bnrelu_fwd / _bwd (training BatchNorm2d + ReLU of the image pyramid on channels-last bf16 maps), a3vt_cast_weights_bf16; 160: a3vt_adj_split, a3vt_adj_split_validate, a3vt_gcn_stack_fwd_adj / _bwd_adj (the fused vision + touch adjacency as P + a complete bipartite block); 150: a3vt_dbg_path_counts, larger a3vt_chamfer_workspace_bytes (oriented boxes of the pruned search), a3vt_gcn_stack_scratch_bytes covers every gemm mode, gemm_bf16 outside 0..3 refused; 140: gemm_bf16 = 3 ("fp32x3": fp32 products as six bf16 MFMA passes on exactly split operands), a3vt_split3_bf16; 0.2.x: bf16 storage mode (gemm_bf16 = 2), a3vt_gcn_stack_stash_bytes / _scratch_bytes_mode, deterministic backward scatters; 120: a3vt_chamfer_fwd_ws (pruned exact search); 130: a3vt_posenc_wide_* (448-wide vertex-feature encoder), larger a3vt_gcn_stack_mask_bytes / _scratch_bytes (channel-sliced aggregation) */
+#define A3VT_VERSION 161 /* 161: a3vt_bnrelu_fwd / _bwd (training BatchNorm2d + ReLU of the image pyramid on channels-last bf16 maps), a3vt_cast_weights_bf16, a3vt_image_pool_fwd_add; 160: a3vt_adj_split, a3vt_adj_split_validate, a3vt_gcn_stack_fwd_adj / _bwd_adj (the fused vision + touch adjacency as P + a complete bipartite block); 150: a3vt_dbg_path_counts, larger a3vt_chamfer_workspace_bytes (oriented boxes of the pruned search), a3vt_gcn_stack_scratch_bytes covers every gemm mode, gemm_bf16 outside 0..3 refused; 140: gemm_bf16 = 3 ("fp32x3": fp32 products as six bf16 MFMA passes on exactly split operands), a3vt_split3_bf16; 0.2.x: bf16 storage mode (gemm_bf16 = 2), a3vt_gcn_stack_stash_bytes / _scratch_bytes_mode, deterministic backward scatters; 120: a3vt_chamfer_fwd_ws (pruned exact search); 130: a3vt_posenc_wide_* (448-wide vertex-feature encoder), larger a3vt_gcn_stack_mask_bytes / _scratch_bytes (channel-sliced aggregation) */
 
 int a3vt_version(void);
 const char *a3vt_last_error(void);
@@ -257,6 +257,12 @@ int a3vt_posenc_wide_bwd(const float *verts, const float *mask, int m, int input
 int a3vt_image_pool_fwd(const float *verts, int batch, int n_vert, const float *proj_host, int n_maps,
                         const float *const *maps, const int *chans, const int *heights, const int *widths,
                         float *feats, int ld_feats, void *stream);
+/* The same with the sum of model.py:243,265,277 folded in: feats = base + pooled, `base` = the positional + mask features
+ * [B*N][ld_feats] (a3vt_posenc_mask_fwd); ld_feats must equal sum C_k.  One pass instead of the pooling's store plus a
+ * separate 3 x 220 MB element-wise add per refinement stage of configs[3].  feats may not alias base. */
+int a3vt_image_pool_fwd_add(const float *verts, int batch, int n_vert, const float *proj_host, int n_maps,
+                            const float *const *maps, const int *chans, const int *heights, const int *widths,
+                            const float *base, float *feats, int ld_feats, void *stream);
 int a3vt_image_pool_bwd(const float *verts, int batch, int n_vert, const float *proj_host, int n_maps,
                         const float *const *maps, const int *chans, const int *heights, const int *widths,
                         const float *grad_feats, int ld_feats, float *const *grad_maps, float *grad_verts,

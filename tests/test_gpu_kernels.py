@@ -228,6 +228,18 @@ def test_image_pool_fwd_bwd(cuda):
     md2 = [m.to(cuda).requires_grad_(True) for m in maps]
     (ops.image_pool(vd2, matrix, md2) * gout.to(cuda)).sum().backward()
     assert torch.equal(vd2.grad, vd.grad) and all(torch.equal(a.grad, b.grad) for a, b in zip(md, md2))
+    # round 6: the vertex-feature sum of the image models (model.py:243,265,277) in the pooling's own pass — the same fp32 add,
+    # so the same bits as `base + image_pool(...)`; the gradient of `base` is the output gradient itself
+    base = torch.randn(B, N, 448, generator=g).to(cuda).requires_grad_(True)
+    vd3 = verts.to(cuda).requires_grad_(True)
+    md3 = [m.to(cuda).requires_grad_(True) for m in maps]
+    f3 = ops.image_pool(vd3, matrix, md3, base=base)
+    assert torch.equal(f3.detach(), base.detach() + f.detach())
+    (f3 * gout.to(cuda)).sum().backward()
+    assert torch.equal(base.grad, gout.to(cuda)) and torch.equal(vd3.grad, vd.grad)
+    assert all(torch.equal(a.grad, b.grad) for a, b in zip(md, md3))
+    with pytest.raises(RuntimeError):
+        ops.image_pool(vd3.detach(), matrix, [m.detach() for m in md3], base=base.detach()[..., :440])
 
 
 @pytest.mark.parametrize("m,k,n", [(1000, 52, 300), (4099, 300, 300), (33000, 300, 300), (777, 300, 52)])
