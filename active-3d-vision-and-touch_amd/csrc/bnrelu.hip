@@ -178,6 +178,8 @@ struct BnFwd {
   long long n_elem, rows;
   int c;
   const float *gamma, *beta;
+  const float *pre_bias;   // optional [c]: a per-channel constant the producer did NOT add to x (a Conv2d bias): the statistics of x + pre_bias
+                           // differ from x's by the mean alone, so y is unchanged and only running_mean takes it
   float eps, momentum;
   float *running_mean, *running_var;
   long long *num_batches;
@@ -243,7 +245,8 @@ __global__ __launch_bounds__(kBnThreads) void bnrelu_stats_final_kernel(BnFwd p,
       p.save[3 * c + c0 + ch] = shift;
       if (p.running_mean) {
         const float unb = (float)(var * m / (m - 1.0));
-        p.running_mean[c0 + ch] = fmaf(p.momentum, meanf - p.running_mean[c0 + ch], p.running_mean[c0 + ch]);
+        const float mean_in = p.pre_bias ? meanf + p.pre_bias[c0 + ch] : meanf;
+        p.running_mean[c0 + ch] = fmaf(p.momentum, mean_in - p.running_mean[c0 + ch], p.running_mean[c0 + ch]);
         p.running_var[c0 + ch] = fmaf(p.momentum, unb - p.running_var[c0 + ch], p.running_var[c0 + ch]);
       }
     }
@@ -486,9 +489,9 @@ static int bnrelu_reduce_wgs(long long n_elem, int c) { return bnrelu_wgs(n_elem
 // scratch: 64 bytes unused, then the backward's coefficients [2][c], then the partial rows [kBnMaxWgs][2][c]
 size_t bnrelu_scratch_bytes(int c) { return 64 + ((size_t)2 * c + (size_t)kBnMaxWgs * 2 * c) * sizeof(float); }
 
-int launch_bnrelu_fwd(const void *x, long long rows, int c, const float *gamma, const float *beta, float eps, float momentum,
-                      float *running_mean, float *running_var, long long *num_batches, void *y, float *save, void *scratch,
-                      hipStream_t s) {
+int launch_bnrelu_fwd(const void *x, long long rows, int c, const float *gamma, const float *beta, const float *pre_bias, float eps,
+                      float momentum, float *running_mean, float *running_var, long long *num_batches, void *y, float *save,
+                      void *scratch, hipStream_t s) {
   BnFwd p;
   p.x = static_cast<const uint16_t *>(x);
   p.y = static_cast<uint16_t *>(y);
@@ -497,6 +500,7 @@ int launch_bnrelu_fwd(const void *x, long long rows, int c, const float *gamma, 
   p.c = c;
   p.gamma = gamma;
   p.beta = beta;
+  p.pre_bias = pre_bias;
   p.eps = eps;
   p.momentum = momentum;
   p.running_mean = running_mean;

@@ -1543,8 +1543,8 @@ int a3vt_bias_grad_nhwc(const void *grad, int bf16, long long rows, int channels
 
 size_t a3vt_bnrelu_scratch_bytes(int channels) { return channels > 0 ? bnrelu_scratch_bytes(channels) : 0; }
 
-int a3vt_bnrelu_fwd(const void *x, long long rows, int channels, const float *gamma, const float *beta, float eps,
-                    float momentum, float *running_mean, float *running_var, long long *num_batches_tracked, void *y,
+int a3vt_bnrelu_fwd(const void *x, long long rows, int channels, const float *gamma, const float *beta, const float *pre_bias,
+                    float eps, float momentum, float *running_mean, float *running_var, long long *num_batches_tracked, void *y,
                     float *save, void *scratch, size_t scratch_bytes, void *stream) {
   A3VT_CHECK_ARG(x && y && gamma && beta && save && scratch);
   A3VT_CHECK_ARG(rows >= 2 && channels > 0 && rows <= (1ll << 40) / channels);
@@ -1553,7 +1553,7 @@ int a3vt_bnrelu_fwd(const void *x, long long rows, int channels, const float *ga
   A3VT_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(scratch)) & 15) == 0);
   A3VT_CHECK_ARG(bnrelu_wgs(rows * channels, channels, 4, 1024) > 0 && scratch_bytes >= bnrelu_scratch_bytes(channels));
   ProfScope psc(PROF_ENC, static_cast<hipStream_t>(stream));
-  return launch_bnrelu_fwd(x, rows, channels, gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, y,
+  return launch_bnrelu_fwd(x, rows, channels, gamma, beta, pre_bias, eps, momentum, running_mean, running_var, num_batches_tracked, y,
                            save, scratch, static_cast<hipStream_t>(stream));
 }
 

@@ -320,9 +320,9 @@ int launch_bias_grad(const void *g, int bf16, long long rows, int c, float *out,
 // bnrelu.hip: training BatchNorm2d + ReLU on channels-last bf16 maps (save: [4][c] mean, invstd, scale, shift)
 int bnrelu_wgs(long long n_elem, int c, int per_thread, int cap);
 size_t bnrelu_scratch_bytes(int c);
-int launch_bnrelu_fwd(const void *x, long long rows, int c, const float *gamma, const float *beta, float eps, float momentum,
-                      float *running_mean, float *running_var, long long *num_batches, void *y, float *save, void *scratch,
-                      hipStream_t s);
+int launch_bnrelu_fwd(const void *x, long long rows, int c, const float *gamma, const float *beta, const float *pre_bias, float eps,
+                      float momentum, float *running_mean, float *running_var, long long *num_batches, void *y, float *save,
+                      void *scratch, hipStream_t s);
 int launch_bnrelu_bwd(const void *dy, const void *x, long long rows, int c, const float *save, void *dx, float *dgamma,
                       float *dbeta, float *dx_colsum, void *scratch, hipStream_t s);
 

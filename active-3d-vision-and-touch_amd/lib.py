@@ -72,7 +72,7 @@ SIGNATURES = {
     "a3vt_bias_grad_nhwc": (_i, [_vp, _i, ctypes.c_longlong, _i, _vp, _vp, _sz, _vp]),
     "a3vt_cast_weights_bf16": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "a3vt_bnrelu_scratch_bytes": (_sz, [_i]),
-    "a3vt_bnrelu_fwd": (_i, [_vp, ctypes.c_longlong, _i, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "a3vt_bnrelu_fwd": (_i, [_vp, ctypes.c_longlong, _i, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "a3vt_bnrelu_bwd": (_i, [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "a3vt_vertex_update": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "a3vt_face_cdf": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),

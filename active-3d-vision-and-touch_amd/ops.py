@@ -550,10 +550,12 @@ class ConvNHWCFn(torch.autograd.Function):
     reduction of the channels-last output gradient takes 1.3 ms on the 3-channel full-resolution map)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding):
+    def forward(ctx, x, weight, bias, stride, padding, add_bias=True):
+        """``add_bias=False``: the output feeds a training-mode BatchNorm only (``BNReLUFn(..., pre_bias=bias)``), which removes
+        the shift again: the bias-add launch is skipped; the bias gradient is formed as before."""
         xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         wb = _bf16_copy(weight, True)
-        y = torch.ops.aten.convolution(xb, wb, _bf16_copy(bias, False), stride, padding, [1, 1], False, [0, 0], 1)
+        y = torch.ops.aten.convolution(xb, wb, _bf16_copy(bias, False) if add_bias else None, stride, padding, [1, 1], False, [0, 0], 1)
         ctx.save_for_backward(xb, wb)
         ctx.conf = (stride, padding, x.dtype, weight.dtype, bias.dtype)
         return y
@@ -571,7 +573,7 @@ class ConvNHWCFn(torch.autograd.Function):
             STATS["bias_grad_from_bnrelu"] = STATS.get("bias_grad_from_bnrelu", 0) + 1
         else:
             gb = bias_grad_nhwc(gy)
-        return (gx.to(xdt) if gx is not None else None), gw.to(wdt, memory_format=torch.contiguous_format), gb.to(bdt), None, None
+        return (gx.to(xdt) if gx is not None else None), gw.to(wdt, memory_format=torch.contiguous_format), gb.to(bdt), None, None, None
 
 
 _BNRELU_SCRATCH = {}   # (device index, stream) -> zero-initialised scratch of a3vt_bnrelu_*; the launches leave it zero
@@ -591,10 +593,12 @@ def _bnrelu_scratch(dev):
 class BNReLUFn(torch.autograd.Function):
     """Training-mode ``nn.BatchNorm2d`` followed by ``nn.ReLU`` of a ``CNN_layer`` (vision/model.py:15-23) on a channels-last
     bf16 map: ``a3vt_bnrelu_fwd / _bwd``, two launches each way.  Updates the module's running statistics and
-    ``num_batches_tracked`` in place like the module does.  Returns a channels-last bf16 tensor."""
+    ``num_batches_tracked`` in place like the module does.  Returns a channels-last bf16 tensor.  ``pre_bias``: the bias of the
+    convolution in front when that convolution did NOT add it (``ConvNHWCFn(..., add_bias=False)``): batch statistics remove a
+    per-channel shift, so the output is the same and only ``running_mean`` takes the bias."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, num_batches, eps, momentum):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, num_batches, eps, momentum, pre_bias=None):
         L = _lib.load()
         if not x.is_cuda or x.dim() != 4 or x.dtype != torch.bfloat16:
             raise RuntimeError("a3vt: bnrelu takes a bfloat16 (B,C,H,W) tensor on the GPU")
@@ -607,7 +611,9 @@ class BNReLUFn(torch.autograd.Function):
         y = torch.empty_like(x, memory_format=torch.channels_last)
         save = torch.empty((4, C), dtype=torch.float32, device=x.device)
         scratch = _bnrelu_scratch(x.device)
-        _lib.check(L.a3vt_bnrelu_fwd(_lib.ptr(x), rows, C, _lib.ptr(gamma), _lib.ptr(beta), float(eps), float(momentum),
+        if pre_bias is not None:
+            pre_bias = _req(pre_bias.detach(), "pre_bias")
+        _lib.check(L.a3vt_bnrelu_fwd(_lib.ptr(x), rows, C, _lib.ptr(gamma), _lib.ptr(beta), _lib.ptr(pre_bias), float(eps), float(momentum),
                                      _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(num_batches),
                                      _lib.ptr(y), _lib.ptr(save), _lib.ptr(scratch), scratch.numel(), _stream()), "bnrelu_fwd")
         ctx.save_for_backward(x, save)
@@ -629,7 +635,7 @@ class BNReLUFn(torch.autograd.Function):
         # x is a Conv2d output in the pyramid: that layer's bias gradient is the column sum of gx, which the dx launch formed
         # on its way (ConvNHWCFn.backward picks it up if THIS tensor, unmodified, arrives as its output gradient)
         gx._a3vt_colsum = (colsum, gx._version, gx.data_ptr())
-        return gx, dg, db, None, None, None, None, None
+        return gx, dg, db, None, None, None, None, None, None
 
 
 class VertexUpdateFn(torch.autograd.Function):

@@ -111,6 +111,7 @@ class Image_Encoder(nn.Module):
 
     library_bias_grad = True   # (tools flip it to time torch's own reduction)
     fused_bn_relu = True       # training BatchNorm2d + ReLU through a3vt_bnrelu_* (False: MIOpen's BatchNorm + torch's ReLU)
+    fold_conv_bias = True      # a convolution in front of a fused BatchNorm leaves its bias to that operator (no bias-add launch)
     # MIOpen's training BatchNorm crashes the HOST on bf16 NHWC input at batch sizes below 4 (seen for 3 x 254^2, 3 x 64^2 and
     # 64 x 27^2 maps on the ROCm 7.2 image this was built on: tools/experiments/miopen_bn_nhwc_c3_crash.py).  Batches
     # smaller than this take the NCHW kernel instead (a last partial batch of an epoch, or a small per-rank shard: same
@@ -120,20 +121,28 @@ class Image_Encoder(nn.Module):
     _bn_fallback_reported = False
 
     @staticmethod
-    def _block_nhwc(block, x):
+    def _bn_fusable(m, x):
+        """A training-mode BatchNorm2d the library's BatchNorm + ReLU operator takes (csrc/bnrelu.hip)."""
+        return (Image_Encoder.fused_bn_relu and isinstance(m, nn.BatchNorm2d) and m.training and m.affine and m.track_running_stats
+                and m.momentum is not None and x.dtype == torch.bfloat16 and m.running_mean.dtype == torch.float32
+                and m.num_batches_tracked.dtype == torch.int64)
+
+    @staticmethod
+    def _block_nhwc(block, x, pre_bias=None, fold_bias=False):
         """One ``CNN_layer`` Sequential in the bf16 channels-last branch: BatchNorm / ReLU as they are (MIOpen under
-        autocast), the convolution through ``ops.ConvNHWCFn`` (same MIOpen kernels, bias gradient from the library)."""
-        mods, skip = list(block), False
+        autocast), the convolution through ``ops.ConvNHWCFn`` (same MIOpen kernels, bias gradient from the library).
+        ``pre_bias``: the bias the previous block's convolution did not add (this block's fused BatchNorm accounts for it);
+        ``fold_bias``: this block's convolution leaves its bias to the next block's BatchNorm.  Returns (x, bias left out)."""
+        mods, skip, left_out = list(block), False, None
         for i, m in enumerate(mods):
             if skip:          # the ReLU behind a fused BatchNorm
                 skip = False
                 continue
-            if (Image_Encoder.fused_bn_relu and isinstance(m, nn.BatchNorm2d) and m.training and m.affine and m.track_running_stats
-                    and m.momentum is not None and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
-                    and x.dtype == torch.bfloat16 and m.running_mean.dtype == torch.float32
-                    and m.num_batches_tracked.dtype == torch.int64):
-                # BatchNorm2d + ReLU as one operator (csrc/bnrelu.hip): two launches each way, any batch size
-                x = _ops.BNReLUFn.apply(x, m.weight, m.bias, m.running_mean, m.running_var, m.num_batches_tracked, m.eps, m.momentum)
+            if Image_Encoder._bn_fusable(m, x) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU):
+                # BatchNorm2d + ReLU as one operator (csrc/bnrelu.hip): three launches each way, any batch size
+                x = _ops.BNReLUFn.apply(x, m.weight, m.bias, m.running_mean, m.running_var, m.num_batches_tracked, m.eps, m.momentum,
+                                        pre_bias)
+                pre_bias = None
                 skip = True
             elif isinstance(m, nn.BatchNorm2d) and m.training and x.shape[0] < Image_Encoder.bn_nhwc_min_batch:
                 if not Image_Encoder._bn_fallback_reported:
@@ -146,11 +155,14 @@ class Image_Encoder(nn.Module):
             elif not isinstance(m, nn.Conv2d):
                 x = m(x)
             elif Image_Encoder.library_bias_grad and m.bias is not None and m.groups == 1 and tuple(m.dilation) == (1, 1):
-                x = _ops.ConvNHWCFn.apply(x, m.weight, m.bias, list(m.stride), list(m.padding))
+                x = _ops.ConvNHWCFn.apply(x, m.weight, m.bias, list(m.stride), list(m.padding), not fold_bias)
+                left_out = m.bias if fold_bias else None
             else:   # torch's own autocast convolution on a channels-last view of the weights
                 x = nn.functional.conv2d(x, m.weight.contiguous(memory_format=torch.channels_last), m.bias, m.stride,
                                          m.padding, m.dilation, m.groups)
-        return x
+        if pre_bias is not None:      # (never: a bias is only left out in front of a BatchNorm this function fuses)
+            raise RuntimeError("a3vt: a convolution bias was left to a BatchNorm that did not take it")
+        return x, left_out
 
     def forward(self, img):
         """Feature maps of the three layers ``layers_per_block`` apart from the end, plus the last map reached
@@ -171,10 +183,26 @@ class Image_Encoder(nn.Module):
                         size = (size + 2 * m.padding[0] - m.kernel_size[0]) // m.stride[0] + 1
             _ops.prefetch_bf16_copies([(m.weight, True) for m in convs] + [(m.bias, False) for m in convs if m.bias is not None])
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=low):
+            pre_bias = None
             for e, layer in enumerate(self.layers):
                 if x.shape[-1] < self.args.CNN_ker_size:
                     break
-                x = self._block_nhwc(layer, x) if low else layer(x)
+                if low:
+                    # This layer's convolution may leave its bias to the NEXT layer's fused BatchNorm (batch statistics remove a
+                    # per-channel shift: same output, one launch per layer and step less) when nothing else reads its output:
+                    # it is not pooled, the next layer runs, and that layer starts with a BatchNorm the operator takes.
+                    fold = False
+                    if self.fold_conv_bias and e not in picks and e + 1 < len(self.layers):
+                        conv = [m for m in layer if isinstance(m, nn.Conv2d)][0]
+                        out = (x.shape[-1] + 2 * conv.padding[0] - conv.kernel_size[0]) // conv.stride[0] + 1
+                        nxt = list(self.layers[e + 1])
+                        fold = (out >= self.args.CNN_ker_size and self.library_bias_grad and conv.bias is not None
+                                and conv.groups == 1 and tuple(conv.dilation) == (1, 1)
+                                and isinstance(nxt[0], nn.BatchNorm2d) and len(nxt) > 1 and isinstance(nxt[1], nn.ReLU)
+                                and self._bn_fusable(nxt[0], torch.empty(0, dtype=torch.bfloat16)))
+                    x, pre_bias = self._block_nhwc(layer, x, pre_bias, fold)
+                else:
+                    x = layer(x)
                 if e in picks:
                     maps.append(x)
             maps.append(x)

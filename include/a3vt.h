@@ -281,7 +281,9 @@ int a3vt_bias_grad_nhwc(const void *grad, int bf16, long long rows, int channels
  * step, model.py:147-164) on a channels-last bf16 map, three launches each way instead of 3 + 1 (+ the counter increment):
  *   y = relu(gamma * (x - mean_c) / sqrt(var_c + eps) + beta),  statistics over the rows per channel (biased variance);
  *   running_mean / running_var (unbiased variance, `momentum`) and *num_batches_tracked (+1) are updated as nn.BatchNorm2d
- *   does (pass NULL to skip either).  x, y, dy, dx: [rows = N*H*W][channels] bf16, 16-byte aligned; gamma, beta, dgamma,
+ *   does (pass NULL to skip either).  pre_bias (optional, fp32 [channels]): a per-channel constant the producer of x left
+ *   out — the bias of the Conv2d in front: batch statistics remove any such shift, so y is the same without the 28 bias-add
+ *   launches of a step, and only running_mean takes it (mean + pre_bias).  x, y, dy, dx: [rows = N*H*W][channels] bf16, 16-byte aligned; gamma, beta, dgamma,
  *   dbeta: fp32 [channels]; save: fp32 [4][channels] written by the forward (mean, 1/std, scale, shift), read by the backward.
  * Backward: dgamma = sum g * xhat, dbeta = sum g, dx = scale * (g - dbeta / rows - xhat * dgamma / rows), g = dy where y > 0
  * (the mask is recomputed from x with the forward's own coefficients).  dx_colsum (optional, fp32 [channels]): the column sums
@@ -289,8 +291,8 @@ int a3vt_bias_grad_nhwc(const void *grad, int bf16, long long rows, int channels
  * otherwise compute by reading dx again.  Fixed summation order, float64 final sums: repeatable
  * bit for bit.  rows >= 2.  scratch: a3vt_bnrelu_scratch_bytes(channels) bytes; one buffer may serve every layer of a stream. */
 size_t a3vt_bnrelu_scratch_bytes(int channels);
-int a3vt_bnrelu_fwd(const void *x, long long rows, int channels, const float *gamma, const float *beta, float eps,
-                    float momentum, float *running_mean, float *running_var, long long *num_batches_tracked, void *y,
+int a3vt_bnrelu_fwd(const void *x, long long rows, int channels, const float *gamma, const float *beta, const float *pre_bias,
+                    float eps, float momentum, float *running_mean, float *running_var, long long *num_batches_tracked, void *y,
                     float *save, void *scratch, size_t scratch_bytes, void *stream);
 int a3vt_bnrelu_bwd(const void *dy, const void *x, long long rows, int channels, const float *save, void *dx, float *dgamma,
                     float *dbeta, float *dx_colsum, void *scratch, size_t scratch_bytes, void *stream);

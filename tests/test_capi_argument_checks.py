@@ -72,7 +72,7 @@ def test_entry_points_refuse_bad_arguments_before_touching_them(L):
     f32 = ctypes.c_float
     # BatchNorm + ReLU: fewer than two rows, misaligned maps, one running statistic without the other, short scratch
     need = L.a3vt_bnrelu_scratch_bytes(16)
-    args = lambda **kw: [kw.get("x", FAKE), kw.get("rows", 100), kw.get("c", 16), FAKE, FAKE, f32(1e-5), f32(0.1),   # noqa: E731
+    args = lambda **kw: [kw.get("x", FAKE), kw.get("rows", 100), kw.get("c", 16), FAKE, FAKE, None, f32(1e-5), f32(0.1),   # noqa: E731
                          kw.get("rm", FAKE), kw.get("rv", FAKE), None, kw.get("y", FAKE), FAKE, FAKE, kw.get("sb", need), None]
     assert L.a3vt_bnrelu_fwd(*args(rows=1)) != 0
     assert L.a3vt_bnrelu_fwd(*args(x=FAKE_ODD)) != 0

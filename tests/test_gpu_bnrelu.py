@@ -176,3 +176,26 @@ def test_conv_bias_gradient_from_the_batchnorm_backward():
             grads.append((b.grad.clone(), w.grad.clone()))
         torch.testing.assert_close(grads[0][0], grads[1][0], rtol=1e-3, atol=5e-3)
         torch.testing.assert_close(grads[0][1], grads[1][1], rtol=2e-2, atol=2e-2)   # (MIOpen's weight gradient: fp32 atomics, bf16 result)
+
+
+def test_bnrelu_pre_bias_moves_only_the_running_mean():
+    """A Conv2d bias left to the BatchNorm behind it (``pre_bias``): batch statistics remove a per-channel shift, so the output
+    and the gradients are those without it, bit for bit, and ``running_mean`` is the one of ``x + bias``."""
+    from a3vt_amd import ops
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(6, 32, 19, 17, generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gamma, beta = (torch.rand(32, generator=g) + 0.5).to(dev), (torch.randn(32, generator=g) * 0.2).to(dev)
+    pb = (torch.randn(32, generator=g) * 0.7).to(dev)
+    gy = torch.randn(x.shape, generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    outs = []
+    for bias in (None, pb):
+        xx = x.clone().requires_grad_(True)
+        rm, rv = torch.zeros(32, device=dev), torch.ones(32, device=dev)
+        y = ops.BNReLUFn.apply(xx, gamma, beta, rm, rv, None, 1e-5, 0.1, bias)
+        y.backward(gy)
+        outs.append((y.detach(), xx.grad, rm, rv))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][3], outs[1][3])
+    torch.testing.assert_close(outs[1][2], outs[0][2] + 0.1 * pb, rtol=1e-6, atol=1e-7)
+    ref_mean = (x.float() + pb.view(1, -1, 1, 1)).mean(dim=(0, 2, 3))
+    torch.testing.assert_close(outs[1][2], 0.1 * ref_mean, rtol=1e-4, atol=1e-6)
