@@ -337,6 +337,11 @@ struct CastBatch {
 };
 int launch_cast_weights(const CastBatch &b, hipStream_t s);
 
+// conv5.hip: 5 x 5 stride-1 16 -> 16 convolution on channels-last bf16 maps (forward, and with flip = 1 / pad = 3 the input gradient)
+size_t conv5_weight_image_bytes();
+int launch_conv5_weight_image(const float *w, int flip, void *image, hipStream_t s);
+int launch_conv5x16(const void *x, int batch, int h, int w, int pad, const void *image, const float *bias, void *y, hipStream_t s);
+
 // chamfer.hip
 size_t chamfer_scratch_bytes(int draws, int batch, int q);
 // algo: 0 = choose (pruned search when the workspace holds it and the clouds are large enough to pay for the sort),
