@@ -1588,24 +1588,31 @@ int a3vt_cast_weights_bf16(int n, const float *const *src, void *const *dst, con
   return launch_cast_weights(b, static_cast<hipStream_t>(stream));
 }
 
-size_t a3vt_conv5x16_image_bytes(void) { return conv5_weight_image_bytes(); }
+int a3vt_conv5_supported(int cin, int cout, int stride) { return conv5_shape_ok(cin, cout, stride) ? 1 : 0; }
 
-int a3vt_conv5x16_weight_image(const float *weight, int flip, void *image, void *stream) {
-  A3VT_CHECK_ARG(weight && image && (flip == 0 || flip == 1));
-  A3VT_CHECK_ARG((reinterpret_cast<uintptr_t>(image) & 15) == 0);
-  return launch_conv5_weight_image(weight, flip, image, static_cast<hipStream_t>(stream));
+size_t a3vt_conv5_image_bytes(int cout, int cin, int flip) {
+  if ((cin != 16 && cin != 32) || (cout != 16 && cout != 32)) return 0;
+  return flip ? conv5_weight_image_bytes(cin, cout) : conv5_weight_image_bytes(cout, cin);
 }
 
-int a3vt_conv5x16(const void *x, int batch, int height, int width, int pad, const void *image, const float *bias, void *y,
-                  void *stream) {
+int a3vt_conv5_weight_image(const float *weight, int cout, int cin, int flip, void *image, void *stream) {
+  A3VT_CHECK_ARG(weight && image && (flip == 0 || flip == 1));
+  A3VT_CHECK_ARG((cin == 16 || cin == 32) && (cout == 16 || cout == 32));
+  A3VT_CHECK_ARG((reinterpret_cast<uintptr_t>(image) & 15) == 0);
+  return launch_conv5_weight_image(weight, flip, cout, cin, image, static_cast<hipStream_t>(stream));
+}
+
+int a3vt_conv5_nhwc(const void *x, int batch, int height, int width, int cin, int cout, int stride, int pad, const void *image,
+                    const float *bias, void *y, void *stream) {
   A3VT_CHECK_ARG(x && image && y);
+  A3VT_CHECK_ARG(conv5_shape_ok(cin, cout, stride));
   A3VT_CHECK_ARG(batch > 0 && height > 0 && width > 0 && pad >= 0 && pad <= 4);
   A3VT_CHECK_ARG(height + 2 * pad >= 5 && width + 2 * pad >= 5);
-  A3VT_CHECK_ARG((long long)batch * height * width <= (1ll << 31) / 16);
+  A3VT_CHECK_ARG((long long)batch * height * width <= (1ll << 31) / 32);
   A3VT_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(image)) & 15) == 0);
   A3VT_CHECK_ARG(bias == nullptr || (reinterpret_cast<uintptr_t>(bias) & 15) == 0);
   ProfScope psc(PROF_ENC, static_cast<hipStream_t>(stream));
-  return launch_conv5x16(x, batch, height, width, pad, image, bias, y, static_cast<hipStream_t>(stream));
+  return launch_conv5(x, batch, height, width, cin, cout, stride, pad, image, bias, y, static_cast<hipStream_t>(stream));
 }
 
 int a3vt_profile_enable(int on) {

@@ -23,9 +23,20 @@ using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using u16 = unsigned short;
 
-constexpr int kC = 16, kTaps = 25, kSteps = 13;   // channels in and out; taps; k-steps of 32 (two taps each)
-constexpr int kTile = 16, kPatch = kTile + 4;     // output tile edge; input patch edge
-constexpr int kPatchBytes = kPatch * kPatch * kC * 2;
+constexpr int kTaps = 25;
+constexpr int kTile = 16;                         // output tile edge (pixels)
+
+// Shape of an instantiation: CIN, COUT in {16, 32}, STRIDE in {1, 2}.  k index of the MFMA = (tap, input channel): two taps per
+// k-step of 32 with 16 input channels (13 steps, the 26th tap has zero weights), one tap per step with 32 (25 steps).
+template <int CIN, int COUT, int STRIDE>
+struct C5 {
+  static constexpr int kSteps = CIN == 16 ? 13 : 25;
+  static constexpr int kMB = COUT / 16;                              // 16-channel blocks of the output
+  static constexpr int kPatch = (kTile - 1) * STRIDE + 5;            // input patch edge: 20 (stride 1) or 35 (stride 2)
+  static constexpr int kPix = CIN * 2;                               // bytes per input pixel
+  static constexpr int kPatchBytes = kPatch * kPatch * kPix;
+  static constexpr int kImageElems = kMB * kSteps * 64 * 8;          // A fragments: [m-block][step][lane][8]
+};
 
 __device__ __attribute__((aligned(16))) unsigned g_conv5_zero[4];   // 16 bytes of zeros: the source of out-of-map patch pieces
 
@@ -40,99 +51,138 @@ __device__ __forceinline__ unsigned c5_pack(float a, float b) {   // two floats 
 }
 
 struct Conv5Args {
-  const u16 *x;       // [B][H][W][16] bf16
-  u16 *y;             // [B][Ho][Wo][16] bf16,  Ho = H + 2 pad - 4
-  const u16 *wfrag;   // [13][64][8] bf16: the A fragments (conv5_weight_image_kernel)
-  const float *bias;  // optional [16]
+  const u16 *x;       // [B][H][W][CIN] bf16
+  u16 *y;             // [B][Ho][Wo][COUT] bf16,  Ho = (H + 2 pad - 5) / stride + 1
+  const u16 *wfrag;   // the A fragments (conv5_weight_image_kernel)
+  const float *bias;  // optional [COUT]
   int B, H, W, Ho, Wo, pad, tiles_x, tiles_y;
 };
 
-// A fragments of the weights.  Forward: Wm[co][tap = 5 ky + kx][ci] = w[co][ci][ky][kx] (w fp32, OIHW); gradient with respect to
-// the input (flip != 0): Wm[ci][tap][co] = w[co][ci][4 - ky][4 - kx].  Fragment of k-step s for lane (m = lane & 15, q = lane >> 4):
-// the eight values Wm[m][2 s + (q >> 1)][8 (q & 1) .. + 8]; tap 25 is zeros.
-__global__ void conv5_weight_image_kernel(const float *__restrict__ w, int flip, u16 *__restrict__ out) {
+// A fragments of the weights.  Forward: Wm[co][tap = 5 ky + kx][ci] = w[co][ci][ky][kx] (w fp32, OIHW [cout][cin][5][5]); gradient
+// with respect to the input (flip != 0; then the roles of the channel counts swap): Wm[ci][tap][co] = w[co][ci][4 - ky][4 - kx].
+// Fragment of m-block mb, k-step s for lane (m = lane & 15, q = lane >> 4): eight consecutive k of row 16 mb + m, where
+// k = 8 q + e is (tap 2 s + (q >> 1), channel 8 (q & 1) + e) with 16 inner channels and (tap s, channel 8 q + e) with 32.
+__global__ void conv5_weight_image_kernel(const float *__restrict__ w, int flip, int rows, int inner, u16 *__restrict__ out) {
+  const int steps = inner == 16 ? 13 : 25;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= kSteps * 64 * 8) return;
-  const int e = i & 7, lane = (i >> 3) & 63, s = i >> 9;
-  const int m = lane & 15, q = lane >> 4;
-  const int tap = 2 * s + (q >> 1), c = 8 * (q & 1) + e;
+  if (i >= (rows / 16) * steps * 64 * 8) return;
+  const int e = i & 7, lane = (i >> 3) & 63, s = (i >> 9) % steps, mb = (i >> 9) / steps;
+  const int m = mb * 16 + (lane & 15), q = lane >> 4;
+  const int tap = inner == 16 ? 2 * s + (q >> 1) : s, c = inner == 16 ? 8 * (q & 1) + e : 8 * q + e;
   float v = 0.f;
   if (tap < kTaps) {
     const int ky = tap / 5, kx = tap % 5;
-    v = flip ? w[((c * kC + m) * 5 + (4 - ky)) * 5 + (4 - kx)] : w[((m * kC + c) * 5 + ky) * 5 + kx];
+    // forward: rows = cout, inner = cin, w[m][c]; flipped: rows = cin, inner = cout, w[co = c][ci = m]
+    v = flip ? w[((c * rows + m) * 5 + (4 - ky)) * 5 + (4 - kx)] : w[((m * inner + c) * 5 + ky) * 5 + kx];
   }
   out[i] = (u16)(c5_pack(v, 0.f) & 0xffffu);
 }
 
-__global__ __launch_bounds__(256) void conv5x16_kernel(Conv5Args a) {
+template <int CIN, int COUT, int STRIDE>
+__global__ __launch_bounds__(256) void conv5_kernel(Conv5Args a) {
+  using S = C5<CIN, COUT, STRIDE>;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l16 = lane & 15, q = lane >> 4;
   const int tx = blockIdx.x % a.tiles_x, ty = (blockIdx.x / a.tiles_x) % a.tiles_y, b = blockIdx.x / (a.tiles_x * a.tiles_y);
   const int ox0 = tx * kTile, oy0 = ty * kTile;
-  // ---- the input patch: pixel (py, px) of the patch is map pixel (oy0 + py - pad, ox0 + px - pad); two 16-byte pieces per pixel
+  // ---- the input patch: patch pixel (py, px) is map pixel (oy0 STRIDE + py - pad, ox0 STRIDE + px - pad); 16-byte pieces
   {
-    const u16 *xb = a.x + (size_t)b * a.H * a.W * kC;
-    constexpr int kPieces = kPatch * kPatch * 2;   // 800
+    const u16 *xb = a.x + (size_t)b * a.H * a.W * CIN;
+    constexpr int kPP = S::kPix / 16;                             // pieces per pixel: 2 or 4
+    constexpr int kPieces = S::kPatch * S::kPatch * kPP;
     for (int i0 = wave * 64; i0 < kPieces; i0 += 256) {
       const int i = i0 + lane;
       if (i < kPieces) {
-        const int p = i >> 1, half = i & 1;
-        const int py = p / kPatch, px = p - py * kPatch;
-        const int iy = oy0 + py - a.pad, ix = ox0 + px - a.pad;
+        const int p = i / kPP, part = i - p * kPP;
+        const int py = p / S::kPatch, px = p - py * S::kPatch;
+        const int iy = oy0 * STRIDE + py - a.pad, ix = ox0 * STRIDE + px - a.pad;
         const void *src = (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-                              ? static_cast<const void *>(xb + ((size_t)iy * a.W + ix) * kC + half * 8)
+                              ? static_cast<const void *>(xb + ((size_t)iy * a.W + ix) * CIN + part * 8)
                               : static_cast<const void *>(g_conv5_zero);
         c5_glds16(src, lds + i0 * 16);
       }
     }
   }
-  // ---- the weights' A fragments (13 x 16 bytes per lane) and this lane's LDS offsets per k-step
-  u32x4 wf[kSteps];
-  int off[kSteps];
+  // ---- the weights' A fragments and this lane's LDS offsets per k-step
+  u32x4 wf[S::kMB][S::kSteps];
+  int off[S::kSteps];
 #pragma unroll
-  for (int s = 0; s < kSteps; ++s) {
-    wf[s] = *reinterpret_cast<const u32x4 *>(a.wfrag + ((size_t)s * 64 + lane) * 8);
-    int tap = 2 * s + (q >> 1);
+  for (int s = 0; s < S::kSteps; ++s) {
+#pragma unroll
+    for (int mb = 0; mb < S::kMB; ++mb)
+      wf[mb][s] = *reinterpret_cast<const u32x4 *>(a.wfrag + (((size_t)mb * S::kSteps + s) * 64 + lane) * 8);
+    int tap = CIN == 16 ? 2 * s + (q >> 1) : s;
     tap = tap < kTaps ? tap : kTaps - 1;          // (the 26th tap: zero weights; any finite pixel will do)
     const int ky = tap / 5, kx = tap - ky * 5;
-    off[s] = ((ky * kPatch + kx) * kC + (q & 1) * 8) * 2;
+    off[s] = (ky * S::kPatch + kx) * S::kPix + (CIN == 16 ? (q & 1) : q) * 16;
   }
-  f32x4 bs = {0.f, 0.f, 0.f, 0.f};
-  if (a.bias) bs = *reinterpret_cast<const f32x4 *>(a.bias + 4 * q);
+  f32x4 bs[S::kMB];
+#pragma unroll
+  for (int mb = 0; mb < S::kMB; ++mb) {
+    bs[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.bias) bs[mb] = *reinterpret_cast<const f32x4 *>(a.bias + mb * 16 + 4 * q);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // ---- four output rows of 16 pixels per wave; D[m = channel][n = pixel]: this lane holds channels 4 q .. 4 q + 3 of pixel l16
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
     const int r = wave * 4 + rr;
-    const char *base = lds + ((r * kPatch + l16) * kC) * 2;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const char *base = lds + (r * STRIDE * S::kPatch + l16 * STRIDE) * S::kPix;
+    f32x4 acc[S::kMB];
 #pragma unroll
-    for (int s = 0; s < kSteps; ++s) {
+    for (int mb = 0; mb < S::kMB; ++mb) acc[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < S::kSteps; ++s) {
       const u32x4 pix = *reinterpret_cast<const u32x4 *>(base + off[s]);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[s]), __builtin_bit_cast(bf16x8, pix), acc, 0, 0, 0);
+#pragma unroll
+      for (int mb = 0; mb < S::kMB; ++mb)
+        acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[mb][s]), __builtin_bit_cast(bf16x8, pix), acc[mb], 0, 0, 0);
     }
     const int oy = oy0 + r, ox = ox0 + l16;
     if (oy < a.Ho && ox < a.Wo) {
-      acc += bs;
-      const u32x2 o = {c5_pack(acc[0], acc[1]), c5_pack(acc[2], acc[3])};
-      *reinterpret_cast<u32x2 *>(a.y + (((size_t)b * a.Ho + oy) * a.Wo + ox) * kC + 4 * q) = o;
+#pragma unroll
+      for (int mb = 0; mb < S::kMB; ++mb) {
+        const f32x4 v = acc[mb] + bs[mb];
+        const u32x2 o = {c5_pack(v[0], v[1]), c5_pack(v[2], v[3])};
+        *reinterpret_cast<u32x2 *>(a.y + (((size_t)b * a.Ho + oy) * a.Wo + ox) * COUT + mb * 16 + 4 * q) = o;
+      }
     }
   }
 }
 
-}  // namespace
-
-size_t conv5_weight_image_bytes() { return (size_t)kSteps * 64 * 8 * sizeof(u16); }
-
-int launch_conv5_weight_image(const float *w, int flip, void *image, hipStream_t s) {
-  const int n = kSteps * 64 * 8;
-  A3VT_LAUNCH(conv5_weight_image_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, flip, static_cast<u16 *>(image));
+template <int CIN, int COUT, int STRIDE>
+int conv5_launch(const Conv5Args &a, hipStream_t s) {
+  using S = C5<CIN, COUT, STRIDE>;
+  static OncePerDevice once;
+  once.run([] {
+    (void)hipFuncSetAttribute((const void *)conv5_kernel<CIN, COUT, STRIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, S::kPatchBytes);
+  });
+  A3VT_LAUNCH((conv5_kernel<CIN, COUT, STRIDE>), dim3((unsigned)(a.B * a.tiles_x * a.tiles_y)), dim3(256), S::kPatchBytes, s, a);
   A3VT_CHECK_LAUNCH();
   return 0;
 }
 
-int launch_conv5x16(const void *x, int batch, int h, int w, int pad, const void *image, const float *bias, void *y, hipStream_t s) {
+}  // namespace
+
+// the shapes taken: (cin, cout, stride) in {(16,16,1), (32,32,1), (16,32,2)} — layers 2-3, 5-6 and 4 of the pyramid; with stride 1 the
+// input gradient is the same kernel (weights flipped, padding 3)
+bool conv5_shape_ok(int cin, int cout, int stride) {
+  return (cin == 16 && cout == 16 && stride == 1) || (cin == 32 && cout == 32 && stride == 1) || (cin == 16 && cout == 32 && stride == 2);
+}
+
+size_t conv5_weight_image_bytes(int rows, int inner) { return (size_t)(rows / 16) * (inner == 16 ? 13 : 25) * 64 * 8 * sizeof(u16); }
+
+int launch_conv5_weight_image(const float *w, int flip, int cout, int cin, void *image, hipStream_t s) {
+  const int rows = flip ? cin : cout, inner = flip ? cout : cin;
+  const int n = (rows / 16) * (inner == 16 ? 13 : 25) * 64 * 8;
+  A3VT_LAUNCH(conv5_weight_image_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, flip, rows, inner, static_cast<u16 *>(image));
+  A3VT_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_conv5(const void *x, int batch, int h, int w, int cin, int cout, int stride, int pad, const void *image, const float *bias,
+                 void *y, hipStream_t s) {
   Conv5Args a{};
   a.x = static_cast<const u16 *>(x);
   a.y = static_cast<u16 *>(y);
@@ -142,13 +192,15 @@ int launch_conv5x16(const void *x, int batch, int h, int w, int pad, const void 
   a.H = h;
   a.W = w;
   a.pad = pad;
-  a.Ho = h + 2 * pad - 4;
-  a.Wo = w + 2 * pad - 4;
+  a.Ho = (h + 2 * pad - 5) / stride + 1;
+  a.Wo = (w + 2 * pad - 5) / stride + 1;
   a.tiles_x = (a.Wo + kTile - 1) / kTile;
   a.tiles_y = (a.Ho + kTile - 1) / kTile;
-  A3VT_LAUNCH(conv5x16_kernel, dim3((unsigned)(batch * a.tiles_x * a.tiles_y)), dim3(256), kPatchBytes, s, a);
-  A3VT_CHECK_LAUNCH();
-  return 0;
+  if (cin == 16 && cout == 16 && stride == 1) return conv5_launch<16, 16, 1>(a, s);
+  if (cin == 32 && cout == 32 && stride == 1) return conv5_launch<32, 32, 1>(a, s);
+  if (cin == 16 && cout == 32 && stride == 2) return conv5_launch<16, 32, 2>(a, s);
+  set_error("conv5: shape %d -> %d stride %d not taken", cin, cout, stride);
+  return -1;
 }
 
 }  // namespace a3vt

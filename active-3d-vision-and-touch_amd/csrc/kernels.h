@@ -337,10 +337,13 @@ struct CastBatch {
 };
 int launch_cast_weights(const CastBatch &b, hipStream_t s);
 
-// conv5.hip: 5 x 5 stride-1 16 -> 16 convolution on channels-last bf16 maps (forward, and with flip = 1 / pad = 3 the input gradient)
-size_t conv5_weight_image_bytes();
-int launch_conv5_weight_image(const float *w, int flip, void *image, hipStream_t s);
-int launch_conv5x16(const void *x, int batch, int h, int w, int pad, const void *image, const float *bias, void *y, hipStream_t s);
+// conv5.hip: 5 x 5 convolutions of the image pyramid on channels-last bf16 maps, (cin, cout, stride) in {(16,16,1), (32,32,1),
+// (16,32,2)}; with flip = 1 / pad = 3 (stride 1 only) the input gradient
+bool conv5_shape_ok(int cin, int cout, int stride);
+size_t conv5_weight_image_bytes(int rows, int inner);
+int launch_conv5_weight_image(const float *w, int flip, int cout, int cin, void *image, hipStream_t s);
+int launch_conv5(const void *x, int batch, int h, int w, int cin, int cout, int stride, int pad, const void *image, const float *bias,
+                 void *y, hipStream_t s);
 
 // chamfer.hip
 size_t chamfer_scratch_bytes(int draws, int batch, int q);

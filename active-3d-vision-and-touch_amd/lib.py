@@ -71,9 +71,10 @@ SIGNATURES = {
     "a3vt_bias_grad_scratch_bytes": (_sz, [ctypes.c_longlong, _i]),
     "a3vt_bias_grad_nhwc": (_i, [_vp, _i, ctypes.c_longlong, _i, _vp, _vp, _sz, _vp]),
     "a3vt_cast_weights_bf16": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "a3vt_conv5x16_image_bytes": (_sz, []),
-    "a3vt_conv5x16_weight_image": (_i, [_vp, _i, _vp, _vp]),
-    "a3vt_conv5x16": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "a3vt_conv5_supported": (_i, [_i, _i, _i]),
+    "a3vt_conv5_image_bytes": (_sz, [_i, _i, _i]),
+    "a3vt_conv5_weight_image": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "a3vt_conv5_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "a3vt_bnrelu_scratch_bytes": (_sz, [_i]),
     "a3vt_bnrelu_fwd": (_i, [_vp, ctypes.c_longlong, _i, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "a3vt_bnrelu_bwd": (_i, [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

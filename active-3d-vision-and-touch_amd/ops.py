@@ -548,8 +548,8 @@ _CONV5_IMAGES = {}   # (id(weight), flip) -> (weakref, version, data_ptr, optimi
 
 
 def _conv5_image(weight, flip):
-    """The bf16 A-fragment image of a (16,16,5,5) weight for ``a3vt_conv5x16`` (``flip``: the input-gradient form), cached until
-    the weight can have changed (same rules as :func:`_bf16_copy`)."""
+    """The bf16 A-fragment image of a (cout,cin,5,5) weight for ``a3vt_conv5_nhwc`` (``flip``: the input-gradient form), cached
+    until the weight can have changed (same rules as :func:`_bf16_copy`)."""
     L = _lib.load()
     on = _bf16_cache_on()
     key = (id(weight), flip)
@@ -557,24 +557,33 @@ def _conv5_image(weight, flip):
     if (hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] == weight.data_ptr() and hit[3] == _OPT_EPOCH[0]):
         return hit[4]
     w = _req(weight.detach(), "conv weight")
-    img = torch.empty(L.a3vt_conv5x16_image_bytes(), dtype=torch.uint8, device=w.device)
-    _lib.check(L.a3vt_conv5x16_weight_image(_lib.ptr(w), flip, _lib.ptr(img), _stream()), "conv5x16_weight_image")
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    img = torch.empty(L.a3vt_conv5_image_bytes(cout, cin, flip), dtype=torch.uint8, device=w.device)
+    _lib.check(L.a3vt_conv5_weight_image(_lib.ptr(w), cout, cin, flip, _lib.ptr(img), _stream()), "conv5_weight_image")
     if on:
         ref = weakref.ref(weight, lambda r, key=key: _CONV5_IMAGES.pop(key, None))
         _CONV5_IMAGES[key] = (ref, weight._version, weight.data_ptr(), _OPT_EPOCH[0], img)
     return img
 
 
-def conv5x16(x, image, bias, pad):
-    """``a3vt_conv5x16`` on a channels-last bf16 (B,16,H,W) tensor -> (B,16,H+2 pad-4,W+2 pad-4), channels-last bf16."""
+def conv5_nhwc(x, image, bias, cout, stride, pad):
+    """``a3vt_conv5_nhwc`` on a channels-last bf16 (B,cin,H,W) tensor -> (B,cout,Ho,Wo), channels-last bf16."""
     L = _lib.load()
     B, C, H, W = x.shape
-    y = torch.empty((B, 16, H + 2 * pad - 4, W + 2 * pad - 4), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
-    _lib.check(L.a3vt_conv5x16(_lib.ptr(x), B, H, W, pad, _lib.ptr(image), _lib.ptr(bias), _lib.ptr(y), _stream()), "conv5x16")
+    Ho, Wo = (H + 2 * pad - 5) // stride + 1, (W + 2 * pad - 5) // stride + 1
+    y = torch.empty((B, cout, Ho, Wo), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    _lib.check(L.a3vt_conv5_nhwc(_lib.ptr(x), B, H, W, C, cout, stride, pad, _lib.ptr(image), _lib.ptr(bias), _lib.ptr(y), _stream()),
+               "conv5_nhwc")
     return y
 
 
-LIBRARY_CONV5 = [True]   # the 16 -> 16 stride-1 layers of the bf16 image branch on a3vt_conv5x16 (False: MIOpen, for A/B)
+def conv5_supported(weight, stride, padding):
+    if weight.dim() != 4 or tuple(weight.shape[2:]) != (5, 5) or list(padding) != [1, 1] or stride[0] != stride[1]:
+        return False
+    return bool(_lib.load().a3vt_conv5_supported(int(weight.shape[1]), int(weight.shape[0]), int(stride[0])))
+
+
+LIBRARY_CONV5 = [True]   # layers 2-6 of the bf16 image branch on a3vt_conv5_nhwc (False: MIOpen, for A/B)
 
 
 class ConvNHWCFn(torch.autograd.Function):
@@ -588,11 +597,12 @@ class ConvNHWCFn(torch.autograd.Function):
         the shift again: the bias-add launch is skipped; the bias gradient is formed as before."""
         xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         wb = _bf16_copy(weight, True)
-        # layers 2 and 3 of the pyramid (16 -> 16, stride 1, padding 1): the library's direct convolution (csrc/conv5.hip)
-        ctx.own = (LIBRARY_CONV5[0] and tuple(weight.shape) == (16, 16, 5, 5) and list(stride) == [1, 1] and list(padding) == [1, 1]
-                   and weight.dtype == torch.float32 and bias.dtype == torch.float32 and xb.shape[2] >= 3 and xb.shape[3] >= 3)
+        # layers 2-6 of the pyramid (16 -> 16 and 32 -> 32 at stride 1, 16 -> 32 at stride 2): the library's direct convolution
+        ctx.own = (LIBRARY_CONV5[0] and conv5_supported(weight, stride, padding) and weight.dtype == torch.float32
+                   and bias.dtype == torch.float32 and xb.shape[2] >= 3 and xb.shape[3] >= 3)
         if ctx.own:
-            y = conv5x16(xb, _conv5_image(weight, 0), _req(bias.detach(), "conv bias") if add_bias else None, 1)
+            y = conv5_nhwc(xb, _conv5_image(weight, 0), _req(bias.detach(), "conv bias") if add_bias else None,
+                           int(weight.shape[0]), int(stride[0]), 1)
             ctx.weight = weight
         else:
             y = torch.ops.aten.convolution(xb, wb, _bf16_copy(bias, False) if add_bias else None, stride, padding, [1, 1], False, [0, 0], 1)
@@ -605,9 +615,9 @@ class ConvNHWCFn(torch.autograd.Function):
         xb, wb = ctx.saved_tensors
         stride, padding, xdt, wdt, bdt = ctx.conf
         gy = gy.contiguous(memory_format=torch.channels_last)
-        if ctx.own and ctx.needs_input_grad[0] and gy.dtype == torch.bfloat16:
+        if ctx.own and ctx.needs_input_grad[0] and gy.dtype == torch.bfloat16 and list(stride) == [1, 1]:
             # the input gradient is the same convolution on gy with the weights transposed and flipped, padding 3
-            gx = conv5x16(gy, _conv5_image(ctx.weight, 1), None, 3)
+            gx = conv5_nhwc(gy, _conv5_image(ctx.weight, 1), None, int(ctx.weight.shape[1]), 1, 3)
             _, gw, _ = torch.ops.aten.convolution_backward(gy, xb, wb, None, stride, padding, [1, 1], False, [0, 0], 1, [False, True, False])
         else:
             gx, gw, _ = torch.ops.aten.convolution_backward(gy, xb, wb, None, stride, padding, [1, 1], False, [0, 0], 1,

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define A3VT_VERSION 161 /* 161: a3vt_bnrelu_fwd / _bwd (training BatchNorm2d + ReLU of the image pyramid on channels-last bf16 maps), a3vt_cast_weights_bf16, a3vt_image_pool_fwd_add, a3vt_conv5x16; 160: a3vt_adj_split, a3vt_adj_split_validate, a3vt_gcn_stack_fwd_adj / _bwd_adj (the fused vision + touch adjacency as P + a complete bipartite block); 150: a3vt_dbg_path_counts, larger a3vt_chamfer_workspace_bytes (oriented boxes of the pruned search), a3vt_gcn_stack_scratch_bytes covers every gemm mode, gemm_bf16 outside 0..3 refused; 140: gemm_bf16 = 3 ("fp32x3": fp32 products as six bf16 MFMA passes on exactly split operands), a3vt_split3_bf16; 0.2.x: bf16 storage mode (gemm_bf16 = 2), a3vt_gcn_stack_stash_bytes / _scratch_bytes_mode, deterministic backward scatters; 120: a3vt_chamfer_fwd_ws (pruned exact search); 130: a3vt_posenc_wide_* (448-wide vertex-feature encoder), larger a3vt_gcn_stack_mask_bytes / _scratch_bytes (channel-sliced aggregation) */
+#define A3VT_VERSION 161 /* 161: a3vt_bnrelu_fwd / _bwd (training BatchNorm2d + ReLU of the image pyramid on channels-last bf16 maps), a3vt_cast_weights_bf16, a3vt_image_pool_fwd_add, a3vt_conv5_nhwc; 160: a3vt_adj_split, a3vt_adj_split_validate, a3vt_gcn_stack_fwd_adj / _bwd_adj (the fused vision + touch adjacency as P + a complete bipartite block); 150: a3vt_dbg_path_counts, larger a3vt_chamfer_workspace_bytes (oriented boxes of the pruned search), a3vt_gcn_stack_scratch_bytes covers every gemm mode, gemm_bf16 outside 0..3 refused; 140: gemm_bf16 = 3 ("fp32x3": fp32 products as six bf16 MFMA passes on exactly split operands), a3vt_split3_bf16; 0.2.x: bf16 storage mode (gemm_bf16 = 2), a3vt_gcn_stack_stash_bytes / _scratch_bytes_mode, deterministic backward scatters; 120: a3vt_chamfer_fwd_ws (pruned exact search); 130: a3vt_posenc_wide_* (448-wide vertex-feature encoder), larger a3vt_gcn_stack_mask_bytes / _scratch_bytes (channel-sliced aggregation) */
 
 int a3vt_version(void);
 const char *a3vt_last_error(void);
@@ -305,18 +305,21 @@ int a3vt_bnrelu_bwd(const void *dy, const void *x, long long rows, int channels,
 int a3vt_cast_weights_bf16(int n, const float *const *src, void *const *dst, const long long *outer, const int *inner,
                            const int *hw, void *stream);
 
-/* The 5 x 5, stride-1, 16 -> 16 channel convolutions of the image pyramid (layers 2 and 3 of Image_Encoder: `CNN_layer`'s
- * nn.Conv2d(16, 16, kernel_size = 5, padding = 1), model.py:15-47) on channels-last bf16 maps, which MIOpen runs at a tenth of the
- * rate their bytes allow.   y[b][oy][ox][co] = bias[co] + sum over (ky, kx, ci) of x[b][oy + ky - pad][ox + kx - pad][ci] * Wm[co][ky][kx][ci]
- * (pixels outside the map are zeros), x: [batch][height][width][16] bf16, y: [batch][height + 2 pad - 4][width + 2 pad - 4][16] bf16,
- * fp32 accumulation, one rounding.  `image` (a3vt_conv5x16_image_bytes bytes, 16-byte aligned) is written by
- * a3vt_conv5x16_weight_image from the fp32 weight [16][16][5][5] (OIHW): flip = 0, pad = 1 is the layer's forward; flip = 1 (Wm
- * transposed and flipped), pad = 3 applied to the OUTPUT gradient is the gradient with respect to the layer's input.  bias: fp32
- * [16] or NULL.  (The weight gradient stays on MIOpen.) */
-size_t a3vt_conv5x16_image_bytes(void);
-int a3vt_conv5x16_weight_image(const float *weight, int flip, void *image, void *stream);
-int a3vt_conv5x16(const void *x, int batch, int height, int width, int pad, const void *image, const float *bias, void *y,
-                  void *stream);
+/* The 5 x 5 convolutions of the image pyramid's small-channel layers (`CNN_layer`'s nn.Conv2d(kernel_size = 5, padding = 1),
+ * model.py:15-47) on channels-last bf16 maps, which MIOpen runs at a tenth of the rate their bytes allow.  Shapes taken
+ * (a3vt_conv5_supported): (cin, cout, stride) = (16, 16, 1), (32, 32, 1) — layers 2-3 and 5-6 of Image_Encoder — and (16, 32, 2),
+ * layer 4.   y[b][oy][ox][co] = bias[co] + sum over (ky, kx, ci) of x[b][oy stride + ky - pad][ox stride + kx - pad][ci] * Wm[co][ky][kx][ci]
+ * (pixels outside the map are zeros); x: [batch][height][width][cin] bf16, y: [batch][Ho][Wo][cout] bf16 with
+ * Ho = (height + 2 pad - 5) / stride + 1; fp32 accumulation, one rounding.  `image` (a3vt_conv5_image_bytes bytes, 16-byte
+ * aligned) is written by a3vt_conv5_weight_image from the fp32 weight [cout][cin][5][5] (OIHW): flip = 0 with pad = 1 is the
+ * layer's forward; for the stride-1 shapes flip = 1 (Wm transposed and flipped: call the convolution with cin and cout swapped)
+ * with pad = 3 applied to the OUTPUT gradient is the gradient with respect to the layer's input.  bias: fp32 [cout] or NULL.
+ * (Weight gradients, and the input gradient of the stride-2 layer, stay on MIOpen.) */
+int a3vt_conv5_supported(int cin, int cout, int stride);
+size_t a3vt_conv5_image_bytes(int cout, int cin, int flip);
+int a3vt_conv5_weight_image(const float *weight, int cout, int cin, int flip, void *image, void *stream);
+int a3vt_conv5_nhwc(const void *x, int batch, int height, int width, int cin, int cout, int stride, int pad, const void *image,
+                    const float *bias, void *y, void *stream);
 
 /* Vertex update, model.py:250,270,283:  out[b][v] = in[b][v] + (v < n_vision ? update[b][v] : 0). */
 int a3vt_vertex_update(const float *verts_in, const float *update, int batch, int n_vert, int n_vision,

@@ -208,30 +208,36 @@ def test_bnrelu_pre_bias_moves_only_the_running_mean():
     torch.testing.assert_close(outs[1][2], 0.1 * ref_mean, rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("shape", [(2, 16, 20, 20), (3, 16, 37, 29), (64, 16, 126, 126), (1, 16, 3, 5)])
-def test_conv5x16_against_torch(shape):
-    """a3vt_conv5x16 (csrc/conv5.hip: the pyramid's 16 -> 16, 5 x 5, stride-1, padding-1 layers on channels-last bf16 maps) against
-    torch's fp32 convolution of the same bf16 values: forward with and without the bias, and the input gradient (the same kernel
-    on the output gradient with flipped weights, padding 3); through ``ops.ConvNHWCFn`` the weight gradient stays MIOpen's."""
+@pytest.mark.parametrize("shape,cout,stride", [((2, 16, 20, 20), 16, 1), ((3, 16, 37, 29), 16, 1), ((64, 16, 126, 126), 16, 1),
+                                               ((1, 16, 3, 5), 16, 1), ((3, 32, 23, 31), 32, 1), ((64, 32, 60, 60), 32, 1),
+                                               ((2, 16, 37, 30), 32, 2), ((64, 16, 122, 122), 32, 2)])
+def test_conv5_against_torch(shape, cout, stride):
+    """a3vt_conv5_nhwc (csrc/conv5.hip: layers 2-6 of the pyramid — 16 -> 16 and 32 -> 32 at stride 1, 16 -> 32 at stride 2; 5 x 5,
+    padding 1, channels-last bf16 maps) against torch's fp32 convolution of the same bf16 values: forward with and without the
+    bias, and for the stride-1 shapes the input gradient (the same kernel on the output gradient with flipped weights, padding
+    3); through ``ops.ConvNHWCFn`` the weight gradient stays MIOpen's."""
     from a3vt_amd import ops
     dev = torch.device("cuda", 0)
-    g = torch.Generator().manual_seed(sum(shape))
+    g = torch.Generator().manual_seed(sum(shape) + cout)
+    cin = shape[1]
     x = torch.randn(shape, generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    w = (torch.randn(16, 16, 5, 5, generator=g) * 0.08).to(dev)
-    b = (torch.randn(16, generator=g) * 0.3).to(dev)
+    w = (torch.randn(cout, cin, 5, 5, generator=g) * 0.08).to(dev)
+    b = (torch.randn(cout, generator=g) * 0.3).to(dev)
     wb = w.to(torch.bfloat16).float()          # the values the kernel multiplies
-    ref = torch.nn.functional.conv2d(x.float(), wb, b, padding=1)
+    ref = torch.nn.functional.conv2d(x.float(), wb, b, stride=stride, padding=1)
     gy = torch.randn(ref.shape, generator=torch.Generator().manual_seed(5)).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    ref_gx = torch.nn.grad.conv2d_input(x.shape, wb, gy.float(), padding=1)
-    img_f, img_b = ops._conv5_image(w, 0), ops._conv5_image(w, 1)
-    y = ops.conv5x16(x, img_f, b, 1)
-    y0 = ops.conv5x16(x, img_f, None, 1)
-    gx = ops.conv5x16(gy, img_b, None, 3)
-    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last) and gx.shape == x.shape
-    tol = lambda r: r.abs() * 2.0 ** -7 + 1e-2 * float(r.abs().mean())     # noqa: E731  one bf16 rounding of an fp32 sum of 400 terms
+    tol = lambda r: r.abs() * 2.0 ** -7 + 1e-2 * float(r.abs().mean())     # noqa: E731  one bf16 rounding of an fp32 sum of 400-800 terms
+    img_f = ops._conv5_image(w, 0)
+    y = ops.conv5_nhwc(x, img_f, b, cout, stride, 1)
+    y0 = ops.conv5_nhwc(x, img_f, None, cout, stride, 1)
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
     assert bool(((y.float() - ref).abs() <= tol(ref)).all()), float((y.float() - ref).abs().max())
     assert bool(((y0.float() - (ref - b.view(1, -1, 1, 1))).abs() <= tol(ref)).all())
-    assert bool(((gx.float() - ref_gx).abs() <= tol(ref_gx)).all()), float((gx.float() - ref_gx).abs().max())
+    if stride == 1:
+        ref_gx = torch.nn.grad.conv2d_input(x.shape, wb, gy.float(), padding=1)
+        gx = ops.conv5_nhwc(gy, ops._conv5_image(w, 1), None, cin, 1, 3)
+        assert gx.shape == x.shape
+        assert bool(((gx.float() - ref_gx).abs() <= tol(ref_gx)).all()), float((gx.float() - ref_gx).abs().max())
     # through the autograd function: same forward, same input gradient, the weight gradient as MIOpen's own
     res = []
     for own in (True, False):
@@ -239,7 +245,7 @@ def test_conv5x16_against_torch(shape):
         try:
             xx = x.clone().requires_grad_(True)
             ww, bb = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
-            out = ops.ConvNHWCFn.apply(xx, ww, bb, [1, 1], [1, 1])
+            out = ops.ConvNHWCFn.apply(xx, ww, bb, [stride, stride], [1, 1])
             out.backward(gy)
             res.append((out.detach().float(), xx.grad.float(), ww.grad, bb.grad))
         finally:
