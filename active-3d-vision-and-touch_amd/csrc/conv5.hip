@@ -151,6 +151,99 @@ __global__ __launch_bounds__(256) void conv5_kernel(Conv5Args a) {
   }
 }
 
+// ---- the two 3-channel layers of the pyramid: layer 0 (3 -> 3, stride 1) and layer 1 (3 -> 16, stride 2) ---------------------------
+// A pixel is 6 bytes in the map and 8 in LDS (a zero fourth channel): the patch is staged through registers (three 2-byte loads and
+// one ds_write_b64 per pixel).  k index = (tap, channel of 4): eight taps per k-step, FOUR k-steps for the 25 taps — a lane's B
+// fragment is two 8-byte LDS reads (taps 8 s + 2 q and 8 s + 2 q + 1 of its pixel).  Output rows beyond COUT (3 -> 3: thirteen of
+// the sixteen) have zero weights and are not stored.
+template <int COUT, int STRIDE>
+__global__ __launch_bounds__(256) void conv5c3_kernel(Conv5Args a) {
+  constexpr int kPatch = (kTile - 1) * STRIDE + 5, kSteps3 = 4;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l16 = lane & 15, q = lane >> 4;
+  const int tx = blockIdx.x % a.tiles_x, ty = (blockIdx.x / a.tiles_x) % a.tiles_y, b = blockIdx.x / (a.tiles_x * a.tiles_y);
+  const int ox0 = tx * kTile, oy0 = ty * kTile;
+  {
+    const u16 *xb = a.x + (size_t)b * a.H * a.W * 3;
+    for (int p = t; p < kPatch * kPatch; p += 256) {
+      const int py = p / kPatch, px = p - py * kPatch;
+      const int iy = oy0 * STRIDE + py - a.pad, ix = ox0 * STRIDE + px - a.pad;
+      u32x2 v = {0u, 0u};
+      if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+        const u16 *src = xb + ((size_t)iy * a.W + ix) * 3;
+        v[0] = (unsigned)src[0] | ((unsigned)src[1] << 16);
+        v[1] = (unsigned)src[2];
+      }
+      *reinterpret_cast<u32x2 *>(lds + p * 8) = v;
+    }
+  }
+  u32x4 wf[kSteps3];
+  int off0[kSteps3], off1[kSteps3];
+#pragma unroll
+  for (int s = 0; s < kSteps3; ++s) {
+    wf[s] = *reinterpret_cast<const u32x4 *>(a.wfrag + ((size_t)s * 64 + lane) * 8);
+    int t0 = 8 * s + 2 * q, t1 = t0 + 1;
+    t0 = t0 < kTaps ? t0 : kTaps - 1;             // (taps 25 .. 31: zero weights)
+    t1 = t1 < kTaps ? t1 : kTaps - 1;
+    off0[s] = ((t0 / 5) * kPatch + t0 % 5) * 8;
+    off1[s] = ((t1 / 5) * kPatch + t1 % 5) * 8;
+  }
+  f32x4 bs = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) {
+    if (COUT == 16) bs = *reinterpret_cast<const f32x4 *>(a.bias + 4 * q);
+    else if (q == 0) bs = f32x4{a.bias[0], a.bias[1], a.bias[2], 0.f};
+  }
+  __syncthreads();
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int r = wave * 4 + rr;
+    const char *base = lds + (r * STRIDE * kPatch + l16 * STRIDE) * 8;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < kSteps3; ++s) {
+      const u32x2 p0 = *reinterpret_cast<const u32x2 *>(base + off0[s]);
+      const u32x2 p1 = *reinterpret_cast<const u32x2 *>(base + off1[s]);
+      const u32x4 pix = {p0[0], p0[1], p1[0], p1[1]};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[s]), __builtin_bit_cast(bf16x8, pix), acc, 0, 0, 0);
+    }
+    const int oy = oy0 + r, ox = ox0 + l16;
+    if (oy < a.Ho && ox < a.Wo) {
+      const f32x4 v = acc + bs;
+      if (COUT == 16) {
+        const u32x2 o = {c5_pack(v[0], v[1]), c5_pack(v[2], v[3])};
+        *reinterpret_cast<u32x2 *>(a.y + (((size_t)b * a.Ho + oy) * a.Wo + ox) * 16 + 4 * q) = o;
+      } else if (q == 0) {
+        u16 *o = a.y + (((size_t)b * a.Ho + oy) * a.Wo + ox) * 3;
+        const unsigned lo = c5_pack(v[0], v[1]), hi = c5_pack(v[2], 0.f);
+        o[0] = (u16)(lo & 0xffffu);
+        o[1] = (u16)(lo >> 16);
+        o[2] = (u16)(hi & 0xffffu);
+      }
+    }
+  }
+}
+
+// A fragments for the 3-channel layers: Wm[co][tap][ci of 4] = w[co][ci][ky][kx] (ci 3, taps >= 25 and rows >= cout: zeros); lane
+// (m, q) of k-step s holds taps 8 s + 2 q and 8 s + 2 q + 1, four channels each
+__global__ void conv5c3_weight_image_kernel(const float *__restrict__ w, int cout, u16 *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 4 * 64 * 8) return;
+  const int e = i & 7, lane = (i >> 3) & 63, s = i >> 9;
+  const int m = lane & 15, q = lane >> 4;
+  const int tap = 8 * s + 2 * q + (e >> 2), c = e & 3;
+  float v = 0.f;
+  if (tap < kTaps && c < 3 && m < cout) v = w[((m * 3 + c) * 5 + tap / 5) * 5 + tap % 5];
+  out[i] = (u16)(c5_pack(v, 0.f) & 0xffffu);
+}
+
+template <int COUT, int STRIDE>
+int conv5c3_launch(const Conv5Args &a, hipStream_t s) {
+  constexpr int kPatch = (kTile - 1) * STRIDE + 5;
+  A3VT_LAUNCH((conv5c3_kernel<COUT, STRIDE>), dim3((unsigned)(a.B * a.tiles_x * a.tiles_y)), dim3(256), kPatch * kPatch * 8, s, a);
+  A3VT_CHECK_LAUNCH();
+  return 0;
+}
+
 template <int CIN, int COUT, int STRIDE>
 int conv5_launch(const Conv5Args &a, hipStream_t s) {
   using S = C5<CIN, COUT, STRIDE>;
@@ -166,14 +259,23 @@ int conv5_launch(const Conv5Args &a, hipStream_t s) {
 }  // namespace
 
 // the shapes taken: (cin, cout, stride) in {(16,16,1), (32,32,1), (16,32,2)} — layers 2-3, 5-6 and 4 of the pyramid; with stride 1 the
-// input gradient is the same kernel (weights flipped, padding 3)
+// input gradient is the same kernel (weights flipped, padding 3) — and the 3-channel layers 0 and 1, (3,3,1) and (3,16,2), forward only
 bool conv5_shape_ok(int cin, int cout, int stride) {
-  return (cin == 16 && cout == 16 && stride == 1) || (cin == 32 && cout == 32 && stride == 1) || (cin == 16 && cout == 32 && stride == 2);
+  return (cin == 16 && cout == 16 && stride == 1) || (cin == 32 && cout == 32 && stride == 1) || (cin == 16 && cout == 32 && stride == 2) ||
+         (cin == 3 && cout == 3 && stride == 1) || (cin == 3 && cout == 16 && stride == 2);
 }
 
-size_t conv5_weight_image_bytes(int rows, int inner) { return (size_t)(rows / 16) * (inner == 16 ? 13 : 25) * 64 * 8 * sizeof(u16); }
+size_t conv5_weight_image_bytes(int rows, int inner) {
+  if (inner == 3) return (size_t)4 * 64 * 8 * sizeof(u16);
+  return (size_t)(rows / 16) * (inner == 16 ? 13 : 25) * 64 * 8 * sizeof(u16);
+}
 
 int launch_conv5_weight_image(const float *w, int flip, int cout, int cin, void *image, hipStream_t s) {
+  if (cin == 3) {
+    A3VT_LAUNCH(conv5c3_weight_image_kernel, dim3(8), dim3(256), 0, s, w, cout, static_cast<u16 *>(image));
+    A3VT_CHECK_LAUNCH();
+    return 0;
+  }
   const int rows = flip ? cin : cout, inner = flip ? cout : cin;
   const int n = (rows / 16) * (inner == 16 ? 13 : 25) * 64 * 8;
   A3VT_LAUNCH(conv5_weight_image_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, flip, rows, inner, static_cast<u16 *>(image));
@@ -199,6 +301,8 @@ int launch_conv5(const void *x, int batch, int h, int w, int cin, int cout, int 
   if (cin == 16 && cout == 16 && stride == 1) return conv5_launch<16, 16, 1>(a, s);
   if (cin == 32 && cout == 32 && stride == 1) return conv5_launch<32, 32, 1>(a, s);
   if (cin == 16 && cout == 32 && stride == 2) return conv5_launch<16, 32, 2>(a, s);
+  if (cin == 3 && cout == 3 && stride == 1) return conv5c3_launch<3, 1>(a, s);
+  if (cin == 3 && cout == 16 && stride == 2) return conv5c3_launch<16, 2>(a, s);
   set_error("conv5: shape %d -> %d stride %d not taken", cin, cout, stride);
   return -1;
 }

@@ -615,7 +615,7 @@ class ConvNHWCFn(torch.autograd.Function):
         xb, wb = ctx.saved_tensors
         stride, padding, xdt, wdt, bdt = ctx.conf
         gy = gy.contiguous(memory_format=torch.channels_last)
-        if ctx.own and ctx.needs_input_grad[0] and gy.dtype == torch.bfloat16 and list(stride) == [1, 1]:
+        if ctx.own and ctx.needs_input_grad[0] and gy.dtype == torch.bfloat16 and list(stride) == [1, 1] and ctx.weight.shape[1] != 3:
             # the input gradient is the same convolution on gy with the weights transposed and flipped, padding 3
             gx = conv5_nhwc(gy, _conv5_image(ctx.weight, 1), None, int(ctx.weight.shape[1]), 1, 3)
             _, gw, _ = torch.ops.aten.convolution_backward(gy, xb, wb, None, stride, padding, [1, 1], False, [0, 0], 1, [False, True, False])

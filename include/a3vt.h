@@ -307,8 +307,8 @@ int a3vt_cast_weights_bf16(int n, const float *const *src, void *const *dst, con
 
 /* The 5 x 5 convolutions of the image pyramid's small-channel layers (`CNN_layer`'s nn.Conv2d(kernel_size = 5, padding = 1),
  * model.py:15-47) on channels-last bf16 maps, which MIOpen runs at a tenth of the rate their bytes allow.  Shapes taken
- * (a3vt_conv5_supported): (cin, cout, stride) = (16, 16, 1), (32, 32, 1) — layers 2-3 and 5-6 of Image_Encoder — and (16, 32, 2),
- * layer 4.   y[b][oy][ox][co] = bias[co] + sum over (ky, kx, ci) of x[b][oy stride + ky - pad][ox stride + kx - pad][ci] * Wm[co][ky][kx][ci]
+ * (a3vt_conv5_supported): (cin, cout, stride) = (16, 16, 1), (32, 32, 1) — layers 2-3 and 5-6 of Image_Encoder —, (16, 32, 2),
+ * layer 4, and the 3-channel layers 0 and 1: (3, 3, 1) and (3, 16, 2), forward only (flip = 0).   y[b][oy][ox][co] = bias[co] + sum over (ky, kx, ci) of x[b][oy stride + ky - pad][ox stride + kx - pad][ci] * Wm[co][ky][kx][ci]
  * (pixels outside the map are zeros); x: [batch][height][width][cin] bf16, y: [batch][Ho][Wo][cout] bf16 with
  * Ho = (height + 2 pad - 5) / stride + 1; fp32 accumulation, one rounding.  `image` (a3vt_conv5_image_bytes bytes, 16-byte
  * aligned) is written by a3vt_conv5_weight_image from the fp32 weight [cout][cin][5][5] (OIHW): flip = 0 with pad = 1 is the

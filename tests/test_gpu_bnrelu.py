@@ -210,7 +210,8 @@ def test_bnrelu_pre_bias_moves_only_the_running_mean():
 
 @pytest.mark.parametrize("shape,cout,stride", [((2, 16, 20, 20), 16, 1), ((3, 16, 37, 29), 16, 1), ((64, 16, 126, 126), 16, 1),
                                                ((1, 16, 3, 5), 16, 1), ((3, 32, 23, 31), 32, 1), ((64, 32, 60, 60), 32, 1),
-                                               ((2, 16, 37, 30), 32, 2), ((64, 16, 122, 122), 32, 2)])
+                                               ((2, 16, 37, 30), 32, 2), ((64, 16, 122, 122), 32, 2),
+                                               ((2, 3, 40, 33), 3, 1), ((64, 3, 256, 256), 3, 1), ((3, 3, 41, 38), 16, 2), ((64, 3, 254, 254), 16, 2)])
 def test_conv5_against_torch(shape, cout, stride):
     """a3vt_conv5_nhwc (csrc/conv5.hip: layers 2-6 of the pyramid — 16 -> 16 and 32 -> 32 at stride 1, 16 -> 32 at stride 2; 5 x 5,
     padding 1, channels-last bf16 maps) against torch's fp32 convolution of the same bf16 values: forward with and without the
@@ -233,7 +234,7 @@ def test_conv5_against_torch(shape, cout, stride):
     assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
     assert bool(((y.float() - ref).abs() <= tol(ref)).all()), float((y.float() - ref).abs().max())
     assert bool(((y0.float() - (ref - b.view(1, -1, 1, 1))).abs() <= tol(ref)).all())
-    if stride == 1:
+    if stride == 1 and cin != 3:
         ref_gx = torch.nn.grad.conv2d_input(x.shape, wb, gy.float(), padding=1)
         gx = ops.conv5_nhwc(gy, ops._conv5_image(w, 1), None, cin, 1, 3)
         assert gx.shape == x.shape
