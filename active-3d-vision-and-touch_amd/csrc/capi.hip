@@ -1591,14 +1591,16 @@ int a3vt_cast_weights_bf16(int n, const float *const *src, void *const *dst, con
 int a3vt_conv5_supported(int cin, int cout, int stride) { return conv5_shape_ok(cin, cout, stride) ? 1 : 0; }
 
 size_t a3vt_conv5_image_bytes(int cout, int cin, int flip) {
-  if (cin == 3) return flip == 0 && (cout == 3 || cout == 16) ? conv5_weight_image_bytes(cout, 3) : 0;
+  if (cin == 3 && flip) return cout == 16 ? conv5_weight_image_bytes(16, 16) : 0;     // (the input gradient of layer 1)
+  if (cin == 3) return cout == 3 || cout == 16 ? conv5_weight_image_bytes(cout, 3) : 0;
   if ((cin != 16 && cin != 32) || (cout != 16 && cout != 32)) return 0;
   return flip ? conv5_weight_image_bytes(cin, cout) : conv5_weight_image_bytes(cout, cin);
 }
 
 int a3vt_conv5_weight_image(const float *weight, int cout, int cin, int flip, void *image, void *stream) {
   A3VT_CHECK_ARG(weight && image && (flip == 0 || flip == 1));
-  A3VT_CHECK_ARG(((cin == 16 || cin == 32) && (cout == 16 || cout == 32)) || (cin == 3 && flip == 0 && (cout == 3 || cout == 16)));
+  A3VT_CHECK_ARG(((cin == 16 || cin == 32) && (cout == 16 || cout == 32)) || (cin == 3 && flip == 0 && (cout == 3 || cout == 16)) ||
+                 (cin == 3 && flip == 1 && cout == 16));
   A3VT_CHECK_ARG((reinterpret_cast<uintptr_t>(image) & 15) == 0);
   return launch_conv5_weight_image(weight, flip, cout, cin, image, static_cast<hipStream_t>(stream));
 }
@@ -1615,6 +1617,16 @@ int a3vt_conv5_nhwc(const void *x, int batch, int height, int width, int cin, in
   A3VT_CHECK_ARG(bias == nullptr || (reinterpret_cast<uintptr_t>(bias) & (cout == 3 ? 3 : 15)) == 0);
   ProfScope psc(PROF_ENC, static_cast<hipStream_t>(stream));
   return launch_conv5(x, batch, height, width, cin, cout, stride, pad, image, bias, y, static_cast<hipStream_t>(stream));
+}
+
+int a3vt_conv5_input_grad_3x16s2(const void *grad_out, int batch, int out_height, int out_width, const void *image, void *grad_in,
+                                 void *stream) {
+  A3VT_CHECK_ARG(grad_out && image && grad_in && batch > 0 && out_height > 0 && out_width > 0);
+  A3VT_CHECK_ARG((long long)batch * (2 * out_height + 2) * (2 * out_width + 2) <= (1ll << 31) / 16);
+  A3VT_CHECK_ARG(((reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(image)) & 15) == 0);
+  A3VT_CHECK_ARG((reinterpret_cast<uintptr_t>(grad_in) & 1) == 0);
+  ProfScope psc(PROF_ENC, static_cast<hipStream_t>(stream));
+  return launch_conv5_up3(grad_out, batch, out_height, out_width, image, grad_in, static_cast<hipStream_t>(stream));
 }
 
 int a3vt_profile_enable(int on) {

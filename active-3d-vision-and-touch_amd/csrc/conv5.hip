@@ -62,7 +62,7 @@ struct Conv5Args {
 // with respect to the input (flip != 0; then the roles of the channel counts swap): Wm[ci][tap][co] = w[co][ci][4 - ky][4 - kx].
 // Fragment of m-block mb, k-step s for lane (m = lane & 15, q = lane >> 4): eight consecutive k of row 16 mb + m, where
 // k = 8 q + e is (tap 2 s + (q >> 1), channel 8 (q & 1) + e) with 16 inner channels and (tap s, channel 8 q + e) with 32.
-__global__ void conv5_weight_image_kernel(const float *__restrict__ w, int flip, int rows, int inner, u16 *__restrict__ out) {
+__global__ void conv5_weight_image_kernel(const float *__restrict__ w, int flip, int rows, int inner, int real_rows, u16 *__restrict__ out) {
   const int steps = inner == 16 ? 13 : 25;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (rows / 16) * steps * 64 * 8) return;
@@ -70,15 +70,19 @@ __global__ void conv5_weight_image_kernel(const float *__restrict__ w, int flip,
   const int m = mb * 16 + (lane & 15), q = lane >> 4;
   const int tap = inner == 16 ? 2 * s + (q >> 1) : s, c = inner == 16 ? 8 * (q & 1) + e : 8 * q + e;
   float v = 0.f;
-  if (tap < kTaps) {
+  if (tap < kTaps && m < real_rows) {     // (real_rows < rows: the flipped image of the 3-channel layer 1, rows 3 .. 15 zero)
     const int ky = tap / 5, kx = tap % 5;
     // forward: rows = cout, inner = cin, w[m][c]; flipped: rows = cin, inner = cout, w[co = c][ci = m]
-    v = flip ? w[((c * rows + m) * 5 + (4 - ky)) * 5 + (4 - kx)] : w[((m * inner + c) * 5 + ky) * 5 + kx];
+    v = flip ? w[((c * real_rows + m) * 5 + (4 - ky)) * 5 + (4 - kx)] : w[((m * inner + c) * 5 + ky) * 5 + kx];
   }
   out[i] = (u16)(c5_pack(v, 0.f) & 0xffffu);
 }
 
-template <int CIN, int COUT, int STRIDE>
+// UP3 (the input gradient of layer 1, 3 <- 16 at stride 2, as a stride-1 convolution): the input is read as if upsampled by two with
+// zeros in between — patch pixel (iy, ix) exists when both are even and is map pixel (iy / 2, ix / 2); a.H, a.W are the UPSAMPLED
+// sizes — and only channels 0 .. 2 of the result are stored, 6 bytes per pixel.  Three quarters of the products are with zeros:
+// 13 MFMAs per 16 pixels do not care, and the kernel and its staging stay the ones above.
+template <int CIN, int COUT, int STRIDE, bool UP3 = false>
 __global__ __launch_bounds__(256) void conv5_kernel(Conv5Args a) {
   using S = C5<CIN, COUT, STRIDE>;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -87,7 +91,8 @@ __global__ __launch_bounds__(256) void conv5_kernel(Conv5Args a) {
   const int ox0 = tx * kTile, oy0 = ty * kTile;
   // ---- the input patch: patch pixel (py, px) is map pixel (oy0 STRIDE + py - pad, ox0 STRIDE + px - pad); 16-byte pieces
   {
-    const u16 *xb = a.x + (size_t)b * a.H * a.W * CIN;
+    const int mh = UP3 ? a.H >> 1 : a.H, mw = UP3 ? a.W >> 1 : a.W;    // the map as stored
+    const u16 *xb = a.x + (size_t)b * mh * mw * CIN;
     constexpr int kPP = S::kPix / 16;                             // pieces per pixel: 2 or 4
     constexpr int kPieces = S::kPatch * S::kPatch * kPP;
     for (int i0 = wave * 64; i0 < kPieces; i0 += 256) {
@@ -96,9 +101,10 @@ __global__ __launch_bounds__(256) void conv5_kernel(Conv5Args a) {
         const int p = i / kPP, part = i - p * kPP;
         const int py = p / S::kPatch, px = p - py * S::kPatch;
         const int iy = oy0 * STRIDE + py - a.pad, ix = ox0 * STRIDE + px - a.pad;
-        const void *src = (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-                              ? static_cast<const void *>(xb + ((size_t)iy * a.W + ix) * CIN + part * 8)
-                              : static_cast<const void *>(g_conv5_zero);
+        const bool in = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && (!UP3 || ((iy | ix) & 1) == 0);
+        const int sy = UP3 ? iy >> 1 : iy, sx = UP3 ? ix >> 1 : ix;
+        const void *src = in ? static_cast<const void *>(xb + ((size_t)sy * mw + sx) * CIN + part * 8)
+                             : static_cast<const void *>(g_conv5_zero);
         c5_glds16(src, lds + i0 * 16);
       }
     }
@@ -141,11 +147,21 @@ __global__ __launch_bounds__(256) void conv5_kernel(Conv5Args a) {
     }
     const int oy = oy0 + r, ox = ox0 + l16;
     if (oy < a.Ho && ox < a.Wo) {
+      if (UP3) {
+        if (q == 0) {
+          u16 *o = a.y + (((size_t)b * a.Ho + oy) * a.Wo + ox) * 3;
+          const unsigned lo = c5_pack(acc[0][0], acc[0][1]), hi = c5_pack(acc[0][2], 0.f);
+          o[0] = (u16)(lo & 0xffffu);
+          o[1] = (u16)(lo >> 16);
+          o[2] = (u16)(hi & 0xffffu);
+        }
+      } else {
 #pragma unroll
-      for (int mb = 0; mb < S::kMB; ++mb) {
-        const f32x4 v = acc[mb] + bs[mb];
-        const u32x2 o = {c5_pack(v[0], v[1]), c5_pack(v[2], v[3])};
-        *reinterpret_cast<u32x2 *>(a.y + (((size_t)b * a.Ho + oy) * a.Wo + ox) * COUT + mb * 16 + 4 * q) = o;
+        for (int mb = 0; mb < S::kMB; ++mb) {
+          const f32x4 v = acc[mb] + bs[mb];
+          const u32x2 o = {c5_pack(v[0], v[1]), c5_pack(v[2], v[3])};
+          *reinterpret_cast<u32x2 *>(a.y + (((size_t)b * a.Ho + oy) * a.Wo + ox) * COUT + mb * 16 + 4 * q) = o;
+        }
       }
     }
   }
@@ -244,14 +260,14 @@ int conv5c3_launch(const Conv5Args &a, hipStream_t s) {
   return 0;
 }
 
-template <int CIN, int COUT, int STRIDE>
+template <int CIN, int COUT, int STRIDE, bool UP3 = false>
 int conv5_launch(const Conv5Args &a, hipStream_t s) {
   using S = C5<CIN, COUT, STRIDE>;
   static OncePerDevice once;
   once.run([] {
-    (void)hipFuncSetAttribute((const void *)conv5_kernel<CIN, COUT, STRIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, S::kPatchBytes);
+    (void)hipFuncSetAttribute((const void *)conv5_kernel<CIN, COUT, STRIDE, UP3>, hipFuncAttributeMaxDynamicSharedMemorySize, S::kPatchBytes);
   });
-  A3VT_LAUNCH((conv5_kernel<CIN, COUT, STRIDE>), dim3((unsigned)(a.B * a.tiles_x * a.tiles_y)), dim3(256), S::kPatchBytes, s, a);
+  A3VT_LAUNCH((conv5_kernel<CIN, COUT, STRIDE, UP3>), dim3((unsigned)(a.B * a.tiles_x * a.tiles_y)), dim3(256), S::kPatchBytes, s, a);
   A3VT_CHECK_LAUNCH();
   return 0;
 }
@@ -267,20 +283,40 @@ bool conv5_shape_ok(int cin, int cout, int stride) {
 
 size_t conv5_weight_image_bytes(int rows, int inner) {
   if (inner == 3) return (size_t)4 * 64 * 8 * sizeof(u16);
+  rows = rows < 16 ? 16 : rows;
   return (size_t)(rows / 16) * (inner == 16 ? 13 : 25) * 64 * 8 * sizeof(u16);
 }
 
 int launch_conv5_weight_image(const float *w, int flip, int cout, int cin, void *image, hipStream_t s) {
-  if (cin == 3) {
+  if (cin == 3 && !flip) {
     A3VT_LAUNCH(conv5c3_weight_image_kernel, dim3(8), dim3(256), 0, s, w, cout, static_cast<u16 *>(image));
     A3VT_CHECK_LAUNCH();
     return 0;
   }
-  const int rows = flip ? cin : cout, inner = flip ? cout : cin;
+  // (flipped image of layer 1, cin = 3, cout = 16: sixteen rows of which three are real)
+  const int real_rows = flip ? cin : cout, rows = real_rows < 16 ? 16 : real_rows, inner = flip ? cout : cin;
   const int n = (rows / 16) * (inner == 16 ? 13 : 25) * 64 * 8;
-  A3VT_LAUNCH(conv5_weight_image_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, flip, rows, inner, static_cast<u16 *>(image));
+  A3VT_LAUNCH(conv5_weight_image_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w, flip, rows, inner, real_rows, static_cast<u16 *>(image));
   A3VT_CHECK_LAUNCH();
   return 0;
+}
+
+// the input gradient of layer 1 (3 <- 16, stride 2): gy [batch][ho][wo][16] -> gx [batch][2 ho + 2][2 wo + 2][3] (image: flip = 1 of the
+// (16, 3, 5, 5) weight)
+int launch_conv5_up3(const void *gy, int batch, int ho, int wo, const void *image, void *gx, hipStream_t s) {
+  Conv5Args a{};
+  a.x = static_cast<const u16 *>(gy);
+  a.y = static_cast<u16 *>(gx);
+  a.wfrag = static_cast<const u16 *>(image);
+  a.B = batch;
+  a.H = 2 * ho;
+  a.W = 2 * wo;
+  a.pad = 3;
+  a.Ho = a.H + 2;
+  a.Wo = a.W + 2;
+  a.tiles_x = (a.Wo + kTile - 1) / kTile;
+  a.tiles_y = (a.Ho + kTile - 1) / kTile;
+  return conv5_launch<16, 16, 1, true>(a, s);
 }
 
 int launch_conv5(const void *x, int batch, int h, int w, int cin, int cout, int stride, int pad, const void *image, const float *bias,

@@ -619,6 +619,14 @@ class ConvNHWCFn(torch.autograd.Function):
             # the input gradient is the same convolution on gy with the weights transposed and flipped, padding 3
             gx = conv5_nhwc(gy, _conv5_image(ctx.weight, 1), None, int(ctx.weight.shape[1]), 1, 3)
             _, gw, _ = torch.ops.aten.convolution_backward(gy, xb, wb, None, stride, padding, [1, 1], False, [0, 0], 1, [False, True, False])
+        elif (ctx.own and ctx.needs_input_grad[0] and gy.dtype == torch.bfloat16 and list(stride) == [2, 2]
+              and tuple(ctx.weight.shape[:2]) == (16, 3) and xb.shape[2] == 2 * gy.shape[2] + 2 and xb.shape[3] == 2 * gy.shape[3] + 2):
+            # layer 1 (3 -> 16, stride 2): its input gradient as a stride-1 convolution of gy read as if upsampled with zeros
+            L = _lib.load()
+            gx = torch.empty_like(xb, memory_format=torch.channels_last)
+            _lib.check(L.a3vt_conv5_input_grad_3x16s2(_lib.ptr(gy), gy.shape[0], gy.shape[2], gy.shape[3], _lib.ptr(_conv5_image(ctx.weight, 1)),
+                                                      _lib.ptr(gx), _stream()), "conv5_input_grad_3x16s2")
+            _, gw, _ = torch.ops.aten.convolution_backward(gy, xb, wb, None, stride, padding, [1, 1], False, [0, 0], 1, [False, True, False])
         else:
             gx, gw, _ = torch.ops.aten.convolution_backward(gy, xb, wb, None, stride, padding, [1, 1], False, [0, 0], 1,
                                                             [ctx.needs_input_grad[0], True, False])

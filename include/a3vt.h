@@ -321,6 +321,13 @@ int a3vt_conv5_weight_image(const float *weight, int cout, int cin, int flip, vo
 int a3vt_conv5_nhwc(const void *x, int batch, int height, int width, int cin, int cout, int stride, int pad, const void *image,
                     const float *bias, void *y, void *stream);
 
+/* The input gradient of the pyramid's layer 1 (nn.Conv2d(3, 16, 5, stride 2, padding 1)): grad_out [batch][out_height][out_width][16]
+ * bf16 -> grad_in [batch][2 out_height + 2][2 out_width + 2][3] bf16 (= the layer's input size when (H + 2 - 5) is odd, as for the
+ * 254-pixel map), computed as the stride-1 convolution of a3vt_conv5_nhwc on grad_out read as if upsampled by two with zeros;
+ * `image` = a3vt_conv5_weight_image(weight [16][3][5][5], cout 16, cin 3, flip 1). */
+int a3vt_conv5_input_grad_3x16s2(const void *grad_out, int batch, int out_height, int out_width, const void *image, void *grad_in,
+                                 void *stream);
+
 /* Vertex update, model.py:250,270,283:  out[b][v] = in[b][v] + (v < n_vision ? update[b][v] : 0). */
 int a3vt_vertex_update(const float *verts_in, const float *update, int batch, int n_vert, int n_vision,
                        float *verts_out, void *stream);

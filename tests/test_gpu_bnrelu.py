@@ -211,7 +211,7 @@ def test_bnrelu_pre_bias_moves_only_the_running_mean():
 @pytest.mark.parametrize("shape,cout,stride", [((2, 16, 20, 20), 16, 1), ((3, 16, 37, 29), 16, 1), ((64, 16, 126, 126), 16, 1),
                                                ((1, 16, 3, 5), 16, 1), ((3, 32, 23, 31), 32, 1), ((64, 32, 60, 60), 32, 1),
                                                ((2, 16, 37, 30), 32, 2), ((64, 16, 122, 122), 32, 2),
-                                               ((2, 3, 40, 33), 3, 1), ((64, 3, 256, 256), 3, 1), ((3, 3, 41, 38), 16, 2), ((64, 3, 254, 254), 16, 2)])
+                                               ((2, 3, 40, 33), 3, 1), ((64, 3, 256, 256), 3, 1), ((3, 3, 41, 38), 16, 2), ((2, 3, 40, 34), 16, 2), ((64, 3, 254, 254), 16, 2)])
 def test_conv5_against_torch(shape, cout, stride):
     """a3vt_conv5_nhwc (csrc/conv5.hip: layers 2-6 of the pyramid — 16 -> 16 and 32 -> 32 at stride 1, 16 -> 32 at stride 2; 5 x 5,
     padding 1, channels-last bf16 maps) against torch's fp32 convolution of the same bf16 values: forward with and without the
