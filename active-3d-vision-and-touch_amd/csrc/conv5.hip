@@ -10,6 +10,9 @@
 // tap has zero weights), the weights sit in 52 registers per lane as A fragments, a lane's B fragment is one ds_read_b128 (eight
 // channels of one tap of its pixel), and the result tile D[channel][pixel] leaves a lane with four consecutive channels of its
 // pixel: 8-byte stores, 512 contiguous bytes per wave instruction.  fp32 accumulation, bias (optional) in fp32, one rounding to bf16.
+#include <type_traits>
+#include <utility>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -274,6 +277,207 @@ int conv5_launch(const Conv5Args &a, hipStream_t s) {
 
 }  // namespace
 
+// ---- weight gradients ------------------------------------------------------------------------------------------------------------
+// gw[co][ci][ky][kx] = sum over (b, oy, ox) of gy[b][oy][ox][co] * x[b][oy S + ky - 1][ox S + kx - 1][ci]: per tap a [COUT x CIN] product
+// summed over PIXELS — both MFMA operands are needed pixel-wise from channels-last data, which is what ds_read_b64_tr_b16 delivers
+// (dw16_kernel's tr_operand, gcn_bf16s.hip).  A k-step is 32 consecutive output pixels of one row: A = gy^T (rows of 16 output
+// channels), B = the same 32 pixels of x shifted by the tap.  A workgroup loops over tiles of 8 rows x 32 pixels (gy tile and x
+// patch by LDS-DMA into two stages, out-of-map pieces from the zero page); wave ky of five owns the taps (ky, 0 .. 4) and keeps
+// their COUT x CIN sums in registers across ALL its tiles; at the end every workgroup writes one partial image [25][COUT][CIN] and a second launch adds the
+// images in a fixed order, straight into the fp32 [cout][cin][5][5] gradient: no atomics, no fp32 workspace to zero and cast
+// (MIOpen: a fill, the kernel, a cast, then torch's cast to fp32 — four launches per layer).
+constexpr int kWR = 8, kWC = 32;                  // tile: output rows x output pixels per row
+constexpr int kWrwWgs = 512;                     // most partial images a launch writes
+
+struct Conv5WrwArgs {
+  const u16 *x, *gy;    // [B][H][W][CIN], [B][Ho][Wo][COUT] bf16
+  float *partial;       // [workgroups][25][COUT][CIN]
+  int B, H, W, Ho, Wo, tiles_x, tiles_y;
+};
+
+// Transposed LDS reads as written instructions: with an LDS-DMA in flight the compiler puts s_waitcnt vmcnt(0) in front of every
+// LDS read it issues itself (csr16t_kernel, gcn_bf16s.hip) — here that is the NEXT tile's prefetch.  The waits are written too and
+// tied to the registers they release.
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+template <int OFF>
+__device__ __forceinline__ u32x2 c5_tr64(unsigned addr) {
+  u32x2 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+struct C5Op { u32x2 lo, hi; };      // one MFMA operand: pixels 4 g .. 4 g + 3 and 16 + 4 g .. 16 + 4 g + 3 of the k-step
+template <int OFF, int BLOCK2>
+__device__ __forceinline__ C5Op c5_op(unsigned addr) { return C5Op{c5_tr64<OFF>(addr), c5_tr64<OFF + BLOCK2>(addr)}; }
+__device__ __forceinline__ bf16x8 c5_bf(const C5Op &o) { return __builtin_bit_cast(bf16x8, (u32x4){o.lo[0], o.lo[1], o.hi[0], o.hi[1]}); }
+template <int I, int N, class F>
+__device__ __forceinline__ void c5_static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    c5_static_for<I + 1, N>(f);
+  }
+}
+template <int N>
+__device__ __forceinline__ void c5_wait_tied(C5Op *a, int na, C5Op *b) {      // lgkmcnt(N), releasing a[0 .. na) and b[0 .. 5)
+  if (na == 2)
+    asm volatile("s_waitcnt lgkmcnt(%14)" : "+v"(a[0].lo), "+v"(a[0].hi), "+v"(a[1].lo), "+v"(a[1].hi), "+v"(b[0].lo), "+v"(b[0].hi), "+v"(b[1].lo),
+                 "+v"(b[1].hi), "+v"(b[2].lo), "+v"(b[2].hi), "+v"(b[3].lo), "+v"(b[3].hi), "+v"(b[4].lo), "+v"(b[4].hi) : "n"(N));
+  else
+    asm volatile("s_waitcnt lgkmcnt(%12)" : "+v"(a[0].lo), "+v"(a[0].hi), "+v"(b[0].lo), "+v"(b[0].hi), "+v"(b[1].lo),
+                 "+v"(b[1].hi), "+v"(b[2].lo), "+v"(b[2].hi), "+v"(b[3].lo), "+v"(b[3].hi), "+v"(b[4].lo), "+v"(b[4].hi) : "n"(N));
+}
+
+// Five waves: wave ky owns the taps (ky, 0 .. 4).  A "group" is (tile row r, input-channel block nb): its reads are the gy operands
+// of row r (with nb == 0) and the five x operands of block nb; the reads of group i + 1 are issued in front of the MFMAs of group i.
+template <int CIN, int COUT, int STRIDE>
+__global__ __launch_bounds__(320) void conv5_wrw_kernel(Conv5WrwArgs a) {
+  constexpr int kMB = COUT / 16, kNB = CIN / 16;
+  constexpr int kPH = (kWR - 1) * STRIDE + 5, kPW = (kWC - 1) * STRIDE + 5;      // x patch
+  constexpr int kGyBytes = kWR * kWC * COUT * 2, kXBytes = kPH * kPW * CIN * 2, kStage = kGyBytes + kXBytes;
+  constexpr int kThreads = 320;
+  extern __shared__ __attribute__((aligned(16))) char lds[];      // two stages: the next tile arrives while this one is multiplied
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l16 = lane & 15, g = lane >> 4;
+  const int bq = l16 >> 2, bp = l16 & 3;          // transposed-read address role (dw16_kernel): block row bq, column quad bp
+  f32x4 acc[5][kMB][kNB];
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int mb = 0; mb < kMB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < kNB; ++nb) acc[i][mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int tiles = a.B * a.tiles_x * a.tiles_y;
+  auto stage = [&](int tile, char *st) {
+    const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / (a.tiles_x * a.tiles_y);
+    const int ox0 = tx * kWC, oy0 = ty * kWR;
+    {   // gy tile: pixel (r, c) of the tile = (oy0 + r, ox0 + c); pieces of 16 bytes
+      const u16 *gb = a.gy + (size_t)b * a.Ho * a.Wo * COUT;
+      constexpr int kPP = COUT / 8, kPieces = kWR * kWC * kPP;
+      for (int i0 = wave * 64; i0 < kPieces; i0 += kThreads) {
+        const int i = i0 + lane;
+        if (i < kPieces) {
+          const int p = i / kPP, part = i - p * kPP;
+          const int r = p / kWC, c = p - r * kWC;
+          const int oy = oy0 + r, ox = ox0 + c;
+          const void *src = (oy < a.Ho && ox < a.Wo) ? static_cast<const void *>(gb + ((size_t)oy * a.Wo + ox) * COUT + part * 8)
+                                                      : static_cast<const void *>(g_conv5_zero);
+          c5_glds16(src, st + i0 * 16);
+        }
+      }
+    }
+    {   // x patch: pixel (py, px) = map pixel (oy0 S + py - 1, ox0 S + px - 1)
+      const u16 *xb = a.x + (size_t)b * a.H * a.W * CIN;
+      constexpr int kPP = CIN / 8, kPieces = kPH * kPW * kPP;
+      for (int i0 = wave * 64; i0 < kPieces; i0 += kThreads) {
+        const int i = i0 + lane;
+        if (i < kPieces) {
+          const int p = i / kPP, part = i - p * kPP;
+          const int py = p / kPW, px = p - py * kPW;
+          const int iy = oy0 * STRIDE + py - 1, ix = ox0 * STRIDE + px - 1;
+          const void *src = (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? static_cast<const void *>(xb + ((size_t)iy * a.W + ix) * CIN + part * 8)
+                                                                         : static_cast<const void *>(g_conv5_zero);
+          c5_glds16(src, st + kGyBytes + i0 * 16);
+        }
+      }
+    }
+  };
+  // LDS byte addresses of this lane's transposed reads in stage 0: gy pixel (4 g + bq) of row 0, channel quad bp; x pixel
+  // ((4 g + bq) S, row ky) of the patch
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds;
+  const unsigned a_addr0 = lds0 + ((4 * g + bq) * COUT + 4 * bp) * 2;
+  const unsigned b_addr0 = lds0 + kGyBytes + ((wave * kPW + (4 * g + bq) * STRIDE) * CIN + 4 * bp) * 2;
+  int buf = 0;
+  if ((int)blockIdx.x < tiles) stage(blockIdx.x, lds);
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of the tile have landed ...
+    __builtin_amdgcn_s_barrier();                        // ... everyone's have, and everyone has left the other stage
+    if (tile + (int)gridDim.x < tiles) stage(tile + gridDim.x, lds + (buf ^ 1) * kStage);
+    const unsigned a_addr = a_addr0 + buf * kStage, b_addr = b_addr0 + buf * kStage;
+    C5Op af[2][kMB], bf[2][5];
+    auto reads = [&](auto R, auto NB, auto SLOT) {       // the reads of group (R, NB) into operand set SLOT
+      constexpr int r = decltype(R)::value, nb = decltype(NB)::value, slot = decltype(SLOT)::value;
+      if constexpr (nb == 0) {
+        af[r & 1][0] = c5_op<r * kWC * COUT * 2, 16 * COUT * 2>(a_addr);
+        if constexpr (kMB == 2) af[r & 1][1] = c5_op<r * kWC * COUT * 2 + 32, 16 * COUT * 2>(a_addr);
+      }
+      bf[slot][0] = c5_op<((r * STRIDE) * kPW + 0) * CIN * 2 + nb * 32, 16 * STRIDE * CIN * 2>(b_addr);
+      bf[slot][1] = c5_op<((r * STRIDE) * kPW + 1) * CIN * 2 + nb * 32, 16 * STRIDE * CIN * 2>(b_addr);
+      bf[slot][2] = c5_op<((r * STRIDE) * kPW + 2) * CIN * 2 + nb * 32, 16 * STRIDE * CIN * 2>(b_addr);
+      bf[slot][3] = c5_op<((r * STRIDE) * kPW + 3) * CIN * 2 + nb * 32, 16 * STRIDE * CIN * 2>(b_addr);
+      bf[slot][4] = c5_op<((r * STRIDE) * kPW + 4) * CIN * 2 + nb * 32, 16 * STRIDE * CIN * 2>(b_addr);
+    };
+    auto group = [&](auto GI) {
+      constexpr int gi = decltype(GI)::value, r = gi / kNB, nb = gi % kNB, slot = gi & 1;
+      constexpr int gn = gi + 1, rn = gn / kNB, nbn = gn % kNB;
+      constexpr int next_reads = gn < kWR * kNB ? 10 + (nbn == 0 ? 2 * kMB : 0) : 0;
+      if constexpr (gn < kWR * kNB) reads(std::integral_constant<int, rn>{}, std::integral_constant<int, nbn>{}, std::integral_constant<int, (slot ^ 1)>{});
+      c5_wait_tied<next_reads>(af[r & 1], kMB, bf[slot]);
+#pragma unroll
+      for (int kx = 0; kx < 5; ++kx)
+#pragma unroll
+        for (int mb = 0; mb < kMB; ++mb)
+          acc[kx][mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c5_bf(af[r & 1][mb]), c5_bf(bf[slot][kx]), acc[kx][mb][nb], 0, 0, 0);
+    };
+    reads(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    c5_static_for<0, kWR * kNB>(group);
+    buf ^= 1;
+  }
+  // ---- this workgroup's image: D[m = co][n = ci]: the lane holds co = 16 mb + 4 g + e, ci = 16 nb + l16
+  float *img = a.partial + (size_t)blockIdx.x * kTaps * COUT * CIN;
+#pragma unroll
+  for (int kx = 0; kx < 5; ++kx)
+#pragma unroll
+    for (int mb = 0; mb < kMB; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < kNB; ++nb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) img[((size_t)(wave * 5 + kx) * COUT + mb * 16 + 4 * g + e) * CIN + nb * 16 + l16] = acc[kx][mb][nb][e];
+}
+
+// gw[co][ci][ky][kx] (fp32, OIHW) = sum over the workgroups' images [wg][tap][co][ci] in a fixed order: a workgroup owns 64
+// consecutive entries (16 lanes x float4) and splits the images over 32 slices of lanes; slice s adds images s, s + 32, ... in
+// that order, then 64 lanes add the 32 slice sums of their entry in slice order.
+constexpr int kRedSlices = 32;
+__global__ __launch_bounds__(16 * kRedSlices) void conv5_wrw_reduce_kernel(const float *__restrict__ partial, int nwg, int cout, int cin, float *__restrict__ gw) {
+  __shared__ f32x4 part[kRedSlices][16];
+  const int n = kTaps * cout * cin;                  // a multiple of 64
+  const int q = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const size_t i4 = (size_t)blockIdx.x * 64 + q * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int w = sl; w < nwg; w += kRedSlices) {
+    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(partial + (size_t)w * n + i4));
+    s += v;
+  }
+  part[sl][q] = s;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const float *p = reinterpret_cast<const float *>(&part[0][0]) + threadIdx.x;
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < kRedSlices; ++k) r += p[k * 64];
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int tap = i / (cout * cin), co = (i / cin) % cout, ci = i % cin;
+    gw[((size_t)co * cin + ci) * kTaps + tap] = r;
+  }
+}
+
+template <int CIN, int COUT, int STRIDE>
+int conv5_wrw_launch(const Conv5WrwArgs &a, float *gw, hipStream_t s) {
+  constexpr int kPH = (kWR - 1) * STRIDE + 5, kPW = (kWC - 1) * STRIDE + 5;
+  constexpr int kLds = 2 * (kWR * kWC * COUT * 2 + kPH * kPW * CIN * 2);
+  static OncePerDevice once;
+  once.run([] { (void)hipFuncSetAttribute((const void *)conv5_wrw_kernel<CIN, COUT, STRIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds); });
+  const int tiles = a.B * a.tiles_x * a.tiles_y;
+  // 16 -> 16 (44 KB of LDS: three workgroups per CU) takes two workgroups per CU, the other two shapes (87 / 114 KB) one: measured
+  // 23.5 / 23.2 / 18.4 us at the configs[3] maps, against 33.4 / 25.8 / 20.9 with the other choice
+  constexpr int cap = CIN == 16 && COUT == 16 ? kWrwWgs : kWrwWgs / 2;
+  const int grid = tiles < cap ? tiles : cap;
+  A3VT_LAUNCH((conv5_wrw_kernel<CIN, COUT, STRIDE>), dim3(grid), dim3(320), kLds, s, a);
+  A3VT_CHECK_LAUNCH();
+  const int n = kTaps * COUT * CIN;
+  A3VT_LAUNCH(conv5_wrw_reduce_kernel, dim3(n / 64), dim3(16 * kRedSlices), 0, s, (const float *)a.partial, grid, COUT, CIN, gw);
+  A3VT_CHECK_LAUNCH();
+  return 0;
+}
+
 // the shapes taken: (cin, cout, stride) in {(16,16,1), (32,32,1), (16,32,2)} — layers 2-3, 5-6 and 4 of the pyramid; with stride 1 the
 // input gradient is the same kernel (weights flipped, padding 3) — and the 3-channel layers 0 and 1, (3,3,1) and (3,16,2), forward only
 bool conv5_shape_ok(int cin, int cout, int stride) {
@@ -340,6 +544,29 @@ int launch_conv5(const void *x, int batch, int h, int w, int cin, int cout, int 
   if (cin == 3 && cout == 3 && stride == 1) return conv5c3_launch<3, 1>(a, s);
   if (cin == 3 && cout == 16 && stride == 2) return conv5c3_launch<16, 2>(a, s);
   set_error("conv5: shape %d -> %d stride %d not taken", cin, cout, stride);
+  return -1;
+}
+
+size_t conv5_wrw_scratch_bytes(int cin, int cout) { return (size_t)kWrwWgs * kTaps * cout * cin * sizeof(float); }
+
+// weight gradient of the (16,16,1), (32,32,1), (16,32,2) layers: x [B][h][w][cin], gy [B][ho][wo][cout] bf16 -> gw fp32 [cout][cin][5][5]
+int launch_conv5_wrw(const void *x, const void *gy, int batch, int h, int w, int cin, int cout, int stride, float *gw, void *scratch,
+                     hipStream_t s) {
+  Conv5WrwArgs a{};
+  a.x = static_cast<const u16 *>(x);
+  a.gy = static_cast<const u16 *>(gy);
+  a.partial = static_cast<float *>(scratch);
+  a.B = batch;
+  a.H = h;
+  a.W = w;
+  a.Ho = (h + 2 - 5) / stride + 1;
+  a.Wo = (w + 2 - 5) / stride + 1;
+  a.tiles_x = (a.Wo + kWC - 1) / kWC;
+  a.tiles_y = (a.Ho + kWR - 1) / kWR;
+  if (cin == 16 && cout == 16 && stride == 1) return conv5_wrw_launch<16, 16, 1>(a, gw, s);
+  if (cin == 32 && cout == 32 && stride == 1) return conv5_wrw_launch<32, 32, 1>(a, gw, s);
+  if (cin == 16 && cout == 32 && stride == 2) return conv5_wrw_launch<16, 32, 2>(a, gw, s);
+  set_error("conv5_wrw: shape %d -> %d stride %d not taken", cin, cout, stride);
   return -1;
 }
 

@@ -345,6 +345,9 @@ int launch_conv5_weight_image(const float *w, int flip, int cout, int cin, void 
 int launch_conv5(const void *x, int batch, int h, int w, int cin, int cout, int stride, int pad, const void *image, const float *bias,
                  void *y, hipStream_t s);
 int launch_conv5_up3(const void *gy, int batch, int ho, int wo, const void *image, void *gx, hipStream_t s);
+size_t conv5_wrw_scratch_bytes(int cin, int cout);
+int launch_conv5_wrw(const void *x, const void *gy, int batch, int h, int w, int cin, int cout, int stride, float *gw, void *scratch,
+                     hipStream_t s);
 
 // chamfer.hip
 size_t chamfer_scratch_bytes(int draws, int batch, int q);

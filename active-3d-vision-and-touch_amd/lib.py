@@ -76,6 +76,8 @@ SIGNATURES = {
     "a3vt_conv5_weight_image": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "a3vt_conv5_nhwc": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "a3vt_conv5_input_grad_3x16s2": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    "a3vt_conv5_wrw_scratch_bytes": (_sz, [_i, _i]),
+    "a3vt_conv5_weight_grad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "a3vt_bnrelu_scratch_bytes": (_sz, [_i]),
     "a3vt_bnrelu_fwd": (_i, [_vp, ctypes.c_longlong, _i, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "a3vt_bnrelu_bwd": (_i, [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -584,6 +584,29 @@ def conv5_supported(weight, stride, padding):
 
 
 LIBRARY_CONV5 = [True]   # layers 2-6 of the bf16 image branch on a3vt_conv5_nhwc (False: MIOpen, for A/B)
+LIBRARY_CONV5_WRW = [True]   # their weight gradients on a3vt_conv5_weight_grad (False: MIOpen's split-K kernel + fill + cast)
+_CONV5_WRW_SCRATCH = {}   # (device index, stream) -> scratch of a3vt_conv5_weight_grad (per-workgroup partial images)
+
+
+def _conv5_weight_grad(xb, gy, weight, stride, padding, wb):
+    """fp32 (cout,cin,5,5) weight gradient of a layer ``conv5_supported`` takes with cin >= 16, from the layer's channels-last bf16
+    input ``xb`` and output gradient ``gy``: ``a3vt_conv5_weight_grad`` (fixed summation order, no fill / cast launches)."""
+    if not LIBRARY_CONV5_WRW[0]:
+        return torch.ops.aten.convolution_backward(gy, xb, wb, None, stride, padding, [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    L = _lib.load()
+    cout, cin = int(weight.shape[0]), int(weight.shape[1])
+    key = (xb.device.index, int(torch.cuda.current_stream().cuda_stream))
+    need = L.a3vt_conv5_wrw_scratch_bytes(32, 32)
+    buf = _CONV5_WRW_SCRATCH.get(key)
+    if buf is None:
+        buf = torch.empty(need, dtype=torch.uint8, device=xb.device)
+        _CONV5_WRW_SCRATCH[key] = buf
+    gw = torch.empty((cout, cin, 5, 5), dtype=torch.float32, device=xb.device)
+    B, _, H, W = xb.shape
+    _lib.check(L.a3vt_conv5_weight_grad(_lib.ptr(xb), _lib.ptr(gy), B, H, W, cin, cout, int(stride[0]), _lib.ptr(gw), _lib.ptr(buf), need,
+                                        _stream()), "conv5_weight_grad")
+    STATS["conv5_weight_grad"] = STATS.get("conv5_weight_grad", 0) + 1
+    return gw
 
 
 class ConvNHWCFn(torch.autograd.Function):
@@ -618,7 +641,7 @@ class ConvNHWCFn(torch.autograd.Function):
         if ctx.own and ctx.needs_input_grad[0] and gy.dtype == torch.bfloat16 and list(stride) == [1, 1] and ctx.weight.shape[1] != 3:
             # the input gradient is the same convolution on gy with the weights transposed and flipped, padding 3
             gx = conv5_nhwc(gy, _conv5_image(ctx.weight, 1), None, int(ctx.weight.shape[1]), 1, 3)
-            _, gw, _ = torch.ops.aten.convolution_backward(gy, xb, wb, None, stride, padding, [1, 1], False, [0, 0], 1, [False, True, False])
+            gw = _conv5_weight_grad(xb, gy, ctx.weight, stride, padding, wb)
         elif (ctx.own and ctx.needs_input_grad[0] and gy.dtype == torch.bfloat16 and list(stride) == [2, 2]
               and tuple(ctx.weight.shape[:2]) == (16, 3) and xb.shape[2] == 2 * gy.shape[2] + 2 and xb.shape[3] == 2 * gy.shape[3] + 2):
             # layer 1 (3 -> 16, stride 2): its input gradient as a stride-1 convolution of gy read as if upsampled with zeros
@@ -627,6 +650,12 @@ class ConvNHWCFn(torch.autograd.Function):
             _lib.check(L.a3vt_conv5_input_grad_3x16s2(_lib.ptr(gy), gy.shape[0], gy.shape[2], gy.shape[3], _lib.ptr(_conv5_image(ctx.weight, 1)),
                                                       _lib.ptr(gx), _stream()), "conv5_input_grad_3x16s2")
             _, gw, _ = torch.ops.aten.convolution_backward(gy, xb, wb, None, stride, padding, [1, 1], False, [0, 0], 1, [False, True, False])
+        elif ctx.own and gy.dtype == torch.bfloat16 and ctx.weight.shape[1] != 3:
+            # (16 -> 32, stride 2: the input gradient stays MIOpen's)
+            gx = None
+            if ctx.needs_input_grad[0]:
+                gx, _, _ = torch.ops.aten.convolution_backward(gy, xb, wb, None, stride, padding, [1, 1], False, [0, 0], 1, [True, False, False])
+            gw = _conv5_weight_grad(xb, gy, ctx.weight, stride, padding, wb)
         else:
             gx, gw, _ = torch.ops.aten.convolution_backward(gy, xb, wb, None, stride, padding, [1, 1], False, [0, 0], 1,
                                                             [ctx.needs_input_grad[0], True, False])

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define A3VT_VERSION 161 /* 161: a3vt_bnrelu_fwd / _bwd (training BatchNorm2d + ReLU of the image pyramid on channels-last bf16 maps), a3vt_cast_weights_bf16, a3vt_image_pool_fwd_add, a3vt_conv5_nhwc; 160: a3vt_adj_split, a3vt_adj_split_validate, a3vt_gcn_stack_fwd_adj / _bwd_adj (the fused vision + touch adjacency as P + a complete bipartite block); 150: a3vt_dbg_path_counts, larger a3vt_chamfer_workspace_bytes (oriented boxes of the pruned search), a3vt_gcn_stack_scratch_bytes covers every gemm mode, gemm_bf16 outside 0..3 refused; 140: gemm_bf16 = 3 ("fp32x3": fp32 products as six bf16 MFMA passes on exactly split operands), a3vt_split3_bf16; 0.2.x: bf16 storage mode (gemm_bf16 = 2), a3vt_gcn_stack_stash_bytes / _scratch_bytes_mode, deterministic backward scatters; 120: a3vt_chamfer_fwd_ws (pruned exact search); 130: a3vt_posenc_wide_* (448-wide vertex-feature encoder), larger a3vt_gcn_stack_mask_bytes / _scratch_bytes (channel-sliced aggregation) */
+#define A3VT_VERSION 162 /* 162: a3vt_conv5_weight_grad (the weight gradients of the image pyramid's 5 x 5 layers: fixed-order sums, no fill / cast launches); 161: a3vt_bnrelu_fwd / _bwd (training BatchNorm2d + ReLU of the image pyramid on channels-last bf16 maps), a3vt_cast_weights_bf16, a3vt_image_pool_fwd_add, a3vt_conv5_nhwc; 160: a3vt_adj_split, a3vt_adj_split_validate, a3vt_gcn_stack_fwd_adj / _bwd_adj (the fused vision + touch adjacency as P + a complete bipartite block); 150: a3vt_dbg_path_counts, larger a3vt_chamfer_workspace_bytes (oriented boxes of the pruned search), a3vt_gcn_stack_scratch_bytes covers every gemm mode, gemm_bf16 outside 0..3 refused; 140: gemm_bf16 = 3 ("fp32x3": fp32 products as six bf16 MFMA passes on exactly split operands), a3vt_split3_bf16; 0.2.x: bf16 storage mode (gemm_bf16 = 2), a3vt_gcn_stack_stash_bytes / _scratch_bytes_mode, deterministic backward scatters; 120: a3vt_chamfer_fwd_ws (pruned exact search); 130: a3vt_posenc_wide_* (448-wide vertex-feature encoder), larger a3vt_gcn_stack_mask_bytes / _scratch_bytes (channel-sliced aggregation) */
 
 int a3vt_version(void);
 const char *a3vt_last_error(void);
@@ -327,6 +327,16 @@ int a3vt_conv5_nhwc(const void *x, int batch, int height, int width, int cin, in
  * `image` = a3vt_conv5_weight_image(weight [16][3][5][5], cout 16, cin 3, flip 1). */
 int a3vt_conv5_input_grad_3x16s2(const void *grad_out, int batch, int out_height, int out_width, const void *image, void *grad_in,
                                  void *stream);
+
+/* The weight gradient of the same layers ((cin, cout, stride) = (16, 16, 1), (32, 32, 1), (16, 32, 2); padding 1):
+ *   grad_weight[co][ci][ky][kx] = sum over (b, oy, ox) of grad_out[b][oy][ox][co] * x[b][oy stride + ky - 1][ox stride + kx - 1][ci],
+ * x: [batch][height][width][cin] bf16 (the layer's input), grad_out: [batch][Ho][Wo][cout] bf16, grad_weight: fp32 [cout][cin][5][5]
+ * (OIHW), overwritten.  fp32 accumulation on the matrix pipe, partial sums per workgroup added in a fixed order (repeatable bit
+ * for bit; MIOpen's kernel accumulates with atomics into an fp32 workspace it first fills and then casts).  scratch:
+ * a3vt_conv5_wrw_scratch_bytes(cin, cout) bytes. */
+size_t a3vt_conv5_wrw_scratch_bytes(int cin, int cout);
+int a3vt_conv5_weight_grad(const void *x, const void *grad_out, int batch, int height, int width, int cin, int cout, int stride,
+                           float *grad_weight, void *scratch, size_t scratch_bytes, void *stream);
 
 /* Vertex update, model.py:250,270,283:  out[b][v] = in[b][v] + (v < n_vision ? update[b][v] : 0). */
 int a3vt_vertex_update(const float *verts_in, const float *update, int batch, int n_vert, int n_vision,

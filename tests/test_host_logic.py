@@ -110,7 +110,7 @@ def test_header_symbols_all_bound_and_exported():
     for name in declared:
         assert hasattr(dll, name), name
     L = lib.load()
-    assert L.a3vt_version() == 161
+    assert L.a3vt_version() == 162
     assert L.a3vt_posenc_param_count(50) == 12 * 63 + 12 + 25 * 12 + 25 + 50 * 25 + 50 + 200
     assert L.a3vt_wt_rows(300) >= 304 and L.a3vt_wt_ld(300) == 304
     # host-only entry point: CSR validation
