@@ -1630,15 +1630,16 @@ int a3vt_conv5_input_grad_3x16s2(const void *grad_out, int batch, int out_height
 }
 
 size_t a3vt_conv5_wrw_scratch_bytes(int cin, int cout) {
-  return (cin == 16 || cin == 32) && (cout == 16 || cout == 32) ? conv5_wrw_scratch_bytes(cin, cout) : 0;
+  return ((cin == 16 || cin == 32) && (cout == 16 || cout == 32)) || (cin == 3 && (cout == 3 || cout == 16)) ? conv5_wrw_scratch_bytes(cin, cout) : 0;
 }
 
 int a3vt_conv5_weight_grad(const void *x, const void *grad_out, int batch, int height, int width, int cin, int cout, int stride,
                            float *grad_weight, void *scratch, size_t scratch_bytes, void *stream) {
   A3VT_CHECK_ARG(x && grad_out && grad_weight && scratch);
-  A3VT_CHECK_ARG(cin >= 16 && conv5_shape_ok(cin, cout, stride));
+  A3VT_CHECK_ARG(conv5_shape_ok(cin, cout, stride));
   A3VT_CHECK_ARG(batch > 0 && height >= 3 && width >= 3 && (long long)batch * height * width <= (1ll << 31) / 32);
-  A3VT_CHECK_ARG(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(scratch)) & 15) == 0);
+  A3VT_CHECK_ARG((reinterpret_cast<uintptr_t>(scratch) & 15) == 0);
+  A3VT_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & (cin == 3 ? 1 : 15)) == 0 && (reinterpret_cast<uintptr_t>(grad_out) & (cout == 3 ? 1 : 15)) == 0);
   A3VT_CHECK_ARG(scratch_bytes >= conv5_wrw_scratch_bytes(cin, cout));
   ProfScope psc(PROF_ENC, static_cast<hipStream_t>(stream));
   return launch_conv5_wrw(x, grad_out, batch, height, width, cin, cout, stride, grad_weight, scratch, static_cast<hipStream_t>(stream));

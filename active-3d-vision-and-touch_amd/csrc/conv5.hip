@@ -459,6 +459,149 @@ __global__ __launch_bounds__(16 * kRedSlices) void conv5_wrw_reduce_kernel(const
   }
 }
 
+// ---- weight gradients of the two 3-channel layers (3 -> 3 stride 1, 3 -> 16 stride 2) ------------------------------------------------
+// The same product with the roles the 3-channel forward gives them: the x patch sits in LDS with 8-byte pixels (a zero fourth
+// channel), so the four channels of a pixel are what one lane hands to a transposed read; column n of the B operand is (tap, channel)
+// = (n >> 2, n & 3): 25 taps = 100 columns = SEVEN 16-column blocks (the lane that addresses for column quad bp of block nb points
+// at tap 4 nb + bp of its pixel; taps 25 .. 27 are clamped and their columns dropped).  A = gy^T as above (3 -> 3: gy also with
+// 8-byte pixels, the lanes of channel quads 1 .. 3 read a zero region).  Wave w owns rows 2 w, 2 w + 1 of a tile with all seven
+// accumulators; the four waves' sums are added through LDS and the workgroup writes ONE image in fragment order, which
+// conv5c3_wrw_reduce_kernel adds over the workgroups in a fixed order and scatters into [cout][3][5][5].
+constexpr int kC3Blocks = 7, kC3Image = kC3Blocks * 64 * 4;      // floats per partial image
+constexpr int kC3Wgs = 1024;
+
+__device__ __forceinline__ bf16x8 c5_tr_pair(const char *p, int block2_bytes) {
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(p));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(p + block2_bytes));
+  return __builtin_bit_cast(bf16x8, (s16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]});
+}
+
+// a [rows][cols] window of 6-byte pixels of a map -> 8-byte pixels in LDS (zero outside the map)
+__device__ __forceinline__ void c5_stage_px3(const u16 *map, int H, int W, int y0, int x0, int rows, int cols, char *dst) {
+  for (int p = threadIdx.x; p < rows * cols; p += 256) {
+    const int py = p / cols, px = p - py * cols;
+    const int iy = y0 + py, ix = x0 + px;
+    u32x2 v = {0u, 0u};
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+      const u16 *src = map + ((size_t)iy * W + ix) * 3;
+      v[0] = (unsigned)src[0] | ((unsigned)src[1] << 16);
+      v[1] = (unsigned)src[2];
+    }
+    *reinterpret_cast<u32x2 *>(dst + p * 8) = v;
+  }
+}
+
+template <int COUT, int STRIDE>
+__global__ __launch_bounds__(256) void conv5c3_wrw_kernel(Conv5WrwArgs a) {
+  constexpr int kPH = (kWR - 1) * STRIDE + 5, kPW = (kWC - 1) * STRIDE + 5;
+  constexpr int kXBytes = (kPH * kPW * 8 + 15) / 16 * 16, kGyPix = COUT == 16 ? 32 : 8, kGyBytes = kWR * kWC * kGyPix;
+  extern __shared__ __attribute__((aligned(16))) char lds[];      // x patch | gy tile | 256 zero bytes; at the end the waves' sums
+  char *x_l = lds, *gy_l = lds + kXBytes, *zero_l = lds + kXBytes + kGyBytes;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), l16 = lane & 15, g = lane >> 4;
+  const int bq = l16 >> 2, bp = l16 & 3;
+  if (t < 16) reinterpret_cast<u32x4 *>(zero_l)[t] = u32x4{0u, 0u, 0u, 0u};
+  // this lane's read addresses in row 0 of the tile
+  const char *a_ptr;
+  int a_row;
+  if (COUT == 16) {
+    a_ptr = gy_l + ((4 * g + bq) * 16 + 4 * bp) * 2;
+    a_row = kWC * 32;
+  } else {
+    a_ptr = bp == 0 ? gy_l + (4 * g + bq) * 8 : zero_l;
+    a_row = bp == 0 ? kWC * 8 : 0;
+  }
+  int boff[kC3Blocks];
+#pragma unroll
+  for (int nb = 0; nb < kC3Blocks; ++nb) {
+    int tap = 4 * nb + bp;
+    tap = tap < kTaps ? tap : kTaps - 1;
+    boff[nb] = (((tap / 5) * kPW + tap % 5) + (4 * g + bq) * STRIDE) * 8;
+  }
+  f32x4 acc[kC3Blocks];
+#pragma unroll
+  for (int nb = 0; nb < kC3Blocks; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int tiles = a.B * a.tiles_x * a.tiles_y;
+  for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int tx = tile % a.tiles_x, ty = (tile / a.tiles_x) % a.tiles_y, b = tile / (a.tiles_x * a.tiles_y);
+    const int ox0 = tx * kWC, oy0 = ty * kWR;
+    __syncthreads();        // everyone has left the previous tile
+    c5_stage_px3(a.x + (size_t)b * a.H * a.W * 3, a.H, a.W, oy0 * STRIDE - 1, ox0 * STRIDE - 1, kPH, kPW, x_l);
+    if (COUT == 16) {
+      const u16 *gb = a.gy + (size_t)b * a.Ho * a.Wo * 16;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {      // 512 pieces of 16 bytes
+        const int i0 = (wave + 4 * k) * 64, i = i0 + lane;
+        const int p = i >> 1, part = i & 1;
+        const int oy = oy0 + p / kWC, ox = ox0 + p % kWC;
+        const void *src = (oy < a.Ho && ox < a.Wo) ? static_cast<const void *>(gb + ((size_t)oy * a.Wo + ox) * 16 + part * 8)
+                                                    : static_cast<const void *>(g_conv5_zero);
+        c5_glds16(src, gy_l + i0 * 16);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      c5_stage_px3(a.gy + (size_t)b * a.Ho * a.Wo * 3, a.Ho, a.Wo, oy0, ox0, kWR, kWC, gy_l);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int r = wave * 2 + rr;
+      const bf16x8 af = c5_tr_pair(a_ptr + r * a_row, COUT == 16 ? 16 * 32 : 16 * 8);
+      const char *xr = x_l + r * STRIDE * kPW * 8;
+#pragma unroll
+      for (int nb = 0; nb < kC3Blocks; ++nb) {
+        const bf16x8 bf = c5_tr_pair(xr + boff[nb], 16 * STRIDE * 8);
+        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[nb], 0, 0, 0);
+      }
+    }
+  }
+  // ---- the four waves' sums, added in wave order; image entry (nb, lane, e) = D[co = 4 g + e][n = 16 nb + l16]
+  __syncthreads();
+  f32x4 *sum_l = reinterpret_cast<f32x4 *>(lds);
+#pragma unroll
+  for (int nb = 0; nb < kC3Blocks; ++nb) sum_l[(wave * kC3Blocks + nb) * 64 + lane] = acc[nb];
+  __syncthreads();
+  float *img = a.partial + (size_t)blockIdx.x * kC3Image;
+  const float *sf = reinterpret_cast<const float *>(lds);
+  for (int i = t; i < kC3Image; i += 256) img[i] = ((sf[i] + sf[kC3Image + i]) + sf[2 * kC3Image + i]) + sf[3 * kC3Image + i];
+}
+
+// gw[co][ci][ky][kx] (fp32, [cout][3][5][5]) from the workgroups' fragment-order images, added as in conv5_wrw_reduce_kernel
+__global__ __launch_bounds__(16 * 32) void conv5c3_wrw_reduce_kernel(const float *__restrict__ partial, int nwg, int cout, float *__restrict__ gw) {
+  __shared__ f32x4 part[32][16];
+  const int q = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const size_t i4 = (size_t)blockIdx.x * 64 + q * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int w = sl; w < nwg; w += 32) s += __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(partial + (size_t)w * kC3Image + i4));
+  part[sl][q] = s;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const float *p = reinterpret_cast<const float *>(&part[0][0]) + threadIdx.x;
+    float r = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) r += p[k * 64];
+    const int i = blockIdx.x * 64 + threadIdx.x;                 // (nb, lane, e)
+    const int e = i & 3, lane = (i >> 2) & 63, nb = i >> 8;
+    const int co = 4 * (lane >> 4) + e, tap = 4 * nb + ((lane & 15) >> 2), ci = lane & 3;
+    if (co < cout && tap < kTaps && ci < 3) gw[((size_t)co * 3 + ci) * kTaps + tap] = r;
+  }
+}
+
+template <int COUT, int STRIDE>
+int conv5c3_wrw_launch(const Conv5WrwArgs &a, float *gw, hipStream_t s) {
+  constexpr int kPH = (kWR - 1) * STRIDE + 5, kPW = (kWC - 1) * STRIDE + 5;
+  constexpr int kStage = (kPH * kPW * 8 + 15) / 16 * 16 + kWR * kWC * (COUT == 16 ? 32 : 8) + 256;
+  constexpr int kLds = kStage > 4 * kC3Image * 4 ? kStage : 4 * kC3Image * 4;
+  const int tiles = a.B * a.tiles_x * a.tiles_y;
+  const int grid = tiles < kC3Wgs ? tiles : kC3Wgs;
+  A3VT_LAUNCH((conv5c3_wrw_kernel<COUT, STRIDE>), dim3(grid), dim3(256), kLds, s, a);
+  A3VT_CHECK_LAUNCH();
+  A3VT_LAUNCH(conv5c3_wrw_reduce_kernel, dim3(kC3Image / 64), dim3(16 * 32), 0, s, (const float *)a.partial, grid, COUT, gw);
+  A3VT_CHECK_LAUNCH();
+  return 0;
+}
+
 template <int CIN, int COUT, int STRIDE>
 int conv5_wrw_launch(const Conv5WrwArgs &a, float *gw, hipStream_t s) {
   constexpr int kPH = (kWR - 1) * STRIDE + 5, kPW = (kWC - 1) * STRIDE + 5;
@@ -547,9 +690,11 @@ int launch_conv5(const void *x, int batch, int h, int w, int cin, int cout, int 
   return -1;
 }
 
-size_t conv5_wrw_scratch_bytes(int cin, int cout) { return (size_t)kWrwWgs * kTaps * cout * cin * sizeof(float); }
+size_t conv5_wrw_scratch_bytes(int cin, int cout) {
+  return cin == 3 ? (size_t)kC3Wgs * kC3Image * sizeof(float) : (size_t)kWrwWgs * kTaps * cout * cin * sizeof(float);
+}
 
-// weight gradient of the (16,16,1), (32,32,1), (16,32,2) layers: x [B][h][w][cin], gy [B][ho][wo][cout] bf16 -> gw fp32 [cout][cin][5][5]
+// weight gradient of the (3,3,1), (3,16,2), (16,16,1), (32,32,1), (16,32,2) layers: x [B][h][w][cin], gy [B][ho][wo][cout] bf16 -> gw fp32 [cout][cin][5][5]
 int launch_conv5_wrw(const void *x, const void *gy, int batch, int h, int w, int cin, int cout, int stride, float *gw, void *scratch,
                      hipStream_t s) {
   Conv5WrwArgs a{};
@@ -563,6 +708,8 @@ int launch_conv5_wrw(const void *x, const void *gy, int batch, int h, int w, int
   a.Wo = (w + 2 - 5) / stride + 1;
   a.tiles_x = (a.Wo + kWC - 1) / kWC;
   a.tiles_y = (a.Ho + kWR - 1) / kWR;
+  if (cin == 3 && cout == 3 && stride == 1) return conv5c3_wrw_launch<3, 1>(a, gw, s);
+  if (cin == 3 && cout == 16 && stride == 2) return conv5c3_wrw_launch<16, 2>(a, gw, s);
   if (cin == 16 && cout == 16 && stride == 1) return conv5_wrw_launch<16, 16, 1>(a, gw, s);
   if (cin == 32 && cout == 32 && stride == 1) return conv5_wrw_launch<32, 32, 1>(a, gw, s);
   if (cin == 16 && cout == 32 && stride == 2) return conv5_wrw_launch<16, 32, 2>(a, gw, s);

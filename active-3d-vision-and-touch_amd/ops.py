@@ -589,7 +589,7 @@ _CONV5_WRW_SCRATCH = {}   # (device index, stream) -> scratch of a3vt_conv5_weig
 
 
 def _conv5_weight_grad(xb, gy, weight, stride, padding, wb):
-    """fp32 (cout,cin,5,5) weight gradient of a layer ``conv5_supported`` takes with cin >= 16, from the layer's channels-last bf16
+    """fp32 (cout,cin,5,5) weight gradient of a layer ``conv5_supported`` takes, from the layer's channels-last bf16
     input ``xb`` and output gradient ``gy``: ``a3vt_conv5_weight_grad`` (fixed summation order, no fill / cast launches)."""
     if not LIBRARY_CONV5_WRW[0]:
         return torch.ops.aten.convolution_backward(gy, xb, wb, None, stride, padding, [1, 1], False, [0, 0], 1, [False, True, False])[1]
@@ -638,27 +638,26 @@ class ConvNHWCFn(torch.autograd.Function):
         xb, wb = ctx.saved_tensors
         stride, padding, xdt, wdt, bdt = ctx.conf
         gy = gy.contiguous(memory_format=torch.channels_last)
-        if ctx.own and ctx.needs_input_grad[0] and gy.dtype == torch.bfloat16 and list(stride) == [1, 1] and ctx.weight.shape[1] != 3:
-            # the input gradient is the same convolution on gy with the weights transposed and flipped, padding 3
-            gx = conv5_nhwc(gy, _conv5_image(ctx.weight, 1), None, int(ctx.weight.shape[1]), 1, 3)
-            gw = _conv5_weight_grad(xb, gy, ctx.weight, stride, padding, wb)
-        elif (ctx.own and ctx.needs_input_grad[0] and gy.dtype == torch.bfloat16 and list(stride) == [2, 2]
-              and tuple(ctx.weight.shape[:2]) == (16, 3) and xb.shape[2] == 2 * gy.shape[2] + 2 and xb.shape[3] == 2 * gy.shape[3] + 2):
-            # layer 1 (3 -> 16, stride 2): its input gradient as a stride-1 convolution of gy read as if upsampled with zeros
-            L = _lib.load()
-            gx = torch.empty_like(xb, memory_format=torch.channels_last)
-            _lib.check(L.a3vt_conv5_input_grad_3x16s2(_lib.ptr(gy), gy.shape[0], gy.shape[2], gy.shape[3], _lib.ptr(_conv5_image(ctx.weight, 1)),
-                                                      _lib.ptr(gx), _stream()), "conv5_input_grad_3x16s2")
-            _, gw, _ = torch.ops.aten.convolution_backward(gy, xb, wb, None, stride, padding, [1, 1], False, [0, 0], 1, [False, True, False])
-        elif ctx.own and gy.dtype == torch.bfloat16 and ctx.weight.shape[1] != 3:
-            # (16 -> 32, stride 2: the input gradient stays MIOpen's)
-            gx = None
-            if ctx.needs_input_grad[0]:
-                gx, _, _ = torch.ops.aten.convolution_backward(gy, xb, wb, None, stride, padding, [1, 1], False, [0, 0], 1, [True, False, False])
-            gw = _conv5_weight_grad(xb, gy, ctx.weight, stride, padding, wb)
+        own = ctx.own and gy.dtype == torch.bfloat16
+        need_gx = ctx.needs_input_grad[0]
+        if not own:
+            gx, gw, _ = torch.ops.aten.convolution_backward(gy, xb, wb, None, stride, padding, [1, 1], False, [0, 0], 1, [need_gx, True, False])
         else:
-            gx, gw, _ = torch.ops.aten.convolution_backward(gy, xb, wb, None, stride, padding, [1, 1], False, [0, 0], 1,
-                                                            [ctx.needs_input_grad[0], True, False])
+            if need_gx and list(stride) == [1, 1] and ctx.weight.shape[1] != 3:
+                # the input gradient is the same convolution on gy with the weights transposed and flipped, padding 3
+                gx = conv5_nhwc(gy, _conv5_image(ctx.weight, 1), None, int(ctx.weight.shape[1]), 1, 3)
+            elif (need_gx and list(stride) == [2, 2] and tuple(ctx.weight.shape[:2]) == (16, 3)
+                  and xb.shape[2] == 2 * gy.shape[2] + 2 and xb.shape[3] == 2 * gy.shape[3] + 2):
+                # layer 1 (3 -> 16, stride 2): its input gradient as a stride-1 convolution of gy read as if upsampled with zeros
+                L = _lib.load()
+                gx = torch.empty_like(xb, memory_format=torch.channels_last)
+                _lib.check(L.a3vt_conv5_input_grad_3x16s2(_lib.ptr(gy), gy.shape[0], gy.shape[2], gy.shape[3],
+                                                          _lib.ptr(_conv5_image(ctx.weight, 1)), _lib.ptr(gx), _stream()), "conv5_input_grad_3x16s2")
+            elif need_gx:      # (16 -> 32 at stride 2, 3 -> 3: MIOpen)
+                gx = torch.ops.aten.convolution_backward(gy, xb, wb, None, stride, padding, [1, 1], False, [0, 0], 1, [True, False, False])[0]
+            else:
+                gx = None
+            gw = _conv5_weight_grad(xb, gy, ctx.weight, stride, padding, wb)
         cs = getattr(gy, "_a3vt_colsum", None)
         if cs is not None and cs[1] == gy._version and cs[2] == gy.data_ptr() and cs[0].numel() == gy.shape[1]:
             gb = cs[0]            # formed by BNReLUFn.backward while it wrote gy

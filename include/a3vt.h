@@ -328,12 +328,13 @@ int a3vt_conv5_nhwc(const void *x, int batch, int height, int width, int cin, in
 int a3vt_conv5_input_grad_3x16s2(const void *grad_out, int batch, int out_height, int out_width, const void *image, void *grad_in,
                                  void *stream);
 
-/* The weight gradient of the same layers ((cin, cout, stride) = (16, 16, 1), (32, 32, 1), (16, 32, 2); padding 1):
+/* The weight gradient of the same five layers ((cin, cout, stride) = (3, 3, 1), (3, 16, 2), (16, 16, 1), (32, 32, 1), (16, 32, 2);
+ * padding 1) — autograd's third product of nn.Conv2d at vision/model.py:15-23:
  *   grad_weight[co][ci][ky][kx] = sum over (b, oy, ox) of grad_out[b][oy][ox][co] * x[b][oy stride + ky - 1][ox stride + kx - 1][ci],
  * x: [batch][height][width][cin] bf16 (the layer's input), grad_out: [batch][Ho][Wo][cout] bf16, grad_weight: fp32 [cout][cin][5][5]
  * (OIHW), overwritten.  fp32 accumulation on the matrix pipe, partial sums per workgroup added in a fixed order (repeatable bit
  * for bit; MIOpen's kernel accumulates with atomics into an fp32 workspace it first fills and then casts).  scratch:
- * a3vt_conv5_wrw_scratch_bytes(cin, cout) bytes. */
+ * a3vt_conv5_wrw_scratch_bytes(cin, cout) bytes, 16-byte aligned; x / grad_out 16-byte aligned for 16 / 32 channels, 2-byte for 3. */
 size_t a3vt_conv5_wrw_scratch_bytes(int cin, int cout);
 int a3vt_conv5_weight_grad(const void *x, const void *grad_out, int batch, int height, int width, int cin, int cout, int stride,
                            float *grad_weight, void *scratch, size_t scratch_bytes, void *stream);

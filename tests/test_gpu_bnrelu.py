@@ -216,7 +216,7 @@ def test_conv5_against_torch(shape, cout, stride):
     """a3vt_conv5_nhwc (csrc/conv5.hip: layers 2-6 of the pyramid — 16 -> 16 and 32 -> 32 at stride 1, 16 -> 32 at stride 2; 5 x 5,
     padding 1, channels-last bf16 maps) against torch's fp32 convolution of the same bf16 values: forward with and without the
     bias, and for the stride-1 shapes the input gradient (the same kernel on the output gradient with flipped weights, padding
-    3), and for the 16- / 32-channel inputs the weight gradient (a3vt_conv5_weight_grad)."""
+    3), and the weight gradient (a3vt_conv5_weight_grad)."""
     from a3vt_amd import ops
     dev = torch.device("cuda", 0)
     g = torch.Generator().manual_seed(sum(shape) + cout)
@@ -239,7 +239,7 @@ def test_conv5_against_torch(shape, cout, stride):
         gx = ops.conv5_nhwc(gy, ops._conv5_image(w, 1), None, cin, 1, 3)
         assert gx.shape == x.shape
         assert bool(((gx.float() - ref_gx).abs() <= tol(ref_gx)).all()), float((gx.float() - ref_gx).abs().max())
-    if cin >= 16:
+    if True:
         # the weight gradient (a3vt_conv5_weight_grad): fp32 sums of exact bf16 products in a fixed order — against torch's fp32
         # gradient of the same values, and bit-repeatable
         ref_gw = torch.nn.grad.conv2d_weight(x.float(), w.shape, gy.float(), stride=stride, padding=1)

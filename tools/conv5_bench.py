@@ -10,7 +10,7 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from a3vt_amd import ops  # noqa: E402
 
-SHAPES = [((64, 16, 126, 126), 16, 1), ((64, 16, 124, 124), 16, 1), ((64, 16, 122, 122), 32, 2), ((64, 32, 60, 60), 32, 1), ((64, 32, 58, 58), 32, 1)]
+SHAPES = [((64, 3, 256, 256), 3, 1), ((64, 3, 254, 254), 16, 2), ((64, 16, 126, 126), 16, 1), ((64, 16, 124, 124), 16, 1), ((64, 16, 122, 122), 32, 2), ((64, 32, 60, 60), 32, 1), ((64, 32, 58, 58), 32, 1)]
 
 
 def main():
