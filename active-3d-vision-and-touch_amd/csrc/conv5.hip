@@ -1,7 +1,9 @@
-// conv5.hip — the 5 x 5, stride-1, 16 -> 16 channel convolutions of the image pyramid on channels-last bf16 maps (round 6):
-// layers 2 and 3 of `Image_Encoder` (reference: `CNN_layer` = BatchNorm2d -> ReLU -> Conv2d(k = 5, padding = 1),
-// pterotactyl/reconstruction/vision/model.py:15-47; 16 -> 16 on the 126^2 and 124^2 maps) and — the same arithmetic with the
-// weights transposed and flipped and padding 3 — the gradients of those layers with respect to their inputs.
+// conv5.hip — the 5 x 5 convolutions of the image pyramid's first seven layers on channels-last bf16 maps (round 6): `Image_Encoder`
+// (reference: `CNN_layer` = BatchNorm2d -> ReLU -> Conv2d(k = 5, padding = 1), pterotactyl/reconstruction/vision/model.py:15-47) runs
+// 3 -> 3, 3 -> 16 stride 2, 16 -> 16 twice, 16 -> 32 stride 2, 32 -> 32 twice on 256^2 ... 58^2 maps before its channel counts become
+// GEMM-sized.  This file holds, for those shapes: the forward (conv5_kernel / conv5c3_kernel), the gradients with respect to the
+// inputs (the same arithmetic with the weights transposed and flipped and padding 3; layer 1's through the zero-upsampled form) and
+// the gradients with respect to the weights (conv5_wrw_kernel / conv5c3_wrw_kernel + their fixed-order reduces, further down).
 //
 // MIOpen runs these shapes on its generic NHWC implicit-GEMM kernel: 138 us per launch forward at bs 64 where the bytes (32 MB in,
 // 31 MB out) are 13 us at 5 TB/s — K = 25 x 16 = 400, N = 16 is nothing for a 256 x 32 GEMM tile.  Here a workgroup owns a 16 x 16
@@ -567,21 +569,30 @@ __global__ __launch_bounds__(256) void conv5c3_wrw_kernel(Conv5WrwArgs a) {
   for (int i = t; i < kC3Image; i += 256) img[i] = ((sf[i] + sf[kC3Image + i]) + sf[2 * kC3Image + i]) + sf[3 * kC3Image + i];
 }
 
-// gw[co][ci][ky][kx] (fp32, [cout][3][5][5]) from the workgroups' fragment-order images, added as in conv5_wrw_reduce_kernel
-__global__ __launch_bounds__(16 * 32) void conv5c3_wrw_reduce_kernel(const float *__restrict__ partial, int nwg, int cout, float *__restrict__ gw) {
-  __shared__ f32x4 part[32][16];
-  const int q = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const size_t i4 = (size_t)blockIdx.x * 64 + q * 4;
+// gw[co][ci][ky][kx] (fp32, [cout][3][5][5]) from the workgroups' fragment-order images.  An image is only 1 792 entries: a workgroup
+// owns 16 of them (4 lanes x float4) and splits the images over 128 slices (slice s adds images s, s + 128, ... in that order); then
+// 64 lanes add 32 slice sums each in slice order and 16 lanes the four results — a fixed order, 112 workgroups.
+__global__ __launch_bounds__(512) void conv5c3_wrw_reduce_kernel(const float *__restrict__ partial, int nwg, int cout, float *__restrict__ gw) {
+  __shared__ f32x4 part[128][4];
+  __shared__ float part2[4][16];
+  const int q = threadIdx.x & 3, sl = threadIdx.x >> 2;
+  const size_t i4 = (size_t)blockIdx.x * 16 + q * 4;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  for (int w = sl; w < nwg; w += 32) s += __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(partial + (size_t)w * kC3Image + i4));
+  for (int w = sl; w < nwg; w += 128) s += __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(partial + (size_t)w * kC3Image + i4));
   part[sl][q] = s;
   __syncthreads();
   if (threadIdx.x < 64) {
-    const float *p = reinterpret_cast<const float *>(&part[0][0]) + threadIdx.x;
+    const int en = threadIdx.x & 15, sub = threadIdx.x >> 4;
+    const float *p = reinterpret_cast<const float *>(&part[sub * 32][0]) + en;
     float r = 0.f;
 #pragma unroll
-    for (int k = 0; k < 32; ++k) r += p[k * 64];
-    const int i = blockIdx.x * 64 + threadIdx.x;                 // (nb, lane, e)
+    for (int k = 0; k < 32; ++k) r += p[k * 16];
+    part2[sub][en] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    const float r = ((part2[0][threadIdx.x] + part2[1][threadIdx.x]) + part2[2][threadIdx.x]) + part2[3][threadIdx.x];
+    const int i = blockIdx.x * 16 + threadIdx.x;                 // (nb, lane, e)
     const int e = i & 3, lane = (i >> 2) & 63, nb = i >> 8;
     const int co = 4 * (lane >> 4) + e, tap = 4 * nb + ((lane & 15) >> 2), ci = lane & 3;
     if (co < cout && tap < kTaps && ci < 3) gw[((size_t)co * 3 + ci) * kTaps + tap] = r;
@@ -597,7 +608,7 @@ int conv5c3_wrw_launch(const Conv5WrwArgs &a, float *gw, hipStream_t s) {
   const int grid = tiles < kC3Wgs ? tiles : kC3Wgs;
   A3VT_LAUNCH((conv5c3_wrw_kernel<COUT, STRIDE>), dim3(grid), dim3(256), kLds, s, a);
   A3VT_CHECK_LAUNCH();
-  A3VT_LAUNCH(conv5c3_wrw_reduce_kernel, dim3(kC3Image / 64), dim3(16 * 32), 0, s, (const float *)a.partial, grid, COUT, gw);
+  A3VT_LAUNCH(conv5c3_wrw_reduce_kernel, dim3(kC3Image / 16), dim3(512), 0, s, (const float *)a.partial, grid, COUT, gw);
   A3VT_CHECK_LAUNCH();
   return 0;
 }
