@@ -29,6 +29,7 @@ python tools/touch_bench.py --precision fp32x3 2>/dev/null | tail -1 >> $O/${R}_
 [ -f gpurun_variants/liba3vt_RGW_OFF.so ] && (echo '== round-5 product kernels (liba3vt_RGW_OFF.so)'; A3VT_LIB=$GRAFT_REPO_ROOT/gpurun_variants/liba3vt_RGW_OFF.so python tools/stack_bench.py | tail -4 | head -3; A3VT_LIB=$GRAFT_REPO_ROOT/gpurun_variants/liba3vt_RGW_OFF.so python tools/stack_bench.py --reps 20 --no-profile | tail -1; echo '== shipped'; python tools/stack_bench.py | tail -4 | head -3; python tools/stack_bench.py --reps 20 --no-profile | tail -1) > $O/${R}_product_kernels_ab.txt 2>/dev/null
 # round 6, bf16 configurations: the fused BatchNorm + ReLU operator against MIOpen's per map shape; the tiled aggregation's stamps and its A/B builds
 python tools/bnrelu_bench.py > $O/${R}_bnrelu_vs_miopen.txt 2>/dev/null
+python tools/conv5_bench.py > $O/${R}_conv5_vs_miopen.txt 2>/dev/null; tail -2 $O/${R}_conv5_vs_miopen.txt
 [ -f gpurun_variants/liba3vt_T16_STAMPS.so ] && A3VT_LIB=$GRAFT_REPO_ROOT/gpurun_variants/liba3vt_T16_STAMPS.so python tools/csr16t_stamps.py > $O/${R}_csr16t_stamps.txt 2>/dev/null
 # (whole forward + backward calls of one 20-layer stack without per-launch events, the builds interleaved, three rounds behind a warm-up process:
 #  a launch's isolated rocprofv3 average overstates what the tiles gain in situ — 35 / 33 -> 28 / 24 us isolated, ~3 us per launch in the stack)
