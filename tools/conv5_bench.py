@@ -63,7 +63,7 @@ def main():
         gy = torch.randn((a.batch, cout, ho, ho), generator=g).to(dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         st, pd = [stride, stride], [1, 1]
         img_f = ops._conv5_image(w, 0)
-        img_b = ops._conv5_image(w, 1)
+        img_b = ops._conv5_image(w, 1) if (stride == 1 and cin != 3) or (cin, cout) == (3, 16) else None
         L = ops._lib.load()
         gx_buf = torch.empty_like(x, memory_format=torch.channels_last)
 
