@@ -46,7 +46,7 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 // ---- optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg).
 // Off by default; when on, every MFMA launch of the GCN stack is bracketed by an event pair.
 enum { PROF_GEMM_FWD = 0, PROF_GEMM_DX = 1, PROF_DW = 2, PROF_AGG = 3, PROF_OUT = 4, PROF_SEARCH = 5, PROF_LOSS = 6, PROF_ENC = 7,
-       PROF_CLASSES = 8 };   // a3vt_profile_read: the first three; a3vt_profile_read_classes: all
+       PROF_OPT = 8, PROF_CLASSES = 9 };   // a3vt_profile_read: the first three; a3vt_profile_read_classes: all
 struct Prof {
   bool on = false;
   static constexpr int kMax = 8192;
@@ -1643,6 +1643,19 @@ int a3vt_conv5_weight_grad(const void *x, const void *grad_out, int batch, int h
   A3VT_CHECK_ARG(scratch_bytes >= conv5_wrw_scratch_bytes(cin, cout));
   ProfScope psc(PROF_ENC, static_cast<hipStream_t>(stream));
   return launch_conv5_wrw(x, grad_out, batch, height, width, cin, cout, stride, grad_weight, scratch, static_cast<hipStream_t>(stream));
+}
+
+int a3vt_adam_chunk_elems(void) { return adam_chunk_elems(); }
+
+int a3vt_adam_step(void *const *param, const void *const *grad, void *const *exp_avg, void *const *exp_avg_sq,
+                   const long long *numel, const int *chunk_tensor, const long long *chunk_off, int n_chunks, double lr, double beta1,
+                   double beta2, double eps, double weight_decay, long long step, void *stream) {
+  A3VT_CHECK_ARG(n_chunks >= 0 && step >= 1);
+  A3VT_CHECK_ARG(n_chunks == 0 || (param && grad && exp_avg && exp_avg_sq && numel && chunk_tensor && chunk_off));
+  A3VT_CHECK_ARG(lr >= 0.0 && beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0 && weight_decay >= 0.0);
+  ProfScope psc(PROF_OPT, static_cast<hipStream_t>(stream));
+  return launch_adam(param, grad, exp_avg, exp_avg_sq, numel, chunk_tensor, chunk_off, n_chunks, lr, beta1, beta2, eps, weight_decay, step,
+                     static_cast<hipStream_t>(stream));
 }
 
 int a3vt_profile_enable(int on) {

@@ -349,6 +349,12 @@ size_t conv5_wrw_scratch_bytes(int cin, int cout);
 int launch_conv5_wrw(const void *x, const void *gy, int batch, int h, int w, int cin, int cout, int stride, float *gw, void *scratch,
                      hipStream_t s);
 
+// adam.hip: torch's Adam step over a table of fp32 tensors cut into chunks of adam_chunk_elems() elements (device tables)
+int adam_chunk_elems();
+int launch_adam(void *const *param, const void *const *grad, void *const *exp_avg, void *const *exp_avg_sq,
+                const long long *numel, const int *chunk_tensor, const long long *chunk_off, int n_chunks, double lr, double beta1,
+                double beta2, double eps, double weight_decay, long long step, hipStream_t s);
+
 // chamfer.hip
 size_t chamfer_scratch_bytes(int draws, int batch, int q);
 // algo: 0 = choose (pruned search when the workspace holds it and the clouds are large enough to pay for the sort),

@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("A3VT_LIB", os.path.join(_HERE, "liba3vt.so"))  # A3VT_LIB: developer override (variant builds)
-SOURCES = ["capi.hip", "gcn_gemm.hip", "gcn_gemmw.hip", "gcn_dww.hip", "gcn_gemm16.hip", "gcn_gemm3.hip", "gcn_csr.hip", "gcn_csrq.hip", "gcn_csrqs.hip", "gcn_bf16s.hip", "posenc.hip", "posenc_wide.hip", "bias_grad.hip", "bnrelu.hip", "conv5.hip", "sample.hip", "chamfer.hip", "nn_prune.hip",
+SOURCES = ["capi.hip", "gcn_gemm.hip", "gcn_gemmw.hip", "gcn_dww.hip", "gcn_gemm16.hip", "gcn_gemm3.hip", "gcn_csr.hip", "gcn_csrq.hip", "gcn_csrqs.hip", "gcn_bf16s.hip", "posenc.hip", "posenc_wide.hip", "bias_grad.hip", "bnrelu.hip", "conv5.hip", "adam.hip", "sample.hip", "chamfer.hip", "nn_prune.hip",
            "pooling.hip"]
 # Per-file extra flags (none at present; sample.hip / gcn_csr.hip rely on IEEE NaN semantics — the reference's NaN
 # scrubs, a3vt_check_finite — so fast-math style flags must never be applied globally).
@@ -78,6 +78,9 @@ SIGNATURES = {
     "a3vt_conv5_input_grad_3x16s2": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "a3vt_conv5_wrw_scratch_bytes": (_sz, [_i, _i]),
     "a3vt_conv5_weight_grad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "a3vt_adam_chunk_elems": (_i, []),
+    "a3vt_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                       ctypes.c_longlong, _vp]),
     "a3vt_bnrelu_scratch_bytes": (_sz, [_i]),
     "a3vt_bnrelu_fwd": (_i, [_vp, ctypes.c_longlong, _i, _vp, _vp, _vp, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "a3vt_bnrelu_bwd": (_i, [_vp, _vp, ctypes.c_longlong, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -29,6 +29,7 @@ from . import model
 from ...utility import data_loaders, utils
 from .... import distributed as adist
 from .... import ops as _ops
+from .... import optim as a3vt_optim
 
 try:
     from torch.utils.tensorboard import SummaryWriter
@@ -101,10 +102,9 @@ class Engine:
             # args.force_collectives (this package's knob, default off): issue the gradient all-reduces on a process group of
             # one rank as well — the RCCL path on a single GPU (tests)
             self.bucket = adist.FlatGradBucket(params, early=early, force_collectives=getattr(self.args, "force_collectives", False))
-            try:
-                self.optimizer = optim.Adam(params, lr=self.args.lr, weight_decay=0, fused=True)
-            except (RuntimeError, TypeError):
-                self.optimizer = optim.Adam(params, lr=self.args.lr, weight_decay=0, foreach=True)
+            # optim.Adam(params, lr, weight_decay=0) of the reference (:64) with its step as one launch of the library (a3vt_amd/optim.py;
+            # args.library_adam = False — this package's knob — keeps torch's fused kernel: same state, same checkpoints)
+            self.optimizer = a3vt_optim.make_adam(params, self.args.lr, library=getattr(self.args, "library_adam", True))
 
     def __call__(self):
         self.setup()

@@ -98,6 +98,9 @@ def gcn_activation_bytes(batch, n_vert, in_features, hidden, layers, stages=3, e
     return batch * stages * 3 * sum(elem * n_vert * (a + b) for a, b in zip(dims[:-1], dims[1:]))
 
 
+LIBRARY_ADAM = [True]   # False: torch's fused Adam in the named configurations' step (tools/named_configs.py --torch-adam, A/B)
+
+
 def named_config(which, dev, precision="bf16s", batch=None):
     """Model and synthetic inputs of BASELINE.json configs[3] (vision + touch: image model with the default CNNs + chart
     atlas with 4 touch charts laid on the ground-truth surface, N = 1924, 25 000-point Chamfer, bs 64) or configs[4]'s per-GPU shard (10 242-vertex
@@ -143,14 +146,15 @@ def named_config(which, dev, precision="bf16s", batch=None):
 
 
 class NamedStep:
-    """The trainer's step (``Engine.train_step``: flat bucket, fused Adam) on a ``named_config``."""
+    """The trainer's step (``Engine.train_step``: flat bucket, the library's Adam) on a ``named_config``."""
 
     def __init__(self, cfg):
         from . import distributed as adist
         self.cfg = cfg
         self.params = list(cfg["net"].parameters())
         self.bucket = adist.FlatGradBucket(self.params)
-        self.opt = torch.optim.Adam(self.params, lr=cfg["args"].lr, fused=True)
+        from . import optim as a3vt_optim
+        self.opt = a3vt_optim.make_adam(self.params, cfg["args"].lr, library=LIBRARY_ADAM[0])
 
     def __call__(self):
         from .pterotactyl.utility import utils
@@ -184,14 +188,14 @@ class NamedStep:
 
 
 PROFILE_CLASSES = ("product_fwd", "product_dx", "product_dw", "aggregation", "output_layer", "search", "sampling_and_chamfer_bwd",
-                   "encoders_and_pooling")
+                   "encoders_and_pooling", "optimizer")
 
 
 def kernel_classes(step, cfg, precision, step_ms):
     """Where one training step's device time goes, by kernel class, from the library's own HIP events (``a3vt_profile_*``: an
     event pair around every call of the class on its launch stream) over ONE extra step: ms per step, launches, and — for the
     GCN classes whose algorithmic bytes are a closed form — the HBM rate they reach against 8 TB/s.  ``not_this_library`` is
-    the rest of the step: MIOpen convolutions / batch-norm, torch element-wise kernels, Adam, gaps between kernels."""
+    the rest of the step: MIOpen convolutions / batch-norm, torch element-wise kernels, gaps between kernels."""
     import ctypes
     from . import lib as _lib
     L = _lib.load()
@@ -218,7 +222,7 @@ def kernel_classes(step, cfg, precision, step_ms):
         out[k] = rec
     ours = sum(tot[i] for i in range(n))
     out["not_this_library"] = {"ms_per_step": max(step_ms - ours, 0.0),
-                               "what": "MIOpen convolutions and batch-norm, torch element-wise kernels, fused Adam, gaps between kernels"}
+                               "what": "MIOpen convolutions (image layers 7-12) and fp32 batch-norm, torch element-wise kernels, gaps between kernels"}
     return out
 
 

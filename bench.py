@@ -71,6 +71,7 @@ def parse():
                    help="bf16 = operand mode, bf16s = bf16 activation storage (BASELINE configs[3]/[4]), fp32x3 = fp32 products as "
                         "six bf16 MFMA passes on exactly split operands; NOT the headline")
     p.add_argument("--alt-steps", type=int, default=10, help="timed steps of the alt_modes leg (0 = skip it)")
+    p.add_argument("--torch-adam", action="store_true", help="A/B: torch's fused Adam instead of the library's one-launch step (a3vt_amd/optim.py)")
     p.add_argument("--no-named-configs", action="store_true", help="skip the configs[3] / configs[4] leg")
     p.add_argument("--named-steps", type=int, default=10, help="timed steps of each named configuration")
     p.add_argument("--launcher", default="auto", choices=["auto", "spawn", "none"],
@@ -399,10 +400,8 @@ def main():
     if getattr(eng, "bucket", None) is not None:
         eng.bucket.close()
     eng.bucket = adist.FlatGradBucket(params, early=early)
-    try:
-        eng.optimizer = torch.optim.Adam(params, lr=args.lr, weight_decay=0, fused=True)
-    except (RuntimeError, TypeError):
-        eng.optimizer = torch.optim.Adam(params, lr=args.lr, weight_decay=0, foreach=True)
+    from a3vt_amd import optim as a3vt_optim
+    eng.optimizer = a3vt_optim.make_adam(params, args.lr, library=not a.torch_adam)     # as Engine.setup()
 
     nsteps = a.warmup + a.steps + a.profile_steps
     # inputs resident in HBM before the timed region; a few distinct clouds cycled

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define A3VT_VERSION 162 /* 162: a3vt_conv5_weight_grad (the weight gradients of the image pyramid's 5 x 5 layers: fixed-order sums, no fill / cast launches); 161: a3vt_bnrelu_fwd / _bwd (training BatchNorm2d + ReLU of the image pyramid on channels-last bf16 maps), a3vt_cast_weights_bf16, a3vt_image_pool_fwd_add, a3vt_conv5_nhwc; 160: a3vt_adj_split, a3vt_adj_split_validate, a3vt_gcn_stack_fwd_adj / _bwd_adj (the fused vision + touch adjacency as P + a complete bipartite block); 150: a3vt_dbg_path_counts, larger a3vt_chamfer_workspace_bytes (oriented boxes of the pruned search), a3vt_gcn_stack_scratch_bytes covers every gemm mode, gemm_bf16 outside 0..3 refused; 140: gemm_bf16 = 3 ("fp32x3": fp32 products as six bf16 MFMA passes on exactly split operands), a3vt_split3_bf16; 0.2.x: bf16 storage mode (gemm_bf16 = 2), a3vt_gcn_stack_stash_bytes / _scratch_bytes_mode, deterministic backward scatters; 120: a3vt_chamfer_fwd_ws (pruned exact search); 130: a3vt_posenc_wide_* (448-wide vertex-feature encoder), larger a3vt_gcn_stack_mask_bytes / _scratch_bytes (channel-sliced aggregation) */
+#define A3VT_VERSION 163 /* 163: a3vt_adam_step (the trainer's Adam step over all parameter tensors in one launch); 162: a3vt_conv5_weight_grad (the weight gradients of the image pyramid's 5 x 5 layers: fixed-order sums, no fill / cast launches); 161: a3vt_bnrelu_fwd / _bwd (training BatchNorm2d + ReLU of the image pyramid on channels-last bf16 maps), a3vt_cast_weights_bf16, a3vt_image_pool_fwd_add, a3vt_conv5_nhwc; 160: a3vt_adj_split, a3vt_adj_split_validate, a3vt_gcn_stack_fwd_adj / _bwd_adj (the fused vision + touch adjacency as P + a complete bipartite block); 150: a3vt_dbg_path_counts, larger a3vt_chamfer_workspace_bytes (oriented boxes of the pruned search), a3vt_gcn_stack_scratch_bytes covers every gemm mode, gemm_bf16 outside 0..3 refused; 140: gemm_bf16 = 3 ("fp32x3": fp32 products as six bf16 MFMA passes on exactly split operands), a3vt_split3_bf16; 0.2.x: bf16 storage mode (gemm_bf16 = 2), a3vt_gcn_stack_stash_bytes / _scratch_bytes_mode, deterministic backward scatters; 120: a3vt_chamfer_fwd_ws (pruned exact search); 130: a3vt_posenc_wide_* (448-wide vertex-feature encoder), larger a3vt_gcn_stack_mask_bytes / _scratch_bytes (channel-sliced aggregation) */
 
 int a3vt_version(void);
 const char *a3vt_last_error(void);
@@ -339,6 +339,19 @@ size_t a3vt_conv5_wrw_scratch_bytes(int cin, int cout);
 int a3vt_conv5_weight_grad(const void *x, const void *grad_out, int batch, int height, int width, int cin, int cout, int stride,
                            float *grad_weight, void *scratch, size_t scratch_bytes, void *stream);
 
+/* The optimizer step of the trainer, `optim.Adam(params, lr, weight_decay=0)` + `optimizer.step()` (vision/train.py:64,148), over ALL
+ * parameter tensors in one launch — torch's Adam (amsgrad off, maximize off) in its own order of operations per element:
+ *   g' = g + weight_decay p;  m += (g' - m)(1 - beta1);  v = v beta2 + ((1 - beta2) g') g';
+ *   p -= lr / (1 - beta1^step) * (m / (sqrt(v) / sqrt(1 - beta2^step) + eps)),      step = 1 for the first call.
+ * The tensors (fp32, contiguous, any alignment; 16-byte aligned ones take the vector path) are described by DEVICE tables the caller
+ * builds once: param / grad / exp_avg / exp_avg_sq [tensors] pointers, numel [tensors], and a chunk list — chunk k covers elements
+ * [chunk_off[k], chunk_off[k] + a3vt_adam_chunk_elems()) of tensor chunk_tensor[k] (cut off at numel); every element must be covered
+ * exactly once.  Element-wise and without reductions: bit-repeatable. */
+int a3vt_adam_chunk_elems(void);
+int a3vt_adam_step(void *const *param, const void *const *grad, void *const *exp_avg, void *const *exp_avg_sq,
+                   const long long *numel, const int *chunk_tensor, const long long *chunk_off, int n_chunks, double lr, double beta1,
+                   double beta2, double eps, double weight_decay, long long step, void *stream);
+
 /* Vertex update, model.py:250,270,283:  out[b][v] = in[b][v] + (v < n_vision ? update[b][v] : 0). */
 int a3vt_vertex_update(const float *verts_in, const float *update, int batch, int n_vert, int n_vision,
                        float *verts_out, void *stream);
@@ -456,8 +469,8 @@ int a3vt_profile_read(double *total_ms /*[3]*/, int *count /*[3]*/);
 /* The same for n classes (round 6; every call of this library on a step, so that a bench line can say where a step's time
  * goes without a profiler): [0..2] as above, [3] neighbour aggregation of the hidden layers (forward and A^T backward),
  * [4] output layer (300 -> 3 product, its aggregation, their backward), [5] Chamfer forward (sort, boxes, exact search,
- * reduction), [6] surface sampling forward / backward + Chamfer backward, [7] vertex-feature encoders and image pooling
- * (forward and backward).  A class's time is the span from the first to the last launch of each call, summed over calls.
+ * reduction), [6] surface sampling forward / backward + Chamfer backward, [7] vertex-feature encoders, image pooling and the
+ * image pyramid's library kernels (forward and backward), [8] the optimizer step (a3vt_adam_step).  A class's time is the span from the first to the last launch of each call, summed over calls.
  * Returns the number of classes the library keeps. */
 int a3vt_profile_read_classes(double *total_ms, int *count, int n);
 

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 def test_library_loads(cuda):
     from a3vt_amd import lib
-    assert lib.load().a3vt_version() == 162
+    assert lib.load().a3vt_version() == 163
 
 
 @pytest.mark.parametrize("m,k,n", [(128, 16, 16), (1000, 52, 300), (4099, 300, 300), (300, 300, 50), (77, 300, 3),

@@ -110,7 +110,7 @@ def test_header_symbols_all_bound_and_exported():
     for name in declared:
         assert hasattr(dll, name), name
     L = lib.load()
-    assert L.a3vt_version() == 162
+    assert L.a3vt_version() == 163
     assert L.a3vt_posenc_param_count(50) == 12 * 63 + 12 + 25 * 12 + 25 + 50 * 25 + 50 + 200
     assert L.a3vt_wt_rows(300) >= 304 and L.a3vt_wt_ld(300) == 304
     # host-only entry point: CSR validation
@@ -514,3 +514,26 @@ def test_bench_self_launch_command_line(monkeypatch):
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     monkeypatch.setattr(bench.torch.cuda, "device_count", lambda: 2)
     assert bench.self_launch(a) == 2                                      # refused: 4 asked, 2 visible
+
+
+def test_library_adam_on_cpu_tensors_is_torch_adam():
+    """a3vt_amd.optim.Adam (the trainer's optimizer, vision/train.py:64) IS a torch.optim.Adam: what its kernel does not take — here
+    CPU parameters — goes through torch's own step, bit for bit, and the state_dict has torch's layout."""
+    from a3vt_amd import optim as aopt
+    g = torch.Generator().manual_seed(0)
+    mk = lambda: [torch.nn.Parameter(torch.randn(5, 7, generator=torch.Generator().manual_seed(1))), torch.nn.Parameter(torch.ones(3))]  # noqa: E731
+    pa, pb = mk(), mk()
+    oa, ob = aopt.Adam(pa, lr=1e-2), torch.optim.Adam(pb, lr=1e-2, foreach=False)
+    assert isinstance(oa, torch.optim.Adam)
+    for _ in range(3):
+        grads = [torch.randn(p.shape, generator=g) for p in pa]
+        for ps in (pa, pb):
+            for p, gr in zip(ps, grads):
+                p.grad = gr.clone()
+        oa.step()
+        ob.step()
+    assert oa.library_steps == 0
+    assert all(torch.equal(a, b) for a, b in zip(pa, pb))
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert sa["param_groups"][0].keys() == sb["param_groups"][0].keys() and sa["state"].keys() == sb["state"].keys()
+    assert all(sa["state"][k].keys() == sb["state"][k].keys() for k in sa["state"])

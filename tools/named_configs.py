@@ -22,8 +22,11 @@ def main():
     p.add_argument("--precision", default="bf16s", choices=["fp32", "bf16", "bf16s", "fp32x3"])
     p.add_argument("--only", type=int, default=0, choices=[0, 3, 4])
     p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--torch-adam", action="store_true", help="A/B: torch's fused Adam instead of the library's one-launch step")
     a = p.parse_args()
+    from a3vt_amd import synthetic
     from a3vt_amd.synthetic import time_named_config   # the same leg bench.py prints under `named_configs`
+    synthetic.LIBRARY_ADAM[0] = not a.torch_adam
     dev = torch.device("cuda", 0)
     for which, batch in ((3, a.batch3), (4, a.batch4)):
         if a.only in (0, which):

@@ -29,7 +29,8 @@ def main():
     net = model.Deformation(info, verts, args).to(dev)
     params = list(net.parameters())
     bucket = adist.FlatGradBucket(params)
-    opt = torch.optim.Adam(params, lr=args.lr, fused=True)
+    from a3vt_amd import optim as a3vt_optim
+    opt = a3vt_optim.make_adam(params, args.lr)
     g = torch.Generator().manual_seed(0)
     tc = torch.zeros(B, 5, 4, 25, 4)
     tc[..., :3] = (torch.rand(B, 5, 4, 25, 3, generator=g) - 0.5) * 0.3
