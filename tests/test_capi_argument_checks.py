@@ -97,3 +97,34 @@ def test_entry_points_refuse_bad_arguments_before_touching_them(L):
     assert _err(L) != ""
     assert L.a3vt_gcn_stack_fwd(FAKE, 51, 50, FAKE, FAKE, 20, 300, 99, FAKE, FAKE, FAKE, 7, 2562, 64, 7, None, None, FAKE, FAKE, None) != 0   # mode 7
     assert L.a3vt_dbg_csr_algo(9) != 0
+
+
+def test_conv5_and_adam_entry_points_refuse_bad_arguments(L):
+    """Round 6 entry points: the direct convolution's weight gradient and the one-launch optimizer step."""
+    # shapes: only the five layer shapes of the pyramid; scratch sizes are 0 for everything else
+    assert L.a3vt_conv5_supported(16, 16, 1) == 1 and L.a3vt_conv5_supported(3, 16, 2) == 1 and L.a3vt_conv5_supported(64, 64, 1) == 0
+    for cin, cout in ((3, 3), (3, 16), (16, 16), (16, 32), (32, 32)):
+        assert L.a3vt_conv5_wrw_scratch_bytes(cin, cout) > 0
+    assert L.a3vt_conv5_wrw_scratch_bytes(64, 64) == 0 and L.a3vt_conv5_wrw_scratch_bytes(0, 0) == 0
+    need = L.a3vt_conv5_wrw_scratch_bytes(16, 16)
+    wg = lambda **kw: [kw.get("x", FAKE), kw.get("gy", FAKE), kw.get("b", 2), kw.get("h", 20), kw.get("w", 20), kw.get("cin", 16),   # noqa: E731
+                       kw.get("cout", 16), kw.get("s", 1), kw.get("gw", FAKE), kw.get("scr", FAKE), kw.get("sb", need), None]
+    assert L.a3vt_conv5_weight_grad(*wg(x=None)) != 0
+    assert L.a3vt_conv5_weight_grad(*wg(gw=None)) != 0
+    assert L.a3vt_conv5_weight_grad(*wg(x=FAKE_ODD)) != 0            # 16-channel maps: 16-byte aligned
+    assert L.a3vt_conv5_weight_grad(*wg(scr=FAKE_ODD)) != 0
+    assert L.a3vt_conv5_weight_grad(*wg(sb=need - 1)) != 0
+    assert L.a3vt_conv5_weight_grad(*wg(cin=64, cout=64)) != 0
+    assert L.a3vt_conv5_weight_grad(*wg(s=2)) != 0                   # 16 -> 16 exists at stride 1 only
+    assert L.a3vt_conv5_weight_grad(*wg(h=2)) != 0 and L.a3vt_conv5_weight_grad(*wg(b=0)) != 0
+    assert "argument check failed" in _err(L)
+    # Adam: an empty table is a no-op; NULL tables, step 0 and hyper-parameters outside their ranges are refused
+    d = ctypes.c_double
+    ad = lambda **kw: [kw.get("p", FAKE), FAKE, FAKE, FAKE, FAKE, FAKE, FAKE, kw.get("n", 4), d(kw.get("lr", 3e-4)), d(kw.get("b1", 0.9)),   # noqa: E731
+                       d(kw.get("b2", 0.999)), d(1e-8), d(0.0), kw.get("step", 1), None]
+    assert L.a3vt_adam_step(None, None, None, None, None, None, None, 0, d(3e-4), d(0.9), d(0.999), d(1e-8), d(0.0), 1, None) == 0
+    assert L.a3vt_adam_step(*ad(p=None)) != 0
+    assert L.a3vt_adam_step(*ad(step=0)) != 0
+    assert L.a3vt_adam_step(*ad(b1=1.0)) != 0 and L.a3vt_adam_step(*ad(b2=-0.1)) != 0 and L.a3vt_adam_step(*ad(lr=-1.0)) != 0
+    assert L.a3vt_adam_step(*ad(n=-1)) != 0
+    assert L.a3vt_adam_chunk_elems() == 4096
