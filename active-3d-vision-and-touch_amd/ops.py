@@ -468,8 +468,8 @@ def invalidate_bf16_copies():
 
 def _bf16_cache_on():
     """The process-wide optimizer post-step hook is registered on the FIRST use of the bf16 convolution branch, not at import
-    (a host process that imports this module for the fp32 path gets no hook).  torch's fused Adam — the trainer's optimizer —
-    updates the weights in place WITHOUT moving their ``_version``; without a global step hook (older torch) nothing tells a
+    (a host process that imports this module for the fp32 path gets no hook).  The trainer's optimizer — the library's one-launch
+    Adam (optim.py) as well as torch's fused Adam — updates the weights in place WITHOUT moving their ``_version``; without a global step hook (older torch) nothing tells a
     stale copy from a fresh one, and every call casts."""
     if _BF16_HOOK[0] is None:
         try:
@@ -489,7 +489,7 @@ def _bf16_forget(key, ref):
 
 def _bf16_copy(t, channels_last):
     """bf16 (channels-last) copy of a convolution weight / bias, kept until the tensor can have changed: an in-place torch
-    op (load_state_dict, copy_) moves ``t._version``; an optimizer step — torch's fused Adam does NOT move it — moves the
+    op (load_state_dict, copy_) moves ``t._version``; an optimizer step — neither the library's Adam nor torch's fused Adam moves it — moves the
     process-wide optimizer epoch (a global step post-hook); ``.data`` writers call :func:`invalidate_bf16_copies`.  A training
     loop casts once per step as before; the forward-only loops (validation, the K-candidate scoring of
     policies/environment.py:174-180) stop re-casting the 32 weights of the image pyramid on every call (64 copy launches per

@@ -650,16 +650,21 @@ def test_image_encoder_bf16_branch_batches_1_to_4(cuda):   # (batches 1, 3 and 4
         assert sum("bn_nhwc_min_batch" in str(x.message) for x in w) == reports, fused      # reported once, by the MIOpen branch only
 
 
-def test_bf16_weight_copies_follow_the_fused_optimizer(cuda):
-    """ops._bf16_copy caches the bf16 channels-last copy of a convolution weight per weight VERSION; the trainer's optimizer is
-    torch's fused Adam (vision/train.py mirror), an in-place multi-tensor kernel — the cache must see its updates."""
-    from a3vt_amd import ops
-    w = torch.nn.Parameter(torch.randn(16, 8, 5, 5, device=cuda))
-    opt = torch.optim.Adam([w], lr=0.1, fused=True)
+@pytest.mark.parametrize("library", [True, False])
+def test_bf16_weight_copies_follow_the_fused_optimizer(cuda, library):
+    """ops._bf16_copy caches the bf16 channels-last copy of a convolution weight per weight VERSION; the trainer's optimizer —
+    the library's one-launch Adam (a3vt_amd/optim.py) or torch's fused Adam (``library_adam = False``) — writes the weights in
+    place without moving ``_version``: the cache (and the direct convolution's weight images, ops._conv5_image) must see its updates."""
+    from a3vt_amd import ops, optim as aopt
+    w = torch.nn.Parameter(torch.randn(16, 16, 5, 5, device=cuda))
+    opt = aopt.make_adam([w], 0.1, library=library)
     a = ops._bf16_copy(w, True)
-    assert ops._bf16_copy(w, True) is a
+    img = ops._conv5_image(w, 0)
+    assert ops._bf16_copy(w, True) is a and ops._conv5_image(w, 0) is img
     w.grad = torch.ones_like(w)
     opt.step()
+    assert getattr(opt, "library_steps", 0) == (1 if library else 0)
     b = ops._bf16_copy(w, True)
-    assert b is not a
+    img2 = ops._conv5_image(w, 0)
+    assert b is not a and img2 is not img and not torch.equal(img, img2)
     assert torch.equal(b.float(), w.detach().to(torch.bfloat16).float()) and not torch.equal(a.float(), b.float())
