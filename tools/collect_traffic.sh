@@ -20,7 +20,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         if r["Counter_Name"] == c:
             agg[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
-        if "rowgemm" in k or "dw_kernel" in k or "dww_kernel" in k or "dw3" in k or "csr" in k or "slab" in k or "thin" in k:
+        if "rowgemm" in k or "dw_kernel" in k or "dww_kernel" in k or "dw16" in k or "dw3" in k or "csr" in k or "slab" in k or "thin" in k:
             res[k][c + "_KiB_max"] = max(v)       # hidden x hidden launches are the largest
             res[k][c + "_KiB_mean"] = sum(v) / len(v)
             res[k]["launches"] = len(v)
