@@ -88,7 +88,9 @@ class Adam(torch.optim.Adam):
                 break
             plans.append(got)
         if plans is None:
-            torch.optim.Adam.step(self)        # everything the kernel does not take: torch's own step, same state
+            # everything the kernel does not take: torch's own step on the same state (the function under the step-hook wrapper: this
+            # call is already inside that wrapper, and the hooks must fire once)
+            getattr(torch.optim.Adam.step, "__wrapped__", torch.optim.Adam.step)(self)
             return loss
         L = _lib.load()
         for gi, (group, (ps, gs, ms, vs, steps)) in enumerate(zip(self.param_groups, plans)):
